@@ -1,0 +1,137 @@
+"""Seeded synthetic sensor frames: a world of axis-aligned boxes over a ground
+slab, a fraction of which toggles present/absent every frame so that all three wavefronts are
+exercised, seen by a moving pinhole depth camera or a multi-ring lidar.
+
+Pure numpy, used by tests/ and bench.py to produce INPUT data only (depth images, range images,
+point clouds, poses).  Sensor-frame convention is the reference's: x forward, y left, z up;
+depth = x (src/kernel/realsense/camera_helper.h:11-38).
+"""
+import math
+
+import numpy as np
+
+
+class BoxWorld:
+    def __init__(self, seed, extent, n_boxes=48, toggle_frac=0.25, ground_z=-1.0, min_size=0.3, max_size=1.6):
+        rng = np.random.default_rng(seed)
+        ext = np.asarray(extent, dtype=np.float64)  # half-extent of the populated region (m)
+        ctr = rng.uniform(-ext, ext, size=(n_boxes, 3))
+        ctr[:, 2] = rng.uniform(ground_z, ground_z + 2.0 * 1.2, size=n_boxes)
+        half = rng.uniform(min_size, max_size, size=(n_boxes, 3)) * 0.5
+        lo = ctr - half
+        hi = ctr + half
+        # keep the sensor start position (origin) free
+        near = np.all((lo < 0.6) & (hi > -0.6), axis=1)
+        lo[near] += 2.0
+        hi[near] += 2.0
+        ground_lo = np.array([[-4.0 * ext[0], -4.0 * ext[1], ground_z - 0.3]])
+        ground_hi = np.array([[4.0 * ext[0], 4.0 * ext[1], ground_z]])
+        self.lo = np.vstack([ground_lo, lo])
+        self.hi = np.vstack([ground_hi, hi])
+        self.toggles = np.zeros(n_boxes + 1, dtype=bool)
+        k = int(round(toggle_frac * n_boxes))
+        if k > 0:
+            self.toggles[1 + rng.choice(n_boxes, size=k, replace=False)] = True
+        self.phase = rng.integers(0, 2, size=n_boxes + 1)
+
+    def active(self, frame):
+        on = np.ones(self.lo.shape[0], dtype=bool)
+        t = self.toggles
+        on[t] = ((frame + self.phase[t]) % 2) == 0
+        return on
+
+    def cast(self, origin, dirs, frame, chunk=65536):
+        """Nearest hit parameter t >= 0 along origin + t*dirs (dirs: [R,3]); inf when none."""
+        on = self.active(frame)
+        lo = self.lo[on]
+        hi = self.hi[on]
+        o = np.asarray(origin, dtype=np.float64)
+        out = np.full(dirs.shape[0], np.inf)
+        for s in range(0, dirs.shape[0], chunk):
+            d = dirs[s:s + chunk].astype(np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv = 1.0 / d
+                t0 = (lo[None, :, :] - o[None, None, :]) * inv[:, None, :]
+                t1 = (hi[None, :, :] - o[None, None, :]) * inv[:, None, :]
+            tmin = np.minimum(t0, t1)
+            tmax = np.maximum(t0, t1)
+            # rays parallel to a slab: inside → (-inf, inf), outside → no hit
+            par = d[:, None, :] == 0.0
+            inside = (o[None, None, :] >= lo[None, :, :]) & (o[None, None, :] <= hi[None, :, :])
+            tmin = np.where(par, np.where(inside, -np.inf, np.inf), tmin)
+            tmax = np.where(par, np.where(inside, np.inf, -np.inf), tmax)
+            tn = tmin.max(axis=2)
+            tf = tmax.min(axis=2)
+            hit = (tf >= tn) & (tf >= 0.0)
+            tn = np.where(hit, np.maximum(tn, 0.0), np.inf)
+            out[s:s + chunk] = tn.min(axis=1)
+        return out
+
+
+def yaw_quat(yaw):
+    return (math.cos(0.5 * yaw), 0.0, 0.0, math.sin(0.5 * yaw))
+
+
+def rot_from_quat(q):
+    w, x, y, z = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def pose(frame, voxel_width, delta_vox=4, yaw_deg=2.0, z=0.0):
+    """Sensor pose of `frame` (0-based): +delta_vox voxels in x and yaw_deg of yaw per frame."""
+    pos = (np.float32(frame * delta_vox * voxel_width), np.float32(0.0), np.float32(z))
+    return pos, yaw_quat(math.radians(yaw_deg) * frame)
+
+
+def depth_frame(world, frame, pos, quat, rows=480, cols=640, fx=525.0, fy=525.0, cx=319.5, cy=239.5,
+                max_depth=8.0):
+    """Pinhole depth image (float32 [rows, cols]); NaN where nothing is hit within max_depth."""
+    u, v = np.meshgrid(np.arange(cols, dtype=np.float64), np.arange(rows, dtype=np.float64))
+    d_s = np.stack([np.ones_like(u), (cx - u) / fx, (cy - v) / fy], axis=-1).reshape(-1, 3)
+    d_w = d_s @ rot_from_quat(quat).T
+    t = world.cast(pos, d_w, frame)
+    depth = np.where(t <= max_depth, t, np.nan).astype(np.float32)
+    return depth.reshape(rows, cols)
+
+
+def depth_to_points(depth, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
+    """Sensor-frame point cloud of the valid pixels (CAM_HELPER::L2G without the pose)."""
+    rows, cols = depth.shape
+    u, v = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
+    ok = np.isfinite(depth)
+    d = depth[ok]
+    pts = np.stack([d, (np.float32(cx) - u[ok]) * d / np.float32(fx), (np.float32(cy) - v[ok]) * d / np.float32(fy)],
+                   axis=-1)
+    return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+def lidar_frame(world, frame, pos, quat, rings=16, az=1800, phi_min_deg=-15.0, phi_inc_deg=2.0, max_range=100.0):
+    """Multi-ring lidar: returns (points_sensor_frame [P,3] float32, hit range per (ring, az))."""
+    phi = np.radians(phi_min_deg + phi_inc_deg * np.arange(rings))
+    th = -np.pi + 2.0 * np.pi * (np.arange(az) + 0.5) / az
+    ph, tt = np.meshgrid(phi, th, indexing="ij")
+    d_s = np.stack([np.cos(ph) * np.cos(tt), np.cos(ph) * np.sin(tt), np.sin(ph)], axis=-1).reshape(-1, 3)
+    d_w = d_s @ rot_from_quat(quat).T
+    t = world.cast(pos, d_w, frame)
+    ok = t <= max_range
+    pts = (d_s[ok] * t[ok, None]).astype(np.float32)
+    return np.ascontiguousarray(pts), np.where(ok, t, np.inf).reshape(rings, az)
+
+
+def range_image(points, scan_num=440, ring_num=16, phi_min_deg=-15.0, phi_inc_deg=2.0):
+    """Vlp16MapMaker::convertPyntCld binning (src/vlp16_map_maker.cpp:73-147): horizontal range
+    per (ring, azimuth bin), +inf where no return.  Ring = nearest elevation ring."""
+    img = np.full((ring_num, scan_num), np.inf, dtype=np.float32)
+    if points.shape[0] == 0:
+        return img
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    res = np.float32(2.0 * math.pi / scan_num)
+    b = ((np.arctan2(y, x).astype(np.float32) + np.float32(math.pi)) / res).astype(np.int64)
+    hor = np.sqrt(x * x + y * y).astype(np.float32)
+    ring = np.rint((np.degrees(np.arctan2(z, hor)) - phi_min_deg) / phi_inc_deg).astype(np.int64)
+    ok = (b >= 0) & (b < scan_num) & (ring >= 0) & (ring < ring_num)
+    img[ring[ok], b[ok]] = hor[ok]
+    return img

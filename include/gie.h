@@ -1,0 +1,178 @@
+/*
+ * gie.h — C-ABI of the MI355X-native incremental-EDT map-update path.
+ *
+ * This is the drop-in boundary for the per-frame hot path of JINXER000/GIE-mapping
+ * (VOLMAPNODE::publishMap, src/volumetric_mapper.cpp:138-224).  The reference has no FFI
+ * layer; its boundary is the set of C++ objects the ROS node calls.  Every entry point below
+ * names the reference symbol it replaces (file:line relative to the reference tree).
+ *
+ * Conventions: opaque handle, int status codes (0 = GIE_OK), gie_last_error() for the text,
+ * no exceptions cross the ABI, one handle is not thread-safe (the reference is single-threaded,
+ * src/main.cpp:7), buffers are caller-owned HOST pointers unless the name ends in _dev.
+ * All dense local-volume arrays are x-fastest: idx = z*X*Y + y*X + x (local_batch.h:394-407).
+ */
+#ifndef GIE_H
+#define GIE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIE_OK 0
+#define GIE_ERR_INVALID 1   /* bad argument / bad call order            */
+#define GIE_ERR_DEVICE 2    /* HIP runtime error                        */
+#define GIE_ERR_CAPACITY 3  /* block pool / hash / frontier queue full  */
+
+/* voxel types, local_batch.h:7-10 */
+#define GIE_VOX_UNKNOWN 0
+#define GIE_VOX_FREE 1
+#define GIE_VOX_OCCUPIED 2
+#define GIE_VOX_FNT 3
+
+/* sentinels, voxmap_utils.cuh:8-9 */
+#define GIE_EMPTY_VALUE 999999
+
+typedef struct gie_mapper gie_mapper;
+
+/* LocMap ctor arguments (local_batch.h:35-60) + the Parameters fields that reach the GPU code
+ * (parameters.h:69-132) + GlbHashMap capacity (glb_hash_map.cu:9-47). */
+typedef struct gie_config {
+    float voxel_width;            /* m, Parameters::voxel_width                               */
+    int32_t local_size[3];        /* voxels (X,Y,Z) = local_size_{x,y,z}/voxel_width           */
+    int32_t occupancy_threshold;  /* 0..255, default 180                                       */
+    float ogm_min_h, ogm_max_h;   /* height gate for occupied hits (ogm/min_height,max_height) */
+    int32_t cutoff_grids_sq;      /* ceil(cutoff_dist/voxel_width)^2, parameters.h:95,134-138  */
+    int32_t fast_mode;            /* wave/fast_mode (code default true, parameters.h:93)       */
+    int32_t for_motion_planner;   /* robot sphere forced FREE in the OGM kernels               */
+    int32_t robot_r2_grids;       /* ceil(robot_r/voxel_width)^2                               */
+    int32_t max_blocks;           /* block pool capacity (hash/block_max); 0 = size from volume */
+    int32_t device_id;            /* HIP device ordinal                                         */
+    int32_t reserved[6];
+} gie_config;
+
+/* MulScanParam, include/cuda_toolkit/occupancy/vlp16/multiscan_param.h:4-27 */
+typedef struct gie_multiscan_param {
+    int32_t scan_num, ring_num;
+    float max_r, theta_inc, theta_min, phi_inc, phi_min;
+} gie_multiscan_param;
+
+/* CamParam, include/cuda_toolkit/occupancy/realsense/camera_param.h:4-27 */
+typedef struct gie_cam_param {
+    int32_t rows, cols;
+    float cx, cy, fx, fy;
+    int32_t valid_nan;
+} gie_cam_param;
+
+/* ScanParam, include/cuda_toolkit/occupancy/hokuyo/scan_param.h:4-19 */
+typedef struct gie_scan_param {
+    int32_t scan_num;
+    float max_r, theta_inc, theta_min;
+} gie_scan_param;
+
+/* One global voxel as planners see it (GlbVoxel, voxmap_utils.cuh:29-44). */
+typedef struct gie_voxel {
+    uint8_t occ_val;
+    int8_t vox_type;
+    int16_t pad;
+    int32_t dist_sq;
+    int32_t coc[3];
+} gie_voxel;
+
+/* CostMap.msg header fields (msg/CostMap.msg:1-15, volumetric_mapper.cpp:375-389). */
+typedef struct gie_costmap_hdr {
+    int32_t x_size, y_size, z_size;
+    float x_origin, y_origin, z_origin;
+    float width;
+    uint8_t type; /* TYPE_EDT = 1 */
+    uint8_t pad[3];
+} gie_costmap_hdr;
+
+/* SeenDist payload element, local_batch.h:19-24 (8 bytes). */
+typedef struct gie_seendist {
+    float d;
+    uint8_t s;
+    uint8_t o;
+    uint8_t pad[2];
+} gie_seendist;
+
+/* Per-frame counters (the reference prints/keeps: glb_hash_map.cu:86,170-172; wave_helper.h). */
+typedef struct gie_frame_stats {
+    int32_t frame;            /* map_ct (_time)                                  */
+    int32_t blocks_total;     /* blocks in the pool                              */
+    int32_t blocks_new;       /* "New blocks allocated"                          */
+    int32_t seeds_a, seeds_b, seeds_c; /* after obtainFrontiers                 */
+    int32_t front_b, front_c; /* |B| after wave A, |C| after wave B              */
+    int32_t visits_a, visits_b, visits_c; /* frontier entries expanded          */
+    int32_t levels_a, levels_b, levels_c;
+    float us_ogm, us_fuse, us_edt, us_merge; /* device time of the last step    */
+} gie_frame_stats;
+
+const char *gie_last_error(void);
+
+/* LocMap::LocMap + create_gpu_map (local_batch.h:35-89), GlbHashMap::GlbHashMap
+ * (glb_hash_map.cu:9-47), setupRotationPlan (volumetric_mapper.cpp:344-373), warmupCuda. */
+gie_mapper *gie_create(const gie_config *cfg);
+void gie_destroy(gie_mapper *h);
+
+/* odom2trans/trans2proj (projection.h:14-33) + LocMap::calculate_pivot_origin /
+ * calculate_update_pivot (local_batch.h:129-166).  Also advances the map tick (_time++). */
+int gie_set_pose(gie_mapper *h, const float pos[3], const float quat_wxyz[4]);
+
+/* PntcldMapMaker::updateLocalOGM (pntcld_map_maker.cpp:63-73) →
+ * PNTCLD_RAYCAST::localOGMKernels (pntcld_raycast.cu:105-117). xyz: n sensor-frame points. */
+int gie_ogm_pointcloud(gie_mapper *h, const float *xyz, int n);
+int gie_ogm_pointcloud_dev(gie_mapper *h, const float *d_xyz, int n);
+/* Vlp16MapMaker::updateLocalOGM (vlp16_map_maker.cpp:51-71) → VLP_FAST::localOGMKernels
+ * (vlp16_fast.cu:89-97). ranges: ring-major [ring_num][scan_num] horizontal ranges. */
+int gie_ogm_multiscan(gie_mapper *h, const float *ranges, const gie_multiscan_param *p);
+int gie_ogm_multiscan_dev(gie_mapper *h, const float *d_ranges, const gie_multiscan_param *p);
+/* RealsenseMapMaker::updateLocalOGM (realsense_map_maker.cpp:46-52) →
+ * REALSENSE_FAST::localOGMKernels (realsense_fast.cu:97-104). depth: row-major rows x cols. */
+int gie_ogm_depth(gie_mapper *h, const float *depth, const gie_cam_param *p);
+int gie_ogm_depth_dev(gie_mapper *h, const float *d_depth, const gie_cam_param *p);
+/* HokuyoMapMaker::updateLocalOGM (hokuyo_map_maker.cpp:44-50) → HOKUYO_FAST::localOGMKernels. */
+int gie_ogm_scan2d(gie_mapper *h, const float *ranges, const gie_scan_param *p);
+
+/* Ext_Obs_Wrapper boxes as consumed by the fuse kernels (pre_map.cu:80-101,
+ * unify_helper.cuh:68-86). ll/ur: n x 3 floats (metres); active: n flags. Box 0 is the inverted
+ * "fence". n = 0 clears. */
+int gie_set_ext_boxes(gie_mapper *h, const float *ll, const float *ur, const uint8_t *active, int n);
+
+/* GlbHashMap::updateHashOGM (glb_hash_map.cu:115-143): allocHashTB + updateHashOGMWith*. */
+int gie_fuse(gie_mapper *h);
+/* EDT_OCC::batchEDTUpdate (local_edt.cu:7-28). */
+int gie_batch_edt(gie_mapper *h);
+/* GlbHashMap::mergeNewObsv (glb_hash_map.cu:146-207). */
+int gie_merge(gie_mapper *h);
+/* fuse + batch_edt + merge, asynchronous on the mapper's stream. */
+int gie_step(gie_mapper *h);
+/* GPU_DEV_SYNC (cuda_macro.h:38); also surfaces device-side capacity errors. */
+int gie_sync(gie_mapper *h);
+
+/* LocMap::copy_edt_2_host / copy_ogm_2_host (local_batch.h:370-378) + the pair contents.
+ * Any pointer may be NULL. edt: N floats (_edt_D, voxel units); type: N (_glb_type);
+ * dist_sq: N (pair distance); coc_xyz: 3N global coords of the closest obstacle
+ * (GIE_EMPTY_VALUE x3 when there is none). */
+int gie_read_local(gie_mapper *h, float *edt, int8_t *type, int32_t *dist_sq, int32_t *coc_xyz);
+/* Intermediate state for parity tests: OGM scan labels / hit-miss counters (before fuse). */
+int gie_read_ogm(gie_mapper *h, int8_t *inst_type, int32_t *ray_count);
+/* Batch EDT result before the merge: dist² (_aux) and local closest-obstacle coords
+ * (_coc_idx_aux unpacked; -1 x3 when the volume holds no obstacle). */
+int gie_read_batch_edt(gie_mapper *h, int32_t *dist_sq, int32_t *coc_xyz_local);
+/* LocMap::convertCostMap (local_batch.h:382-391) + setupEDTmsg4Motion
+ * (volumetric_mapper.cpp:375-389). payload: N gie_seendist. */
+int gie_read_costmap(gie_mapper *h, gie_seendist *payload, gie_costmap_hdr *hdr);
+/* Hash lookup + retrive_vox_D (voxmap_utils.cuh:94-132) for n global coords. Voxels of
+ * unallocated blocks come back as a default GlbVoxel (UNKNOWN, EMPTY_VALUE, EMPTY_KEY). */
+int gie_query_global(gie_mapper *h, const int32_t *xyz, int n, gie_voxel *out);
+int gie_get_stats(gie_mapper *h, gie_frame_stats *out);
+/* local pivot _pvt (global coord of local voxel 0,0,0) of the current frame. */
+int gie_get_pivot(gie_mapper *h, int32_t pvt[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIE_H */

@@ -1,0 +1,110 @@
+/*
+ * gie_math.h — deterministic fp32 geometry shared by the HIP kernels and the CPU oracle.
+ *
+ * Voxelisation must agree bit-for-bit between the GPU path and the CPU checker, so everything
+ * here is spelled as explicit IEEE-754 binary32 +,-,*,/,sqrt,floor in a fixed evaluation order
+ * and both sides are compiled with -ffp-contract=off (no FMA contraction).  No libm
+ * transcendental is used: atan2 is a fixed polynomial (Cephes-style atanf reduction), because
+ * device and host libm differ in the last ulp and a one-ulp difference flips floor() bins.
+ *
+ * What is restated here (math only; the reference's se3.cuh/matrix.cuh are GPL, helper_math.h
+ * is NVIDIA-EULA, so nothing is copied — formulas are re-derived):
+ *   SE3 from unit quaternion + translation, inverse, point transform
+ *       (include/cuda_toolkit/se3.cuh:47-77, 91-108, 123-149, 200-204)
+ *   LocMap::pos2coord  floorf(p/w + 0.5f)           (include/map_structure/local_batch.h:250-258)
+ */
+#ifndef GIE_MATH_H
+#define GIE_MATH_H
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define GIE_HD __host__ __device__ __forceinline__
+#else
+#define GIE_HD static inline
+#endif
+
+typedef struct gie_se3 {
+    float m[12]; /* row-major 3x4: r00 r01 r02 tx / r10 r11 r12 ty / r20 r21 r22 tz */
+} gie_se3;
+
+/* se3.cuh:47-77 — rotation from a normalised quaternion (w,x,y,z), translation t. */
+GIE_HD gie_se3 gie_se3_from_quat(float qw, float qx, float qy, float qz, float tx, float ty, float tz)
+{
+    gie_se3 s;
+    const float x = 2 * qx, y = 2 * qy, z = 2 * qz;
+    const float wx = x * qw, wy = y * qw, wz = z * qw;
+    const float xx = x * qx, xy = y * qx, xz = z * qx;
+    const float yy = y * qy, yz = z * qy, zz = z * qz;
+    s.m[0] = 1 - (yy + zz); s.m[1] = xy - wz;       s.m[2] = xz + wy;        s.m[3] = tx;
+    s.m[4] = xy + wz;       s.m[5] = 1 - (xx + zz); s.m[6] = yz - wx;        s.m[7] = ty;
+    s.m[8] = xz - wy;       s.m[9] = yz + wx;       s.m[10] = 1 - (xx + yy); s.m[11] = tz;
+    return s;
+}
+
+/* se3.cuh:91-108 — rigid inverse: R^T, -R^T t (same term order). */
+GIE_HD gie_se3 gie_se3_inv(const gie_se3 a)
+{
+    gie_se3 r;
+    r.m[0] = a.m[0]; r.m[1] = a.m[4]; r.m[2] = a.m[8];
+    r.m[4] = a.m[1]; r.m[5] = a.m[5]; r.m[6] = a.m[9];
+    r.m[8] = a.m[2]; r.m[9] = a.m[6]; r.m[10] = a.m[10];
+    r.m[3] = -a.m[0] * a.m[3] - a.m[4] * a.m[7] - a.m[8] * a.m[11];
+    r.m[7] = -a.m[1] * a.m[3] - a.m[5] * a.m[7] - a.m[9] * a.m[11];
+    r.m[11] = -a.m[2] * a.m[3] - a.m[6] * a.m[7] - a.m[10] * a.m[11];
+    return r;
+}
+
+/* se3.cuh:123-149,200-204 — rotate then translate. */
+GIE_HD void gie_se3_apply(const gie_se3 s, float px, float py, float pz, float *ox, float *oy, float *oz)
+{
+    const float rx = s.m[0] * px + s.m[1] * py + s.m[2] * pz;
+    const float ry = s.m[4] * px + s.m[5] * py + s.m[6] * pz;
+    const float rz = s.m[8] * px + s.m[9] * py + s.m[10] * pz;
+    *ox = rx + s.m[3];
+    *oy = ry + s.m[7];
+    *oz = rz + s.m[11];
+}
+
+/* local_batch.h:250-258 */
+GIE_HD int gie_pos2coord(float p, float w) { return (int)floorf(p / w + 0.5f); }
+
+/* atan on [0, inf) by the classic three-interval reduction and a degree-4 (in z = x*x) odd
+ * polynomial; |error| < 2 ulp.  The reference calls CUDA atan2f under -use_fast_math, which is
+ * not reproducible anywhere else; this is the pinned stand-in on both sides. */
+GIE_HD float gie_atan_pos(float x)
+{
+    float y;
+    if (x > 2.414213562373095f) { /* tan(3pi/8) */
+        y = 1.5707963267948966f;
+        x = -(1.0f / x);
+    } else if (x > 0.4142135623730950f) { /* tan(pi/8) */
+        y = 0.7853981633974483f;
+        x = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y = 0.0f;
+    }
+    const float z = x * x;
+    float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    p = p * z * x + x;
+    return y + p;
+}
+
+GIE_HD float gie_atan2f(float y, float x)
+{
+    const float PI_F = 3.14159265358979323846f;
+    const float PIO2_F = 1.57079632679489661923f;
+    if (x == 0.0f) {
+        if (y > 0.0f) return PIO2_F;
+        if (y < 0.0f) return -PIO2_F;
+        return 0.0f;
+    }
+    if (y == 0.0f) return x > 0.0f ? 0.0f : PI_F;
+    const float a = gie_atan_pos(fabsf(y) / fabsf(x)); /* (0, pi/2) */
+    if (x > 0.0f) return y > 0.0f ? a : -a;
+    return y > 0.0f ? PI_F - a : a - PI_F;
+}
+
+#endif /* GIE_MATH_H */

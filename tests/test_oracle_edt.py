@@ -1,0 +1,119 @@
+"""Pins the oracle's batch-EDT stage (EDTphase1-3 restatement) against the mathematical
+definition (brute force), and pins the closest-obstacle tie rule the HIP kernels rely on."""
+import numpy as np
+import pytest
+
+import gie
+from oracle_py import OracleMapper, brute_force_edt
+
+
+def _edt(shape_xyz, occ):
+    cfg = gie.make_config(0.1, shape_xyz)
+    m = OracleMapper(cfg)
+    t = np.where(occ, 2, 1).astype(np.int8)
+    d, c = m.edt_only(t)
+    m.close()
+    return d, c
+
+
+@pytest.mark.parametrize("shape,dens,seed", [
+    ((24, 24, 24), 0.02, 1), ((32, 32, 32), 0.005, 2), ((40, 40, 16), 0.01, 3), ((32, 48, 16), 0.002, 4),
+    ((48, 32, 16), 0.02, 5), ((16, 16, 1), 0.05, 6), ((33, 17, 9), 0.01, 7), ((8, 8, 8), 0.3, 8),
+    ((64, 64, 24), 0.0005, 9), ((20, 20, 20), 1.0, 10),
+])
+def test_edt_matches_brute_force(oracle_lib, shape, dens, seed):
+    X, Y, Z = shape
+    rng = np.random.default_rng(seed)
+    occ = rng.random((Z, Y, X)) < dens
+    if not occ.any():
+        occ[Z // 2, Y // 3, X // 4] = True
+    d, c = _edt(shape, occ)
+    bf = brute_force_edt(occ.astype(np.int8))
+    assert np.array_equal(d, bf)
+    # witness: coc is an obstacle at exactly that distance
+    zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    assert (c >= 0).all()
+    dd = (c[..., 0] - xx) ** 2 + (c[..., 1] - yy) ** 2 + (c[..., 2] - zz) ** 2
+    assert np.array_equal(dd, d)
+    assert occ[c[..., 2], c[..., 1], c[..., 0]].all()
+
+
+def test_empty_volume_is_invalid(oracle_lib):
+    d, c = _edt((12, 10, 8), np.zeros((8, 10, 12), bool))
+    assert (c == -1).all()
+    assert (d >= (12 + 10 + 8) ** 2).all()
+
+
+def _tie_rule_reference(occ):
+    """Closed form the HIP passes implement: pass Y nearest in column, ties -> LARGER y;
+    pass X argmin_x' (x-x')^2+g^2, ties -> SMALLER x'; pass Z likewise ties -> SMALLER z'."""
+    Z, Y, X = occ.shape
+    BIG = 1 << 28
+    cy = np.full((Z, Y, X), -1, np.int64)
+    g2 = np.full((Z, Y, X), BIG, np.int64)
+    ys = np.arange(Y)
+    for z in range(Z):
+        for x in range(X):
+            sites = ys[occ[z, :, x]]
+            if sites.size == 0:
+                continue
+            dist = np.abs(ys[:, None] - sites[None, :])
+            best = dist.min(axis=1)
+            # ties -> larger y': last index achieving the min
+            idx = dist.shape[1] - 1 - np.argmin(dist[:, ::-1], axis=1)
+            cy[z, :, x] = sites[idx]
+            g2[z, :, x] = best ** 2
+    xs = np.arange(X)
+    cx2 = np.full((Z, Y, X), -1, np.int64)
+    cy2 = np.full((Z, Y, X), -1, np.int64)
+    d2 = np.full((Z, Y, X), BIG, np.int64)
+    for z in range(Z):
+        for y in range(Y):
+            f = (xs[:, None] - xs[None, :]) ** 2 + g2[z, y, None, :]
+            i = np.argmin(f, axis=1)  # first (smallest x') minimum
+            ok = g2[z, y, i] < BIG
+            d2[z, y, :] = np.where(ok, f[xs, i], BIG)
+            cx2[z, y, :] = np.where(ok, i, -1)
+            cy2[z, y, :] = np.where(ok, cy[z, y, i], -1)
+    zs = np.arange(Z)
+    out_d = np.full((Z, Y, X), BIG, np.int64)
+    out_c = np.full((Z, Y, X, 3), -1, np.int64)
+    for y in range(Y):
+        for x in range(X):
+            f = (zs[:, None] - zs[None, :]) ** 2 + d2[None, :, y, x]
+            i = np.argmin(f, axis=1)
+            ok = d2[i, y, x] < BIG
+            out_d[:, y, x] = np.where(ok, f[zs, i], BIG)
+            out_c[:, y, x, 0] = np.where(ok, cx2[i, y, x], -1)
+            out_c[:, y, x, 1] = np.where(ok, cy2[i, y, x], -1)
+            out_c[:, y, x, 2] = np.where(ok, i, -1)
+    return out_d, out_c
+
+
+@pytest.mark.parametrize("shape,dens,seed", [
+    ((16, 16, 16), 0.05, 11), ((24, 12, 8), 0.02, 12), ((9, 31, 5), 0.1, 13), ((32, 32, 8), 0.004, 14),
+    ((12, 12, 12), 0.5, 15), ((20, 7, 11), 0.01, 16),
+])
+def test_meijster_tie_rule(oracle_lib, shape, dens, seed):
+    """The literal Meijster scans of the oracle pick exactly the closed-form argmin with the
+    tie rule above — so a kernel may compute the envelope any way it likes as long as it keeps
+    that rule."""
+    X, Y, Z = shape
+    rng = np.random.default_rng(seed)
+    occ = rng.random((Z, Y, X)) < dens
+    occ[Z // 2, Y // 2, X // 2] = True
+    d, c = _edt(shape, occ)
+    rd, rc = _tie_rule_reference(occ)
+    assert np.array_equal(d, rd)
+    assert np.array_equal(c, rc)
+
+
+def test_tie_rule_exhaustive_1d(oracle_lib):
+    """All 2^10 occupancy patterns of a 10x1x1 row and of a 1x1x10 column, plus structured 2-D cases."""
+    for n in range(1, 1 << 10):
+        bits = np.array([(n >> i) & 1 for i in range(10)], bool)
+        for shape, occ in (((10, 1, 1), bits.reshape(1, 1, 10)), ((1, 10, 1), bits.reshape(1, 10, 1)),
+                           ((1, 1, 10), bits.reshape(10, 1, 1))):
+            d, c = _edt(shape, occ)
+            rd, rc = _tie_rule_reference(occ)
+            assert np.array_equal(d, rd) and np.array_equal(c, rc), (n, shape)
