@@ -1,0 +1,454 @@
+/*
+ * gie_api.inc.h — the C-ABI of include/gie.h: allocation, per-frame orchestration
+ * (VOLMAPNODE::publishMap's call sequence, src/volumetric_mapper.cpp:138-224) and readers.
+ * Written against the small `be_*` backend interface; gie_hip.hip supplies the HIP backend
+ * (the product), tests/emu supplies a sequential stand-in used only by CPU-side logic tests.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_gie_err;
+static void gie_set_err(const std::string &s) { g_gie_err = s; }
+extern "C" const char *gie_last_error(void) { return g_gie_err.c_str(); }
+
+struct gie_mapper {
+    gie_config cfg;
+    gie_ctx c;
+    be_state be;
+    int ncell;
+    int has_pose, has_ogm;
+    float msg_origin[3];
+    float *d_sensor; size_t sensor_cap;   /* device copy of the last sensor frame */
+    float *d_pts_g; size_t pts_cap;       /* ray casting: points in the global frame */
+    float *d_box_ll, *d_box_ur; uint8_t *d_box_act; int box_cap;
+    int32_t *d_rank;
+    std::vector<void *> allocs;
+    int32_t h_cnt[GIE_CNT_NUM];
+    float us[4];
+};
+
+template <class T> static T *gie_dalloc(gie_mapper *m, size_t n, bool zero = true)
+{
+    void *p = be_alloc(&m->be, n * sizeof(T), zero);
+    if (p) m->allocs.push_back(p);
+    return (T *)p;
+}
+
+static int gie_pow2_ge(long long v) { int p = 1; while ((long long)p < v) p <<= 1; return p; }
+
+extern "C" gie_mapper *gie_create(const gie_config *cfg)
+{
+    if (!cfg || cfg->voxel_width <= 0.f || cfg->local_size[0] < 1 || cfg->local_size[1] < 1 || cfg->local_size[2] < 1) {
+        gie_set_err("gie_create: bad config"); return nullptr;
+    }
+    const int X = cfg->local_size[0], Y = cfg->local_size[1], Z = cfg->local_size[2];
+    const long long M = (long long)X * X + (long long)Y * Y + (long long)Z * Z;
+    const int L = X > Z ? X : Z;
+    if (X > 1024 || Y > 1024 || Z > 1024 || M + 1 + (long long)L * L >= (1ll << 22) || (long long)X * Y * Z > 0x7fffffffll) {
+        gie_set_err("gie_create: local volume too large (side <= 1024 and X²+Y²+Z²+max(X,Z)² < 2^22)"); return nullptr;
+    }
+    gie_mapper *m = new gie_mapper();
+    m->cfg = *cfg;
+    m->has_pose = m->has_ogm = 0;
+    m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
+    m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
+    memset(m->h_cnt, 0, sizeof(m->h_cnt)); memset(m->us, 0, sizeof(m->us));
+    if (be_init(&m->be, cfg->device_id) != 0) { delete m; return nullptr; }
+    gie_ctx &c = m->c;
+    memset(&c, 0, sizeof(c));
+    c.X = X; c.Y = Y; c.Z = Z; c.N = X * Y * Z;
+    c.voxel_width = cfg->voxel_width; c.occ_thresh = cfg->occupancy_threshold;
+    c.min_h = cfg->ogm_min_h; c.max_h = cfg->ogm_max_h; c.cutoff_sq = cfg->cutoff_grids_sq;
+    c.fast_mode = cfg->fast_mode; c.for_motion_planner = cfg->for_motion_planner; c.robot_r2 = cfg->robot_r2_grids;
+    c.max_width = X + Y + Z; c.max_loc_dist_sq = (int)M;
+    if (c.max_width < 1022) {   /* the reference's envelope: local_batch.h:51-58, voxmap_utils.cuh:8,161-165 */
+        c.wr[0] = 2046; c.wr[1] = 2046; c.wr[2] = 1022; c.empty_value = GIE_EMPTY_VALUE; c.invalid_dist_min = 900000;
+    } else {                    /* documented extension for larger volumes */
+        c.wr[0] = 16382; c.wr[1] = 16382; c.wr[2] = 8190; c.empty_value = 4194303; c.invalid_dist_min = 4000000;
+    }
+    c.L2G = gie_se3_from_quat(1, 0, 0, 0, 0, 0, 0); c.G2L = gie_se3_inv(c.L2G);
+    const size_t N = (size_t)c.N;
+    c.ray_count = gie_dalloc<int32_t>(m, N);
+    c.inst_type = gie_dalloc<int8_t>(m, N);
+    c.glb_type = gie_dalloc<int8_t>(m, N);
+    c.edt = gie_dalloc<float>(m, N);
+    c.cy1 = gie_dalloc<uint16_t>(m, N);
+    c.cxy2 = gie_dalloc<uint32_t>(m, N);
+    c.aux = gie_dalloc<int32_t>(m, N);
+    c.bcoc = gie_dalloc<uint32_t>(m, N);
+    c.pair = gie_dalloc<uint64_t>(m, N);      /* zero-initialised: SURVEY App. B #3 */
+    c.pair0 = gie_dalloc<uint64_t>(m, N);
+    c.wl = gie_dalloc<uint32_t>(m, N);
+    const int bdr = 2 * (X * Y + Y * Z + X * Z);
+    c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
+    for (int i = 0; i < 3; i++) c.tdim[i] = cfg->local_size[i] / 8 + 3;
+    m->ncell = c.tdim[0] * c.tdim[1] * c.tdim[2];
+    c.blk_tab = gie_dalloc<int32_t>(m, (size_t)m->ncell, false);
+    c.blk_need = gie_dalloc<uint8_t>(m, (size_t)m->ncell);
+    c.blk_new = gie_dalloc<int32_t>(m, (size_t)m->ncell);
+    m->d_rank = gie_dalloc<int32_t>(m, (size_t)m->ncell);
+    long long mb = cfg->max_blocks > 0 ? cfg->max_blocks : 3ll * m->ncell + 4096;
+    if (mb > 4000000) mb = 4000000;            /* slot*512 must stay below 2^31 */
+    c.max_blocks = (int)mb;
+    const int hcap = gie_pow2_ge(2 * mb);
+    c.hmask = (uint32_t)(hcap - 1);
+    c.hkeys = gie_dalloc<uint64_t>(m, (size_t)hcap, false);
+    c.hvals = gie_dalloc<int32_t>(m, (size_t)hcap, false);
+    c.pool_count = gie_dalloc<int32_t>(m, 1);
+    const size_t GV = (size_t)mb * GIE_VBSZ;
+    c.g_key = gie_dalloc<uint64_t>(m, (size_t)mb, false);
+    c.g_occ = gie_dalloc<uint8_t>(m, GV, false);
+    c.g_type = gie_dalloc<int8_t>(m, GV, false);
+    c.g_dist = gie_dalloc<int32_t>(m, GV, false);
+    c.g_coc = gie_dalloc<uint64_t>(m, GV, false);
+    c.g_pair = gie_dalloc<uint64_t>(m, GV, false);
+    c.g_prop = gie_dalloc<uint64_t>(m, GV, false);
+    c.g_wl = gie_dalloc<int32_t>(m, GV, false);
+    long long qab = 16ll * bdr; if (qab < 65536) qab = 65536; if (qab > (16 << 20)) qab = 16 << 20;
+    long long qc = (long long)c.N; if (qc < 4096) qc = 4096; if (qc > (16 << 20)) qc = 16 << 20;
+    c.qcap_ab = (int)qab; c.qcap_c = (int)qc;
+    for (int i = 0; i < 2; i++) {
+        c.qa[i] = gie_dalloc<uint64_t>(m, (size_t)qab, false);
+        c.qb[i] = gie_dalloc<uint64_t>(m, (size_t)qab, false);
+        c.qc[i] = gie_dalloc<int32_t>(m, (size_t)qc, false);
+    }
+    const size_t rec = (size_t)(qab > qc ? qab : qc);
+    c.rec0 = gie_dalloc<uint64_t>(m, rec, false);
+    c.rec1 = gie_dalloc<uint64_t>(m, rec, false);
+    c.rec2 = gie_dalloc<uint64_t>(m, rec, false);
+    c.rec3 = gie_dalloc<int32_t>(m, rec, false);
+    c.cnt = gie_dalloc<int32_t>(m, GIE_CNT_NUM);
+    bool ok = c.cnt != nullptr;
+    for (void *p : m->allocs) ok = ok && p != nullptr;
+    if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
+    be_memset(&m->be, c.hkeys, 0xff, (size_t)hcap * sizeof(uint64_t));
+    be_memset(&m->be, c.lprop, 0xff, (size_t)bdr * sizeof(uint64_t));
+    be_sync(&m->be);
+    return m;
+}
+
+extern "C" void gie_destroy(gie_mapper *m)
+{
+    if (!m) return;
+    be_sync(&m->be);
+    for (void *p : m->allocs) be_free(&m->be, p);
+    if (m->d_sensor) be_free(&m->be, m->d_sensor);
+    if (m->d_pts_g) be_free(&m->be, m->d_pts_g);
+    if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
+    be_fini(&m->be);
+    delete m;
+}
+
+extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
+{
+    if (!m || !pos || !q) { gie_set_err("gie_set_pose: null"); return GIE_ERR_INVALID; }
+    gie_ctx &c = m->c;
+    c.map_ct += 1;                                        /* _time++, volumetric_mapper.cpp:144 */
+    c.L2G = gie_se3_from_quat(q[0], q[1], q[2], q[3], pos[0], pos[1], pos[2]);
+    c.G2L = gie_se3_inv(c.L2G);
+    const int sz[3] = { c.X, c.Y, c.Z };
+    for (int i = 0; i < 3; i++) {
+        c.origin[i] = pos[i];
+        const int crd = gie_pos2coord(pos[i], c.voxel_width);
+        c.pvt[i] = crd - sz[i] / 2;                       /* calculate_pivot_origin, local_batch.h:128-142 */
+        m->msg_origin[i] = (float)c.pvt[i] * c.voxel_width;
+        c.upvt[i] = crd - c.wr[i] / 2;                    /* calculate_update_pivot, :159-166 */
+        c.tb0[i] = (c.pvt[i] - 1) >> 3;
+        if (crd > 900000 || crd < -900000) { gie_set_err("gie_set_pose: position outside the representable map"); return GIE_ERR_INVALID; }
+    }
+    const uint32_t f = (uint32_t)c.map_ct & 0x3ffffu;
+    if (f == 0) {                                         /* stamp wrap: clear the stamp planes once */
+        be_memset(&m->be, c.wl, 0, (size_t)c.N * sizeof(uint32_t));
+        be_memset(&m->be, c.g_wl, 0xff, (size_t)c.max_blocks * GIE_VBSZ * sizeof(int32_t));
+    }
+    c.stamp_base = (f + 1u) << 12;
+    /* per-frame counters (the sticky error flag survives) */
+    be_memset(&m->be, c.cnt, 0, GIE_CNT_ERR * sizeof(int32_t));
+    be_memset(&m->be, c.cnt + GIE_CNT_ERR + 1, 0, (GIE_CNT_NUM - GIE_CNT_ERR - 1) * sizeof(int32_t));
+    m->has_pose = 1;
+    return GIE_OK;
+}
+
+static int gie_need_pose(gie_mapper *m, const char *who)
+{
+    if (!m) { gie_set_err(std::string(who) + ": null handle"); return GIE_ERR_INVALID; }
+    if (!m->has_pose) { gie_set_err(std::string(who) + ": gie_set_pose has not been called"); return GIE_ERR_INVALID; }
+    return GIE_OK;
+}
+
+static int gie_stage_sensor(gie_mapper *m, const float *host, size_t n)
+{
+    if (n > m->sensor_cap) {
+        if (m->d_sensor) { be_sync(&m->be); be_free(&m->be, m->d_sensor); }
+        m->d_sensor = (float *)be_alloc(&m->be, n * sizeof(float), false);
+        m->sensor_cap = m->d_sensor ? n : 0;
+        if (!m->d_sensor) { gie_set_err("sensor buffer allocation failed"); return GIE_ERR_DEVICE; }
+    }
+    be_h2d(&m->be, m->d_sensor, host, n * sizeof(float));
+    return GIE_OK;
+}
+
+/* ---- OGM */
+extern "C" int gie_ogm_depth_dev(gie_mapper *m, const float *d_depth, const gie_cam_param *p)
+{
+    int rc = gie_need_pose(m, "gie_ogm_depth"); if (rc) return rc;
+    if (!d_depth || !p || p->rows < 1 || p->cols < 1) { gie_set_err("gie_ogm_depth: bad arguments"); return GIE_ERR_INVALID; }
+    m->c.pntcld_mode = 0;
+    be_time(&m->be, 0);
+    op_classify_depth op; op.img = d_depth; op.p = *p;
+    be_vox(&m->be, m->c, op);
+    be_time(&m->be, 1);
+    m->has_ogm = 1;
+    return GIE_OK;
+}
+extern "C" int gie_ogm_depth(gie_mapper *m, const float *depth, const gie_cam_param *p)
+{
+    int rc = gie_need_pose(m, "gie_ogm_depth"); if (rc) return rc;
+    if (!depth || !p || p->rows < 1 || p->cols < 1) { gie_set_err("gie_ogm_depth: bad arguments"); return GIE_ERR_INVALID; }
+    rc = gie_stage_sensor(m, depth, (size_t)p->rows * p->cols); if (rc) return rc;
+    return gie_ogm_depth_dev(m, m->d_sensor, p);
+}
+extern "C" int gie_ogm_multiscan_dev(gie_mapper *m, const float *d_ranges, const gie_multiscan_param *p)
+{
+    int rc = gie_need_pose(m, "gie_ogm_multiscan"); if (rc) return rc;
+    if (!d_ranges || !p || p->scan_num < 1 || p->ring_num < 1) { gie_set_err("gie_ogm_multiscan: bad arguments"); return GIE_ERR_INVALID; }
+    m->c.pntcld_mode = 0;
+    be_time(&m->be, 0);
+    op_classify_multiscan op; op.img = d_ranges; op.p = *p;
+    be_vox(&m->be, m->c, op);
+    be_time(&m->be, 1);
+    m->has_ogm = 1;
+    return GIE_OK;
+}
+extern "C" int gie_ogm_multiscan(gie_mapper *m, const float *ranges, const gie_multiscan_param *p)
+{
+    int rc = gie_need_pose(m, "gie_ogm_multiscan"); if (rc) return rc;
+    if (!ranges || !p || p->scan_num < 1 || p->ring_num < 1) { gie_set_err("gie_ogm_multiscan: bad arguments"); return GIE_ERR_INVALID; }
+    rc = gie_stage_sensor(m, ranges, (size_t)p->scan_num * p->ring_num); if (rc) return rc;
+    return gie_ogm_multiscan_dev(m, m->d_sensor, p);
+}
+extern "C" int gie_ogm_scan2d(gie_mapper *m, const float *ranges, const gie_scan_param *p)
+{
+    int rc = gie_need_pose(m, "gie_ogm_scan2d"); if (rc) return rc;
+    if (!ranges || !p || p->scan_num < 1) { gie_set_err("gie_ogm_scan2d: bad arguments"); return GIE_ERR_INVALID; }
+    rc = gie_stage_sensor(m, ranges, (size_t)p->scan_num); if (rc) return rc;
+    m->c.pntcld_mode = 0;
+    be_time(&m->be, 0);
+    op_classify_scan2d op; op.img = m->d_sensor; op.p = *p;
+    be_vox(&m->be, m->c, op);
+    be_time(&m->be, 1);
+    m->has_ogm = 1;
+    return GIE_OK;
+}
+extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
+{
+    int rc = gie_need_pose(m, "gie_ogm_pointcloud"); if (rc) return rc;
+    if (n < 0 || (n > 0 && !d_xyz)) { gie_set_err("gie_ogm_pointcloud: bad arguments"); return GIE_ERR_INVALID; }
+    if ((size_t)n * 3 > m->pts_cap) {
+        if (m->d_pts_g) { be_sync(&m->be); be_free(&m->be, m->d_pts_g); }
+        m->d_pts_g = (float *)be_alloc(&m->be, (size_t)n * 3 * sizeof(float), false);
+        m->pts_cap = m->d_pts_g ? (size_t)n * 3 : 0;
+        if (!m->d_pts_g) { gie_set_err("point buffer allocation failed"); return GIE_ERR_DEVICE; }
+    }
+    m->c.pntcld_mode = 1;
+    be_time(&m->be, 0);
+    if (n > 0) {
+        op_register_point r; r.xyz = d_xyz; r.g = m->d_pts_g;
+        be_lin(&m->be, m->c, r, n);                        /* registerLocObs */
+        op_free_ray fr; fr.g = m->d_pts_g;
+        be_lin(&m->be, m->c, fr, n);                       /* freeLocObs */
+    }
+    be_vox(&m->be, m->c, op_raycast_finalize());           /* getAllocKeys */
+    be_time(&m->be, 1);
+    m->has_ogm = 1;
+    return GIE_OK;
+}
+extern "C" int gie_ogm_pointcloud(gie_mapper *m, const float *xyz, int n)
+{
+    int rc = gie_need_pose(m, "gie_ogm_pointcloud"); if (rc) return rc;
+    if (n < 0 || (n > 0 && !xyz)) { gie_set_err("gie_ogm_pointcloud: bad arguments"); return GIE_ERR_INVALID; }
+    if (n > 0) { rc = gie_stage_sensor(m, xyz, (size_t)n * 3); if (rc) return rc; }
+    return gie_ogm_pointcloud_dev(m, m->d_sensor, n);
+}
+
+extern "C" int gie_set_ext_boxes(gie_mapper *m, const float *ll, const float *ur, const uint8_t *act, int n)
+{
+    if (!m || n < 0 || (n > 0 && (!ll || !ur || !act))) { gie_set_err("gie_set_ext_boxes: bad arguments"); return GIE_ERR_INVALID; }
+    if (n > m->box_cap) {
+        be_sync(&m->be);
+        if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
+        m->d_box_ll = (float *)be_alloc(&m->be, (size_t)n * 3 * sizeof(float), false);
+        m->d_box_ur = (float *)be_alloc(&m->be, (size_t)n * 3 * sizeof(float), false);
+        m->d_box_act = (uint8_t *)be_alloc(&m->be, (size_t)n, false);
+        m->box_cap = n;
+    }
+    if (n > 0) {
+        be_h2d(&m->be, m->d_box_ll, ll, (size_t)n * 3 * sizeof(float));
+        be_h2d(&m->be, m->d_box_ur, ur, (size_t)n * 3 * sizeof(float));
+        be_h2d(&m->be, m->d_box_act, act, (size_t)n);
+    }
+    m->c.nbox = n; m->c.box_ll = m->d_box_ll; m->c.box_ur = m->d_box_ur; m->c.box_act = m->d_box_act;
+    return GIE_OK;
+}
+
+/* ---- stages */
+extern "C" int gie_fuse(gie_mapper *m)
+{
+    int rc = gie_need_pose(m, "gie_fuse"); if (rc) return rc;
+    be_time(&m->be, 2);
+    /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
+     * scan, insert + initialise, then resolve the frame's block table */
+    be_lin(&m->be, m->c, op_cell_flag(), m->ncell);
+    be_exclusive_scan(&m->be, m->c.blk_new, m->d_rank, m->ncell);
+    op_cell_insert ins; ins.flag = m->c.blk_new; ins.rank = m->d_rank;
+    be_lin(&m->be, m->c, ins, m->ncell);
+    be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
+    be_lin(&m->be, m->c, op_cell_table(), m->ncell);
+    be_vox(&m->be, m->c, op_fuse());
+    be_time(&m->be, 3);
+    return GIE_OK;
+}
+
+extern "C" int gie_batch_edt(gie_mapper *m)
+{
+    int rc = gie_need_pose(m, "gie_batch_edt"); if (rc) return rc;
+    be_time(&m->be, 4);
+    be_edt(&m->be, m->c);
+    be_time(&m->be, 5);
+    return GIE_OK;
+}
+
+extern "C" int gie_merge(gie_mapper *m)
+{
+    int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
+    be_time(&m->be, 6);
+    be_vox(&m->be, m->c, op_mark());
+    be_vox(&m->be, m->c, op_frontier());
+    if (!m->c.fast_mode) { be_wave_a(&m->be, m->c); be_wave_b(&m->be, m->c); }
+    be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0);
+    be_vox(&m->be, m->c, op_commit());
+    be_time(&m->be, 7);
+    return GIE_OK;
+}
+
+extern "C" int gie_step(gie_mapper *m)
+{
+    int rc = gie_fuse(m); if (rc) return rc;
+    rc = gie_batch_edt(m); if (rc) return rc;
+    return gie_merge(m);
+}
+
+static int gie_fetch_counters(gie_mapper *m)
+{
+    be_d2h(&m->be, m->h_cnt, m->c.cnt, sizeof(m->h_cnt));
+    const int e = m->h_cnt[GIE_CNT_ERR];
+    if (e) {
+        std::string s = "device capacity exceeded:";
+        if (e & GIE_ERRF_POOL) s += " block pool (raise gie_config.max_blocks)";
+        if (e & GIE_ERRF_QUEUE) s += " frontier queue";
+        if (e & GIE_ERRF_HASH) s += " hash table";
+        gie_set_err(s);
+        return GIE_ERR_CAPACITY;
+    }
+    return GIE_OK;
+}
+
+extern "C" int gie_sync(gie_mapper *m)
+{
+    if (!m) { gie_set_err("gie_sync: null handle"); return GIE_ERR_INVALID; }
+    if (be_sync(&m->be) != 0) return GIE_ERR_DEVICE;
+    return gie_fetch_counters(m);
+}
+
+/* ---- readers */
+extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *dist_sq, int32_t *coc_xyz)
+{
+    if (!m) { gie_set_err("gie_read_local: null handle"); return GIE_ERR_INVALID; }
+    const size_t N = (size_t)m->c.N;
+    if (edt) be_d2h(&m->be, edt, m->c.edt, N * sizeof(float));
+    if (type) be_d2h(&m->be, type, m->c.glb_type, N);
+    if (dist_sq || coc_xyz) {
+        int32_t *dd = dist_sq ? (int32_t *)be_alloc(&m->be, N * 4, false) : nullptr;
+        int32_t *dc = coc_xyz ? (int32_t *)be_alloc(&m->be, N * 12, false) : nullptr;
+        op_export_pair op; op.d = dd; op.coc = dc;
+        be_lin(&m->be, m->c, op, m->c.N);
+        if (dd) { be_d2h(&m->be, dist_sq, dd, N * 4); be_free(&m->be, dd); }
+        if (dc) { be_d2h(&m->be, coc_xyz, dc, N * 12); be_free(&m->be, dc); }
+    }
+    return gie_sync(m);
+}
+extern "C" int gie_read_ogm(gie_mapper *m, int8_t *inst_type, int32_t *ray_count)
+{
+    if (!m) { gie_set_err("gie_read_ogm: null handle"); return GIE_ERR_INVALID; }
+    if (inst_type) be_d2h(&m->be, inst_type, m->c.inst_type, (size_t)m->c.N);
+    if (ray_count) be_d2h(&m->be, ray_count, m->c.ray_count, (size_t)m->c.N * 4);
+    return gie_sync(m);
+}
+extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
+{
+    if (!m) { gie_set_err("gie_read_batch_edt: null handle"); return GIE_ERR_INVALID; }
+    const size_t N = (size_t)m->c.N;
+    if (dist_sq) be_d2h(&m->be, dist_sq, m->c.aux, N * 4);
+    if (coc) {
+        int32_t *dc = (int32_t *)be_alloc(&m->be, N * 12, false);
+        op_export_bcoc op; op.coc = dc;
+        be_lin(&m->be, m->c, op, m->c.N);
+        be_d2h(&m->be, coc, dc, N * 12); be_free(&m->be, dc);
+    }
+    return gie_sync(m);
+}
+extern "C" int gie_read_costmap(gie_mapper *m, gie_seendist *payload, gie_costmap_hdr *hdr)
+{
+    if (!m) { gie_set_err("gie_read_costmap: null handle"); return GIE_ERR_INVALID; }
+    if (payload) {
+        const size_t N = (size_t)m->c.N;
+        gie_seendist *d = (gie_seendist *)be_alloc(&m->be, N * sizeof(gie_seendist), false);
+        op_costmap op; op.out = d;
+        be_lin(&m->be, m->c, op, m->c.N);
+        be_d2h(&m->be, payload, d, N * sizeof(gie_seendist)); be_free(&m->be, d);
+    }
+    if (hdr) {
+        hdr->x_size = m->c.X; hdr->y_size = m->c.Y; hdr->z_size = m->c.Z;
+        hdr->x_origin = m->msg_origin[0]; hdr->y_origin = m->msg_origin[1]; hdr->z_origin = m->msg_origin[2];
+        hdr->width = m->c.voxel_width; hdr->type = 1; hdr->pad[0] = hdr->pad[1] = hdr->pad[2] = 0;
+    }
+    return gie_sync(m);
+}
+extern "C" int gie_query_global(gie_mapper *m, const int32_t *xyz, int n, gie_voxel *out)
+{
+    if (!m || n < 0 || (n > 0 && (!xyz || !out))) { gie_set_err("gie_query_global: bad arguments"); return GIE_ERR_INVALID; }
+    if (n == 0) return GIE_OK;
+    int32_t *dx = (int32_t *)be_alloc(&m->be, (size_t)n * 12, false);
+    gie_voxel *dv = (gie_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_voxel), false);
+    be_h2d(&m->be, dx, xyz, (size_t)n * 12);
+    op_query op; op.xyz = dx; op.out = dv;
+    be_lin(&m->be, m->c, op, n);
+    be_d2h(&m->be, out, dv, (size_t)n * sizeof(gie_voxel));
+    be_free(&m->be, dx); be_free(&m->be, dv);
+    return gie_sync(m);
+}
+extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
+{
+    if (!m || !s) { gie_set_err("gie_get_stats: bad arguments"); return GIE_ERR_INVALID; }
+    int rc = gie_sync(m);
+    int32_t pc = 0;
+    be_d2h(&m->be, &pc, m->c.pool_count, 4);
+    const int32_t *h = m->h_cnt;
+    memset(s, 0, sizeof(*s));
+    s->frame = m->c.map_ct; s->blocks_total = pc; s->blocks_new = h[GIE_CNT_NEWBLK];
+    s->seeds_a = h[GIE_CNT_SEED_A]; s->seeds_b = h[GIE_CNT_SEED_B]; s->seeds_c = h[GIE_CNT_SEED_C];
+    s->front_b = h[GIE_CNT_FRONT_B]; s->front_c = h[GIE_CNT_FRONT_C];
+    s->visits_a = h[GIE_CNT_VIS_A]; s->visits_b = h[GIE_CNT_VIS_B]; s->visits_c = h[GIE_CNT_VIS_C];
+    s->levels_a = h[GIE_CNT_LVL_A]; s->levels_b = h[GIE_CNT_LVL_B]; s->levels_c = h[GIE_CNT_LVL_C];
+    be_times(&m->be, &s->us_ogm, &s->us_fuse, &s->us_edt, &s->us_merge);
+    return rc;
+}
+extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])
+{
+    if (!m || !pvt) { gie_set_err("gie_get_pivot: bad arguments"); return GIE_ERR_INVALID; }
+    pvt[0] = m->c.pvt[0]; pvt[1] = m->c.pvt[1]; pvt[2] = m->c.pvt[2];
+    return GIE_OK;
+}

@@ -1,0 +1,81 @@
+/*
+ * gie_functors.h — the per-voxel / per-item operations as functors, shared by the HIP kernels
+ * (k_vox / k_lin in gie_kernels.hip.h) and by the test-only sequential emulation (tests/emu).
+ */
+#ifndef GIE_FUNCTORS_H
+#define GIE_FUNCTORS_H
+
+#include "gie_ops.h"
+
+#if defined(GIE_HOST_EMU)
+#define GIE_DEVM inline
+#else
+#define GIE_DEVM __device__ __forceinline__
+#endif
+
+struct op_classify_depth { const float *img; gie_cam_param p;
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
+        const int t = gie_classify_depth(c, img, p, x, y, z);
+        if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
+struct op_classify_multiscan { const float *img; gie_multiscan_param p;
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
+        const int t = gie_classify_multiscan(c, img, p, x, y, z);
+        if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
+struct op_classify_scan2d { const float *img; gie_scan_param p;
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
+        const int t = gie_classify_scan2d(c, img, p, x, y, z);
+        if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
+struct op_raycast_finalize { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_raycast_finalize(c, x, y, z); } };
+struct op_fuse { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_fuse_voxel(c, x, y, z); } };
+struct op_mark { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_mark_voxel(c, x, y, z); } };
+struct op_commit { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_commit_voxel(c, x, y, z); } };
+
+/* obtainFrontiers with wave64 ballot compaction of the C seeds: one atomicAdd per wave */
+struct op_frontier {
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
+        const int push = gie_frontier_voxel(c, x, y, z);
+#if defined(GIE_HOST_EMU)
+        if (push) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, gie_lid(c, x, y, z));
+#else
+        const unsigned long long m = __ballot(push);
+        if (m) {
+            const int lane = __lane_id();
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&c.cnt[GIE_CNT_C], __popcll(m));
+            base = __shfl(base, leader);
+            if (push) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < c.qcap_c) c.qc[0][slot] = gie_lid(c, x, y, z);
+                else atomicOr(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+            }
+        }
+#endif
+    }
+};
+
+struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
+struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
+struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
+struct op_export_pair { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_pair(c, i, d, coc); } };
+struct op_export_bcoc { int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_bcoc(c, i, coc); } };
+struct op_costmap { gie_seendist *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const {
+        gie_seendist s; s.d = c.edt[i]; s.s = 0; s.o = (uint8_t)c.glb_type[i]; s.pad[0] = s.pad[1] = 0; out[i] = s; } };
+
+/* block allocation (allocHashTB, glb_hash_map.cu:58-113) */
+struct op_cell_flag { GIE_DEVM void operator()(const gie_ctx &c, int i) const { c.blk_new[i] = gie_cell_needs_new(c, i); } };
+struct op_cell_insert { const int32_t *flag; const int32_t *rank;
+    GIE_DEVM void operator()(const gie_ctx &c, int i) const {
+        if (!flag[i]) return;
+        const int slot = *c.pool_count + rank[i];
+        if (slot >= c.max_blocks) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_POOL); return; }
+        gie_cell_insert(c, i, slot);
+    } };
+struct op_cell_table { GIE_DEVM void operator()(const gie_ctx &c, int i) const {
+        const int bx = i % c.tdim[0], by = (i / c.tdim[0]) % c.tdim[1], bz = i / (c.tdim[0] * c.tdim[1]);
+        c.blk_tab[i] = gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]);
+        c.blk_need[i] = 0;
+    } };
+
+
+#endif /* GIE_FUNCTORS_H */

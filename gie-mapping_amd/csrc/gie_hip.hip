@@ -1,0 +1,153 @@
+/*
+ * gie_hip.hip — libgie_hip.so: the MI355X (gfx950) implementation of include/gie.h.
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC gie_hip.hip -o libgie_hip.so
+ * One HIP stream per mapper; a frame is a fixed sequence of kernel launches with no host
+ * synchronisation inside (the reference syncs ≥12 times per frame through thrust scalars,
+ * SURVEY.md §2.3).
+ */
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "gie_kernels.hip.h"
+
+#define GIE_NEV 8
+
+struct be_state {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[GIE_NEV];
+    int ev_set[GIE_NEV];
+    void *scan_tmp; size_t scan_bytes;
+};
+
+static void gie_set_err(const std::string &s);
+#include <string>
+
+#define GIE_HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { gie_set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+
+static int be_init(be_state *b, int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { gie_set_err("no HIP device visible (libgie_hip.so needs an AMD GPU; there is no CPU fallback)"); return 1; }
+    if (device < 0 || device >= n) { gie_set_err("bad device_id"); return 1; }
+    b->device = device;
+    if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
+    for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
+    b->scan_tmp = nullptr; b->scan_bytes = 0;
+    return 0;
+}
+static void be_fini(be_state *b)
+{
+    if (b->scan_tmp) (void)hipFree(b->scan_tmp);
+    for (int i = 0; i < GIE_NEV; i++) (void)hipEventDestroy(b->ev[i]);
+    (void)hipStreamDestroy(b->stream);
+}
+static void *be_alloc(be_state *b, size_t bytes, bool zero)
+{
+    void *p = nullptr;
+    (void)hipSetDevice(b->device);
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    if (zero) GIE_HIP_OK(hipMemsetAsync(p, 0, bytes, b->stream));
+    return p;
+}
+static void be_free(be_state *b, void *p) { (void)hipStreamSynchronize(b->stream); (void)hipFree(p); }
+static void be_memset(be_state *b, void *p, int v, size_t bytes) { GIE_HIP_OK(hipMemsetAsync(p, v, bytes, b->stream)); }
+static void be_h2d(be_state *b, void *d, const void *h, size_t bytes)
+{   /* blocking like the reference's GPU_MEMCPY_H2D (cuda_macro.h:33): the caller may reuse h */
+    GIE_HIP_OK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, b->stream));
+    GIE_HIP_OK(hipStreamSynchronize(b->stream));
+}
+static void be_d2h(be_state *b, void *h, const void *d, size_t bytes)
+{
+    GIE_HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, b->stream));
+    GIE_HIP_OK(hipStreamSynchronize(b->stream));
+}
+static int be_sync(be_state *b)
+{
+    hipError_t e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) { gie_set_err(std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); return 1; }
+    e = hipGetLastError();
+    if (e != hipSuccess) { gie_set_err(std::string("HIP error: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+}
+static void be_time(be_state *b, int i) { GIE_HIP_OK(hipEventRecord(b->ev[i], b->stream)); b->ev_set[i] = 1; }
+static void be_times(be_state *b, float *ogm, float *fuse, float *edt, float *merge)
+{
+    float *out[4] = { ogm, fuse, edt, merge };
+    for (int k = 0; k < 4; k++) {
+        float ms = 0.f;
+        if (b->ev_set[2 * k] && b->ev_set[2 * k + 1] && hipEventElapsedTime(&ms, b->ev[2 * k], b->ev[2 * k + 1]) == hipSuccess) *out[k] = ms * 1000.f;
+        else *out[k] = 0.f;
+    }
+}
+
+template <class F> static void be_vox(be_state *b, const gie_ctx &c, const F &f)
+{
+    dim3 blk(GIE_VOX_BX, GIE_VOX_BY, 1);
+    dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, c.Z);
+    hipLaunchKernelGGL(k_vox<F>, grd, blk, 0, b->stream, c, f);
+}
+template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f, int n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, b->stream, c, f, n);
+}
+static void be_exclusive_scan(be_state *b, const int32_t *flag, int32_t *rank, int n)
+{
+    size_t bytes = 0;
+    GIE_HIP_OK(rocprim::exclusive_scan(nullptr, bytes, flag, rank, 0, (size_t)n, rocprim::plus<int32_t>(), b->stream));
+    if (bytes > b->scan_bytes) {
+        if (b->scan_tmp) { (void)hipStreamSynchronize(b->stream); (void)hipFree(b->scan_tmp); }
+        GIE_HIP_OK(hipMalloc(&b->scan_tmp, bytes)); b->scan_bytes = bytes;
+    }
+    GIE_HIP_OK(rocprim::exclusive_scan(b->scan_tmp, bytes, flag, rank, 0, (size_t)n, rocprim::plus<int32_t>(), b->stream));
+}
+static void be_block_init(be_state *b, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell)
+{
+    hipLaunchKernelGGL(k_block_init, dim3(ncell), dim3(256), 0, b->stream, c, flag, rank);
+    hipLaunchKernelGGL(k_pool_advance, dim3(1), dim3(1), 0, b->stream, c, flag, rank, ncell);
+}
+
+template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass)
+{
+    constexpr int LP = 64 * CP;
+    if (!zpass) {
+        const int rows = c.Y * c.Z;
+        hipLaunchKernelGGL(k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, b->stream, c);
+    } else {
+        const size_t tile = ((size_t)c.Z * GIE_EDTZ_TS + 3) & ~(size_t)3;
+        const size_t lds = (2 * tile + (size_t)GIE_EDTZ_WAVES * LP) * 4 + (size_t)GIE_EDTZ_WAVES * (LP + 2) * 2;
+        static bool attr_done[17] = { false };
+        if (!attr_done[CP]) {
+            GIE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_z<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done[CP] = true;
+        }
+        hipLaunchKernelGGL(k_edt_z<CP>, dim3((c.X + GIE_EDTZ_TX - 1) / GIE_EDTZ_TX, c.Y), dim3(64 * GIE_EDTZ_WAVES), lds, b->stream, c);
+    }
+}
+static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass)
+{
+    if (L <= 64) gie_launch_edt_xz<1>(b, c, zpass);
+    else if (L <= 128) gie_launch_edt_xz<2>(b, c, zpass);
+    else if (L <= 256) gie_launch_edt_xz<4>(b, c, zpass);
+    else if (L <= 512) gie_launch_edt_xz<8>(b, c, zpass);
+    else gie_launch_edt_xz<16>(b, c, zpass);
+}
+/* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
+static void be_edt(be_state *b, const gie_ctx &c)
+{
+    dim3 gy((c.X + 255) / 256, c.Z);
+    if (c.Y <= 256) hipLaunchKernelGGL(k_edt_y<8>, gy, dim3(256), 0, b->stream, c);
+    else if (c.Y <= 512) hipLaunchKernelGGL(k_edt_y<16>, gy, dim3(256), 0, b->stream, c);
+    else hipLaunchKernelGGL(k_edt_y<32>, gy, dim3(256), 0, b->stream, c);
+    gie_launch_edt_dim(b, c, c.X, false);
+    gie_launch_edt_dim(b, c, c.Z, true);
+}
+static void be_wave_a(be_state *b, const gie_ctx &c) { hipLaunchKernelGGL(k_wave_a, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c); }
+static void be_wave_b(be_state *b, const gie_ctx &c) { hipLaunchKernelGGL(k_wave_b, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c); }
+static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds) { hipLaunchKernelGGL(k_wave_c, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c, record_seeds); }
+
+#include "gie_api.inc.h"

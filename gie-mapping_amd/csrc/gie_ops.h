@@ -1,0 +1,689 @@
+/*
+ * gie_ops.h — per-voxel and per-frontier-entry logic of the map update, written once and used
+ * by the HIP kernels (gie_kernels.hip.h).  Each function cites the reference code it replaces.
+ * Order-free by construction: conflicting writers go through 64-bit atomicMin / CAS, frontier
+ * entries read a level-start snapshot (DESIGN.md "Canonical wave schedule").
+ */
+#ifndef GIE_OPS_H
+#define GIE_OPS_H
+
+#include "gie_types.h"
+
+/* ------------------------------------------------------------------ memory primitives */
+#if defined(GIE_HOST_EMU)
+/* test-only sequential emulation (tests/emu): plain memory */
+template <class T> static inline T gie_ld(const T *p) { return *p; }
+template <class T> static inline void gie_st(T *p, T v) { *p = v; }
+static inline uint64_t gie_amin64(uint64_t *p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
+static inline uint64_t gie_acas64(uint64_t *p, uint64_t c, uint64_t v) { uint64_t o = *p; if (o == c) *p = v; return o; }
+static inline uint64_t gie_aand64(uint64_t *p, uint64_t v) { uint64_t o = *p; *p = o & v; return o; }
+static inline uint32_t gie_axchg32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
+static inline int32_t gie_axchg32(int32_t *p, int32_t v) { int32_t o = *p; *p = v; return o; }
+static inline int32_t gie_aadd32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+static inline int32_t gie_aor32(int32_t *p, int32_t v) { int32_t o = *p; *p = o | v; return o; }
+#define GIE_DEV static inline
+#else
+/* agent-scope relaxed accesses: served by L2, never by a stale per-CU L1 line */
+template <class T> __device__ __forceinline__ T gie_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void gie_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t gie_amin64(uint64_t *p, uint64_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t gie_acas64(uint64_t *p, uint64_t c, uint64_t v) { __hip_atomic_compare_exchange_strong(p, &c, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return c; }
+__device__ __forceinline__ uint64_t gie_aand64(uint64_t *p, uint64_t v) { return __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t gie_axchg32(uint32_t *p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t gie_axchg32(int32_t *p, int32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t gie_aadd32(int32_t *p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t gie_aor32(int32_t *p, int32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define GIE_DEV __device__ __forceinline__
+#endif
+
+/* append to a frontier queue; overflow raises the sticky error flag */
+GIE_DEV void gie_push64(const gie_ctx &c, uint64_t *q, int32_t *counter, int cap, uint64_t v)
+{
+    const int i = gie_aadd32(counter, 1);
+    if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+}
+GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap, int32_t v)
+{
+    const int i = gie_aadd32(counter, 1);
+    if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+}
+
+/* global voxel address: block slot through the frame's block table (volume +-1 voxel) */
+GIE_DEV int gie_gvox_tab(const gie_ctx &c, int gx, int gy, int gz)
+{
+    const int s = c.blk_tab[gie_tab_index(c, gx, gy, gz)];
+    return s < 0 ? -1 : s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+}
+/* … or through the hash (anywhere) */
+GIE_DEV int gie_gvox_hash(const gie_ctx &c, int gx, int gy, int gz)
+{
+    const int s = gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3);
+    return s < 0 ? -1 : s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+}
+
+/* ================================================================== OGM: projective */
+GIE_DEV int gie_robot_sphere(const gie_ctx &c, int x, int y, int z)
+{   /* pntcld_raycast.cu:33-41, vlp16_fast.cu:30-40: |crd - _half_shift|² <= rbt_r2_grids */
+    if (!c.for_motion_planner) return 0;
+    const int cx = x - c.X / 2, cy = y - c.Y / 2, cz = z - c.Z / 2;
+    return cx * cx + cy * cy + cz * cz <= c.robot_r2;
+}
+GIE_DEV int gie_pos_mod(int i, int n) { return (i % n + n) % n; }
+
+/* REALSENSE_FAST::setLocalOccupancy (realsense_fast.cu:9-94) + CAM_HELPER::G2L
+ * (camera_helper.h:11-23).  Returns the scan label of local voxel (x,y,z). */
+GIE_DEV int gie_classify_depth(const gie_ctx &c, const float *depth, const gie_cam_param &p, int x, int y, int z)
+{
+    if (gie_robot_sphere(c, x, y, z)) return GIE_VOX_FREE;
+    const float w = c.voxel_width;
+    const float gx = (float)(x + c.pvt[0]) * w, gy = (float)(y + c.pvt[1]) * w, gz = (float)(z + c.pvt[2]) * w;
+    float lx, ly, lz;
+    gie_se3_apply(c.G2L, gx, gy, gz, &lx, &ly, &lz);
+    const float ideal = lx;
+    if (ideal <= 0.3f || ideal > 6.0f) return GIE_VOX_UNKNOWN;
+    const float fpx = floorf(-ly * p.fx / ideal + p.cx + 0.5f);
+    const float fpy = floorf(-lz * p.fy / ideal + p.cy + 0.5f);
+    if (!(fpx >= 0.0f && fpx < (float)p.cols && fpy >= 0.0f && fpy < (float)p.rows)) return GIE_VOX_UNKNOWN;
+    float real = depth[p.cols * (int)fpy + (int)fpx];
+    if (real <= 0.21f) return GIE_VOX_UNKNOWN;
+    if (real != real) { if (p.valid_nan) real = 1000.f; else return GIE_VOX_UNKNOWN; }
+    if (ideal < real - w) return GIE_VOX_FREE;
+    if (ideal > real + w) return GIE_VOX_UNKNOWN;
+    if (gz >= c.min_h && gz <= c.max_h) return GIE_VOX_OCCUPIED;
+    return GIE_VOX_UNKNOWN;
+}
+
+/* VLP_FAST::setLocalOccupancy (vlp16_fast.cu:8-87) + VLP_HELPER::G2L (vlp16_helper.h:35-65) */
+GIE_DEV int gie_classify_multiscan(const gie_ctx &c, const float *ranges, const gie_multiscan_param &p, int x, int y, int z)
+{
+    if (gie_robot_sphere(c, x, y, z)) return GIE_VOX_FREE;
+    const float w = c.voxel_width;
+    const float gx = (float)(x + c.pvt[0]) * w, gy = (float)(y + c.pvt[1]) * w, gz = (float)(z + c.pvt[2]) * w;
+    float lx, ly, lz;
+    gie_se3_apply(c.G2L, gx, gy, gz, &lx, &ly, &lz);
+    const float theta = gie_atan2f(ly, lx);
+    int theta_idx = (int)floorf((theta - p.theta_min) / p.theta_inc + 0.5f);
+    theta_idx = gie_pos_mod(theta_idx, p.scan_num);
+    const float range_hor = sqrtf(ly * ly + lx * lx);
+    const float phi = gie_atan2f(lz, range_hor);
+    const int phi_idx = (int)floorf((phi - p.phi_min) / p.phi_inc + 0.5f);
+    if (phi_idx < 0 || phi_idx >= p.ring_num) return GIE_VOX_UNKNOWN;
+    const float ideal = sqrtf(lx * lx + ly * ly);
+    if (ideal < 0 || theta_idx < 0 || theta_idx >= p.scan_num) return GIE_VOX_UNKNOWN;
+    const float real = ranges[phi_idx * p.scan_num + theta_idx];
+    if (real != real || real <= 0.3f) return GIE_VOX_UNKNOWN;
+    if (ideal < real - 0.1f) return (ideal < real - 0.3f) ? GIE_VOX_FREE : GIE_VOX_UNKNOWN;
+    if ((double)ideal > (double)real + 0.1) return GIE_VOX_UNKNOWN;
+    if (gz >= c.min_h && gz <= c.max_h) return GIE_VOX_OCCUPIED;
+    return GIE_VOX_UNKNOWN;
+}
+
+/* HOKUYO_FAST::setLocalOccupancy (hokuyo_fast.cu:9-81) + SCAN_HELPER::G2L (hokuyo_helper.h:17-33) */
+GIE_DEV int gie_classify_scan2d(const gie_ctx &c, const float *ranges, const gie_scan_param &p, int x, int y, int z)
+{
+    if (gie_robot_sphere(c, x, y, z)) return GIE_VOX_FREE;
+    const float w = c.voxel_width;
+    const float gx = (float)(x + c.pvt[0]) * w, gy = (float)(y + c.pvt[1]) * w, gz = (float)(z + c.pvt[2]) * w;
+    float lx, ly, lz;
+    gie_se3_apply(c.G2L, gx, gy, gz, &lx, &ly, &lz);
+    const float theta = gie_atan2f(ly, lx);
+    int theta_idx = (int)floorf((theta - p.theta_min) / p.theta_inc + 0.5f);
+    theta_idx = gie_pos_mod(theta_idx, p.scan_num);
+    if (!(fabsf(lz) < w)) return GIE_VOX_UNKNOWN;
+    const float ideal = sqrtf(lx * lx + ly * ly);
+    const float real = ranges[theta_idx];
+    if (real != real || real <= 0.3f) return GIE_VOX_UNKNOWN;
+    if (ideal < real - 0.3f) return GIE_VOX_FREE;
+    if ((double)ideal > (double)real + 0.3) return GIE_VOX_UNKNOWN;
+    if (gz >= c.min_h && gz <= c.max_h) return GIE_VOX_OCCUPIED;
+    return GIE_VOX_UNKNOWN;
+}
+
+/* the block of an observed voxel needs to exist (the reference's per-voxel VB_keys_loc_D entry) */
+GIE_DEV void gie_mark_block_needed(const gie_ctx &c, int x, int y, int z)
+{
+    c.blk_need[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])] = 1;
+}
+
+/* ================================================================== OGM: ray casting */
+/* registerLocObs, pntcld_raycast.cu:83-102.  g_out receives the global-frame point. */
+GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out, int i)
+{
+    float gx, gy, gz;
+    gie_se3_apply(c.L2G, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &gx, &gy, &gz);
+    g_out[3 * i] = gx; g_out[3 * i + 1] = gy; g_out[3 * i + 2] = gz;
+    if (gz >= c.min_h && gz <= c.max_h) {
+        const int lx = gie_pos2coord(gx, c.voxel_width) - c.pvt[0];
+        const int ly = gie_pos2coord(gy, c.voxel_width) - c.pvt[1];
+        const int lz = gie_pos2coord(gz, c.voxel_width) - c.pvt[2];
+        if (gie_in_loc(c, lx, ly, lz)) {
+            const int id = gie_lid(c, lx, ly, lz);
+            c.inst_type[id] = GIE_VOX_OCCUPIED;      /* all writers store the same value */
+            gie_aadd32(&c.ray_count[id], 1);
+        }
+    }
+}
+
+/* clearRayLoc, pntcld_raycast.cu:9-18 */
+GIE_DEV int gie_clear_ray(const gie_ctx &c, int lx, int ly, int lz)
+{
+    if (!gie_in_loc(c, lx, ly, lz)) return 1;
+    const int id = gie_lid(c, lx, ly, lz);
+    if (c.inst_type[id] != GIE_VOX_OCCUPIED) { gie_aadd32(&c.ray_count[id], -1); return 1; }
+    return 0;
+}
+
+/* freeLocObs (pntcld_raycast.cu:67-80) → RAY::rayCastLoc (ray_cast.h:57-144) */
+GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
+{
+    const float w = c.voxel_width;
+    const float p0[3] = { c.origin[0], c.origin[1], c.origin[2] };
+    const float p1[3] = { g[3 * i], g[3 * i + 1], g[3 * i + 2] };
+    const float max_length = 0.707f * (float)c.X * w;
+    int i0[3], i1[3];
+    for (int k = 0; k < 3; k++) { i0[k] = gie_pos2coord(p0[k], w); i1[k] = gie_pos2coord(p1[k], w); }
+    gie_clear_ray(c, i0[0] - c.pvt[0], i0[1] - c.pvt[1], i0[2] - c.pvt[2]);
+    if (i0[0] == i1[0] && i0[1] == i1[1] && i0[2] == i1[2]) return;
+    float dir[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
+    const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    for (int k = 0; k < 3; k++) dir[k] = dir[k] / len;
+    int step[3]; float tMax[3], tDelta[3];
+    int cur[3] = { i0[0], i0[1], i0[2] };
+    for (int k = 0; k < 3; k++) {
+        if (dir[k] > 0.0f) step[k] = 1; else if (dir[k] < 0.0f) step[k] = -1; else step[k] = 0;
+        if (step[k] != 0) {
+            const float border = (float)cur[k] * w + (float)step[k] * w * 0.5f;
+            tMax[k] = (border - p0[k]) / dir[k];
+            tDelta[k] = w / fabsf(dir[k]);
+        } else { tMax[k] = 3.402823466e+38f; tDelta[k] = 3.402823466e+38f; }
+    }
+    for (;;) {
+        int dim;
+        if (tMax[0] < tMax[1]) dim = (tMax[0] < tMax[2]) ? 0 : 2;
+        else dim = (tMax[1] < tMax[2]) ? 1 : 2;
+        /* unrolled select instead of dynamic indexing keeps everything in registers */
+        if (dim == 0) { cur[0] += step[0]; tMax[0] += tDelta[0]; }
+        else if (dim == 1) { cur[1] += step[1]; tMax[1] += tDelta[1]; }
+        else { cur[2] += step[2]; tMax[2] += tDelta[2]; }
+        if (!gie_clear_ray(c, cur[0] - c.pvt[0], cur[1] - c.pvt[1], cur[2] - c.pvt[2])) break;
+        if (cur[0] == i1[0] && cur[1] == i1[1] && cur[2] == i1[2]) break;
+        const float m01 = tMax[0] < tMax[1] ? tMax[0] : tMax[1];
+        const float dist = m01 < tMax[2] ? m01 : tMax[2];
+        if (dist > max_length || dist > len) break;
+    }
+}
+
+/* getAllocKeys, pntcld_raycast.cu:21-63 */
+GIE_DEV void gie_raycast_finalize(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    if (gie_robot_sphere(c, x, y, z)) c.ray_count[id] = -1;
+    const int cnt = c.ray_count[id];
+    if (cnt == 0) return;
+    c.inst_type[id] = cnt > 0 ? GIE_VOX_OCCUPIED : GIE_VOX_FREE;
+    gie_mark_block_needed(c, x, y, z);
+}
+
+/* ================================================================== block allocation */
+/* RequiresAllocation (alloc_helper.cuh:13-21): table cell needs a block that does not exist */
+GIE_DEV int gie_cell_needs_new(const gie_ctx &c, int cell)
+{
+    if (!c.blk_need[cell]) return 0;
+    const int bx = cell % c.tdim[0], by = (cell / c.tdim[0]) % c.tdim[1], bz = cell / (c.tdim[0] * c.tdim[1]);
+    return gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]) < 0;
+}
+
+/* TryAllocateKernel / insert_to_id (alloc_helper.cuh:30-50, vhashing.h:387-455) without locks:
+ * the slot comes from an exclusive scan (deterministic), the key is claimed by CAS. */
+GIE_DEV void gie_cell_insert(const gie_ctx &c, int cell, int slot)
+{
+    const int bx = cell % c.tdim[0] + c.tb0[0], by = (cell / c.tdim[0]) % c.tdim[1] + c.tb0[1], bz = cell / (c.tdim[0] * c.tdim[1]) + c.tb0[2];
+    const uint64_t key = gie_pack_crd(bx, by, bz);
+    uint32_t h = gie_hash_key(bx, by, bz) & c.hmask;
+    for (uint32_t probes = 0; probes <= c.hmask; probes++) {
+        const uint64_t old = gie_acas64(&c.hkeys[h], GIE_KEY_EMPTY, key);
+        if (old == GIE_KEY_EMPTY) { c.hvals[h] = slot; c.g_key[slot] = key; return; }
+        h = (h + 1) & c.hmask;
+    }
+    gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_HASH);
+}
+
+/* GlbVoxel defaults (voxmap_utils.cuh:30-43) for voxel i of a fresh block */
+GIE_DEV void gie_init_voxel(const gie_ctx &c, int slot, int i)
+{
+    const int a = slot * GIE_VBSZ + i;
+    c.g_occ[a] = 0; c.g_type[a] = GIE_VOX_UNKNOWN;
+    c.g_dist[a] = c.empty_value;
+    c.g_coc[a] = gie_pack_crd(GIE_EMPTY_VALUE, GIE_EMPTY_VALUE, GIE_EMPTY_VALUE);
+    c.g_pair[a] = 0; c.g_prop[a] = GIE_NOPROP; c.g_wl[a] = -1;
+}
+
+/* ================================================================== fuse */
+GIE_DEV int gie_inside_aabb(float px, float py, float pz, const float *ll, const float *ur)
+{ return px >= ll[0] && py >= ll[1] && pz >= ll[2] && px <= ur[0] && py <= ur[1] && pz <= ur[2]; }
+
+/* set_hashvoxel_occ_val, voxmap_utils.cuh:181-200 */
+GIE_DEV void gie_set_occ(uint8_t *occ, int8_t *type, float val, float a, int thresh)
+{
+    if (*type != GIE_VOX_UNKNOWN) val = a * val + (1.0f - a) * (float)(*occ);
+    else val = a * val + (1.0f - a) * 0.0f;
+    if (val > 254.0f) val = 254.0f;
+    if (val < 1.0f) val = 1.0f;
+    *occ = (uint8_t)val;
+    *type = (*occ > thresh) ? GIE_VOX_OCCUPIED : GIE_VOX_FREE;
+}
+
+/* updateHashOGMWithPntCld / updateHashOGMWithSensor, unify_helper.cuh:35-197 */
+GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    int count = 0;
+    if (c.pntcld_mode) { count = c.ray_count[id]; c.ray_count[id] = 0; }
+    const int8_t nt = c.inst_type[id];
+    c.inst_type[id] = GIE_VOX_UNKNOWN;
+    const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz = z + c.pvt[2];
+    const int a = gie_gvox_tab(c, gx, gy, gz);
+    if (a < 0) { c.glb_type[id] = GIE_VOX_UNKNOWN; return; }
+    int occ_flag = 0;
+    if (c.nbox > 0) {
+        const float w = c.voxel_width;
+        const float px = (float)gx * w, py = (float)gy * w, pz = (float)gz * w;
+        if (c.box_act[0] && !gie_inside_aabb(px, py, pz, c.box_ll, c.box_ur)) occ_flag = 1;
+        else for (int i = 1; i < c.nbox; i++)
+            if (c.box_act[i] && gie_inside_aabb(px, py, pz, c.box_ll + 3 * i, c.box_ur + 3 * i)) { occ_flag = 1; break; }
+    }
+    uint8_t occ = c.g_occ[a];
+    int8_t ty = c.g_type[a];
+    const int8_t ty0 = ty;
+    const uint8_t occ0 = occ;
+    if (c.pntcld_mode) {
+        if (count > 0 || occ_flag) gie_set_occ(&occ, &ty, 250.f, 1.f, c.occ_thresh);
+        else if (count < 0) { float pb = (float)(-count) / 10.f; if (pb > 1.f) pb = 1.f; gie_set_occ(&occ, &ty, 0.f, pb, c.occ_thresh); }
+    } else {
+        if (nt == GIE_VOX_OCCUPIED || occ_flag) gie_set_occ(&occ, &ty, 250.f, 0.8f, c.occ_thresh);
+        else if (nt == GIE_VOX_FREE) gie_set_occ(&occ, &ty, 0.f, 0.5f, c.occ_thresh);
+    }
+    if (occ != occ0) c.g_occ[a] = occ;
+    if (ty != ty0) c.g_type[a] = ty;
+    c.glb_type[id] = ty;
+}
+
+/* ================================================================== Mark */
+/* MarkLimitedObserve, unify_helper.cuh:201-273 */
+GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;
+    const uint32_t bc = c.bcoc[id];
+    int cn[3];
+    const int dn = c.aux[id];
+    int auxv = dn;
+    uint64_t pr = c.pair[id];
+    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    if (a < 0) return;
+    const int batch_invalid = (bc == GIE_BCOC_NONE);
+    if (batch_invalid) {
+        pr = gie_pair_make(c.empty_value, GIE_PAR_NONE);
+        auxv = c.empty_value;
+        cn[0] = cn[2] = 0; cn[1] = 16383;          /* the oracle's invalid marker: outside every wave range */
+    } else { cn[0] = (int)(bc & 1023u); cn[1] = (int)((bc >> 10) & 1023u); cn[2] = (int)(bc >> 20); }
+    const int dold = c.g_dist[a];
+    int ox, oy, oz;
+    gie_unpack_crd(c.g_coc[a], &ox, &oy, &oz);
+    const int ol[3] = { ox - c.pvt[0], oy - c.pvt[1], oz - c.pvt[2] };
+    if (dn > dold && !gie_in_loc(c, ol[0], ol[1], ol[2])) { cn[0] = ol[0]; cn[1] = ol[1]; cn[2] = ol[2]; auxv = dold; }
+    const long long wx = (long long)cn[0] + c.pvt[0] - c.upvt[0];
+    const long long wy = (long long)cn[1] + c.pvt[1] - c.upvt[1];
+    const long long wz = (long long)cn[2] + c.pvt[2] - c.upvt[2];
+    if (!(wx >= 0 && wx < c.wr[0] && wy >= 0 && wy < c.wr[1] && wz >= 0 && wz < c.wr[2])) {
+        pr = gie_pair_make(c.empty_value, gie_pair_par(pr));       /* parent id left as is */
+        auxv = c.empty_value;
+    } else {
+        pr = gie_pair_make(auxv, gie_pack_wr((int)wx, (int)wy, (int)wz));
+    }
+    if (auxv != dn) c.aux[id] = auxv;
+    c.pair[id] = pr;
+    c.pair0[id] = pr;
+}
+
+/* ================================================================== obtainFrontiers */
+/* obtainFrontiers, unify_helper.cuh:275-446.  Returns a bit mask of what this voxel did so
+ * that the kernel can compact the C-queue append with a wave ballot: bit0 = push to C. */
+GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    const int8_t ty = c.glb_type[id];
+    if (ty == GIE_VOX_UNKNOWN) return 0;
+    const uint64_t p0 = c.pair0[id];
+    int cw[3];
+    gie_unpack_wr(gie_pair_par(p0), &cw[0], &cw[1], &cw[2]);
+    const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
+    const int cd = gie_pair_dist(p0);
+    if (!gie_in_loc(c, cl[0], cl[1], cl[2])) return 0;
+    int cur_in_q = 0, has_unknown = 0;
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    for (int k = 0; k < 6; k++) {
+        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        if (gie_in_loc(c, nx, ny, nz)) {
+            const int nid = gie_lid(c, nx, ny, nz);
+            const int8_t nty = c.glb_type[nid];
+            if (nty == GIE_VOX_UNKNOWN) { has_unknown = 1; continue; }
+            int nw[3];
+            gie_unpack_wr(gie_pair_par(c.pair0[nid]), &nw[0], &nw[1], &nw[2]);
+            const int nl[3] = { nw[0] + c.upvt[0] - c.pvt[0], nw[1] + c.upvt[1] - c.pvt[1], nw[2] + c.upvt[2] - c.pvt[2] };
+            if (!gie_in_loc(c, nl[0], nl[1], nl[2]) && gie_in_wr(c, nw[0], nw[1], nw[2])) {
+                const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
+                if (d < cd) {
+                    c.pair[id] = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+                    cur_in_q = 1;
+                }
+            }
+        } else {
+            const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
+            const int a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
+            if (a < 0) { has_unknown = 1; continue; }
+            if (c.g_type[a] == GIE_VOX_UNKNOWN) { has_unknown = 1; continue; }
+            const int nd = c.g_dist[a];
+            if (gie_invalid_dist(c, nd)) continue;
+            int ncx, ncy, ncz;
+            gie_unpack_crd(c.g_coc[a], &ncx, &ncy, &ncz);
+            if (gie_invalid_coc(ncx, ncy, ncz)) continue;
+            const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
+            const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
+            const int n_valid = gie_in_wr(c, nw[0], nw[1], nw[2]);
+            const int n_local = gie_in_loc(c, nl[0], nl[1], nl[2]);
+            if (!n_local && n_valid) {
+                const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
+                if (d < cd) {
+                    c.pair[id] = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+                    cur_in_q = 1;
+                }
+            }
+            if (c.fast_mode) continue;
+            const int c2n = gie_d2(nx, ny, nz, cl[0], cl[1], cl[2]);
+            if (c2n < nd) {                                       /* lower out → frontier B */
+                c.g_wl[a] = 1;
+                c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
+                gie_push64(c, c.qb[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+            } else if (c2n > nd && n_local) {                     /* raise out → frontier A */
+                /* the reference reads the live _glb_type here; FNT never aliases OCCUPIED */
+                if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
+                    c.g_dist[a] = c2n;
+                    c.g_coc[a] = gie_pack_crd(cl[0] + c.pvt[0], cl[1] + c.pvt[1], cl[2] + c.pvt[2]);
+                    c.g_wl[a] = -c.map_ct;
+                    c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
+                    gie_push64(c, c.qa[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+                }
+            }
+        }
+    }
+    if (cur_in_q) c.wl[id] = GIE_WL_SEED(c);
+    if (ty == GIE_VOX_FREE && has_unknown) c.glb_type[id] = GIE_VOX_FNT;
+    return cur_in_q;
+}
+
+/* ================================================================== wave A (raise_outside) */
+/* wave_core.cuh:103-224, two phases per BFS level.  rec0 = lowered (dist<<… see below),
+ * rec layout per entry e: rec0[e] = packed new coc (or GIE_KEY_EMPTY = not lowered),
+ * rec1[e] = pair to store (or GIE_NOPROP), rec3[e] = new dist | raise-direction mask << 24. */
+GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, const uint64_t *cur, int e)
+{
+    int g[3];
+    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    c.rec0[e] = GIE_KEY_EMPTY; c.rec1[e] = GIE_NOPROP; c.rec3[e] = 0;
+    const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
+    if (a < 0) return;
+    int cd = gie_ld(&c.g_dist[a]);
+    if (cd > c.cutoff_sq) return;
+    int lc[3];
+    gie_unpack_crd(gie_ld(&c.g_coc[a]), &lc[0], &lc[1], &lc[2]);
+    const uint64_t lpar = gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]);
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    int mask = 0, lowered = 0;
+    uint64_t newcoc = GIE_KEY_EMPTY, newpair = GIE_NOPROP;
+    for (int k = 0; k < 6; k++) {
+        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
+        if (gie_in_loc(c, ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2])) continue;
+        const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+        if (na < 0) continue;
+        if (gie_ld(&c.g_type[na]) == GIE_VOX_UNKNOWN) continue;
+        int nc[3];
+        gie_unpack_crd(gie_ld(&c.g_coc[na]), &nc[0], &nc[1], &nc[2]);
+        if (gie_invalid_coc(nc[0], nc[1], nc[2]) || gie_invalid_dist(c, gie_ld(&c.g_dist[na]))) continue;
+        if (gie_ld(&c.g_wl[na]) == -c.map_ct) continue;
+        if (nc[0] == lc[0] && nc[1] == lc[1] && nc[2] == lc[2]) continue;
+        const int nl[3] = { nc[0] - c.pvt[0], nc[1] - c.pvt[1], nc[2] - c.pvt[2] };
+        if (gie_in_loc(c, nl[0], nl[1], nl[2]) && c.aux[gie_lid(c, nl[0], nl[1], nl[2])] != 0) {
+            const int d = gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
+            gie_amin64(&c.g_prop[na], gie_pair_make(d, lpar));
+            mask |= 1 << k;
+        } else {
+            const int d = gie_d2(nc[0], nc[1], nc[2], g[0], g[1], g[2]);
+            if (cd > d) {
+                cd = d; lowered = 1;
+                newcoc = gie_pack_crd(nc[0], nc[1], nc[2]);
+                const int nw[3] = { nc[0] - c.upvt[0], nc[1] - c.upvt[1], nc[2] - c.upvt[2] };
+                if (gie_in_wr(c, nw[0], nw[1], nw[2])) newpair = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+            }
+        }
+    }
+    c.rec0[e] = lowered ? newcoc : GIE_KEY_EMPTY;
+    c.rec1[e] = newpair;
+    c.rec2[e] = lpar;
+    c.rec3[e] = (lowered ? cd : 0) | (mask << 24);
+}
+
+GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int e)
+{
+    int g[3];
+    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    const int mask = (c.rec3[e] >> 24) & 63;
+    if (c.rec0[e] != GIE_KEY_EMPTY) {
+        const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
+        gie_st(&c.g_dist[a], (int32_t)(c.rec3[e] & 0xffffff));
+        gie_st(&c.g_coc[a], c.rec0[e]);
+        gie_st(&c.g_wl[a], (int32_t)1);
+        if (c.rec1[e] != GIE_NOPROP) {
+            gie_st(&c.g_pair[a], c.rec1[e]);
+            gie_push64(c, c.qb[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_ld(&cur[e]));
+        }
+    }
+    if (!mask) return;
+    const uint64_t lpar = c.rec2[e];
+    int lw[3];
+    gie_unpack_wr(lpar, &lw[0], &lw[1], &lw[2]);
+    const int lc[3] = { lw[0] + c.upvt[0], lw[1] + c.upvt[1], lw[2] + c.upvt[2] };
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    for (int k = 0; k < 6; k++) {
+        if (!(mask & (1 << k))) continue;
+        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
+        const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+        const int d = gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
+        const uint64_t key = gie_pair_make(d, lpar);
+        if (gie_acas64(&c.g_prop[na], key, GIE_NOPROP) != key) continue;   /* not the (unique) winner */
+        gie_st(&c.g_dist[na], (int32_t)d);
+        gie_st(&c.g_coc[na], gie_pack_crd(lc[0], lc[1], lc[2]));
+        gie_st(&c.g_wl[na], (int32_t)-c.map_ct);
+        gie_st(&c.g_pair[na], key);
+        gie_push64(c, next, &c.cnt[GIE_CNT_NEXT], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+    }
+}
+
+/* ================================================================== wave B (lower_outside) */
+/* wave_core.cuh:229-350, three phases per level. rec0[e] = snapshot parent (GIE_NOPROP =
+ * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask. */
+GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, const uint64_t *cur, int e)
+{
+    int g[3];
+    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    c.rec0[e] = GIE_NOPROP; c.rec3[e] = 0;
+    const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
+    if (a < 0) return;
+    const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
+    if (gie_ld(&c.g_dist[a]) > c.cutoff_sq) return;
+    int cw[3];
+    gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+    const uint64_t coc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
+    gie_st(&c.g_coc[a], coc);
+    gie_st(&c.g_dist[a], (int32_t)gie_pair_dist(pr));
+    c.rec0[e] = gie_pair_par(pr);
+    c.rec1[e] = coc;
+}
+
+GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int level, int e)
+{
+    if (c.rec0[e] == GIE_NOPROP) return;
+    int g[3], cc[3];
+    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
+    const uint64_t par = c.rec0[e];
+    const int32_t stamp = (int32_t)(c.stamp_base + 8u + (uint32_t)(level % 4000));
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    int mask = 0;
+    for (int k = 0; k < 6; k++) {
+        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
+        const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
+        const int cand = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
+        if (!gie_in_loc(c, nb[0], nb[1], nb[2])) {
+            const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+            if (na < 0) continue;
+            if (gie_ld(&c.g_type[na]) == GIE_VOX_UNKNOWN) continue;
+            int nc[3];
+            gie_unpack_crd(gie_ld(&c.g_coc[na]), &nc[0], &nc[1], &nc[2]);
+            if (gie_invalid_coc(nc[0], nc[1], nc[2])) continue;
+            if (cand >= c.empty_value) continue;
+            const uint64_t old = gie_amin64(&c.g_pair[na], gie_pair_make(cand, par) | GIE_PAIR_NEW);
+            if (gie_pair_dist(old) > cand) {
+                if (gie_axchg32(&c.g_wl[na], stamp) != stamp)
+                    gie_push64(c, next, &c.cnt[GIE_CNT_NEXT], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+            }
+        } else {
+            const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
+            if (c.aux[nid] > cand) {
+                gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand, par));
+                mask |= 1 << k;
+            }
+        }
+    }
+    c.rec3[e] = mask;
+}
+
+GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
+{
+    if (c.rec0[e] == GIE_NOPROP) return;
+    const int mask = c.rec3[e];
+    if (!mask) return;
+    int g[3], cc[3];
+    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
+    const uint64_t par = c.rec0[e];
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    for (int k = 0; k < 6; k++) {
+        if (!(mask & (1 << k))) continue;
+        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
+        const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
+        const int cand = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
+        const uint64_t key = gie_pair_make(cand, par);
+        if (gie_acas64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], key, GIE_NOPROP) != key) continue;
+        const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
+        gie_st(&c.pair[nid], key);                         /* the reference's plain store, wave_core.cuh:338-341 */
+        const uint32_t w = gie_ld(&c.wl[nid]);
+        if (w == GIE_WL_SEED(c) || w == GIE_WL_PUSHED(c)) continue;
+        gie_st(&c.wl[nid], GIE_WL_PUSHED(c));              /* this thread is the only writer of nid in this phase */
+        gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, nid);
+    }
+}
+
+/* ================================================================== wave C (lower_inside) */
+/* wave_core.cuh:353-393, two phases per level. rec0[e] = snapshot parent. */
+GIE_DEV void gie_wave_c_phase1(const gie_ctx &c, const int32_t *cur, int e)
+{
+    const int id = gie_ld(&cur[e]);
+    const uint64_t pr = gie_aand64(&c.pair[id], ~GIE_PAIR_NEW);
+    c.rec0[e] = gie_pair_par(pr);
+}
+
+GIE_DEV void gie_wave_c_phase2(const gie_ctx &c, const int32_t *cur, int32_t *next, int level, int e)
+{
+    const int id = gie_ld(&cur[e]);
+    const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
+    const uint64_t par = c.rec0[e];
+    int cw[3];
+    gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
+    const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
+    const uint32_t stamp = c.stamp_base + 8u + (uint32_t)(level % 4000);
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    for (int k = 0; k < 6; k++) {
+        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        if (!gie_in_loc(c, nx, ny, nz)) continue;
+        const int nid = gie_lid(c, nx, ny, nz);
+        const int cand = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
+        if (cand >= c.empty_value) continue;
+        const uint64_t old = gie_amin64(&c.pair[nid], gie_pair_make(cand, par) | GIE_PAIR_NEW);
+        if (gie_pair_dist(old) > cand) {
+            if (gie_axchg32(&c.wl[nid], stamp) != stamp)
+                gie_push32(c, next, &c.cnt[GIE_CNT_NEXT], c.qcap_c, nid);
+        }
+    }
+}
+
+/* ================================================================== commit */
+/* UpdateHashBatch, unify_helper.cuh:448-523 */
+GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    const int8_t ty = c.glb_type[id];
+    if (ty == GIE_VOX_UNKNOWN) return;
+    const uint64_t pr = c.pair[id];
+    const int d = gie_pair_dist(pr);
+    if (d == c.empty_value) {
+        if (gie_pair_par(pr) == GIE_PAR_NONE) c.edt[id] = (float)c.max_loc_dist_sq;
+        return;
+    }
+    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    if (a < 0) return;
+    int cw[3];
+    gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+    c.g_coc[a] = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
+    c.g_dist[a] = d;
+    c.edt[id] = sqrtf((float)d);
+    c.g_pair[a] = pr;
+    if (ty == GIE_VOX_FNT) c.g_type[a] = GIE_VOX_FNT;
+}
+
+/* ================================================================== export for the readers */
+GIE_DEV void gie_export_pair(const gie_ctx &c, int id, int32_t *dist_sq, int32_t *coc_xyz)
+{
+    const uint64_t pr = c.pair[id];
+    const int d = gie_pair_dist(pr);
+    if (dist_sq) dist_sq[id] = d;
+    if (coc_xyz) {
+        if (gie_pair_par(pr) == GIE_PAR_NONE || d >= c.empty_value) {
+            coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = GIE_EMPTY_VALUE;
+        } else {
+            int w[3];
+            gie_unpack_wr(gie_pair_par(pr), &w[0], &w[1], &w[2]);
+            coc_xyz[3 * id] = w[0] + c.upvt[0]; coc_xyz[3 * id + 1] = w[1] + c.upvt[1]; coc_xyz[3 * id + 2] = w[2] + c.upvt[2];
+        }
+    }
+}
+GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *coc_xyz)
+{
+    const uint32_t bc = c.bcoc[id];
+    if (bc == GIE_BCOC_NONE) { coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = -1; }
+    else { coc_xyz[3 * id] = (int)(bc & 1023u); coc_xyz[3 * id + 1] = (int)((bc >> 10) & 1023u); coc_xyz[3 * id + 2] = (int)(bc >> 20); }
+}
+GIE_DEV void gie_query_voxel(const gie_ctx &c, const int32_t *xyz, int i, gie_voxel *out)
+{
+    const int a = gie_gvox_hash(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    out[i].pad = 0;
+    if (a < 0) {
+        out[i].occ_val = 0; out[i].vox_type = GIE_VOX_UNKNOWN; out[i].dist_sq = c.empty_value;
+        out[i].coc[0] = out[i].coc[1] = out[i].coc[2] = GIE_EMPTY_VALUE;
+    } else {
+        out[i].occ_val = c.g_occ[a]; out[i].vox_type = c.g_type[a]; out[i].dist_sq = c.g_dist[a];
+        gie_unpack_crd(c.g_coc[a], &out[i].coc[0], &out[i].coc[1], &out[i].coc[2]);
+    }
+}
+
+#endif /* GIE_OPS_H */

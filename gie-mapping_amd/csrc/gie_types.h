@@ -1,0 +1,197 @@
+/*
+ * gie_types.h — device-side data layout of the MI355X map-update path.
+ *
+ * Local volume (dense, x fastest, N = X*Y*Z; counterpart of LocMap's arrays,
+ * include/map_structure/local_batch.h:541-561) and the block-sparse global map (8x8x8 voxel
+ * blocks, counterpart of GlbVoxel/VoxelBlock + vhashing, include/par_wave/voxmap_utils.cuh:29-48,
+ * include/vox_hash/vhashing.h) laid out as structure-of-arrays planes so that every sweep
+ * touches only the fields it needs.
+ *
+ * All functions that are plain per-voxel logic are GIE_HD so that the test-only host emulation
+ * (tests/emu) can run them; nothing in the product library ever executes them on the CPU.
+ */
+#ifndef GIE_TYPES_H
+#define GIE_TYPES_H
+
+#include <stdint.h>
+#include "../../include/gie.h"
+#include "../../include/gie_math.h"
+
+#define GIE_VB 8
+#define GIE_VBSZ 512
+
+/* ---- 64-bit (dist, parent) pair: [63:42] dist (22 bit) | [41] new-in-this-level | [40:0] parent
+ * parent = closest obstacle in wave-range coordinates, x | y<<14 | z<<28 (x,y < 16384, z < 8192).
+ * One native 64-bit atomicMin gives: lower dist wins; at equal dist a value that was there at
+ * the start of the BFS level beats candidates of the level (the reference's strict '>' in
+ * id_atomicMin, wave_core.cuh:9-22); among candidates of one level the smaller parent id wins
+ * (canonical tie rule). */
+#define GIE_PAIR_DIST_SHIFT 42
+#define GIE_PAIR_NEW (1ull << 41)
+#define GIE_PAIR_PAR_MASK ((1ull << 41) - 1ull)
+#define GIE_PAR_NONE GIE_PAIR_PAR_MASK /* the reference's 0xffffffff "see nothing" id */
+#define GIE_NOPROP 0xffffffffffffffffull
+
+GIE_HD uint64_t gie_pair_make(int dist, uint64_t par) { return ((uint64_t)(uint32_t)dist << GIE_PAIR_DIST_SHIFT) | (par & GIE_PAIR_PAR_MASK); }
+GIE_HD int gie_pair_dist(uint64_t p) { return (int)(p >> GIE_PAIR_DIST_SHIFT); }
+GIE_HD uint64_t gie_pair_par(uint64_t p) { return p & GIE_PAIR_PAR_MASK; }
+GIE_HD uint64_t gie_pack_wr(int x, int y, int z) { return (uint64_t)(uint32_t)x | ((uint64_t)(uint32_t)y << 14) | ((uint64_t)(uint32_t)z << 28); }
+GIE_HD void gie_unpack_wr(uint64_t id, int *x, int *y, int *z)
+{
+    *x = (int)(id & 0x3fff); *y = (int)((id >> 14) & 0x3fff); *z = (int)((id >> 28) & 0x1fff);
+    if ((id & GIE_PAIR_PAR_MASK) == GIE_PAR_NONE) *z = 0x3fff; /* keep NONE outside every wave range */
+}
+
+/* ---- global coordinate packed in 64 bits (21 bits per axis, offset 2^20): block keys, queue
+ * entries and the stored closest obstacle coc_glb.  EMPTY_KEY (999999) is representable. */
+#define GIE_CRD_OFF (1 << 20)
+GIE_HD uint64_t gie_pack_crd(int x, int y, int z)
+{ return (uint64_t)(uint32_t)(x + GIE_CRD_OFF) | ((uint64_t)(uint32_t)(y + GIE_CRD_OFF) << 21) | ((uint64_t)(uint32_t)(z + GIE_CRD_OFF) << 42); }
+GIE_HD void gie_unpack_crd(uint64_t k, int *x, int *y, int *z)
+{ *x = (int)(k & 0x1fffff) - GIE_CRD_OFF; *y = (int)((k >> 21) & 0x1fffff) - GIE_CRD_OFF; *z = (int)((k >> 42) & 0x1fffff) - GIE_CRD_OFF; }
+#define GIE_KEY_EMPTY 0xffffffffffffffffull
+
+/* batch-EDT closest obstacle in local coordinates, 10 bits per axis (dims <= 1024) */
+#define GIE_BCOC_NONE 0xffffffffu
+GIE_HD uint32_t gie_pack_bcoc(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
+
+typedef struct gie_ctx {
+    /* ---- configuration (LocMap members, local_batch.h:523-568) */
+    int X, Y, Z, N;
+    float voxel_width;
+    int occ_thresh;
+    float min_h, max_h;
+    int cutoff_sq;
+    int fast_mode, for_motion_planner, robot_r2;
+    int max_width, max_loc_dist_sq;
+    int wr[3];              /* _wave_range */
+    int empty_value;        /* EMPTY_VALUE or the wide sentinel */
+    int invalid_dist_min;   /* invalid_dist_glb threshold */
+    /* ---- per frame */
+    int map_ct;
+    int pvt[3], upvt[3];
+    float origin[3];
+    gie_se3 L2G, G2L;
+    int pntcld_mode;
+    uint32_t stamp_base;    /* frame-unique base for the local/global de-dup stamps */
+    /* ---- local volume planes */
+    int32_t *ray_count;     /* _ray_count */
+    int8_t *inst_type;      /* _inst_type */
+    int8_t *glb_type;       /* _glb_type  */
+    float *edt;             /* _edt_D     */
+    uint16_t *cy1;          /* EDT pass Y: closest y in the column, 0xffff none */
+    uint32_t *cxy2;         /* EDT pass X: cx | cy<<16, 0xffffffff none */
+    int32_t *aux;           /* _aux: batch dist², then Mark-edited */
+    int32_t *bdist;         /* untouched copy of the batch dist² (parity reads) */
+    uint32_t *bcoc;         /* _coc_idx_aux: batch closest obstacle, local, packed */
+    uint64_t *pair;         /* _dist_id_pair (persists across frames by local index) */
+    uint64_t *pair0;        /* Mark-time copy = the reference's _g/_coc_idx "read-only backups" */
+    uint32_t *wl;           /* _loc_wave_layer as frame-stamped marks */
+    uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
+    /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */
+    int tb0[3];             /* block coordinate of table cell 0 */
+    int tdim[3];
+    int32_t *blk_tab;       /* slot or -1 */
+    uint8_t *blk_need;      /* observed-this-scan flag per table cell */
+    int32_t *blk_new;       /* scratch: new-block flag / rank */
+    /* ---- global map: hash + SoA block pool */
+    uint64_t *hkeys;        /* open addressing, GIE_KEY_EMPTY = free */
+    int32_t *hvals;
+    uint32_t hmask;
+    int max_blocks;
+    int32_t *pool_count;    /* device scalar */
+    uint64_t *g_key;        /* block key per slot */
+    uint8_t *g_occ;         /* planes, 512 per slot, in-block index x | y<<3 | z<<6 */
+    int8_t *g_type;
+    int32_t *g_dist;
+    uint64_t *g_coc;        /* packed global coord */
+    uint64_t *g_pair;
+    uint64_t *g_prop;
+    int32_t *g_wl;          /* wave_layer (-map_ct raise stamp / level stamps) */
+    /* ---- ext boxes */
+    int nbox;
+    const float *box_ll, *box_ur;
+    const uint8_t *box_act;
+    /* ---- frontier queues + counters */
+    uint64_t *qa[2], *qb[2];
+    int32_t *qc[2];
+    int qcap_ab, qcap_c;
+    int32_t *cnt;           /* device counters, see GIE_CNT_* */
+    /* per-entry scratch of the wave phases */
+    uint64_t *rec0, *rec1, *rec2;
+    int32_t *rec3;
+} gie_ctx;
+
+enum {
+    GIE_CNT_A = 0, GIE_CNT_B, GIE_CNT_C,        /* seed counts from obtainFrontiers */
+    GIE_CNT_NEXT,                               /* next-level count inside a wave */
+    GIE_CNT_ERR,                                /* sticky error flags */
+    GIE_CNT_NEWBLK,                             /* blocks allocated this frame */
+    GIE_CNT_VIS_A, GIE_CNT_VIS_B, GIE_CNT_VIS_C,
+    GIE_CNT_LVL_A, GIE_CNT_LVL_B, GIE_CNT_LVL_C,
+    GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
+    GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
+    GIE_CNT_NUM = 32
+};
+#define GIE_ERRF_POOL 1
+#define GIE_ERRF_QUEUE 2
+#define GIE_ERRF_HASH 4
+
+/* stamps in ctx.wl (local) */
+#define GIE_WL_SEED(c) ((c).stamp_base + 1u)
+#define GIE_WL_PUSHED(c) ((c).stamp_base + 2u)
+#define GIE_WL_LEVEL(c, lvl) ((c).stamp_base + 8u + (uint32_t)(lvl))
+
+GIE_HD int gie_in_loc(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.X && y >= 0 && y < c.Y && z >= 0 && z < c.Z; }
+GIE_HD int gie_in_wr(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.wr[0] && y >= 0 && y < c.wr[1] && z >= 0 && z < c.wr[2]; }
+GIE_HD int gie_lid(const gie_ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+GIE_HD int gie_vox_in_blk(int gx, int gy, int gz) { return ((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7); }
+GIE_HD int gie_d2(int ax, int ay, int az, int bx, int by, int bz)
+{
+    const long long dx = ax - bx, dy = ay - by, dz = az - bz;
+    const long long r = dx * dx + dy * dy + dz * dz;
+    return r > 0x7fffffffLL ? 0x7fffffff : (int)r;
+}
+GIE_HD int gie_invalid_dist(const gie_ctx &c, int d) { return d < 0 || d >= c.invalid_dist_min; }
+GIE_HD int gie_invalid_coc(int x, int y, int z) { return x > 900000 || y > 900000 || z > 900000; }
+
+/* table cell of a global voxel (must lie within the volume +-1 voxel) */
+GIE_HD int gie_tab_index(const gie_ctx &c, int gx, int gy, int gz)
+{
+    const int bx = (gx >> 3) - c.tb0[0], by = (gy >> 3) - c.tb0[1], bz = (gz >> 3) - c.tb0[2];
+    return (bz * c.tdim[1] + by) * c.tdim[0] + bx;
+}
+
+/* BlockHasher (voxmap_utils.cuh:69-81) over the packed key */
+GIE_HD uint32_t gie_hash_key(int bx, int by, int bz)
+{
+    const uint64_t h = ((uint64_t)(int64_t)bx * 73856093ull) ^ ((uint64_t)(int64_t)by * 19349669ull) ^ ((uint64_t)(int64_t)bz * 83492791ull);
+    return (uint32_t)(h ^ (h >> 32));
+}
+
+/* read-only lookup: HashTableBase::get_alloc_blk_id (vhashing.h:125-134) */
+GIE_HD int gie_hash_find(const gie_ctx &c, int bx, int by, int bz)
+{
+    const uint64_t key = gie_pack_crd(bx, by, bz);
+    uint32_t h = gie_hash_key(bx, by, bz) & c.hmask;
+    for (;;) {
+        const uint64_t k = c.hkeys[h];
+        if (k == key) return c.hvals[h];
+        if (k == GIE_KEY_EMPTY) return -1;
+        h = (h + 1) & c.hmask;
+    }
+}
+
+/* first face of the volume a boundary voxel lies on → slot in the 2(XY+YZ+XZ) proposal table */
+GIE_HD int gie_bdr_index(const gie_ctx &c, int x, int y, int z)
+{
+    const int YZ = c.Y * c.Z, XZ = c.X * c.Z, XY = c.X * c.Y;
+    if (x == 0) return y + c.Y * z;
+    if (x == c.X - 1) return YZ + y + c.Y * z;
+    if (y == 0) return 2 * YZ + x + c.X * z;
+    if (y == c.Y - 1) return 2 * YZ + XZ + x + c.X * z;
+    if (z == 0) return 2 * YZ + 2 * XZ + x + c.X * y;
+    return 2 * YZ + 2 * XZ + XY + x + c.X * y;
+}
+
+#endif /* GIE_TYPES_H */

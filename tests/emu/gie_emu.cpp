@@ -1,0 +1,108 @@
+/*
+ * gie_emu.cpp — TEST-ONLY sequential stand-in for the HIP backend of gie_api.inc.h.
+ *
+ * Built into tests/emu/libgie_emu.so by the CPU test-suite so that the per-voxel / per-entry
+ * logic in gie_ops.h and the orchestration in gie_api.inc.h (shared verbatim with the product)
+ * can be checked against the oracle in a container without a GPU.  It is never shipped, never
+ * loaded by the gie package, and bench.py never touches it.  The wave-cooperative HIP kernels
+ * (EDT passes, ballot compaction, persistent BFS kernels) are NOT exercised here — only
+ * `pytest -m gpu` covers them.
+ */
+#define GIE_HOST_EMU 1
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "../../gie-mapping_amd/csrc/gie_functors.h"
+
+struct be_state { int dummy; };
+static void gie_set_err(const std::string &s);
+static int be_init(be_state *, int) { return 0; }
+static void be_fini(be_state *) {}
+static void *be_alloc(be_state *, size_t bytes, bool zero) { return zero ? calloc(bytes ? bytes : 1, 1) : malloc(bytes ? bytes : 1); }
+static void be_free(be_state *, void *p) { free(p); }
+static void be_memset(be_state *, void *p, int v, size_t n) { memset(p, v, n); }
+static void be_h2d(be_state *, void *d, const void *h, size_t n) { memcpy(d, h, n); }
+static void be_d2h(be_state *, void *h, const void *d, size_t n) { memcpy(h, d, n); }
+static int be_sync(be_state *) { return 0; }
+static void be_time(be_state *, int) {}
+static void be_times(be_state *, float *a, float *b, float *c, float *d) { *a = *b = *c = *d = 0.f; }
+template <class F> static void be_vox(be_state *, const gie_ctx &c, const F &f)
+{ for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) f(c, x, y, z); }
+template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
+static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }
+static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell)
+{
+    for (int cell = 0; cell < ncell; cell++) {
+        if (!flag[cell]) continue;
+        const int slot = *c.pool_count + rank[cell];
+        if (slot >= c.max_blocks) continue;
+        for (int i = 0; i < GIE_VBSZ; i++) gie_init_voxel(c, slot, i);
+    }
+    const int total = rank[ncell - 1] + flag[ncell - 1];
+    int pc = *c.pool_count + total; if (pc > c.max_blocks) pc = c.max_blocks;
+    *c.pool_count = pc; c.cnt[GIE_CNT_NEWBLK] = total;
+}
+/* plain restatement of the closed form the HIP EDT kernels implement (see
+ * tests/test_oracle_edt.py::test_meijster_tie_rule) */
+static void be_edt(be_state *, const gie_ctx &c)
+{
+    const int X = c.X, Y = c.Y, Z = c.Z;
+    for (int z = 0; z < Z; z++) for (int x = 0; x < X; x++) for (int y = 0; y < Y; y++) {
+        int best = -1, bd = 1 << 30;
+        for (int i = 0; i < Y; i++) if (c.glb_type[gie_lid(c, x, i, z)] == GIE_VOX_OCCUPIED) { const int d = abs(y - i); if (d <= bd) { bd = d; best = i; } }
+        c.cy1[gie_lid(c, x, y, z)] = best < 0 ? 0xffff : (uint16_t)best;
+    }
+    for (int z = 0; z < Z; z++) for (int y = 0; y < Y; y++) for (int u = 0; u < X; u++) {
+        long long bf = 1ll << 60; int bs = -1;
+        for (int i = 0; i < X; i++) { const uint16_t cy = c.cy1[gie_lid(c, i, y, z)]; if (cy == 0xffff) continue;
+            const long long f = (long long)(u - i) * (u - i) + (long long)(y - cy) * (y - cy); if (f < bf) { bf = f; bs = i; } }
+        c.cxy2[gie_lid(c, u, y, z)] = bs < 0 ? 0xffffffffu : ((uint32_t)bs | ((uint32_t)c.cy1[gie_lid(c, bs, y, z)] << 16));
+    }
+    for (int y = 0; y < Y; y++) for (int x = 0; x < X; x++) for (int u = 0; u < Z; u++) {
+        long long bf = 1ll << 60; int bs = -1;
+        for (int i = 0; i < Z; i++) { const uint32_t v = c.cxy2[gie_lid(c, x, y, i)]; if (v == 0xffffffffu) continue;
+            const int dx = x - (int)(v & 0xffff), dy = y - (int)(v >> 16);
+            const long long f = (long long)(u - i) * (u - i) + dx * dx + dy * dy; if (f < bf) { bf = f; bs = i; } }
+        const int id = gie_lid(c, x, y, u);
+        if (bs < 0) { c.aux[id] = c.max_width * c.max_width; c.bcoc[id] = GIE_BCOC_NONE; }
+        else { const uint32_t v = c.cxy2[gie_lid(c, x, y, bs)]; c.aux[id] = (int32_t)bf; c.bcoc[id] = gie_pack_bcoc((int)(v & 0xffff), (int)(v >> 16), bs); }
+    }
+}
+static void be_wave_a(be_state *, const gie_ctx &c)
+{
+    int n = c.cnt[GIE_CNT_A], cur = 0;
+    c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B];
+    while (n > 0) {
+        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1;
+        for (int e = 0; e < n; e++) gie_wave_a_phase1(c, c.qa[cur], e);
+        for (int e = 0; e < n; e++) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], e);
+        n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1;
+    }
+}
+static void be_wave_b(be_state *, const gie_ctx &c)
+{
+    int n = c.cnt[GIE_CNT_B] < c.qcap_ab ? c.cnt[GIE_CNT_B] : c.qcap_ab, cur = 0, level = 0;
+    c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
+    while (n > 0) {
+        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1;
+        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, c.qb[cur], e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], level, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase3(c, c.qb[cur], e);
+        n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
+    }
+}
+static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds)
+{
+    int n = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c, cur = 0, level = 0;
+    c.cnt[GIE_CNT_FRONT_C] = n;
+    if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
+    while (n > 0) {
+        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1;
+        for (int e = 0; e < n; e++) gie_wave_c_phase1(c, c.qc[cur], e);
+        for (int e = 0; e < n; e++) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], level, e);
+        n = c.cnt[GIE_CNT_NEXT] < c.qcap_c ? c.cnt[GIE_CNT_NEXT] : c.qcap_c; cur ^= 1; level++;
+    }
+}
+
+#include "../../gie-mapping_amd/csrc/gie_api.inc.h"

@@ -1,0 +1,31 @@
+"""Loader for the test-only sequential emulation of the device logic (tests/emu)."""
+import ctypes as C
+import os
+import subprocess
+
+from gie import _capi
+from gie.mapper import MapperBase
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+EMU_SO = os.path.join(EMU_DIR, "libgie_emu.so")
+CSRC = os.path.join(os.path.dirname(HERE), "gie-mapping_amd", "csrc")
+_fns = None
+
+
+def load():
+    global _fns
+    if _fns is None:
+        srcs = [os.path.join(EMU_DIR, "gie_emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < newest:
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", EMU_SO,
+                                   os.path.join(EMU_DIR, "gie_emu.cpp")])
+        lib = C.CDLL(EMU_SO)
+        _fns = _capi.bind(lib, "gie_", {"last_error": (C.c_char_p, []), "sync": (C.c_int, [C.c_void_p])})
+    return _fns
+
+
+class EmuMapper(MapperBase):
+    def __init__(self, cfg):
+        super().__init__(load(), cfg)

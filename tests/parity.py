@@ -1,0 +1,133 @@
+"""Shared parity driver: runs the same seeded multi-frame scenario through two mappers that speak
+the C-ABI of include/gie.h (the CPU oracle and either the HIP library or the test-only host
+emulation) and compares every stage bit for bit."""
+import numpy as np
+
+import gie
+from gie import scenes
+
+
+class Scenario:
+    def __init__(self, name, size, voxel=0.1, sensor="depth", frames=6, delta_vox=5, yaw_deg=40.0, seed=2,
+                 cutoff_dist=2.0, fast_mode=False, n_boxes=30, extent=(4.0, 4.0, 1.5), for_motion_planner=False,
+                 img=(120, 160, 130.0), toggle=0.25, lidar_az=360, ext_boxes=False, min_h=-1000.0, max_h=1000.0,
+                 max_depth=6.0):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    def config(self):
+        return gie.make_config(self.voxel, self.size, cutoff_dist=self.cutoff_dist, fast_mode=self.fast_mode,
+                               for_motion_planner=self.for_motion_planner, ogm_min_h=self.min_h, ogm_max_h=self.max_h)
+
+    def frames_iter(self):
+        world = scenes.BoxWorld(self.seed, extent=self.extent, n_boxes=self.n_boxes, toggle_frac=self.toggle)
+        rows, cols, f = self.img
+        cx, cy = (cols - 1) / 2.0, (rows - 1) / 2.0
+        for k in range(self.frames):
+            pos, q = scenes.pose(k, self.voxel, delta_vox=self.delta_vox, yaw_deg=self.yaw_deg)
+            kind = self.sensor
+            if kind == "mixed":
+                kind = ("depth", "pointcloud", "multiscan")[k % 3]
+            if kind in ("depth", "pointcloud"):
+                depth = scenes.depth_frame(world, k, pos, q, rows=rows, cols=cols, fx=f, fy=f, cx=cx, cy=cy,
+                                           max_depth=self.max_depth)
+                if kind == "depth":
+                    yield pos, q, "depth", depth, dict(cx=cx, cy=cy, fx=f, fy=f, valid_nan=True)
+                else:
+                    yield pos, q, "pointcloud", scenes.depth_to_points(depth, f, f, cx, cy), {}
+            elif kind == "lidar_points":
+                pts, _ = scenes.lidar_frame(world, k, pos, q, az=self.lidar_az, max_range=30.0)
+                yield pos, q, "pointcloud", pts, {}
+            elif kind == "multiscan":
+                pts, _ = scenes.lidar_frame(world, k, pos, q, az=self.lidar_az * 4, max_range=30.0)
+                img = scenes.range_image(pts)
+                yield pos, q, "multiscan", img, dict(theta_inc=2.0 * np.pi / 440, theta_min=-np.pi,
+                                                     phi_inc=np.radians(2.0), phi_min=np.radians(-15.0))
+            elif kind == "scan2d":
+                pts, rng = scenes.lidar_frame(world, k, pos, q, rings=1, az=360, phi_min_deg=0.0, max_range=30.0)
+                r = np.where(np.isfinite(rng[0]), rng[0], np.nan).astype(np.float32)
+                yield pos, q, "scan2d", r, dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi + np.pi / 360)
+            else:
+                raise ValueError(kind)
+
+
+def _feed(m, kind, data, kw):
+    if kind == "depth":
+        m.ogm_depth(data, **kw)
+    elif kind == "pointcloud":
+        m.ogm_pointcloud(data)
+    elif kind == "multiscan":
+        m.ogm_multiscan(data, **kw)
+    elif kind == "scan2d":
+        m.ogm_scan2d(data, **kw)
+
+
+def probe_coords(pvt, size, rng, n=4000):
+    """Global voxels in and around the local volume (margin 12 voxels)."""
+    lo = np.array(pvt) - 12
+    hi = np.array(pvt) + np.array(size) + 12
+    return rng.integers(lo, hi, size=(n, 3)).astype(np.int32)
+
+
+def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False):
+    """make_a: reference mapper factory (oracle); make_b: mapper under test. Raises on mismatch.
+    Returns a list of per-frame stats dicts of the reference mapper."""
+    cfg = sc.config()
+    a, b = make_a(cfg), make_b(cfg)
+    rng = np.random.default_rng(sc.seed + 77)
+    out = []
+    try:
+        if sc.ext_boxes:
+            ll = np.array([[-100, -100, -100], [0.5, -1.0, -1.0]], np.float32)
+            ur = np.array([[100, 100, 100], [1.0, 1.0, 0.5]], np.float32)
+            act = np.array([0, 1], np.uint8)
+            a.set_ext_boxes(ll, ur, act)
+            b.set_ext_boxes(ll, ur, act)
+        for k, (pos, q, kind, data, kw) in enumerate(sc.frames_iter()):
+            a.set_pose(pos, q)
+            b.set_pose(pos, q)
+            assert a.pivot() == b.pivot()
+            _feed(a, kind, data, kw)
+            _feed(b, kind, data, kw)
+            oa, ob = a.read_ogm(), b.read_ogm()
+            for key in ("inst_type", "ray_count"):
+                bad = int((oa[key] != ob[key]).sum())
+                assert bad == 0, "%s frame %d: OGM %s differs in %d voxels" % (sc.name, k, key, bad)
+            a.fuse()
+            b.fuse()
+            ta, tb = a.read_local(edt=False, dist_sq=False, coc=False)["type"], b.read_local(edt=False, dist_sq=False, coc=False)["type"]
+            assert np.array_equal(ta, tb), "%s frame %d: fused types differ in %d voxels" % (sc.name, k, int((ta != tb).sum()))
+            a.batch_edt()
+            b.batch_edt()
+            ea, eb = a.read_batch_edt(), b.read_batch_edt()
+            assert np.array_equal(ea["dist_sq"], eb["dist_sq"]), "%s frame %d: batch EDT dist differs in %d voxels" % (
+                sc.name, k, int((ea["dist_sq"] != eb["dist_sq"]).sum()))
+            assert np.array_equal(ea["coc"], eb["coc"]), "%s frame %d: batch EDT coc differs in %d voxels" % (
+                sc.name, k, int((ea["coc"] != eb["coc"]).any(-1).sum()))
+            a.merge()
+            b.merge()
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), "%s frame %d: post-merge %s differs in %d voxels" % (
+                    sc.name, k, key, int((ra[key] != rb[key]).reshape(ra["type"].shape + (-1,)).any(-1).sum()))
+            # float distance: sqrtf of an int, tolerance 1e-6 relative (north_star)
+            assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0.0), "%s frame %d: edt differs" % (sc.name, k)
+            xyz = probe_coords(a.pivot(), sc.size, rng)
+            ga, gb = a.query_global(xyz), b.query_global(xyz)
+            for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+                assert np.array_equal(ga[key], gb[key]), "%s frame %d: global %s differs in %d probes" % (
+                    sc.name, k, key, int((ga[key] != gb[key]).reshape(len(xyz), -1).any(-1).sum()))
+            sa, sb = a.stats(), b.stats()
+            if check_stats:
+                for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_c",
+                            "blocks_total"):
+                    assert sa[key] == sb[key], "%s frame %d: stat %s %d != %d" % (sc.name, k, key, sa[key], sb[key])
+            if verbose:
+                print(sc.name, k, {kk: sa[kk] for kk in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_b",
+                                                         "visits_c", "levels_a", "levels_b", "levels_c")},
+                      "known", int((ra["type"] != 0).sum()))
+            out.append(sa)
+    finally:
+        a.close()
+        b.close()
+    return out

@@ -1,0 +1,59 @@
+"""The C-ABI library must load on a machine without a GPU, export every function declared in
+include/gie.h, and refuse to create a mapper when no device is present (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import gie
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "gie.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gie_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_full_path():
+    names = _declared()
+    for must in ("gie_create", "gie_destroy", "gie_set_pose", "gie_ogm_pointcloud", "gie_ogm_multiscan", "gie_ogm_depth",
+                 "gie_ogm_scan2d", "gie_set_ext_boxes", "gie_fuse", "gie_batch_edt", "gie_merge", "gie_step",
+                 "gie_read_local", "gie_read_costmap", "gie_query_global", "gie_sync", "gie_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(gie.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build_hip()
+    lib = C.CDLL(gie.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_gpu():
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    cfg = gie.make_config(0.1, (16, 16, 16))
+    with pytest.raises(RuntimeError) as e:
+        gie.Mapper(cfg)
+    assert "no HIP device" in str(e.value) or "failed" in str(e.value)
+
+
+def test_bad_config_is_rejected_by_the_checker_too(oracle_lib):
+    # volume beyond the 32-bit envelope key budget must be refused by the device library
+    lib = C.CDLL(gie.LIB_PATH)
+    lib.gie_create.restype = C.c_void_p
+    lib.gie_create.argtypes = [C.POINTER(gie.Config)]
+    lib.gie_last_error.restype = C.c_char_p
+    cfg = gie.make_config(0.05, (1024, 1024, 1024))
+    assert lib.gie_create(C.byref(cfg)) is None
+    assert b"too large" in lib.gie_last_error()

@@ -1,0 +1,115 @@
+"""GPU parity: libgie_hip.so (HIP kernels on the MI355X) against the CPU oracle through the
+C-ABI, every stage of every frame bit-exact (float EDT within 1e-6 relative)."""
+import numpy as np
+import pytest
+
+import gie
+import parity
+from oracle_py import OracleMapper, brute_force_edt
+
+pytestmark = pytest.mark.gpu
+
+SCENARIOS = [
+    parity.Scenario("depth", (48, 40, 24), sensor="depth", frames=14, delta_vox=5, yaw_deg=47.0),
+    parity.Scenario("raycast", (40, 40, 20), sensor="pointcloud", frames=12, delta_vox=5, yaw_deg=47.0),
+    parity.Scenario("vlp16", (48, 48, 16), sensor="multiscan", frames=12, delta_vox=5, yaw_deg=10.0),
+    parity.Scenario("scan2d", (40, 40, 8), sensor="scan2d", frames=6, delta_vox=3, yaw_deg=10.0),
+    parity.Scenario("mixed", (48, 40, 24), sensor="mixed", frames=12, delta_vox=5, yaw_deg=47.0),
+    parity.Scenario("fast_mode", (48, 40, 24), sensor="mixed", frames=12, delta_vox=5, yaw_deg=47.0, fast_mode=True),
+    parity.Scenario("planner_boxes", (40, 40, 24), sensor="mixed", frames=9, delta_vox=4, yaw_deg=30.0,
+                    for_motion_planner=True, ext_boxes=True, min_h=-0.8, max_h=1.0),
+    parity.Scenario("cutoff_small", (32, 32, 16), sensor="lidar_points", frames=12, delta_vox=6, yaw_deg=5.0,
+                    cutoff_dist=0.5),
+    parity.Scenario("odd_dims", (37, 29, 11), sensor="mixed", frames=9, delta_vox=3, yaw_deg=33.0),
+    parity.Scenario("flat_2d", (40, 40, 1), sensor="scan2d", frames=5, delta_vox=3, yaw_deg=10.0),
+    # BASELINE C1: 32^3 dense grid, one point-cloud frame
+    parity.Scenario("c1_32cube", (32, 32, 32), voxel=0.05, sensor="lidar_points", frames=1, delta_vox=0, yaw_deg=0.0,
+                    extent=(0.7, 0.7, 0.7), n_boxes=12),
+    # larger volumes: every EDT template (CP=2,4,8) and multi-block sweeps
+    parity.Scenario("mid_128", (128, 96, 64), voxel=0.05, sensor="mixed", frames=8, delta_vox=6, yaw_deg=25.0,
+                    extent=(3.0, 3.0, 1.2), img=(240, 320, 260.0)),
+    parity.Scenario("c4_slab", (320, 320, 40), voxel=0.05, sensor="lidar_points", frames=5, delta_vox=4, yaw_deg=2.0,
+                    extent=(8.0, 8.0, 1.0), n_boxes=60, cutoff_dist=5.0, lidar_az=900),
+    parity.Scenario("c2_256cube", (256, 256, 256), voxel=0.05, sensor="mixed", frames=4, delta_vox=4, yaw_deg=2.0,
+                    extent=(6.0, 6.0, 3.0), n_boxes=60, img=(480, 640, 525.0)),
+]
+
+
+@pytest.mark.parametrize("sc", SCENARIOS, ids=[s.name for s in SCENARIOS])
+def test_hip_matches_oracle(oracle_lib, sc):
+    parity.run_and_compare(sc, OracleMapper, gie.Mapper)
+
+
+@pytest.mark.parametrize("shape,dens,seed", [
+    ((64, 64, 64), 0.001, 1), ((100, 70, 33), 0.01, 2), ((130, 20, 257), 0.0005, 3), ((16, 300, 16), 0.02, 4),
+    ((512, 8, 8), 0.003, 5), ((8, 8, 512), 0.003, 6), ((8, 512, 8), 0.003, 7), ((65, 129, 1), 0.01, 8),
+    ((1, 1, 1), 1.0, 9), ((40, 40, 40), 1.0, 10),
+])
+def test_batch_edt_random_grids(oracle_lib, shape, dens, seed):
+    """EDT passes alone on random obstacle fields, through the full C-ABI: types are injected
+    by a point cloud (one point per obstacle voxel centre, sensor at a far corner so no ray
+    crosses the volume... simpler: compare HIP with the oracle, and the oracle with brute force
+    where the grid is small enough)."""
+    X, Y, Z = shape
+    rng = np.random.default_rng(seed)
+    occ = rng.random((Z, Y, X)) < dens
+    occ[Z // 2, Y // 2, X // 2] = True
+    w = 0.1
+    cfg = gie.make_config(w, shape, cutoff_dist=1.0)
+    zz, yy, xx = np.nonzero(occ)
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        pos = (0.0, 0.0, 0.0)
+        for m in (a, b):
+            m.set_pose(pos)
+        pv = np.array(a.pivot())
+        pts = ((np.stack([xx, yy, zz], -1) + pv) * np.float32(w)).astype(np.float32)
+        for m in (a, b):
+            m.ogm_pointcloud(pts)
+            m.fuse()
+            m.batch_edt()
+        ea, eb = a.read_batch_edt(), b.read_batch_edt()
+        assert np.array_equal(ea["dist_sq"], eb["dist_sq"])
+        assert np.array_equal(ea["coc"], eb["coc"])
+        ta = a.read_local(edt=False, dist_sq=False, coc=False)["type"]
+        if X * Y * Z <= 300000:
+            bf = brute_force_edt((ta == 2).astype(np.int8))
+            assert np.array_equal(eb["dist_sq"], bf)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_empty_volume(oracle_lib):
+    cfg = gie.make_config(0.1, (24, 20, 12))
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        for m in (a, b):
+            m.set_pose((0.0, 0.0, 0.0))
+            m.ogm_pointcloud(np.zeros((0, 3), np.float32))
+            m.fuse(); m.batch_edt(); m.merge()
+        ea, eb = a.read_batch_edt(), b.read_batch_edt()
+        assert np.array_equal(ea["coc"], eb["coc"]) and (eb["coc"] == -1).all()
+        ra, rb = a.read_local(), b.read_local()
+        for k in ("type", "dist_sq", "coc", "edt"):
+            assert np.array_equal(ra[k], rb[k])
+    finally:
+        a.close(); b.close()
+
+
+def test_costmap_payload(oracle_lib):
+    sc = parity.Scenario("cm", (32, 32, 16), sensor="depth", frames=2)
+    cfg = sc.config()
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        for pos, q, kind, data, kw in sc.frames_iter():
+            for m in (a, b):
+                m.update(pos, q, kind, data, **kw)
+        pa, ha = a.read_costmap()
+        pb, hb = b.read_costmap()
+        assert pa.tobytes() == pb.tobytes()
+        for f in ("x_size", "y_size", "z_size", "x_origin", "y_origin", "z_origin", "width", "type"):
+            assert getattr(ha, f) == getattr(hb, f)
+        assert pb.dtype.itemsize == 8
+    finally:
+        a.close(); b.close()
