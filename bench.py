@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — map-update throughput of the MI355X incremental-EDT path.
+
+One step = one full map update of the 512^3 local volume at 0.05 m voxels (set_pose →
+ray-cast OGM of a synthetic lidar point cloud → block alloc + fuse → batch EDT → Mark /
+frontiers / waves A,B,C / commit), i.e. VOLMAPNODE::publishMap's GPU work
+(src/volumetric_mapper.cpp:138-224).  Sensor frames are generated on the host beforehand and are
+resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 every rank owns one independent 512^3 tile (its own world and global map); there is
+no data-path collective yet (halo exchange is the next §8(e) step), so scaling is "weak".
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# algorithmic bytes per voxel per launch (reference field widths)
+ALG_BYTES = {
+    "ogm_classify": 1, "ray_finalize": 5, "fuse": 15, "edt_pass_y": 9, "edt_pass_x": 16, "edt_pass_z": 16,
+    "mark": 33, "frontiers": 13, "commit": 37,
+}
+EDT_UPDATE_BYTES = 124  # V3..V8
+
+
+def make_frames(scenes, voxel, nframes, seed, rings, az, delta_vox, yaw_deg):
+    world = scenes.BoxWorld(seed, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5,
+                            min_size=0.4, max_size=3.0)
+    out = []
+    for k in range(nframes):
+        pos, q = scenes.pose(k, voxel, delta_vox=delta_vox, yaw_deg=yaw_deg)
+        pts, _ = scenes.lidar_frame(world, k, pos, q, rings=rings, az=az, phi_min_deg=-30.0, phi_inc_deg=60.0 / rings,
+                                    max_range=30.0)
+        out.append((pos, q, pts))
+    return out
+
+
+def cpu_baseline(scenes, voxel, cutoff_dist):
+    """The CPU oracle (a scalar port of the reference's algorithm) on a bounded sample of the
+    same workload: same scene generator / sensor, 256^3 local grid, 3 frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_py import OracleMapper
+    import gie
+    size = (256, 256, 256)
+    frames = make_frames(scenes, voxel, 3, 5, 64, 1800, 8, 2.0)
+    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False)
+    m = OracleMapper(cfg)
+    t0 = time.perf_counter()
+    for pos, q, pts in frames:
+        m.update(pos, q, "pointcloud", pts)
+    dt = time.perf_counter() - t0
+    m.close()
+    n = size[0] * size[1] * size[2] * len(frames)
+    return {"value": round(n / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": "256^3 local grid, same scene/lidar generator, 3 map updates (%.1f s)" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
+    ap.add_argument("--voxel", type=float, default=0.05)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gie
+    from gie import scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    size = tuple(args.size)
+    n_vox = size[0] * size[1] * size[2]
+    cutoff_dist = 2.0
+    rings, az, delta_vox, yaw_deg = 64, 1800, 8, 2.0
+    nframes = args.warmup + args.steps
+    frames = make_frames(scenes, args.voxel, nframes, 5 + rank, rings, az, delta_vox, yaw_deg)
+    dev = torch.device("cuda", local_rank)
+    d_pts = [torch.from_numpy(p).to(dev) for _, _, p in frames]
+    torch.cuda.synchronize()
+
+    cfg = gie.make_config(args.voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank)
+    m = gie.Mapper(cfg)
+
+    def step(i):
+        pos, q, _ = frames[i]
+        m.set_pose(pos, q)
+        m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0])
+        m.step()
+
+    for i in range(args.warmup):
+        step(i)
+    m.sync()
+    m.profile_enable(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nframes):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    m.sync()  # surfaces device-side capacity errors
+    prof = m.profile_read()
+    st = m.stats()
+    known = None
+    if rank == 0:
+        ty = m.read_local(edt=False, dist_sq=False, coc=False)["type"]
+        known = float((ty != 0).mean())
+
+    t_max = dt
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * t_max / args.steps
+        hz = args.steps / t_max
+        value = world * n_vox * args.steps / t_max / 1e6
+        # dominant kernel of the timed region (HIP events on the mapper's own stream)
+        sweeps = {k: v for k, v in prof.items() if v[1] > 0}
+        total_kernel_ms = sum(v[0] for v in sweeps.values())
+        dom = max(sweeps, key=lambda k: sweeps[k][0])
+        dom_ms = sweeps[dom][0] / sweeps[dom][1]
+        roof = None
+        if dom in ALG_BYTES:
+            achieved = ALG_BYTES[dom] * n_vox / (dom_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_voxel": ALG_BYTES[dom]}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "avg_launch_ms": round(dom_ms, 4),
+                    "note": "dominant kernel is not volume-proportional (ray casting / BFS wave)"}
+        line = {
+            "metric": "edt_map_update_throughput", "value": round(value, 2), "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "hz": round(hz, 3),
+            "config": {"workload": "%dx%dx%d local grid @ %.2f m, synthetic %d-ring lidar point cloud (%d pts/frame), "
+                                   "ray-cast OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m"
+                                   % (size[0], size[1], size[2], args.voxel, rings, int(np.mean([p.shape[0] for p in d_pts])),
+                                      cutoff_dist),
+                       "tiles": "one independent %dx%dx%d tile per GPU" % size, "known_voxel_fraction": known,
+                       "wave_visits_last_frame": [st["visits_a"], st["visits_b"], st["visits_c"]],
+                       "blocks": st["blocks_total"]},
+            "edt_update_frac_of_hbm_peak": round(EDT_UPDATE_BYTES * n_vox * hz / (HBM_PEAK_GBS * 1e9), 4),
+            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(sweeps.items(), key=lambda kv: -kv[1][0])},
+            "kernel_time_fraction_of_step": round(total_kernel_ms / (1e3 * dt), 3),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scenes, args.voxel, cutoff_dist)
+        print(json.dumps(line))
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

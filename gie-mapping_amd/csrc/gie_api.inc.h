@@ -10,6 +10,11 @@
 #include <string>
 #include <vector>
 
+enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, GIE_K_ALLOC, GIE_K_FUSE, GIE_K_EDT_Y, GIE_K_EDT_X,
+       GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_NUM };
+static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
+       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "wave_c", "commit" };
+
 static thread_local std::string g_gie_err;
 static void gie_set_err(const std::string &s) { g_gie_err = s; }
 extern "C" const char *gie_last_error(void) { return g_gie_err.c_str(); }
@@ -199,7 +204,7 @@ extern "C" int gie_ogm_depth_dev(gie_mapper *m, const float *d_depth, const gie_
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_depth op; op.img = d_depth; op.p = *p;
-    be_vox(&m->be, m->c, op);
+    be_prof(&m->be, GIE_K_CLASSIFY, 0); be_vox(&m->be, m->c, op); be_prof(&m->be, GIE_K_CLASSIFY, 1);
     be_time(&m->be, 1);
     m->has_ogm = 1;
     return GIE_OK;
@@ -218,7 +223,7 @@ extern "C" int gie_ogm_multiscan_dev(gie_mapper *m, const float *d_ranges, const
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_multiscan op; op.img = d_ranges; op.p = *p;
-    be_vox(&m->be, m->c, op);
+    be_prof(&m->be, GIE_K_CLASSIFY, 0); be_vox(&m->be, m->c, op); be_prof(&m->be, GIE_K_CLASSIFY, 1);
     be_time(&m->be, 1);
     m->has_ogm = 1;
     return GIE_OK;
@@ -238,7 +243,7 @@ extern "C" int gie_ogm_scan2d(gie_mapper *m, const float *ranges, const gie_scan
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_scan2d op; op.img = m->d_sensor; op.p = *p;
-    be_vox(&m->be, m->c, op);
+    be_prof(&m->be, GIE_K_CLASSIFY, 0); be_vox(&m->be, m->c, op); be_prof(&m->be, GIE_K_CLASSIFY, 1);
     be_time(&m->be, 1);
     m->has_ogm = 1;
     return GIE_OK;
@@ -257,11 +262,11 @@ extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
     be_time(&m->be, 0);
     if (n > 0) {
         op_register_point r; r.xyz = d_xyz; r.g = m->d_pts_g;
-        be_lin(&m->be, m->c, r, n);                        /* registerLocObs */
+        be_prof(&m->be, GIE_K_RAY_REGISTER, 0); be_lin(&m->be, m->c, r, n); be_prof(&m->be, GIE_K_RAY_REGISTER, 1);   /* registerLocObs */
         op_free_ray fr; fr.g = m->d_pts_g;
-        be_lin(&m->be, m->c, fr, n);                       /* freeLocObs */
+        be_prof(&m->be, GIE_K_RAY_FREE, 0); be_lin(&m->be, m->c, fr, n); be_prof(&m->be, GIE_K_RAY_FREE, 1);           /* freeLocObs */
     }
-    be_vox(&m->be, m->c, op_raycast_finalize());           /* getAllocKeys */
+    be_prof(&m->be, GIE_K_RAY_FINAL, 0); be_vox(&m->be, m->c, op_raycast_finalize()); be_prof(&m->be, GIE_K_RAY_FINAL, 1);   /* getAllocKeys */
     be_time(&m->be, 1);
     m->has_ogm = 1;
     return GIE_OK;
@@ -301,13 +306,15 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_time(&m->be, 2);
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
+    be_prof(&m->be, GIE_K_ALLOC, 0);
     be_lin(&m->be, m->c, op_cell_flag(), m->ncell);
     be_exclusive_scan(&m->be, m->c.blk_new, m->d_rank, m->ncell);
     op_cell_insert ins; ins.flag = m->c.blk_new; ins.rank = m->d_rank;
     be_lin(&m->be, m->c, ins, m->ncell);
     be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
     be_lin(&m->be, m->c, op_cell_table(), m->ncell);
-    be_vox(&m->be, m->c, op_fuse());
+    be_prof(&m->be, GIE_K_ALLOC, 1);
+    be_prof(&m->be, GIE_K_FUSE, 0); be_vox(&m->be, m->c, op_fuse()); be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
 }
@@ -316,7 +323,7 @@ extern "C" int gie_batch_edt(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_batch_edt"); if (rc) return rc;
     be_time(&m->be, 4);
-    be_edt(&m->be, m->c);
+    be_edt(&m->be, m->c);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z) */
     be_time(&m->be, 5);
     return GIE_OK;
 }
@@ -325,11 +332,14 @@ extern "C" int gie_merge(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
-    be_vox(&m->be, m->c, op_mark());
-    be_vox(&m->be, m->c, op_frontier());
-    if (!m->c.fast_mode) { be_wave_a(&m->be, m->c); be_wave_b(&m->be, m->c); }
-    be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0);
-    be_vox(&m->be, m->c, op_commit());
+    be_prof(&m->be, GIE_K_MARK, 0); be_vox(&m->be, m->c, op_mark()); be_prof(&m->be, GIE_K_MARK, 1);
+    be_prof(&m->be, GIE_K_FRONTIER, 0); be_vox(&m->be, m->c, op_frontier()); be_prof(&m->be, GIE_K_FRONTIER, 1);
+    if (!m->c.fast_mode) {
+        be_prof(&m->be, GIE_K_WAVE_A, 0); be_wave_a(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_A, 1);
+        be_prof(&m->be, GIE_K_WAVE_B, 0); be_wave_b(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_B, 1);
+    }
+    be_prof(&m->be, GIE_K_WAVE_C, 0); be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
+    be_prof(&m->be, GIE_K_COMMIT, 0); be_vox(&m->be, m->c, op_commit()); be_prof(&m->be, GIE_K_COMMIT, 1);
     be_time(&m->be, 7);
     return GIE_OK;
 }
@@ -451,4 +461,23 @@ extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])
     if (!m || !pvt) { gie_set_err("gie_get_pivot: bad arguments"); return GIE_ERR_INVALID; }
     pvt[0] = m->c.pvt[0]; pvt[1] = m->c.pvt[1]; pvt[2] = m->c.pvt[2];
     return GIE_OK;
+}
+
+extern "C" int gie_profile_enable(gie_mapper *m, int on)
+{
+    if (!m) { gie_set_err("gie_profile_enable: null handle"); return GIE_ERR_INVALID; }
+    be_prof_enable(&m->be, on);
+    return GIE_OK;
+}
+extern "C" int gie_profile_read(gie_mapper *m, gie_kernel_time *out, int max_entries)
+{
+    if (!m || !out || max_entries < GIE_K_NUM) { gie_set_err("gie_profile_read: need room for all kernels"); return GIE_ERR_INVALID; }
+    float ms[GIE_K_NUM]; int n[GIE_K_NUM];
+    be_prof_collect(&m->be, ms, n, GIE_K_NUM);
+    for (int i = 0; i < GIE_K_NUM; i++) {
+        memset(out[i].name, 0, sizeof(out[i].name));
+        strncpy(out[i].name, gie_kernel_names[i], sizeof(out[i].name) - 1);
+        out[i].total_ms = ms[i]; out[i].launches = n[i];
+    }
+    return GIE_K_NUM;
 }

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "gie_kernels.hip.h"
@@ -20,7 +21,15 @@ struct be_state {
     hipEvent_t ev[GIE_NEV];
     int ev_set[GIE_NEV];
     void *scan_tmp; size_t scan_bytes;
+    /* per-kernel event profiling */
+    int prof_on;
+    std::vector<hipEvent_t> *pool;      /* event pool */
+    std::vector<int> *pending;          /* triples (kernel id, start event idx, stop event idx) */
+    int pool_used;
+    int open_start[32];
+    double acc_ms[32]; int acc_n[32];
 };
+#include <vector>
 
 static void gie_set_err(const std::string &s);
 #include <string>
@@ -37,11 +46,15 @@ static int be_init(be_state *b, int device)
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
+    b->prof_on = 0; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
+    for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; b->open_start[i] = -1; }
     return 0;
 }
 static void be_fini(be_state *b)
 {
     if (b->scan_tmp) (void)hipFree(b->scan_tmp);
+    for (hipEvent_t e : *b->pool) (void)hipEventDestroy(e);
+    delete b->pool; delete b->pending;
     for (int i = 0; i < GIE_NEV; i++) (void)hipEventDestroy(b->ev[i]);
     (void)hipStreamDestroy(b->stream);
 }
@@ -84,6 +97,42 @@ static void be_times(be_state *b, float *ogm, float *fuse, float *edt, float *me
     }
 }
 
+static int be_prof_event(be_state *b)
+{
+    if (b->pool_used == (int)b->pool->size()) { hipEvent_t e; GIE_HIP_OK(hipEventCreate(&e)); b->pool->push_back(e); }
+    const int i = b->pool_used++;
+    GIE_HIP_OK(hipEventRecord((*b->pool)[i], b->stream));
+    return i;
+}
+static void be_prof_resolve(be_state *b)
+{
+    if (b->pending->empty()) { b->pool_used = 0; return; }
+    GIE_HIP_OK(hipStreamSynchronize(b->stream));
+    for (size_t i = 0; i + 2 < b->pending->size(); i += 3) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, (*b->pool)[(*b->pending)[i + 1]], (*b->pool)[(*b->pending)[i + 2]]) == hipSuccess) {
+            b->acc_ms[(*b->pending)[i]] += ms; b->acc_n[(*b->pending)[i]] += 1;
+        }
+    }
+    b->pending->clear(); b->pool_used = 0;
+}
+static void be_prof(be_state *b, int id, int end)
+{
+    if (!b->prof_on) return;
+    if (!end) { if (b->pool_used > 4000) be_prof_resolve(b); b->open_start[id] = be_prof_event(b); }
+    else if (b->open_start[id] >= 0) {
+        const int e1 = be_prof_event(b);
+        b->pending->push_back(id); b->pending->push_back(b->open_start[id]); b->pending->push_back(e1);
+        b->open_start[id] = -1;
+    }
+}
+static void be_prof_enable(be_state *b, int on) { be_prof_resolve(b); b->prof_on = on; }
+static void be_prof_collect(be_state *b, float *ms, int *n, int num)
+{
+    be_prof_resolve(b);
+    for (int i = 0; i < num; i++) { ms[i] = (float)b->acc_ms[i]; n[i] = b->acc_n[i]; b->acc_ms[i] = 0; b->acc_n[i] = 0; }
+}
+
 template <class F> static void be_vox(be_state *b, const gie_ctx &c, const F &f)
 {
     dim3 blk(GIE_VOX_BX, GIE_VOX_BY, 1);
@@ -119,7 +168,7 @@ template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, b
         hipLaunchKernelGGL(k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, b->stream, c);
     } else {
         const size_t tile = ((size_t)c.Z * GIE_EDTZ_TS + 3) & ~(size_t)3;
-        const size_t lds = (2 * tile + (size_t)GIE_EDTZ_WAVES * LP) * 4 + (size_t)GIE_EDTZ_WAVES * (LP + 2) * 2;
+        const size_t lds = tile * 4 + (size_t)GIE_EDTZ_WAVES * LP * 8 + (size_t)GIE_EDTZ_WAVES * (LP + 2) * 2;
         static bool attr_done[17] = { false };
         if (!attr_done[CP]) {
             GIE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_z<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -140,11 +189,13 @@ static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass)
 static void be_edt(be_state *b, const gie_ctx &c)
 {
     dim3 gy((c.X + 255) / 256, c.Z);
+    be_prof(b, 6, 0);   /* GIE_K_EDT_Y */
     if (c.Y <= 256) hipLaunchKernelGGL(k_edt_y<8>, gy, dim3(256), 0, b->stream, c);
     else if (c.Y <= 512) hipLaunchKernelGGL(k_edt_y<16>, gy, dim3(256), 0, b->stream, c);
     else hipLaunchKernelGGL(k_edt_y<32>, gy, dim3(256), 0, b->stream, c);
-    gie_launch_edt_dim(b, c, c.X, false);
-    gie_launch_edt_dim(b, c, c.Z, true);
+    be_prof(b, 6, 1);
+    be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
+    be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
 }
 static void be_wave_a(be_state *b, const gie_ctx &c) { hipLaunchKernelGGL(k_wave_a, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c); }
 static void be_wave_b(be_state *b, const gie_ctx &c) { hipLaunchKernelGGL(k_wave_b, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c); }

@@ -113,49 +113,72 @@ __global__ __launch_bounds__(256) void k_edt_y(const gie_ctx c)
  *     argmin_i (u-i)² + a_i     with ties going to the smaller i
  * which is exactly what the reference's Meijster scan with truncating Sep() returns
  * (tests/test_oracle_edt.py::test_meijster_tie_rule pins the equivalence).
- * b[i] = (a_i << 10) | i in LDS; 32-bit keys, so (max a) + L² must stay below 2^22.
- * The argmin is monotone in u, so after a brute-force pass for every CP-th position the rest
- * is found by divide & conquer inside [site(left), site(right)]. */
-template <int CP>
-__device__ __forceinline__ void gie_row_argmin(const uint32_t *b, uint16_t *site, const int L, const int lane)
+ *
+ * Sites without a value (no obstacle behind them) can never win while a real one exists, so
+ * the row is first COMPACTED (wave64 ballot + prefix popcount) to its K real sites:
+ *     ce[j] = { (a << 10) | j ,  32 * i }            j = rank of site i among the real ones
+ * 32-bit keys  ((u-i)² + a) << 10 | j  order by value, then by rank (= by i); (max a) + L² must
+ * stay below 2^22 (checked in gie_create).  The argmin rank is monotone in u, so after a
+ * brute-force pass over the K sites for every CP-th position the rest is found by divide &
+ * conquer inside [rank(left), rank(right)].  jsite[u] receives the winning RANK. */
+__device__ __forceinline__ void gie_wave_sync()
 {
-    const int u0 = lane * CP;
-    {
-        uint32_t best = 0xffffffffu;
-        int dp = u0 << 5;
-        const int L4 = L & ~3;
-        const uint4 *b4 = reinterpret_cast<const uint4 *>(b);
-        for (int i = 0; i < L4; i += 4) {
-            const uint4 v = b4[i >> 2];
-            best = min(best, (uint32_t)__mul24(dp, dp) + v.x); dp -= 32;
-            best = min(best, (uint32_t)__mul24(dp, dp) + v.y); dp -= 32;
-            best = min(best, (uint32_t)__mul24(dp, dp) + v.z); dp -= 32;
-            best = min(best, (uint32_t)__mul24(dp, dp) + v.w); dp -= 32;
-        }
-        for (int i = L4; i < L; i++) { best = min(best, (uint32_t)__mul24(dp, dp) + b[i]); dp -= 32; }
-        site[u0] = (u0 < L) ? (uint16_t)(best & 1023u) : (uint16_t)(L - 1);
-        if (lane == 63) site[64 * CP] = (uint16_t)(L - 1);
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CP>
+__device__ __forceinline__ void gie_row_argmin(const uint2 *ce, uint16_t *jsite, const int K, const int L, const int lane)
+{
+    const int u0 = lane * CP;
+    {
+        uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
+        const int up = u0 << 5;
+        const int K4 = K & ~3;
+        const uint4 *ce2 = reinterpret_cast<const uint4 *>(ce);     /* two sites per 16-byte read */
+        for (int j = 0; j < K4; j += 4) {
+            const uint4 v0 = ce2[j >> 1], v1 = ce2[(j >> 1) + 1];
+            const int d0 = up - (int)(v0.y & 0xffffu), d1 = up - (int)(v0.w & 0xffffu);
+            const int d2 = up - (int)(v1.y & 0xffffu), d3 = up - (int)(v1.w & 0xffffu);
+            b0 = min(b0, (uint32_t)__mul24(d0, d0) + v0.x);
+            b1 = min(b1, (uint32_t)__mul24(d1, d1) + v0.z);
+            b2 = min(b2, (uint32_t)__mul24(d2, d2) + v1.x);
+            b3 = min(b3, (uint32_t)__mul24(d3, d3) + v1.z);
+        }
+        for (int j = K4; j < K; j++) { const uint2 v = ce[j]; const int d = up - (int)(v.y & 0xffffu); b0 = min(b0, (uint32_t)__mul24(d, d) + v.x); }
+        const uint32_t best = min(min(b0, b1), min(b2, b3));
+        jsite[u0] = (u0 < L) ? (uint16_t)(best & 1023u) : (uint16_t)(K - 1);
+        if (lane == 63) jsite[64 * CP] = (uint16_t)(K - 1);
+    }
+    gie_wave_sync();
 #pragma unroll
     for (int step = CP / 2; step >= 1; step >>= 1) {
 #pragma unroll
         for (int m = step; m < CP; m += 2 * step) {
             const int u = u0 + m;
-            const int lo = site[u - step], hi = site[u + step];
+            const int lo = jsite[u - step], hi = jsite[u + step];
             uint32_t best = 0xffffffffu;
             if (u < L) {
-                int dp = (u - lo) << 5;
-                for (int i = lo; i <= hi; i++) { best = min(best, (uint32_t)__mul24(dp, dp) + b[i]); dp -= 32; }
+                const int up = u << 5;
+                for (int j = lo; j <= hi; j++) { const uint2 v = ce[j]; const int d = up - (int)(v.y & 0xffffu); best = min(best, (uint32_t)__mul24(d, d) + v.x); }
             }
-            site[u] = (u < L) ? (uint16_t)(best & 1023u) : (uint16_t)(L - 1);
+            jsite[u] = (u < L) ? (uint16_t)(best & 1023u) : (uint16_t)(K - 1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        gie_wave_sync();
     }
+}
+
+/* wave64 stream compaction of the row's real sites; returns K.  `a` = value or ~0u (none),
+ * `hi16` is carried in the upper half of ce[].y (pass X keeps the site's closest y there). */
+__device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const bool valid, const uint32_t a, const int i, const uint32_t hi16, const int lane)
+{
+    const unsigned long long m = __ballot(valid);
+    if (valid) {
+        const int j = base + __popcll(m & ((1ull << lane) - 1ull));
+        ce[j] = make_uint2((a << 10) | (uint32_t)j, ((uint32_t)i << 5) | (hi16 << 16));
+    }
+    return base + __popcll(m);
 }
 
 /* ------------------------------------------------------------------ EDT pass X */
@@ -165,59 +188,53 @@ template <int CP>
 __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
 {
     constexpr int LP = 64 * CP;
-    __shared__ __attribute__((aligned(16))) uint32_t s_b[GIE_EDTX_WAVES][LP];
+    __shared__ __attribute__((aligned(16))) uint2 s_ce[GIE_EDTX_WAVES][LP];
     __shared__ uint16_t s_site[GIE_EDTX_WAVES][LP + 2];
-    __shared__ uint16_t s_cy[GIE_EDTX_WAVES][LP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * GIE_EDTX_WAVES + wave;        /* row = z*Y + y */
     if (row >= c.Y * c.Z) return;
     const int X = c.X;
     const int y = row % c.Y;
-    const uint32_t a_inf = (uint32_t)c.max_loc_dist_sq + 1u;
     const uint16_t *in = c.cy1 + (size_t)row * X;
-    uint32_t *b = s_b[wave];
-    uint16_t *site = s_site[wave];
-    uint16_t *cyr = s_cy[wave];
-    int any = 0;
-    for (int i = lane; i < X; i += 64) {
-        const uint16_t cy = in[i];
-        cyr[i] = cy;
-        uint32_t a = a_inf;
-        if (cy != 0xffff) { const int d = y - (int)cy; a = (uint32_t)(d * d); any = 1; }
-        b[i] = (a << 10) | (uint32_t)i;
+    uint2 *ce = s_ce[wave];
+    uint16_t *jsite = s_site[wave];
+    int K = 0;
+    for (int i0 = 0; i0 < X; i0 += 64) {
+        const int i = i0 + lane;
+        const uint16_t cy = (i < X) ? in[i] : (uint16_t)0xffff;
+        const int d = y - (int)cy;
+        K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane);
     }
     uint32_t *out = c.cxy2 + (size_t)row * X;
-    if (!__any(any)) {                                          /* slice without obstacle */
+    if (K == 0) {                                               /* slice without obstacle */
         for (int i = lane; i < X; i += 64) out[i] = 0xffffffffu;
         return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    gie_row_argmin<CP>(b, site, X, lane);
+    gie_wave_sync();
+    gie_row_argmin<CP>(ce, jsite, K, X, lane);
     for (int i = lane; i < X; i += 64) {
-        const int s = site[i];
-        out[i] = (uint32_t)s | ((uint32_t)cyr[s] << 16);       /* a valid site always wins when one exists */
+        const uint32_t e = ce[jsite[i]].y;
+        out[i] = ((e & 0xffffu) >> 5) | (e & 0xffff0000u);       /* cx | cy << 16 */
     }
 }
 
 /* ------------------------------------------------------------------ EDT pass Z */
 /* one workgroup per (y, tile of TX columns): the tile [Z][TX] of pass-X results is staged in
- * LDS with coalesced loads, each wave runs the envelope along z for its columns, the results
- * are staged back and written with coalesced stores. */
+ * LDS with coalesced loads, each wave runs the envelope along z for its columns and overwrites
+ * the column in place with the packed closest obstacle; dist² is recomputed from it at the
+ * coalesced write-out. */
 #define GIE_EDTZ_TX 16
 #define GIE_EDTZ_TS 17 /* padded LDS row stride: column walks hit distinct banks */
-#define GIE_EDTZ_WAVES 4
+#define GIE_EDTZ_WAVES 8
 template <int CP>
 __global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
 {
     constexpr int LP = 64 * CP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Z = c.Z, X = c.X, Y = c.Y;
-    uint32_t *tile = reinterpret_cast<uint32_t *>(smem);                    /* [Z][TX] cx|cy<<16 → bcoc */
-    uint32_t *dtile = tile + (size_t)Z * GIE_EDTZ_TS;                       /* [Z][TX] dist² out        */
-    uint32_t *s_b = dtile + (((size_t)Z * GIE_EDTZ_TS + 3) & ~(size_t)3);                        /* [WAVES][LP]              */
-    uint16_t *s_site = reinterpret_cast<uint16_t *>(s_b + GIE_EDTZ_WAVES * LP); /* [WAVES][LP+2]        */
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem);                               /* [Z][TS] cx|cy<<16 → bcoc */
+    uint2 *s_ce = reinterpret_cast<uint2 *>(tile + (((size_t)Z * GIE_EDTZ_TS + 3) & ~(size_t)3));  /* [WAVES][LP] */
+    uint16_t *s_site = reinterpret_cast<uint16_t *>(s_ce + GIE_EDTZ_WAVES * LP);       /* [WAVES][LP+2]            */
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * GIE_EDTZ_TX, y = blockIdx.y;
     const int tx = threadIdx.x & (GIE_EDTZ_TX - 1), tz = threadIdx.x / GIE_EDTZ_TX;
@@ -227,63 +244,57 @@ __global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
         tile[z * GIE_EDTZ_TS + tx] = (x < X) ? c.cxy2[(size_t)z * plane + (size_t)y * X + x] : 0xffffffffu;
     }
     __syncthreads();
-    const uint32_t a_inf = (uint32_t)c.max_loc_dist_sq + 1u;
-    const uint32_t mw2 = (uint32_t)(c.max_width * c.max_width);
-    uint32_t *b = s_b + wave * LP;
-    uint16_t *site = s_site + wave * (LP + 2);
+    uint2 *ce = s_ce + wave * LP;
+    uint16_t *jsite = s_site + wave * (LP + 2);
     for (int col = wave; col < GIE_EDTZ_TX; col += GIE_EDTZ_WAVES) {
         const int x = x0 + col;
         if (x >= X) break;
-        int any = 0;
-        for (int i = lane; i < Z; i += 64) {
-            const uint32_t v = tile[i * GIE_EDTZ_TS + col];
-            uint32_t a = a_inf;
-            if (v != 0xffffffffu) {
-                const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
-                a = (uint32_t)(dx * dx + dy * dy); any = 1;
-            }
-            b[i] = (a << 10) | (uint32_t)i;
+        int K = 0;
+        for (int i0 = 0; i0 < Z; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t v = (i < Z) ? tile[i * GIE_EDTZ_TS + col] : 0xffffffffu;
+            const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
+            K = gie_row_compact_push(ce, K, v != 0xffffffffu, (uint32_t)(dx * dx + dy * dy), i, 0u, lane);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (!__any(any)) {                                      /* the whole volume is empty */
-            for (int i = lane; i < Z; i += 64) { dtile[i * GIE_EDTZ_TS + col] = mw2; tile[i * GIE_EDTZ_TS + col] = GIE_BCOC_NONE; }
+        gie_wave_sync();
+        if (K == 0) {                                           /* the whole volume is empty */
+            for (int i = lane; i < Z; i += 64) tile[i * GIE_EDTZ_TS + col] = GIE_BCOC_NONE;
         } else {
-            gie_row_argmin<CP>(b, site, Z, lane);
+            gie_row_argmin<CP>(ce, jsite, K, Z, lane);
             /* gather first (own column only), then overwrite the column in place */
-            uint32_t oc[CP], od[CP];
+            uint32_t oc[CP];
 #pragma unroll
             for (int j = 0; j < CP; j++) {
                 const int i = lane + 64 * j;
                 if (i < Z) {
-                    const int s = site[i];
+                    const int s = (int)((ce[jsite[i]].y & 0xffffu) >> 5);
                     const uint32_t v = tile[s * GIE_EDTZ_TS + col];
-                    const int dz = i - s;
-                    od[j] = (b[s] >> 10) + (uint32_t)(dz * dz);
                     oc[j] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            gie_wave_sync();
 #pragma unroll
             for (int j = 0; j < CP; j++) {
                 const int i = lane + 64 * j;
-                if (i < Z) { dtile[i * GIE_EDTZ_TS + col] = od[j]; tile[i * GIE_EDTZ_TS + col] = oc[j]; }
+                if (i < Z) tile[i * GIE_EDTZ_TS + col] = oc[j];
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        gie_wave_sync();
     }
     __syncthreads();
+    const int32_t mw2 = c.max_width * c.max_width;
     for (int z = tz; z < Z; z += (64 * GIE_EDTZ_WAVES) / GIE_EDTZ_TX) {
         const int x = x0 + tx;
         if (x < X) {
             const size_t o = (size_t)z * plane + (size_t)y * X + x;
-            c.aux[o] = (int32_t)dtile[z * GIE_EDTZ_TS + tx];
-            c.bcoc[o] = tile[z * GIE_EDTZ_TS + tx];
+            const uint32_t bc = tile[z * GIE_EDTZ_TS + tx];
+            int32_t d = mw2;
+            if (bc != GIE_BCOC_NONE) {
+                const int dx = x - (int)(bc & 1023u), dy = y - (int)((bc >> 10) & 1023u), dz = z - (int)(bc >> 20);
+                d = dx * dx + dy * dy + dz * dz;
+            }
+            c.aux[o] = d;
+            c.bcoc[o] = bc;
         }
     }
 }

@@ -94,8 +94,14 @@ SIGNATURES = {
     "get_stats": (C.c_int, [_H, C.POINTER(FrameStats)]),
     "get_pivot": (C.c_int, [_H, c_i32p]),
 }
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("total_ms", C.c_float), ("launches", C.c_int32)]
+
+
 # entry points only the device library has
 DEVICE_ONLY = {
+    "profile_enable": (C.c_int, [_H, C.c_int]),
+    "profile_read": (C.c_int, [_H, C.POINTER(KernelTime), C.c_int]),
     "last_error": (C.c_char_p, []),
     "sync": (C.c_int, [_H]),
     "ogm_pointcloud_dev": (C.c_int, [_H, C.c_void_p, C.c_int]),

@@ -223,6 +223,17 @@ class Mapper(MapperBase):
     def __init__(self, cfg):
         super().__init__(load_library(), cfg)
 
+    def profile_enable(self, on=True):
+        self._chk(self._f["profile_enable"](self._h, int(on)))
+
+    def profile_read(self):
+        """{kernel name: (total_ms, launches)} since the last read (synchronises)."""
+        buf = (_capi.KernelTime * 32)()
+        n = self._f["profile_read"](self._h, buf, 32)
+        if n < 0:
+            raise RuntimeError(self._err())
+        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}
+
     # device-resident sensor frames (pointers are raw device addresses, e.g. torch .data_ptr())
     def ogm_depth_dev(self, dptr, rows, cols, cx, cy, fx, fy, valid_nan=False):
         p = CamParam(rows, cols, cx, cy, fx, fy, int(valid_nan))

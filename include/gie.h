@@ -169,6 +169,18 @@ int gie_read_costmap(gie_mapper *h, gie_seendist *payload, gie_costmap_hdr *hdr)
  * unallocated blocks come back as a default GlbVoxel (UNKNOWN, EMPTY_VALUE, EMPTY_KEY). */
 int gie_query_global(gie_mapper *h, const int32_t *xyz, int n, gie_voxel *out);
 int gie_get_stats(gie_mapper *h, gie_frame_stats *out);
+
+/* Per-kernel device time (the reference only has the two std::chrono spans of
+ * volumetric_mapper.cpp:153,187-203).  When enabled, every kernel launch of the frame is
+ * bracketed by HIP events on the mapper's stream; gie_profile_read synchronises, returns the
+ * accumulated totals since the last read and resets them. */
+typedef struct gie_kernel_time {
+    char name[24];
+    float total_ms;
+    int32_t launches;
+} gie_kernel_time;
+int gie_profile_enable(gie_mapper *h, int on);
+int gie_profile_read(gie_mapper *h, gie_kernel_time *out, int max_entries);
 /* local pivot _pvt (global coord of local voxel 0,0,0) of the current frame. */
 int gie_get_pivot(gie_mapper *h, int32_t pvt[3]);
 

@@ -26,6 +26,9 @@ static void be_h2d(be_state *, void *d, const void *h, size_t n) { memcpy(d, h, 
 static void be_d2h(be_state *, void *h, const void *d, size_t n) { memcpy(h, d, n); }
 static int be_sync(be_state *) { return 0; }
 static void be_time(be_state *, int) {}
+static void be_prof(be_state *, int, int) {}
+static void be_prof_enable(be_state *, int) {}
+static void be_prof_collect(be_state *, float *ms, int *n, int num) { for (int i = 0; i < num; i++) { ms[i] = 0; n[i] = 0; } }
 static void be_times(be_state *, float *a, float *b, float *c, float *d) { *a = *b = *c = *d = 0.f; }
 template <class F> static void be_vox(be_state *, const gie_ctx &c, const F &f)
 { for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) f(c, x, y, z); }
