@@ -2,7 +2,7 @@
 """bench.py — map-update throughput of the MI355X incremental-EDT path.
 
 One step = one full map update of the 512^3 local volume at 0.05 m voxels (set_pose →
-ray-cast OGM of a synthetic lidar point cloud → block alloc + fuse → batch EDT → Mark /
+OGM of a synthetic lidar point cloud → block alloc + fuse → batch EDT → Mark /
 frontiers / waves A,B,C / commit), i.e. VOLMAPNODE::publishMap's GPU work
 (src/volumetric_mapper.cpp:138-224).  Sensor frames are generated on the host beforehand and are
 resident in HBM when the timed region starts.
@@ -36,36 +36,57 @@ ALG_BYTES = {
 EDT_UPDATE_BYTES = 124  # V3..V8
 
 
-def make_frames(scenes, voxel, nframes, seed, rings, az, delta_vox, yaw_deg):
+# sensor models: name -> (rings, azimuth steps of the synthetic cloud, phi_min_deg, phi_inc_deg, range-image bins or None)
+SENSORS = {
+    # the reference's VLP-16 model MulScanParam(440,16,10,2pi/440,-pi,2deg,-15deg) (volumetric_mapper.cpp:327):
+    # synthetic 16x1800 point cloud → convertPyntCld binning → projective VLP_FAST kernel
+    "vlp16": (16, 1800, -15.0, 2.0, 440),
+    # a denser 64-ring unit, same projective path
+    "lidar64": (64, 1800, -30.0, 60.0 / 64, 1800),
+    # the same 64-ring cloud through the parallel ray-casting path (PNTCLD_RAYCAST)
+    "pointcloud": (64, 1800, -30.0, 60.0 / 64, None),
+}
+
+
+def make_frames(scenes, voxel, nframes, seed, sensor, delta_vox=8, yaw_deg=2.0):
+    rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
     world = scenes.BoxWorld(seed, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5,
                             min_size=0.4, max_size=3.0)
     out = []
     for k in range(nframes):
         pos, q = scenes.pose(k, voxel, delta_vox=delta_vox, yaw_deg=yaw_deg)
-        pts, _ = scenes.lidar_frame(world, k, pos, q, rings=rings, az=az, phi_min_deg=-30.0, phi_inc_deg=60.0 / rings,
+        pts, _ = scenes.lidar_frame(world, k, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc,
                                     max_range=30.0)
-        out.append((pos, q, pts))
+        npts = pts.shape[0]
+        if bins is not None:   # Vlp16MapMaker::convertPyntCld binning of the cloud (vlp16_map_maker.cpp:73-147)
+            pts = scenes.range_image(pts, scan_num=bins, ring_num=rings, phi_min_deg=phi_min, phi_inc_deg=phi_inc)
+        out.append((pos, q, pts, npts))
     return out
 
 
-def cpu_baseline(scenes, voxel, cutoff_dist):
+def cpu_baseline(scenes, voxel, cutoff_dist, sensor):
     """The CPU oracle (a scalar port of the reference's algorithm) on a bounded sample of the
     same workload: same scene generator / sensor, 256^3 local grid, 3 frames."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_py import OracleMapper
     import gie
     size = (256, 256, 256)
-    frames = make_frames(scenes, voxel, 3, 5, 64, 1800, 8, 2.0)
+    frames = make_frames(scenes, voxel, 3, 5, sensor)
+    rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
     cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False)
     m = OracleMapper(cfg)
     t0 = time.perf_counter()
-    for pos, q, pts in frames:
-        m.update(pos, q, "pointcloud", pts)
+    for pos, q, pts, _ in frames:
+        if bins is None:
+            m.update(pos, q, "pointcloud", pts)
+        else:
+            m.update(pos, q, "multiscan", pts, theta_inc=2.0 * math.pi / bins, theta_min=-math.pi,
+                     phi_inc=math.radians(phi_inc), phi_min=math.radians(phi_min))
     dt = time.perf_counter() - t0
     m.close()
     n = size[0] * size[1] * size[2] * len(frames)
     return {"value": round(n / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": "256^3 local grid, same scene/lidar generator, 3 map updates (%.1f s)" % dt}
+            "sample": "256^3 local grid, same scene/%s generator, 3 map updates (%.1f s)" % (sensor, dt)}
 
 
 def main():
@@ -76,6 +97,7 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sensor", choices=sorted(SENSORS), default="vlp16")
     args = ap.parse_args()
 
     import torch
@@ -97,25 +119,30 @@ def main():
     size = tuple(args.size)
     n_vox = size[0] * size[1] * size[2]
     cutoff_dist = 2.0
-    rings, az, delta_vox, yaw_deg = 64, 1800, 8, 2.0
+    rings, az, phi_min, phi_inc, bins = SENSORS[args.sensor]
     nframes = args.warmup + args.steps
-    frames = make_frames(scenes, args.voxel, nframes, 5 + rank, rings, az, delta_vox, yaw_deg)
+    frames = make_frames(scenes, args.voxel, nframes, 5 + rank, args.sensor)
     dev = torch.device("cuda", local_rank)
-    d_pts = [torch.from_numpy(p).to(dev) for _, _, p in frames]
+    d_pts = [torch.from_numpy(f[2]).to(dev) for f in frames]
     torch.cuda.synchronize()
 
     cfg = gie.make_config(args.voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank)
     m = gie.Mapper(cfg)
 
     def step(i):
-        pos, q, _ = frames[i]
+        pos, q = frames[i][0], frames[i][1]
         m.set_pose(pos, q)
-        m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0])
+        if bins is None:
+            m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0])
+        else:
+            m.ogm_multiscan_dev(d_pts[i].data_ptr(), bins, rings, 2.0 * math.pi / bins, -math.pi,
+                                math.radians(phi_inc), math.radians(phi_min))
         m.step()
 
     for i in range(args.warmup):
         step(i)
     m.sync()
+    st0 = m.stats()
     m.profile_enable(True)
     torch.cuda.synchronize()
     if dist is not None:
@@ -172,12 +199,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "hz": round(hz, 3),
-            "config": {"workload": "%dx%dx%d local grid @ %.2f m, synthetic %d-ring lidar point cloud (%d pts/frame), "
-                                   "ray-cast OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m"
-                                   % (size[0], size[1], size[2], args.voxel, rings, int(np.mean([p.shape[0] for p in d_pts])),
+            "config": {"workload": "%dx%dx%d local grid @ %.2f m, synthetic %d-ring x %d lidar point cloud (%d pts/frame) via %s, "
+                                   "OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m"
+                                   % (size[0], size[1], size[2], args.voxel, rings, az, int(np.mean([f[3] for f in frames])),
+                                      "parallel ray casting" if bins is None else "%dx%d range image (projective OGM)" % (rings, bins),
                                       cutoff_dist),
+                       "sensor": args.sensor,
                        "tiles": "one independent %dx%dx%d tile per GPU" % size, "known_voxel_fraction": known,
-                       "wave_visits_last_frame": [st["visits_a"], st["visits_b"], st["visits_c"]],
+                       "wave_visits_per_step": [round((st["total_visits_" + k] - st0["total_visits_" + k]) / args.steps, 1) for k in "abc"],
+                       "wave_levels_last_step": [st["levels_a"], st["levels_b"], st["levels_c"]],
                        "blocks": st["blocks_total"]},
             "edt_update_frac_of_hbm_peak": round(EDT_UPDATE_BYTES * n_vox * hz / (HBM_PEAK_GBS * 1e9), 4),
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(sweeps.items(), key=lambda kv: -kv[1][0])},
@@ -185,7 +215,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scenes, args.voxel, cutoff_dist)
+            line["cpu_baseline"] = cpu_baseline(scenes, args.voxel, cutoff_dist, args.sensor)
         print(json.dumps(line))
     m.close()
     if dist is not None:

@@ -172,7 +172,7 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
     c.stamp_base = (f + 1u) << 12;
     /* per-frame counters (the sticky error flag survives) */
     be_memset(&m->be, c.cnt, 0, GIE_CNT_ERR * sizeof(int32_t));
-    be_memset(&m->be, c.cnt + GIE_CNT_ERR + 1, 0, (GIE_CNT_NUM - GIE_CNT_ERR - 1) * sizeof(int32_t));
+    be_memset(&m->be, c.cnt + GIE_CNT_ERR + 1, 0, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
     m->has_pose = 1;
     return GIE_OK;
 }
@@ -360,6 +360,7 @@ static int gie_fetch_counters(gie_mapper *m)
         if (e & GIE_ERRF_POOL) s += " block pool (raise gie_config.max_blocks)";
         if (e & GIE_ERRF_QUEUE) s += " frontier queue";
         if (e & GIE_ERRF_HASH) s += " hash table";
+        if (e & GIE_ERRF_BARRIER) s += " (grid barrier timed out: wave kernel was not fully resident)";
         gie_set_err(s);
         return GIE_ERR_CAPACITY;
     }
@@ -454,6 +455,7 @@ extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
     s->visits_a = h[GIE_CNT_VIS_A]; s->visits_b = h[GIE_CNT_VIS_B]; s->visits_c = h[GIE_CNT_VIS_C];
     s->levels_a = h[GIE_CNT_LVL_A]; s->levels_b = h[GIE_CNT_LVL_B]; s->levels_c = h[GIE_CNT_LVL_C];
     be_times(&m->be, &s->us_ogm, &s->us_fuse, &s->us_edt, &s->us_merge);
+    memcpy(&s->total_visits_a, &h[GIE_CNT_TOT_A], 8); memcpy(&s->total_visits_b, &h[GIE_CNT_TOT_B], 8); memcpy(&s->total_visits_c, &h[GIE_CNT_TOT_C], 8);
     return rc;
 }
 extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])

@@ -17,6 +17,7 @@
 
 struct be_state {
     int device;
+    int num_cu;
     hipStream_t stream;
     hipEvent_t ev[GIE_NEV];
     int ev_set[GIE_NEV];
@@ -43,6 +44,7 @@ static int be_init(be_state *b, int device)
     if (device < 0 || device >= n) { gie_set_err("bad device_id"); return 1; }
     b->device = device;
     if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
+    { hipDeviceProp_t pr; b->num_cu = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 64; }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
@@ -197,8 +199,21 @@ static void be_edt(be_state *b, const gie_ctx &c)
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
 }
-static void be_wave_a(be_state *b, const gie_ctx &c) { hipLaunchKernelGGL(k_wave_a, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c); }
-static void be_wave_b(be_state *b, const gie_ctx &c) { hipLaunchKernelGGL(k_wave_b, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c); }
-static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds) { hipLaunchKernelGGL(k_wave_c, dim3(1), dim3(GIE_WAVE_THREADS), 0, b->stream, c, record_seeds); }
+/* one workgroup per CU: co-resident by construction (1024 threads, < 72 VGPRs, 16 B of LDS) */
+static void be_wave_a(be_state *b, const gie_ctx &c)
+{
+    GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
+    hipLaunchKernelGGL(k_wave_a, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c);
+}
+static void be_wave_b(be_state *b, const gie_ctx &c)
+{
+    GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
+    hipLaunchKernelGGL(k_wave_b, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c);
+}
+static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds)
+{
+    GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
+    hipLaunchKernelGGL(k_wave_c, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, record_seeds);
+}
 
 #include "gie_api.inc.h"

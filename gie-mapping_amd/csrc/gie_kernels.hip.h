@@ -300,74 +300,118 @@ __global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
 }
 
 /* ------------------------------------------------------------------ persistent BFS waves */
+/* One launch per wave type, one workgroup per CU, all co-resident; BFS levels and the phases
+ * inside a level are separated by a grid barrier (monotonic counter, agent-scope release /
+ * relaxed poll / acquire — cdna_hip_programming.md G16), so a whole wavefront costs one launch
+ * and no host round trip (the reference pays ≈3 PCIe round trips per level, wave_helper.h:20-90).
+ * Every shared word touched inside the phases goes through agent-scope accesses (gie_ld/gie_st/
+ * atomics in gie_ops.h); the per-entry rec* scratch is only re-read by the thread that wrote it
+ * (identical grid-stride mapping in every phase). */
 #define GIE_WAVE_THREADS 1024
+#define GIE_BAR_SPIN_LIMIT (1 << 22)
+
+#define GIE_WAVE_SOLO 4096   /* frontiers this small are finished by workgroup 0 alone (block barriers only) */
+
+struct gie_gridbar { int32_t *word; int epoch; int failed; int solo; };
+
+__device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
+{
+    __syncthreads();
+    if (gb.solo) return;                 /* one workgroup left: its waves share the CU's L2 path */
+    gb.epoch += 1;
+    if (threadIdx.x == 0 && !gb.failed) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int target = gb.epoch * (int)gridDim.x;
+        __hip_atomic_fetch_add(gb.word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(gb.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    /* a timed-out barrier poisons the launch: every block sees the sticky flag and leaves */
+    if (gie_ld(&c.cnt[GIE_CNT_ERR]) & GIE_ERRF_BARRIER) gb.failed = 1;
+}
+
+__device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : hi; }
 
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_a(const gie_ctx c)
 {
-    __shared__ int s_n;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_n = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_A] = s_n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
-    __syncthreads();
-    int n = s_n, cur = 0;
-    while (n > 0) {
-        if (tid == 0) { gie_st(&c.cnt[GIE_CNT_NEXT], 0); c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; }
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_a_phase1(c, c.qa[cur], e);
-        __syncthreads();
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], e);
-        __syncthreads();
-        if (tid == 0) { int m = gie_ld(&c.cnt[GIE_CNT_NEXT]); s_n = m < c.qcap_ab ? m : c.qcap_ab; }
-        __syncthreads();
-        n = s_n; cur ^= 1;
-        __syncthreads();
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0 };
+    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
+    const bool boss = (gtid == 0);
+    int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab), cur = 0, level = 0;
+    if (boss) { c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+    while (n > 0 && !gb.failed) {
+        if (!gb.solo && n <= GIE_WAVE_SOLO) {            /* same n everywhere → same decision everywhere */
+            if (blockIdx.x != 0) return;
+            gb.solo = 1;
+        }
+        const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
+        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
+        if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
+        for (int e = gid; e < n; e += gstep) gie_wave_a_phase1(c, c.qa[cur], e);
+        gie_grid_sync(gb, c);
+        if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
+        for (int e = gid; e < n; e += gstep) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], next_cnt, e);
+        gie_grid_sync(gb, c);
+        n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
     }
 }
 
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_b(const gie_ctx c)
 {
-    __shared__ int s_n;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int m = gie_ld(&c.cnt[GIE_CNT_B]); s_n = m < c.qcap_ab ? m : c.qcap_ab;
-        c.cnt[GIE_CNT_FRONT_B] = s_n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]);
-    }
-    __syncthreads();
-    int n = s_n, cur = 0, level = 0;
-    while (n > 0) {
-        if (tid == 0) { gie_st(&c.cnt[GIE_CNT_NEXT], 0); c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; }
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, c.qb[cur], e);
-        __syncthreads();
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], level, e);
-        __syncthreads();
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_b_phase3(c, c.qb[cur], e);
-        __syncthreads();
-        if (tid == 0) { int m = gie_ld(&c.cnt[GIE_CNT_NEXT]); s_n = m < c.qcap_ab ? m : c.qcap_ab; }
-        __syncthreads();
-        n = s_n; cur ^= 1; level++;
-        __syncthreads();
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0 };
+    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
+    const bool boss = (gtid == 0);
+    int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
+    if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+    while (n > 0 && !gb.failed) {
+        if (!gb.solo && n <= GIE_WAVE_SOLO) {            /* same n everywhere → same decision everywhere */
+            if (blockIdx.x != 0) return;
+            gb.solo = 1;
+        }
+        const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
+        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
+        if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
+        for (int e = gid; e < n; e += gstep) gie_wave_b_phase1(c, c.qb[cur], e);
+        gie_grid_sync(gb, c);
+        if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
+        for (int e = gid; e < n; e += gstep) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], next_cnt, level, e);
+        gie_grid_sync(gb, c);
+        for (int e = gid; e < n; e += gstep) gie_wave_b_phase3(c, c.qb[cur], e);
+        gie_grid_sync(gb, c);
+        n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
     }
 }
 
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, const int record_seeds)
 {
-    __shared__ int s_n;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int m = gie_ld(&c.cnt[GIE_CNT_C]); s_n = m < c.qcap_c ? m : c.qcap_c;
-        c.cnt[GIE_CNT_FRONT_C] = s_n;
-        if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = s_n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0 };
+    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
+    const bool boss = (gtid == 0);
+    int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;
+    if (boss) {
+        c.cnt[GIE_CNT_FRONT_C] = n; gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0);
+        if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
     }
-    __syncthreads();
-    int n = s_n, cur = 0, level = 0;
-    while (n > 0) {
-        if (tid == 0) { gie_st(&c.cnt[GIE_CNT_NEXT], 0); c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1; }
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_c_phase1(c, c.qc[cur], e);
-        __syncthreads();
-        for (int e = tid; e < n; e += GIE_WAVE_THREADS) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], level, e);
-        __syncthreads();
-        if (tid == 0) { int m = gie_ld(&c.cnt[GIE_CNT_NEXT]); s_n = m < c.qcap_c ? m : c.qcap_c; }
-        __syncthreads();
-        n = s_n; cur ^= 1; level++;
-        __syncthreads();
+    while (n > 0 && !gb.failed) {
+        if (!gb.solo && n <= GIE_WAVE_SOLO) {            /* same n everywhere → same decision everywhere */
+            if (blockIdx.x != 0) return;
+            gb.solo = 1;
+        }
+        const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
+        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
+        if (boss) { c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += n; }
+        for (int e = gid; e < n; e += gstep) gie_wave_c_phase1(c, c.qc[cur], e);
+        gie_grid_sync(gb, c);
+        if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
+        for (int e = gid; e < n; e += gstep) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], next_cnt, level, e);
+        gie_grid_sync(gb, c);
+        n = gie_clampi(gie_ld(next_cnt), c.qcap_c); cur ^= 1; level++;
     }
 }
 

@@ -473,7 +473,7 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, const uint64_t *cur, int e)
     c.rec3[e] = (lowered ? cd : 0) | (mask << 24);
 }
 
-GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int e)
+GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int32_t *next_cnt, int e)
 {
     int g[3];
     gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
@@ -505,7 +505,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
         gie_st(&c.g_coc[na], gie_pack_crd(lc[0], lc[1], lc[2]));
         gie_st(&c.g_wl[na], (int32_t)-c.map_ct);
         gie_st(&c.g_pair[na], key);
-        gie_push64(c, next, &c.cnt[GIE_CNT_NEXT], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+        gie_push64(c, next, next_cnt, c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
     }
 }
 
@@ -530,7 +530,7 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, const uint64_t *cur, int e)
     c.rec1[e] = coc;
 }
 
-GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int level, int e)
+GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int32_t *next_cnt, int level, int e)
 {
     if (c.rec0[e] == GIE_NOPROP) return;
     int g[3], cc[3];
@@ -552,10 +552,12 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
             gie_unpack_crd(gie_ld(&c.g_coc[na]), &nc[0], &nc[1], &nc[2]);
             if (gie_invalid_coc(nc[0], nc[1], nc[2])) continue;
             if (cand >= c.empty_value) continue;
-            const uint64_t old = gie_amin64(&c.g_pair[na], gie_pair_make(cand, par) | GIE_PAIR_NEW);
+            const uint64_t key = gie_pair_make(cand, par) | GIE_PAIR_NEW;
+            if (gie_ld(&c.g_pair[na]) <= key) continue;      /* values only decrease: the atomic could not win */
+            const uint64_t old = gie_amin64(&c.g_pair[na], key);
             if (gie_pair_dist(old) > cand) {
                 if (gie_axchg32(&c.g_wl[na], stamp) != stamp)
-                    gie_push64(c, next, &c.cnt[GIE_CNT_NEXT], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+                    gie_push64(c, next, next_cnt, c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
             }
         } else {
             const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
@@ -603,7 +605,7 @@ GIE_DEV void gie_wave_c_phase1(const gie_ctx &c, const int32_t *cur, int e)
     c.rec0[e] = gie_pair_par(pr);
 }
 
-GIE_DEV void gie_wave_c_phase2(const gie_ctx &c, const int32_t *cur, int32_t *next, int level, int e)
+GIE_DEV void gie_wave_c_phase2(const gie_ctx &c, const int32_t *cur, int32_t *next, int32_t *next_cnt, int level, int e)
 {
     const int id = gie_ld(&cur[e]);
     const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
@@ -619,10 +621,12 @@ GIE_DEV void gie_wave_c_phase2(const gie_ctx &c, const int32_t *cur, int32_t *ne
         const int nid = gie_lid(c, nx, ny, nz);
         const int cand = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
         if (cand >= c.empty_value) continue;
-        const uint64_t old = gie_amin64(&c.pair[nid], gie_pair_make(cand, par) | GIE_PAIR_NEW);
+        const uint64_t key = gie_pair_make(cand, par) | GIE_PAIR_NEW;
+        if (gie_ld(&c.pair[nid]) <= key) continue;           /* values only decrease: the atomic could not win */
+        const uint64_t old = gie_amin64(&c.pair[nid], key);
         if (gie_pair_dist(old) > cand) {
             if (gie_axchg32(&c.wl[nid], stamp) != stamp)
-                gie_push32(c, next, &c.cnt[GIE_CNT_NEXT], c.qcap_c, nid);
+                gie_push32(c, next, next_cnt, c.qcap_c, nid);
         }
     }
 }

@@ -124,18 +124,22 @@ typedef struct gie_ctx {
 
 enum {
     GIE_CNT_A = 0, GIE_CNT_B, GIE_CNT_C,        /* seed counts from obtainFrontiers */
-    GIE_CNT_NEXT,                               /* next-level count inside a wave */
+    GIE_CNT_NEXT, GIE_CNT_NEXT1,                /* next-level counts inside a wave (ping-pong) */
     GIE_CNT_ERR,                                /* sticky error flags */
     GIE_CNT_NEWBLK,                             /* blocks allocated this frame */
     GIE_CNT_VIS_A, GIE_CNT_VIS_B, GIE_CNT_VIS_C,
     GIE_CNT_LVL_A, GIE_CNT_LVL_B, GIE_CNT_LVL_C,
     GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
+    GIE_CNT_BAR,                                /* grid-barrier word, zeroed before every wave launch */
+    GIE_CNT_FRAME_END = 20,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
+    GIE_CNT_TOT_A = 20, GIE_CNT_TOT_B = 22, GIE_CNT_TOT_C = 24, /* 64-bit running totals (2 words each) */
     GIE_CNT_NUM = 32
 };
 #define GIE_ERRF_POOL 1
 #define GIE_ERRF_QUEUE 2
 #define GIE_ERRF_HASH 4
+#define GIE_ERRF_BARRIER 8
 
 /* stamps in ctx.wl (local) */
 #define GIE_WL_SEED(c) ((c).stamp_base + 1u)

@@ -108,6 +108,7 @@ typedef struct gie_frame_stats {
     int32_t visits_a, visits_b, visits_c; /* frontier entries expanded          */
     int32_t levels_a, levels_b, levels_c;
     float us_ogm, us_fuse, us_edt, us_merge; /* device time of the last step    */
+    int64_t total_visits_a, total_visits_b, total_visits_c; /* since gie_create */
 } gie_frame_stats;
 
 const char *gie_last_error(void);

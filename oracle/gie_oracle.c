@@ -93,6 +93,7 @@ typedef struct gie_oracle {
     /* ext boxes */
     int nbox; float *box_ll, *box_ur; uint8_t *box_act;
     gie_frame_stats st;
+    long long tot_vis[3];
 } gie_oracle;
 
 /* ------------------------------------------------------------------ small helpers */
@@ -979,6 +980,7 @@ int go_merge(gie_oracle *o)
     o->st.front_c = fc.n;
     wave_c(o, &fc);
     update_hash_batch(o);
+    o->tot_vis[0] += o->st.visits_a; o->tot_vis[1] += o->st.visits_b; o->tot_vis[2] += o->st.visits_c;
     q_free(&fa); q_free(&fb); q_free(&fc);
     return 0;
 }
@@ -1037,7 +1039,12 @@ int go_query_global(gie_oracle *o, const int32_t *xyz, int n, gie_voxel *out)
     }
     return 0;
 }
-int go_get_stats(gie_oracle *o, gie_frame_stats *s) { *s = o->st; s->blocks_total = o->nblocks; return 0; }
+int go_get_stats(gie_oracle *o, gie_frame_stats *s)
+{
+    *s = o->st; s->blocks_total = o->nblocks;
+    s->total_visits_a = o->tot_vis[0]; s->total_visits_b = o->tot_vis[1]; s->total_visits_c = o->tot_vis[2];
+    return 0;
+}
 int go_get_pivot(gie_oracle *o, int32_t p[3]) { p[0] = o->pvt[0]; p[1] = o->pvt[1]; p[2] = o->pvt[2]; return 0; }
 
 /* ------------------------------------------------------------------ ground truth for the EDT stage */

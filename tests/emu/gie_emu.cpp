@@ -77,9 +77,9 @@ static void be_wave_a(be_state *, const gie_ctx &c)
     int n = c.cnt[GIE_CNT_A], cur = 0;
     c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B];
     while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1;
+        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n;
         for (int e = 0; e < n; e++) gie_wave_a_phase1(c, c.qa[cur], e);
-        for (int e = 0; e < n; e++) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], e);
+        for (int e = 0; e < n; e++) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], &c.cnt[GIE_CNT_NEXT], e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1;
     }
 }
@@ -88,9 +88,9 @@ static void be_wave_b(be_state *, const gie_ctx &c)
     int n = c.cnt[GIE_CNT_B] < c.qcap_ab ? c.cnt[GIE_CNT_B] : c.qcap_ab, cur = 0, level = 0;
     c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
     while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1;
+        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n;
         for (int e = 0; e < n; e++) gie_wave_b_phase1(c, c.qb[cur], e);
-        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], level, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], &c.cnt[GIE_CNT_NEXT], level, e);
         for (int e = 0; e < n; e++) gie_wave_b_phase3(c, c.qb[cur], e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
     }
@@ -101,9 +101,9 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds)
     c.cnt[GIE_CNT_FRONT_C] = n;
     if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
     while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1;
+        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += n;
         for (int e = 0; e < n; e++) gie_wave_c_phase1(c, c.qc[cur], e);
-        for (int e = 0; e < n; e++) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], level, e);
+        for (int e = 0; e < n; e++) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], &c.cnt[GIE_CNT_NEXT], level, e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_c ? c.cnt[GIE_CNT_NEXT] : c.qcap_c; cur ^= 1; level++;
     }
 }
