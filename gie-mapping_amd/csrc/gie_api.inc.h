@@ -89,6 +89,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.wl = gie_dalloc<uint32_t>(m, N);
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
+    c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
+    c.cand[1] = gie_dalloc<uint64_t>(m, N, false);
     for (int i = 0; i < 3; i++) c.tdim[i] = cfg->local_size[i] / 8 + 3;
     m->ncell = c.tdim[0] * c.tdim[1] * c.tdim[2];
     c.blk_tab = gie_dalloc<int32_t>(m, (size_t)m->ncell, false);
@@ -131,6 +133,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
     be_memset(&m->be, c.hkeys, 0xff, (size_t)hcap * sizeof(uint64_t));
     be_memset(&m->be, c.lprop, 0xff, (size_t)bdr * sizeof(uint64_t));
+    be_memset(&m->be, c.cand[0], 0xff, N * sizeof(uint64_t));
+    be_memset(&m->be, c.cand[1], 0xff, N * sizeof(uint64_t));
     be_sync(&m->be);
     return m;
 }

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
 
 #define GIE_WAVE_SOLO 4096   /* frontiers this small are finished by workgroup 0 alone (block barriers only) */
 
-struct gie_gridbar { int32_t *word; int epoch; int failed; int solo; };
+struct gie_gridbar { int32_t *word; int epoch; int failed; int solo; int *s_fail; };
 
 __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
 {
@@ -330,27 +330,30 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
             if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        /* a timed-out barrier poisons the launch: every block sees the sticky flag and leaves */
+        *gb.s_fail = (gie_ld(&c.cnt[GIE_CNT_ERR]) & GIE_ERRF_BARRIER) ? 1 : 0;
     }
     __syncthreads();
-    /* a timed-out barrier poisons the launch: every block sees the sticky flag and leaves */
-    if (gie_ld(&c.cnt[GIE_CNT_ERR]) & GIE_ERRF_BARRIER) gb.failed = 1;
+    if (*gb.s_fail) gb.failed = 1;
 }
 
 __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : hi; }
 
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_a(const gie_ctx c)
 {
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0 };
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab), cur = 0, level = 0;
     if (boss) { c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+    if (n <= GIE_WAVE_SOLO) {                            /* small wave: workgroup 0 runs it alone, block barriers only */
+        if (blockIdx.x != 0) return;
+        gb.solo = 1;
+    }
+    const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
     while (n > 0 && !gb.failed) {
-        if (!gb.solo && n <= GIE_WAVE_SOLO) {            /* same n everywhere → same decision everywhere */
-            if (blockIdx.x != 0) return;
-            gb.solo = 1;
-        }
-        const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
         for (int e = gid; e < n; e += gstep) gie_wave_a_phase1(c, c.qa[cur], e);
@@ -364,17 +367,19 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_a(const gie_ctx c)
 
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_b(const gie_ctx c)
 {
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0 };
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
     if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+    if (n <= GIE_WAVE_SOLO) {                            /* small wave: workgroup 0 runs it alone, block barriers only */
+        if (blockIdx.x != 0) return;
+        gb.solo = 1;
+    }
+    const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
     while (n > 0 && !gb.failed) {
-        if (!gb.solo && n <= GIE_WAVE_SOLO) {            /* same n everywhere → same decision everywhere */
-            if (blockIdx.x != 0) return;
-            gb.solo = 1;
-        }
-        const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
         for (int e = gid; e < n; e += gstep) gie_wave_b_phase1(c, c.qb[cur], e);
@@ -388,30 +393,101 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_b(const gie_ctx c)
     }
 }
 
+/* One BFS level of wave C.  `wg_first`/`stride` are workgroup-uniform (every thread of the
+ * workgroup runs the same trips), so queue space is reserved ONCE PER WORKGROUP AND TRIP: ballot
+ * prefix inside the wave, LDS prefix across the 16 waves, one global atomicAdd — instead of up
+ * to six same-address atomics per thread. */
+struct gie_wg_scratch { int32_t tot[GIE_WAVE_THREADS / 64]; int32_t vis[GIE_WAVE_THREADS / 64]; int32_t base; };
+
+__device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cur, int level, int wg_first, int stride, gie_wg_scratch *sc)
+{
+    const int r = level % 3;
+    int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + r];
+    int32_t *next = c.qc[cur ^ 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int b0 = wg_first; b0 < n; b0 += stride) {
+        const int e = b0 + (int)threadIdx.x;
+        int nid[6];
+        int m = 0;
+        if (e < n) m = gie_wave_c_relax(c, c.qc[cur], level, e, nid);
+        int off[6], wtot = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const unsigned long long bm = __ballot((m >> k) & 1);
+            off[k] = wtot + __popcll(bm & lt);
+            wtot += __popcll(bm);
+        }
+        const int wvis = __popcll(__ballot((m >> 6) & 1));
+        if (lane == 0) { sc->tot[wave] = wtot; sc->vis[wave] = wvis; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0, v = 0;
+            for (int w = 0; w < GIE_WAVE_THREADS / 64; w++) { t += sc->tot[w]; v += sc->vis[w]; }
+            sc->base = t ? gie_aadd32(next_cnt, t) : 0;
+            if (v) gie_aadd32(&c.cnt[GIE_CNT_LV0 + r], v);
+        }
+        __syncthreads();
+        int wbase = sc->base;
+        for (int w = 0; w < wave; w++) wbase += sc->tot[w];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if ((m >> k) & 1) {
+                const int slot = wbase + off[k];
+                if (slot < c.qcap_c) gie_st(&next[slot], (int32_t)nid[k]);
+                else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+            }
+        }
+        __syncthreads();                       /* scratch is reused by the next trip */
+    }
+}
+__device__ __forceinline__ void gie_wave_c_account(const gie_ctx &c, int level)
+{
+    const int v = gie_ld(&c.cnt[GIE_CNT_LV0 + level % 3]);
+    if (v > 0) { c.cnt[GIE_CNT_VIS_C] += v; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += v; }
+}
+
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, const int record_seeds)
 {
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0 };
+    __shared__ gie_wg_scratch s_wg;
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;
     if (boss) {
-        c.cnt[GIE_CNT_FRONT_C] = n; gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0);
+        c.cnt[GIE_CNT_FRONT_C] = n;
+        for (int i = 0; i < 3; i++) { gie_st(&c.cnt[GIE_CNT_NEXT + i], 0); gie_st(&c.cnt[GIE_CNT_LV0 + i], 0); }
         if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
     }
+    if (n == 0) return;                        /* same n everywhere */
+    gie_grid_sync(gb, c);                      /* counters are clean before anybody pushes */
     while (n > 0 && !gb.failed) {
-        if (!gb.solo && n <= GIE_WAVE_SOLO) {            /* same n everywhere → same decision everywhere */
-            if (blockIdx.x != 0) return;
-            gb.solo = 1;
+        if (n <= GIE_WAVE_SOLO) {
+            /* solo episode: workgroup 0 runs levels with block barriers while the frontier stays
+             * small, the others wait at ONE grid barrier and then pick up the published state */
+            if (blockIdx.x == 0) {
+                do {
+                    if (boss) { gie_st(&c.cnt[GIE_CNT_NEXT + (level + 1) % 3], 0); gie_st(&c.cnt[GIE_CNT_LV0 + (level + 1) % 3], 0); }
+                    gie_wave_c_level(c, n, cur, level, 0, GIE_WAVE_THREADS, &s_wg);
+                    __syncthreads();
+                    if (boss) gie_wave_c_account(c, level);
+                    n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_NEXT + level % 3]), c.qcap_c); cur ^= 1; level++;
+                    __syncthreads();
+                } while (n > 0 && n <= GIE_WAVE_SOLO);
+                if (boss) { gie_st(&c.cnt[GIE_CNT_STATE], n); gie_st(&c.cnt[GIE_CNT_STATE + 1], cur); gie_st(&c.cnt[GIE_CNT_STATE + 2], level); }
+            }
+            gie_grid_sync(gb, c);
+            n = gie_ld(&c.cnt[GIE_CNT_STATE]); cur = gie_ld(&c.cnt[GIE_CNT_STATE + 1]); level = gie_ld(&c.cnt[GIE_CNT_STATE + 2]);
+            gie_grid_sync(gb, c);              /* everybody has read the state before it can be republished */
+        } else {
+            if (boss) { gie_st(&c.cnt[GIE_CNT_NEXT + (level + 1) % 3], 0); gie_st(&c.cnt[GIE_CNT_LV0 + (level + 1) % 3], 0); }
+            gie_wave_c_level(c, n, cur, level, (int)blockIdx.x * GIE_WAVE_THREADS, gsz, &s_wg);
+            gie_grid_sync(gb, c);
+            if (boss) gie_wave_c_account(c, level);
+            n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_NEXT + level % 3]), c.qcap_c); cur ^= 1; level++;
         }
-        const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
-        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
-        if (boss) { c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += n; }
-        for (int e = gid; e < n; e += gstep) gie_wave_c_phase1(c, c.qc[cur], e);
-        gie_grid_sync(gb, c);
-        if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
-        for (int e = gid; e < n; e += gstep) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], next_cnt, level, e);
-        gie_grid_sync(gb, c);
-        n = gie_clampi(gie_ld(next_cnt), c.qcap_c); cur ^= 1; level++;
     }
 }
 

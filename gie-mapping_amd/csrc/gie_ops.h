@@ -597,38 +597,65 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
 }
 
 /* ================================================================== wave C (lower_inside) */
-/* wave_core.cuh:353-393, two phases per level. rec0[e] = snapshot parent. */
-GIE_DEV void gie_wave_c_phase1(const gie_ctx &c, const int32_t *cur, int e)
+/* wave_core.cuh:353-393 with ONE grid barrier per BFS level.  Relaxations of level k do not
+ * touch `pair`: they atomicMin into the candidate plane cand[k&1]; the thread that later owns
+ * queue entry n merges cand[(k)&1][n] into pair[n] at the start of level k+1 (strict improvement
+ * of the distance, id_atomicMin's '>' — wave_core.cuh:16) and only then expands n.  Nobody else
+ * writes pair[n], so the parent an entry expands with is its level-start value without a
+ * snapshot phase.  The first candidate that turns a slot from "none" into a value enqueues the
+ * voxel (exactly once per level); entries whose candidate does not improve are dropped at the
+ * merge.  The pre-read of pair[m] only filters candidates that cannot improve (values only
+ * decrease), so a stale read costs a dropped entry, never a result.  Returns 1 when the entry
+ * expanded (= one "visit" of the canonical schedule). */
+/* merge + relax of one queue entry.  Returns bit 6 = the entry expanded ("visit"), bits 0..5 =
+ * neighbour k must be appended to the next queue (its id in nid_out[k]). */
+GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, int e, int nid_out[6])
 {
     const int id = gie_ld(&cur[e]);
-    const uint64_t pr = gie_aand64(&c.pair[id], ~GIE_PAIR_NEW);
-    c.rec0[e] = gie_pair_par(pr);
-}
-
-GIE_DEV void gie_wave_c_phase2(const gie_ctx &c, const int32_t *cur, int32_t *next, int32_t *next_cnt, int level, int e)
-{
-    const int id = gie_ld(&cur[e]);
+    uint64_t pr = gie_ld(&c.pair[id]);
+    if (level > 0) {
+        uint64_t *slot = &c.cand[(level - 1) & 1][id];
+        const uint64_t cd = gie_ld(slot);
+        gie_st(slot, (uint64_t)GIE_NOPROP);
+        if (!(gie_pair_dist(cd) < gie_pair_dist(pr))) return 0;
+        pr = cd;
+        gie_st(&c.pair[id], pr);
+    }
     const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
-    const uint64_t par = c.rec0[e];
+    const uint64_t par = gie_pair_par(pr);
     int cw[3];
     gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
     const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
-    const uint32_t stamp = c.stamp_base + 8u + (uint32_t)(level % 4000);
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    int cand[6];
+    uint64_t seen[6];
+    /* stage 1: six independent reads */
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        nid_out[k] = -1;
         if (!gie_in_loc(c, nx, ny, nz)) continue;
-        const int nid = gie_lid(c, nx, ny, nz);
-        const int cand = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
-        if (cand >= c.empty_value) continue;
-        const uint64_t key = gie_pair_make(cand, par) | GIE_PAIR_NEW;
-        if (gie_ld(&c.pair[nid]) <= key) continue;           /* values only decrease: the atomic could not win */
-        const uint64_t old = gie_amin64(&c.pair[nid], key);
-        if (gie_pair_dist(old) > cand) {
-            if (gie_axchg32(&c.wl[nid], stamp) != stamp)
-                gie_push32(c, next, next_cnt, c.qcap_c, nid);
-        }
+        const int d = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
+        if (d >= c.empty_value) continue;
+        nid_out[k] = gie_lid(c, nx, ny, nz); cand[k] = d;
     }
+    for (int k = 0; k < 6; k++) seen[k] = nid_out[k] >= 0 ? gie_ld(&c.pair[nid_out[k]]) : 0ull;
+    /* stage 2: candidates that can still improve */
+    uint64_t *plane = c.cand[level & 1];
+    int mask = 64;
+    for (int k = 0; k < 6; k++) {
+        if (nid_out[k] < 0 || !(cand[k] < gie_pair_dist(seen[k]))) continue;
+        if (gie_amin64(&plane[nid_out[k]], gie_pair_make(cand[k], par)) == GIE_NOPROP) mask |= 1 << k;
+    }
+    return mask;
+}
+
+/* sequential form (test-only emulation) */
+GIE_DEV int gie_wave_c_step(const gie_ctx &c, const int32_t *cur, int32_t *next, int32_t *next_cnt, int level, int e)
+{
+    int nid[6];
+    const int m = gie_wave_c_relax(c, cur, level, e, nid);
+    for (int k = 0; k < 6; k++) if (m & (1 << k)) gie_push32(c, next, next_cnt, c.qcap_c, nid[k]);
+    return m >> 6;
 }
 
 /* ================================================================== commit */

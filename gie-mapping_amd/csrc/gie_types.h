@@ -88,6 +88,7 @@ typedef struct gie_ctx {
     uint64_t *pair0;        /* Mark-time copy = the reference's _g/_coc_idx "read-only backups" */
     uint32_t *wl;           /* _loc_wave_layer as frame-stamped marks */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
+    uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */
     int tb0[3];             /* block coordinate of table cell 0 */
     int tdim[3];
@@ -124,7 +125,8 @@ typedef struct gie_ctx {
 
 enum {
     GIE_CNT_A = 0, GIE_CNT_B, GIE_CNT_C,        /* seed counts from obtainFrontiers */
-    GIE_CNT_NEXT, GIE_CNT_NEXT1,                /* next-level counts inside a wave (ping-pong) */
+    GIE_CNT_NEXT, GIE_CNT_NEXT1, GIE_CNT_NEXT2,  /* next-level counts inside a wave (rotating) */
+    GIE_CNT_LV0, GIE_CNT_LV1, GIE_CNT_LV2,      /* wave C: entries expanded in a level (rotating) */
     GIE_CNT_ERR,                                /* sticky error flags */
     GIE_CNT_NEWBLK,                             /* blocks allocated this frame */
     GIE_CNT_VIS_A, GIE_CNT_VIS_B, GIE_CNT_VIS_C,
@@ -132,9 +134,10 @@ enum {
     GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
     GIE_CNT_BAR,                                /* grid-barrier word, zeroed before every wave launch */
-    GIE_CNT_FRAME_END = 20,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
-    GIE_CNT_TOT_A = 20, GIE_CNT_TOT_B = 22, GIE_CNT_TOT_C = 24, /* 64-bit running totals (2 words each) */
-    GIE_CNT_NUM = 32
+    GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (n, cur, level) published after a solo episode */
+    GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
+    GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
+    GIE_CNT_NUM = 40
 };
 #define GIE_ERRF_POOL 1
 #define GIE_ERRF_QUEUE 2

@@ -101,9 +101,10 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds)
     c.cnt[GIE_CNT_FRONT_C] = n;
     if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
     while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_C] += n; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += n;
-        for (int e = 0; e < n; e++) gie_wave_c_phase1(c, c.qc[cur], e);
-        for (int e = 0; e < n; e++) gie_wave_c_phase2(c, c.qc[cur], c.qc[cur ^ 1], &c.cnt[GIE_CNT_NEXT], level, e);
+        c.cnt[GIE_CNT_NEXT] = 0;
+        int v = 0;
+        for (int e = 0; e < n; e++) v += gie_wave_c_step(c, c.qc[cur], c.qc[cur ^ 1], &c.cnt[GIE_CNT_NEXT], level, e);
+        if (v > 0) { c.cnt[GIE_CNT_VIS_C] += v; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += v; }
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_c ? c.cnt[GIE_CNT_NEXT] : c.qcap_c; cur ^= 1; level++;
     }
 }
