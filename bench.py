@@ -48,13 +48,14 @@ SENSORS = {
 }
 
 
-def make_frames(scenes, voxel, nframes, seed, sensor, delta_vox=8, yaw_deg=2.0):
+def make_frames(scenes, voxel, nframes, seed, sensor, delta_vox=8, yaw_deg=2.0, offset=(0.0, 0.0, 0.0)):
     rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
     world = scenes.BoxWorld(seed, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5,
                             min_size=0.4, max_size=3.0)
     out = []
     for k in range(nframes):
         pos, q = scenes.pose(k, voxel, delta_vox=delta_vox, yaw_deg=yaw_deg)
+        pos = tuple(np.float32(pos[i] + offset[i]) for i in range(3))
         pts, _ = scenes.lidar_frame(world, k, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc,
                                     max_range=30.0)
         npts = pts.shape[0]
@@ -121,7 +122,11 @@ def main():
     cutoff_dist = 2.0
     rings, az, phi_min, phi_inc, bins = SENSORS[args.sensor]
     nframes = args.warmup + args.steps
-    frames = make_frames(scenes, args.voxel, nframes, 5 + rank, args.sensor)
+    # rank r maps tile r of a (2x2x2 for 8 GPUs) arrangement of 512^3 tiles: same world, the
+    # tile's own sensor stream at the tile centre (independent tiles, no exchange yet)
+    from gie import tiling
+    offset = tiling.tile_centre_offset(rank, world, size, args.voxel)
+    frames = make_frames(scenes, args.voxel, nframes, 5, args.sensor, offset=offset)
     dev = torch.device("cuda", local_rank)
     d_pts = [torch.from_numpy(f[2]).to(dev) for f in frames]
     torch.cuda.synchronize()

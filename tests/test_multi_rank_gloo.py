@@ -1,0 +1,90 @@
+"""world_size-2 CPU test (gloo) of the rank plumbing bench.py uses for N > 1: tile assignment,
+per-rank independent mappers, barrier + max-reduce timing, whole-job aggregation."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import torch.distributed as dist
+    import gie
+    from gie import scenes, tiling
+    from emu_py import EmuMapper
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tile = (32, 32, 16)
+    origin, size = tiling.tile_of_rank(rank, world, tile)
+    off = tiling.tile_centre_offset(rank, world, tile, 0.1)
+    cfg = gie.make_config(0.1, size, cutoff_dist=1.0)
+    m = EmuMapper(cfg)
+    world_model = scenes.BoxWorld(3, extent=(3, 3, 1), n_boxes=20)
+    dist.barrier()
+    t0 = time.perf_counter()
+    steps = 3
+    for k in range(steps):
+        pos, q = scenes.pose(k, 0.1, delta_vox=2, yaw_deg=20.0)
+        depth = scenes.depth_frame(world_model, k, pos, q, rows=60, cols=80, fx=65, fy=65, cx=39.5, cy=29.5)
+        # every rank sees the shared sensor pose; its local volume is centred on its own tile
+        m.update((pos[0] + off[0], pos[1] + off[1], pos[2] + off[2]), q, "depth", depth, cx=39.5, cy=29.5, fx=65, fy=65,
+                 valid_nan=True)
+    dist.barrier()
+    dt = time.perf_counter() - t0 + 0.01 * rank          # rank 1 is "slower"
+    value, t_max = tiling.aggregate(dist, dt, size[0] * size[1] * size[2], steps)
+    pv = m.pivot()
+    m.close()
+    out.put((rank, origin, value, t_max, dt, pv))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    from gie import tiling
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, o0, v0, t0, d0, p0), (r1, o1, v1, t1, d1, p1) = res
+    assert o0 == (0, 0, 0) and o1 == (32, 0, 0)               # 2 ranks: split along x
+    assert v0 == pytest.approx(v1) and t0 == pytest.approx(t1)  # everyone agrees on the aggregate
+    assert t0 == pytest.approx(max(d0, d1))                    # max over ranks
+    assert v0 == pytest.approx(2 * 32 * 32 * 16 * 3 / t0 / 1e6)
+    assert p1[0] - p0[0] == 32 and p1[1] == p0[1] and p1[2] == p0[2]   # adjacent, non-overlapping local volumes
+
+
+def test_tile_layouts():
+    from gie import tiling
+    assert tiling.tile_grid(1) == (1, 1, 1) and tiling.tile_grid(2) == (2, 1, 1)
+    assert tiling.tile_grid(4) == (2, 2, 1) and tiling.tile_grid(8) == (2, 2, 2)
+    seen = set()
+    for r in range(8):
+        o, s = tiling.tile_of_rank(r, 8, (512, 512, 512))
+        assert all(v % 8 == 0 for v in o)
+        seen.add(o)
+    assert len(seen) == 8 and max(max(o) for o in seen) == 512   # 2x2x2 tiles of 512^3 = 1024^3
+    offs = np.array([tiling.tile_centre_offset(r, 8, (512, 512, 512), 0.05) for r in range(8)])
+    assert np.allclose(offs.mean(axis=0), 0.0) and np.allclose(np.abs(offs), 12.8)
+    with pytest.raises(ValueError):
+        tiling.tile_grid(3)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 rocpd (.db) output into the text summaries committed under profiles/.
+
+  kernel stats (the --stats table):  python tools/rocpd_summary.py stats  <kernel-trace.db>
+  HBM bytes per launch (PMC passes): python tools/rocpd_summary.py pmc <fetch.db> <write.db>
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE counts 128-B
+requests as 64 B for wide coalesced streams (MI355X_MICROARCH.md §HBM), so the read side is
+doubled ("fetch_corrected"); narrower access patterns are uncalibrated, which is stated in the
+output.  WRITE_SIZE is taken as reported.
+"""
+import json
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+SHORT = [
+    (r"k_vox<op_classify", "ogm_classify"), (r"op_register_point", "ray_register"), (r"op_free_ray", "ray_free"),
+    (r"op_raycast_finalize", "ray_finalize"), (r"op_fuse", "fuse"), (r"k_edt_y", "edt_pass_y"), (r"k_edt_x", "edt_pass_x"),
+    (r"k_edt_z", "edt_pass_z"), (r"op_mark", "mark"), (r"op_frontier", "frontiers"), (r"k_wave_a", "wave_a"),
+    (r"k_wave_b", "wave_b"), (r"k_wave_c", "wave_c"), (r"op_commit", "commit"), (r"op_cell_|k_block_init|k_pool_advance|rocprim", "block_alloc"),
+]
+
+
+def short(name):
+    for pat, s in SHORT:
+        if re.search(pat, name):
+            return s
+    return name[:48]
+
+
+def stats(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels").fetchall() if _has(db, "kernels", "name") else \
+        db.execute("select kernel_name, start, end from kernels").fetchall()
+    agg = defaultdict(list)
+    for n, s, e in rows:
+        agg[short(n)].append(e - s)
+    tot = sum(sum(v) for v in agg.values())
+    out = ["%-16s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        out.append("%-16s %8d %14d %12.0f %12d %12d %6.2f%%" % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100.0 * sum(v) / tot))
+    return "\n".join(out)
+
+
+def _has(db, view, col):
+    try:
+        db.execute("select %s from %s limit 1" % (col, view))
+        return True
+    except sqlite3.Error:
+        return False
+
+
+def pmc_per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    ncol = "kernel_name" if "kernel_name" in cols else "name"
+    ccol = "counter_name" if "counter_name" in cols else "pmc_name"
+    vcol = "value" if "value" in cols else "counter_value"
+    dcol = "dispatch_id" if "dispatch_id" in cols else "id"
+    rows = db.execute("select %s, %s, %s, %s from counters_collection" % (ncol, dcol, ccol, vcol)).fetchall()
+    per = defaultdict(lambda: defaultdict(float))
+    for n, d, c, v in rows:
+        if c == counter:
+            per[short(n)][d] += float(v)
+    return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items()}
+
+
+def pmc(fetch_db, write_db):
+    f = pmc_per_kernel(fetch_db, "FETCH_SIZE")
+    w = pmc_per_kernel(write_db, "WRITE_SIZE")
+    out = ["%-16s %8s %16s %18s %16s %18s" % ("kernel", "launches", "FETCH_SIZE_KiB", "fetch_corrected_MB", "WRITE_SIZE_KiB", "hbm_bytes_MB/launch")]
+    js = {}
+    for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, (0, 0))[0] + w.get(k, (0, 0))[0])):
+        fk, n = f.get(k, (0.0, 0))
+        wk, _ = w.get(k, (0.0, 0))
+        total = (2.0 * fk + wk) * 1024.0
+        js[k] = round(total)
+        out.append("%-16s %8d %16.0f %18.1f %16.0f %18.1f" % (k, n, fk, 2.0 * fk * 1024 / 1e6, wk, total / 1e6))
+    out.append("")
+    out.append("per launch = mean over the launches of the run; fetch_corrected = 2 x FETCH_SIZE (gfx950 wide-stream correction,")
+    out.append("MI355X_MICROARCH.md §HBM; uncalibrated for scattered 4/8-byte accesses); hbm_bytes = fetch_corrected + WRITE_SIZE.")
+    return "\n".join(out), js
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        print(stats(sys.argv[2]))
+    else:
+        txt, js = pmc(sys.argv[2], sys.argv[3])
+        print(txt)
+        if len(sys.argv) > 4:
+            json.dump(js, open(sys.argv[4], "w"), indent=1)
