@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <string>
 #include <vector>
 
@@ -85,8 +86,9 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.aux = gie_dalloc<int32_t>(m, N);
     c.bcoc = gie_dalloc<uint32_t>(m, N);
     c.pair = gie_dalloc<uint64_t>(m, N);      /* zero-initialised: SURVEY App. B #3 */
-    c.pair0 = gie_dalloc<uint64_t>(m, N);
     c.wl = gie_dalloc<uint32_t>(m, N);
+    for (int i = 0; i < 3; i++) c.tfd[i] = (cfg->local_size[i] + 7) / 8;
+    c.tflag = gie_dalloc<uint8_t>(m, (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2]);
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -128,6 +130,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.rec2 = gie_dalloc<uint64_t>(m, rec, false);
     c.rec3 = gie_dalloc<int32_t>(m, rec, false);
     c.cnt = gie_dalloc<int32_t>(m, GIE_CNT_NUM);
+    c.lvl_next = gie_dalloc<int32_t>(m, 2 * GIE_MAX_LEVELS);
+    c.lvl_vis = c.lvl_next + GIE_MAX_LEVELS;
     bool ok = c.cnt != nullptr;
     for (void *p : m->allocs) ok = ok && p != nullptr;
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
@@ -227,6 +231,13 @@ extern "C" int gie_ogm_multiscan_dev(gie_mapper *m, const float *d_ranges, const
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_multiscan op; op.img = d_ranges; op.p = *p;
+    {   /* conservative elevation bounds for the early-out (host double precision, widened) */
+        const double lo = (double)p->phi_min - 0.5 * (double)p->phi_inc, hi = (double)p->phi_min + ((double)p->ring_num - 0.5) * (double)p->phi_inc;
+        const double a = (lo < hi ? lo : hi) - 1e-3, b = (lo < hi ? hi : lo) + 1e-3;
+        op.fov_test = (a > -1.5 && b < 1.5) ? 1 : 0;
+        op.tan_lo = op.fov_test ? (float)(tan(a) - 1e-4 * (1.0 + fabs(tan(a)))) : 0.f;
+        op.tan_hi = op.fov_test ? (float)(tan(b) + 1e-4 * (1.0 + fabs(tan(b)))) : 0.f;
+    }
     be_prof(&m->be, GIE_K_CLASSIFY, 0); be_vox(&m->be, m->c, op); be_prof(&m->be, GIE_K_CLASSIFY, 1);
     be_time(&m->be, 1);
     m->has_ogm = 1;
@@ -318,7 +329,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
     be_lin(&m->be, m->c, op_cell_table(), m->ncell);
     be_prof(&m->be, GIE_K_ALLOC, 1);
-    be_prof(&m->be, GIE_K_FUSE, 0); be_vox(&m->be, m->c, op_fuse()); be_prof(&m->be, GIE_K_FUSE, 1);
+    be_prof(&m->be, GIE_K_FUSE, 0); be_vox_staged(&m->be, m->c, op_fuse()); be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
 }
@@ -336,14 +347,15 @@ extern "C" int gie_merge(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
+    be_memset(&m->be, m->c.tflag, 0, (size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]);
     be_prof(&m->be, GIE_K_MARK, 0); be_vox(&m->be, m->c, op_mark()); be_prof(&m->be, GIE_K_MARK, 1);
-    be_prof(&m->be, GIE_K_FRONTIER, 0); be_vox(&m->be, m->c, op_frontier()); be_prof(&m->be, GIE_K_FRONTIER, 1);
+    be_prof(&m->be, GIE_K_FRONTIER, 0); be_vox(&m->be, m->c, op_frontier());   /* staged variants of this op measured slower */ be_prof(&m->be, GIE_K_FRONTIER, 1);
     if (!m->c.fast_mode) {
         be_prof(&m->be, GIE_K_WAVE_A, 0); be_wave_a(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_A, 1);
         be_prof(&m->be, GIE_K_WAVE_B, 0); be_wave_b(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_B, 1);
     }
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
-    be_prof(&m->be, GIE_K_COMMIT, 0); be_vox(&m->be, m->c, op_commit()); be_prof(&m->be, GIE_K_COMMIT, 1);
+    be_prof(&m->be, GIE_K_COMMIT, 0); be_vox_staged(&m->be, m->c, op_commit()); be_prof(&m->be, GIE_K_COMMIT, 1);
     be_time(&m->be, 7);
     return GIE_OK;
 }

@@ -13,29 +13,70 @@
 #define GIE_DEVM __device__ __forceinline__
 #endif
 
+/* skip(c, id, x, y, z): cheap test (at most one small load, issued for a whole z-column up
+ * front by k_voxz) that is true only when operator() would do nothing for the voxel. */
 struct op_classify_depth { const float *img; gie_cam_param p;
+    GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_depth(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
-struct op_classify_multiscan { const float *img; gie_multiscan_param p;
+struct op_classify_multiscan { const float *img; gie_multiscan_param p; float tan_lo, tan_hi; int fov_test;
+    /* conservative field-of-view test: elevation surely outside [phi_min - inc/2, phi_max + inc/2]
+     * (bounds widened by 1e-3 rad on the host, far above the 2-ulp error of gie_atan2f) */
+    GIE_DEVM bool skip(const gie_ctx &c, int, int x, int y, int z) const {
+        if (!fov_test || gie_robot_sphere(c, x, y, z)) return false;
+        const float w = c.voxel_width;
+        float lx, ly, lz;
+        gie_se3_apply(c.G2L, (float)(x + c.pvt[0]) * w, (float)(y + c.pvt[1]) * w, (float)(z + c.pvt[2]) * w, &lx, &ly, &lz);
+        const float hor = sqrtf(ly * ly + lx * lx);
+        return lz > hor * tan_hi || lz < hor * tan_lo;
+    }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_multiscan(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
 struct op_classify_scan2d { const float *img; gie_scan_param p;
+    GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_scan2d(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
-struct op_raycast_finalize { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_raycast_finalize(c, x, y, z); } };
-struct op_fuse { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_fuse_voxel(c, x, y, z); } };
-struct op_mark { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_mark_voxel(c, x, y, z); } };
-struct op_commit { GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_commit_voxel(c, x, y, z); } };
+struct op_raycast_finalize {
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const { return c.ray_count[id] == 0 && !c.for_motion_planner; }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_raycast_finalize(c, x, y, z); } };
+/* staged ops (k_voxz_staged): st = per-voxel registers, load1/load2/finish as in gie_ops.h */
+struct op_fuse {
+    typedef gie_fuse_st st;
+    GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
+    GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_fuse_load1(c, id, x, y, z, s); }
+    GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_fuse_load2(c, s); }
+    GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_fuse_finish(c, id, x, y, z, s); }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_fuse_voxel(c, x, y, z); } };
+struct op_mark {
+    typedef gie_mark_st st;
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_mark_load1(c, id, x, y, z, s); }
+    GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_mark_load2(c, s); }
+    GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_mark_finish(c, id, x, y, z, s); }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_mark_voxel(c, x, y, z); } };
+struct op_commit {
+    typedef gie_commit_st st;
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_commit_load1(c, id, x, y, z, s); }
+    GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
+    GIE_DEVM void finish(const gie_ctx &c, int id, int, int, int, const st &s) const { gie_commit_finish(c, id, s); }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_commit_voxel(c, x, y, z); } };
 
 /* obtainFrontiers with wave64 ballot compaction of the C seeds: one atomicAdd per wave */
 struct op_frontier {
-    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
-        const int push = gie_frontier_voxel(c, x, y, z);
+    typedef gie_frontier_st st;
+    /* the ballot inside finish() works on whatever lanes are active, so skipping is safe */
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_frontier_load1(c, id, x, y, z, s); }
+    GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
+    GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { push_seed(c, gie_frontier_finish(c, id, x, y, z, s), id); }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { push_seed(c, gie_frontier_voxel(c, x, y, z), gie_lid(c, x, y, z)); }
+    GIE_DEVM void push_seed(const gie_ctx &c, const int push, const int id) const {
 #if defined(GIE_HOST_EMU)
-        if (push) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, gie_lid(c, x, y, z));
+        if (push) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, id);
 #else
         const unsigned long long m = __ballot(push);
         if (m) {
@@ -46,7 +87,7 @@ struct op_frontier {
             base = __shfl(base, leader);
             if (push) {
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < c.qcap_c) c.qc[0][slot] = gie_lid(c, x, y, z);
+                if (slot < c.qcap_c) c.qc[0][slot] = id;
                 else atomicOr(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
             }
         }

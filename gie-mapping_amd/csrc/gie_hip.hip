@@ -45,6 +45,8 @@ static int be_init(be_state *b, int device)
     b->device = device;
     if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
     { hipDeviceProp_t pr; b->num_cu = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 64; }
+    b->num_cu = b->num_cu >= 64 ? b->num_cu / 4 : b->num_cu;   /* wave grids: 64 workgroups measured best (barrier fan-in vs parallelism) */
+    { const char *e = getenv("GIE_WAVE_WGS"); if (e && atoi(e) > 0 && atoi(e) <= 256) b->num_cu = atoi(e); }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
@@ -138,9 +140,16 @@ static void be_prof_collect(be_state *b, float *ms, int *n, int num)
 template <class F> static void be_vox(be_state *b, const gie_ctx &c, const F &f)
 {
     dim3 blk(GIE_VOX_BX, GIE_VOX_BY, 1);
-    dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, c.Z);
-    hipLaunchKernelGGL(k_vox<F>, grd, blk, 0, b->stream, c, f);
+    dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, (c.Z + GIE_VOX_ZPER - 1) / GIE_VOX_ZPER);
+    hipLaunchKernelGGL(k_voxz<F>, grd, blk, 0, b->stream, c, f);
 }
+template <int ZP, class F> static void be_vox_staged_z(be_state *b, const gie_ctx &c, const F &f)
+{
+    dim3 blk(GIE_VOX_BX, GIE_VOX_BY, 1);
+    dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, (c.Z + ZP - 1) / ZP);
+    hipLaunchKernelGGL((k_voxz_staged<F, ZP>), grd, blk, 0, b->stream, c, f);
+}
+template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox_staged_z<8>(b, c, f); }
 template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f, int n)
 {
     if (n <= 0) return;
@@ -162,21 +171,27 @@ static void be_block_init(be_state *b, const gie_ctx &c, const int32_t *flag, co
     hipLaunchKernelGGL(k_pool_advance, dim3(1), dim3(1), 0, b->stream, c, flag, rank, ncell);
 }
 
-template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass)
+template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, const gie_ctx &c)
 {
     constexpr int LP = 64 * CP;
+    const size_t tile = ((size_t)c.Z * (TX + 1) + 3) & ~(size_t)3;
+    const size_t lds = tile * 4 + (size_t)WAVES * LP * 8 + (size_t)WAVES * (LP + 2) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        GIE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_z<CP, TX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_edt_z<CP, TX, WAVES>), dim3((c.X + TX - 1) / TX, c.Y), dim3(64 * WAVES), lds, b->stream, c);
+}
+template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass)
+{
     if (!zpass) {
         const int rows = c.Y * c.Z;
         hipLaunchKernelGGL(k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, b->stream, c);
+    } else if (CP <= 8) {
+        gie_launch_edt_z<CP, 16, 8>(b, c);      /* 2 workgroups per CU overlap load / envelope / store phases */
     } else {
-        const size_t tile = ((size_t)c.Z * GIE_EDTZ_TS + 3) & ~(size_t)3;
-        const size_t lds = tile * 4 + (size_t)GIE_EDTZ_WAVES * LP * 8 + (size_t)GIE_EDTZ_WAVES * (LP + 2) * 2;
-        static bool attr_done[17] = { false };
-        if (!attr_done[CP]) {
-            GIE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_z<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done[CP] = true;
-        }
-        hipLaunchKernelGGL(k_edt_z<CP>, dim3((c.X + GIE_EDTZ_TX - 1) / GIE_EDTZ_TX, c.Y), dim3(64 * GIE_EDTZ_WAVES), lds, b->stream, c);
+        gie_launch_edt_z<CP, 16, 8>(b, c);      /* Z up to 1024 */
     }
 }
 static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass)
@@ -213,6 +228,7 @@ static void be_wave_b(be_state *b, const gie_ctx &c)
 static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds)
 {
     GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
+    GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     hipLaunchKernelGGL(k_wave_c, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, record_seeds);
 }
 

@@ -31,6 +31,53 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_vox(const gie_ctx c,
     if (x < c.X && y < c.Y) f(c, x, y, z);
 }
 
+/* same sweep with a short z-column per thread: 16x fewer workgroups than k_vox (the sweeps over a
+ * mostly-unknown volume are bound by workgroup dispatch and exposed latency, not by HBM), and
+ * the skip tests of the whole column are issued back to back before any voxel is processed. */
+#define GIE_VOX_ZPER 8
+template <class F>
+__global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c, const F f)
+{
+    const int x = blockIdx.x * GIE_VOX_BX + threadIdx.x;
+    const int y = blockIdx.y * GIE_VOX_BY + threadIdx.y;
+    const int z0 = blockIdx.z * GIE_VOX_ZPER;
+    const bool in = (x < c.X && y < c.Y);
+    bool sk[GIE_VOX_ZPER];
+#pragma unroll
+    for (int k = 0; k < GIE_VOX_ZPER; k++) {
+        const int z = z0 + k;
+        sk[k] = !in || z >= c.Z || f.skip(c, in && z < c.Z ? gie_lid(c, x, y, z) : 0, x, y, z);
+    }
+#pragma unroll
+    for (int k = 0; k < GIE_VOX_ZPER; k++)
+        if (!sk[k]) f(c, x, y, z0 + k);
+}
+
+/* staged form: the loads of the whole z-column are in flight before anything is consumed */
+template <class F, int ZP>
+__global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz_staged(const gie_ctx c, const F f)
+{
+    const int x = blockIdx.x * GIE_VOX_BX + threadIdx.x;
+    const int y = blockIdx.y * GIE_VOX_BY + threadIdx.y;
+    const int z0 = blockIdx.z * ZP;
+    const bool in = (x < c.X && y < c.Y);
+    bool sk[ZP];
+    int id[ZP];
+    typename F::st s[ZP];
+#pragma unroll
+    for (int k = 0; k < ZP; k++) {
+        const int z = z0 + k;
+        id[k] = (in && z < c.Z) ? gie_lid(c, x, y, z) : 0;
+        sk[k] = !in || z >= c.Z || f.skip(c, id[k], x, y, z);
+    }
+#pragma unroll
+    for (int k = 0; k < ZP; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
+#pragma unroll
+    for (int k = 0; k < ZP; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
+#pragma unroll
+    for (int k = 0; k < ZP; k++) if (!sk[k]) f.finish(c, id[k], x, y, z0 + k, s[k]);
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const int n)
 {
@@ -223,42 +270,42 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
  * LDS with coalesced loads, each wave runs the envelope along z for its columns and overwrites
  * the column in place with the packed closest obstacle; dist² is recomputed from it at the
  * coalesced write-out. */
-#define GIE_EDTZ_TX 16
-#define GIE_EDTZ_TS 17 /* padded LDS row stride: column walks hit distinct banks */
-#define GIE_EDTZ_WAVES 8
-template <int CP>
-__global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
+/* TX columns per workgroup (TX*4-byte row segments in HBM), padded LDS row stride TX+1 so that
+ * column walks hit distinct banks, WAVES waves per workgroup. */
+template <int CP, int TX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c)
 {
     constexpr int LP = 64 * CP;
+    constexpr int TS = TX + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Z = c.Z, X = c.X, Y = c.Y;
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem);                               /* [Z][TS] cx|cy<<16 → bcoc */
-    uint2 *s_ce = reinterpret_cast<uint2 *>(tile + (((size_t)Z * GIE_EDTZ_TS + 3) & ~(size_t)3));  /* [WAVES][LP] */
-    uint16_t *s_site = reinterpret_cast<uint16_t *>(s_ce + GIE_EDTZ_WAVES * LP);       /* [WAVES][LP+2]            */
+    uint2 *s_ce = reinterpret_cast<uint2 *>(tile + (((size_t)Z * TS + 3) & ~(size_t)3));   /* [WAVES][LP] */
+    uint16_t *s_site = reinterpret_cast<uint16_t *>(s_ce + WAVES * LP);                /* [WAVES][LP+2]            */
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x0 = blockIdx.x * GIE_EDTZ_TX, y = blockIdx.y;
-    const int tx = threadIdx.x & (GIE_EDTZ_TX - 1), tz = threadIdx.x / GIE_EDTZ_TX;
+    const int x0 = blockIdx.x * TX, y = blockIdx.y;
+    const int tx = threadIdx.x & (TX - 1), tz = threadIdx.x / TX;
     const size_t plane = (size_t)X * Y;
-    for (int z = tz; z < Z; z += (64 * GIE_EDTZ_WAVES) / GIE_EDTZ_TX) {
+    for (int z = tz; z < Z; z += (64 * WAVES) / TX) {
         const int x = x0 + tx;
-        tile[z * GIE_EDTZ_TS + tx] = (x < X) ? c.cxy2[(size_t)z * plane + (size_t)y * X + x] : 0xffffffffu;
+        tile[z * TS + tx] = (x < X) ? c.cxy2[(size_t)z * plane + (size_t)y * X + x] : 0xffffffffu;
     }
     __syncthreads();
     uint2 *ce = s_ce + wave * LP;
     uint16_t *jsite = s_site + wave * (LP + 2);
-    for (int col = wave; col < GIE_EDTZ_TX; col += GIE_EDTZ_WAVES) {
+    for (int col = wave; col < TX; col += WAVES) {
         const int x = x0 + col;
         if (x >= X) break;
         int K = 0;
         for (int i0 = 0; i0 < Z; i0 += 64) {
             const int i = i0 + lane;
-            const uint32_t v = (i < Z) ? tile[i * GIE_EDTZ_TS + col] : 0xffffffffu;
+            const uint32_t v = (i < Z) ? tile[i * TS + col] : 0xffffffffu;
             const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
             K = gie_row_compact_push(ce, K, v != 0xffffffffu, (uint32_t)(dx * dx + dy * dy), i, 0u, lane);
         }
         gie_wave_sync();
         if (K == 0) {                                           /* the whole volume is empty */
-            for (int i = lane; i < Z; i += 64) tile[i * GIE_EDTZ_TS + col] = GIE_BCOC_NONE;
+            for (int i = lane; i < Z; i += 64) tile[i * TS + col] = GIE_BCOC_NONE;
         } else {
             gie_row_argmin<CP>(ce, jsite, K, Z, lane);
             /* gather first (own column only), then overwrite the column in place */
@@ -268,7 +315,7 @@ __global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
                 const int i = lane + 64 * j;
                 if (i < Z) {
                     const int s = (int)((ce[jsite[i]].y & 0xffffu) >> 5);
-                    const uint32_t v = tile[s * GIE_EDTZ_TS + col];
+                    const uint32_t v = tile[s * TS + col];
                     oc[j] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
                 }
             }
@@ -276,18 +323,18 @@ __global__ __launch_bounds__(64 * GIE_EDTZ_WAVES) void k_edt_z(const gie_ctx c)
 #pragma unroll
             for (int j = 0; j < CP; j++) {
                 const int i = lane + 64 * j;
-                if (i < Z) tile[i * GIE_EDTZ_TS + col] = oc[j];
+                if (i < Z) tile[i * TS + col] = oc[j];
             }
         }
         gie_wave_sync();
     }
     __syncthreads();
     const int32_t mw2 = c.max_width * c.max_width;
-    for (int z = tz; z < Z; z += (64 * GIE_EDTZ_WAVES) / GIE_EDTZ_TX) {
+    for (int z = tz; z < Z; z += (64 * WAVES) / TX) {
         const int x = x0 + tx;
         if (x < X) {
             const size_t o = (size_t)z * plane + (size_t)y * X + x;
-            const uint32_t bc = tile[z * GIE_EDTZ_TS + tx];
+            const uint32_t bc = tile[z * TS + tx];
             int32_t d = mw2;
             if (bc != GIE_BCOC_NONE) {
                 const int dx = x - (int)(bc & 1023u), dy = y - (int)((bc >> 10) & 1023u), dz = z - (int)(bc >> 20);
@@ -330,8 +377,9 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
             if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        /* a timed-out barrier poisons the launch: every block sees the sticky flag and leaves */
-        *gb.s_fail = (gie_ld(&c.cnt[GIE_CNT_ERR]) & GIE_ERRF_BARRIER) ? 1 : 0;
+        /* a timed-out barrier poisons the launch: this block leaves; the others time out at their
+         * next barrier (bounded spin), so nobody hangs */
+        if (spins > GIE_BAR_SPIN_LIMIT) *gb.s_fail = 1;
     }
     __syncthreads();
     if (*gb.s_fail) gb.failed = 1;
@@ -401,8 +449,7 @@ struct gie_wg_scratch { int32_t tot[GIE_WAVE_THREADS / 64]; int32_t vis[GIE_WAVE
 
 __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cur, int level, int wg_first, int stride, gie_wg_scratch *sc)
 {
-    const int r = level % 3;
-    int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + r];
+    int32_t *next_cnt = &c.lvl_next[level];
     int32_t *next = c.qc[cur ^ 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -425,7 +472,7 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cu
             int t = 0, v = 0;
             for (int w = 0; w < GIE_WAVE_THREADS / 64; w++) { t += sc->tot[w]; v += sc->vis[w]; }
             sc->base = t ? gie_aadd32(next_cnt, t) : 0;
-            if (v) gie_aadd32(&c.cnt[GIE_CNT_LV0 + r], v);
+            if (v) gie_aadd32(&c.lvl_vis[level], v);
         }
         __syncthreads();
         int wbase = sc->base;
@@ -441,12 +488,6 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cu
         __syncthreads();                       /* scratch is reused by the next trip */
     }
 }
-__device__ __forceinline__ void gie_wave_c_account(const gie_ctx &c, int level)
-{
-    const int v = gie_ld(&c.cnt[GIE_CNT_LV0 + level % 3]);
-    if (v > 0) { c.cnt[GIE_CNT_VIS_C] += v; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += v; }
-}
-
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, const int record_seeds)
 {
     __shared__ gie_wg_scratch s_wg;
@@ -458,36 +499,39 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, co
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;
     if (boss) {
         c.cnt[GIE_CNT_FRONT_C] = n;
-        for (int i = 0; i < 3; i++) { gie_st(&c.cnt[GIE_CNT_NEXT + i], 0); gie_st(&c.cnt[GIE_CNT_LV0 + i], 0); }
         if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
     }
     if (n == 0) return;                        /* same n everywhere */
-    gie_grid_sync(gb, c);                      /* counters are clean before anybody pushes */
-    while (n > 0 && !gb.failed) {
+    /* lvl_next[] / lvl_vis[] (one word per BFS level) were zeroed by the host before the launch,
+     * so no counter has to be reset or read back by one thread between levels */
+    while (n > 0 && !gb.failed && level < GIE_MAX_LEVELS - 1) {
         if (n <= GIE_WAVE_SOLO) {
             /* solo episode: workgroup 0 runs levels with block barriers while the frontier stays
              * small, the others wait at ONE grid barrier and then pick up the published state */
             if (blockIdx.x == 0) {
                 do {
-                    if (boss) { gie_st(&c.cnt[GIE_CNT_NEXT + (level + 1) % 3], 0); gie_st(&c.cnt[GIE_CNT_LV0 + (level + 1) % 3], 0); }
                     gie_wave_c_level(c, n, cur, level, 0, GIE_WAVE_THREADS, &s_wg);
                     __syncthreads();
-                    if (boss) gie_wave_c_account(c, level);
-                    n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_NEXT + level % 3]), c.qcap_c); cur ^= 1; level++;
-                    __syncthreads();
-                } while (n > 0 && n <= GIE_WAVE_SOLO);
+                    n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c); cur ^= 1; level++;
+                } while (n > 0 && n <= GIE_WAVE_SOLO && level < GIE_MAX_LEVELS - 1);
                 if (boss) { gie_st(&c.cnt[GIE_CNT_STATE], n); gie_st(&c.cnt[GIE_CNT_STATE + 1], cur); gie_st(&c.cnt[GIE_CNT_STATE + 2], level); }
             }
             gie_grid_sync(gb, c);
             n = gie_ld(&c.cnt[GIE_CNT_STATE]); cur = gie_ld(&c.cnt[GIE_CNT_STATE + 1]); level = gie_ld(&c.cnt[GIE_CNT_STATE + 2]);
             gie_grid_sync(gb, c);              /* everybody has read the state before it can be republished */
         } else {
-            if (boss) { gie_st(&c.cnt[GIE_CNT_NEXT + (level + 1) % 3], 0); gie_st(&c.cnt[GIE_CNT_LV0 + (level + 1) % 3], 0); }
             gie_wave_c_level(c, n, cur, level, (int)blockIdx.x * GIE_WAVE_THREADS, gsz, &s_wg);
             gie_grid_sync(gb, c);
-            if (boss) gie_wave_c_account(c, level);
-            n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_NEXT + level % 3]), c.qcap_c); cur ^= 1; level++;
+            n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c); cur ^= 1; level++;
         }
+    }
+    if (n > 0 && level >= GIE_MAX_LEVELS - 1 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    /* statistics once, after the wave */
+    if (boss) {
+        int lv = 0; long long vis = 0;
+        for (int l = 0; l < level; l++) { const int v = gie_ld(&c.lvl_vis[l]); if (v > 0) { lv++; vis += v; } }
+        c.cnt[GIE_CNT_VIS_C] = (int)vis; c.cnt[GIE_CNT_LVL_C] = lv;
+        *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += vis;
     }
 }
 

@@ -36,6 +36,12 @@ __device__ __forceinline__ int32_t gie_aor32(int32_t *p, int32_t v) { return __h
 #define GIE_DEV __device__ __forceinline__
 #endif
 
+#if defined(GIE_HOST_EMU)
+#define GIE_UNROLL6
+#else
+#define GIE_UNROLL6 _Pragma("unroll 6")
+#endif
+
 /* append to a frontier queue; overflow raises the sticky error flag */
 GIE_DEV void gie_push64(const gie_ctx &c, uint64_t *q, int32_t *counter, int cap, uint64_t v)
 {
@@ -273,17 +279,32 @@ GIE_DEV void gie_set_occ(uint8_t *occ, int8_t *type, float val, float a, int thr
     *type = (*occ > thresh) ? GIE_VOX_OCCUPIED : GIE_VOX_FREE;
 }
 
-/* updateHashOGMWithPntCld / updateHashOGMWithSensor, unify_helper.cuh:35-197 */
-GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
+
+struct gie_fuse_st { int count; int8_t nt, gt0; int a; uint8_t occ; int8_t ty; };
+
+GIE_DEV void gie_fuse_load1(const gie_ctx &c, int id, int x, int y, int z, gie_fuse_st &s)
 {
-    const int id = gie_lid(c, x, y, z);
-    int count = 0;
-    if (c.pntcld_mode) { count = c.ray_count[id]; c.ray_count[id] = 0; }
-    const int8_t nt = c.inst_type[id];
-    c.inst_type[id] = GIE_VOX_UNKNOWN;
+    s.count = c.pntcld_mode ? c.ray_count[id] : 0;
+    s.nt = c.inst_type[id];
+    s.gt0 = c.glb_type[id];
+    s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+}
+GIE_DEV void gie_fuse_load2(const gie_ctx &c, gie_fuse_st &s)
+{
+    if (s.a < 0) return;
+    s.occ = c.g_occ[s.a];
+    s.ty = c.g_type[s.a];
+}
+GIE_DEV void gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_fuse_st &s)
+{
+    const int count = s.count;
+    if (count != 0) c.ray_count[id] = 0;                                 /* write only what changes */
+    const int8_t nt = s.nt;
+    if (nt != GIE_VOX_UNKNOWN) c.inst_type[id] = GIE_VOX_UNKNOWN;
+    const int8_t gt0 = s.gt0;
+    const int a = s.a;
+    if (a < 0) { if (gt0 != GIE_VOX_UNKNOWN) c.glb_type[id] = GIE_VOX_UNKNOWN; return; }
     const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz = z + c.pvt[2];
-    const int a = gie_gvox_tab(c, gx, gy, gz);
-    if (a < 0) { c.glb_type[id] = GIE_VOX_UNKNOWN; return; }
     int occ_flag = 0;
     if (c.nbox > 0) {
         const float w = c.voxel_width;
@@ -292,8 +313,8 @@ GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
         else for (int i = 1; i < c.nbox; i++)
             if (c.box_act[i] && gie_inside_aabb(px, py, pz, c.box_ll + 3 * i, c.box_ur + 3 * i)) { occ_flag = 1; break; }
     }
-    uint8_t occ = c.g_occ[a];
-    int8_t ty = c.g_type[a];
+    uint8_t occ = s.occ;
+    int8_t ty = s.ty;
     const int8_t ty0 = ty;
     const uint8_t occ0 = occ;
     if (c.pntcld_mode) {
@@ -305,76 +326,133 @@ GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
     }
     if (occ != occ0) c.g_occ[a] = occ;
     if (ty != ty0) c.g_type[a] = ty;
-    c.glb_type[id] = ty;
+    if (gt0 != ty) c.glb_type[id] = ty;
+}
+/* updateHashOGMWithPntCld / updateHashOGMWithSensor, unify_helper.cuh:35-197 */
+GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    gie_fuse_st s;
+    gie_fuse_load1(c, id, x, y, z, s);
+    gie_fuse_load2(c, s);
+    gie_fuse_finish(c, id, x, y, z, s);
 }
 
 /* ================================================================== Mark */
 /* MarkLimitedObserve, unify_helper.cuh:201-273 */
-GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
+/* Split in stages so that a thread can keep the loads of several voxels in flight (the sweep is
+ * latency-bound): load1 = independent reads, load2 = reads that need load1's block slot,
+ * finish = arithmetic + writes.  gie_mark_voxel chains them for one voxel. */
+struct gie_mark_st { uint32_t bc; int dn; uint64_t pr; int a; int dold; uint64_t ococ; };
+
+GIE_DEV void gie_mark_load1(const gie_ctx &c, int id, int x, int y, int z, gie_mark_st &s)
 {
-    const int id = gie_lid(c, x, y, z);
-    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;
-    const uint32_t bc = c.bcoc[id];
+    s.bc = c.bcoc[id];
+    s.dn = c.aux[id];
+    s.pr = c.pair[id];
+    s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+}
+GIE_DEV void gie_mark_load2(const gie_ctx &c, gie_mark_st &s)
+{
+    if (s.a < 0) return;
+    s.dold = c.g_dist[s.a];
+    s.ococ = c.g_coc[s.a];
+}
+GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_mark_st &s)
+{
+    if (s.a < 0) return;
+    const uint32_t bc = s.bc;
     int cn[3];
-    const int dn = c.aux[id];
+    const int dn = s.dn;
     int auxv = dn;
-    uint64_t pr = c.pair[id];
-    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
-    if (a < 0) return;
+    uint64_t pr = s.pr;
     const int batch_invalid = (bc == GIE_BCOC_NONE);
     if (batch_invalid) {
         pr = gie_pair_make(c.empty_value, GIE_PAR_NONE);
         auxv = c.empty_value;
         cn[0] = cn[2] = 0; cn[1] = 16383;          /* the oracle's invalid marker: outside every wave range */
     } else { cn[0] = (int)(bc & 1023u); cn[1] = (int)((bc >> 10) & 1023u); cn[2] = (int)(bc >> 20); }
-    const int dold = c.g_dist[a];
+    const int dold = s.dold;
     int ox, oy, oz;
-    gie_unpack_crd(c.g_coc[a], &ox, &oy, &oz);
+    gie_unpack_crd(s.ococ, &ox, &oy, &oz);
     const int ol[3] = { ox - c.pvt[0], oy - c.pvt[1], oz - c.pvt[2] };
     if (dn > dold && !gie_in_loc(c, ol[0], ol[1], ol[2])) { cn[0] = ol[0]; cn[1] = ol[1]; cn[2] = ol[2]; auxv = dold; }
     const long long wx = (long long)cn[0] + c.pvt[0] - c.upvt[0];
     const long long wy = (long long)cn[1] + c.pvt[1] - c.upvt[1];
     const long long wz = (long long)cn[2] + c.pvt[2] - c.upvt[2];
+    int flag_tile = 1;                       /* conservative: the kept (stale) parent may point anywhere */
     if (!(wx >= 0 && wx < c.wr[0] && wy >= 0 && wy < c.wr[1] && wz >= 0 && wz < c.wr[2])) {
         pr = gie_pair_make(c.empty_value, gie_pair_par(pr));       /* parent id left as is */
         auxv = c.empty_value;
+        if (gie_pair_par(pr) == GIE_PAR_NONE) flag_tile = 0;        /* NONE is outside every wave range */
     } else {
         pr = gie_pair_make(auxv, gie_pack_wr((int)wx, (int)wy, (int)wz));
+        flag_tile = !gie_in_loc(c, cn[0], cn[1], cn[2]);
     }
+    if (flag_tile) c.tflag[gie_tile_index(c, x, y, z)] = 1;         /* all writers store 1 */
     if (auxv != dn) c.aux[id] = auxv;
     c.pair[id] = pr;
-    c.pair0[id] = pr;
+}
+GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;
+    gie_mark_st s;
+    gie_mark_load1(c, id, x, y, z, s);
+    gie_mark_load2(c, s);
+    gie_mark_finish(c, id, x, y, z, s);
 }
 
 /* ================================================================== obtainFrontiers */
 /* obtainFrontiers, unify_helper.cuh:275-446.  Returns a bit mask of what this voxel did so
  * that the kernel can compact the C-queue append with a wave ballot: bit0 = push to C. */
-GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
+struct gie_frontier_st { uint64_t p0; int8_t ty; };
+
+GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, gie_frontier_st &s)
 {
-    const int id = gie_lid(c, x, y, z);
-    const int8_t ty = c.glb_type[id];
+    s.ty = c.glb_type[id];
+    s.p0 = c.pair[id];      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
+}
+
+GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s)
+{
+    const int8_t ty = s.ty;
     if (ty == GIE_VOX_UNKNOWN) return 0;
-    const uint64_t p0 = c.pair0[id];
+    const uint64_t p0 = s.p0;
     int cw[3];
     gie_unpack_wr(gie_pair_par(p0), &cw[0], &cw[1], &cw[2]);
     const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
     const int cd = gie_pair_dist(p0);
     if (!gie_in_loc(c, cl[0], cl[1], cl[2])) return 0;
     int cur_in_q = 0, has_unknown = 0;
+    uint64_t seed = 0;
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    /* six neighbour types + six tile flags issued together */
+    int8_t ntys[6]; uint8_t ntf[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        const int inl = gie_in_loc(c, nx, ny, nz);
+        ntys[k] = c.glb_type[inl ? gie_lid(c, nx, ny, nz) : id];
+        ntf[k] = c.tflag[inl ? gie_tile_index(c, nx, ny, nz) : 0];
+    }
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
         if (gie_in_loc(c, nx, ny, nz)) {
             const int nid = gie_lid(c, nx, ny, nz);
-            const int8_t nty = c.glb_type[nid];
+            const int8_t nty = ntys[k];
             if (nty == GIE_VOX_UNKNOWN) { has_unknown = 1; continue; }
+            /* only a neighbour whose closest obstacle is outside the volume can seed C; Mark
+             * flagged the 8x8x8 tiles that contain one */
+            if (!ntf[k]) continue;
             int nw[3];
-            gie_unpack_wr(gie_pair_par(c.pair0[nid]), &nw[0], &nw[1], &nw[2]);
+            gie_unpack_wr(gie_pair_par(c.pair[nid]), &nw[0], &nw[1], &nw[2]);
             const int nl[3] = { nw[0] + c.upvt[0] - c.pvt[0], nw[1] + c.upvt[1] - c.pvt[1], nw[2] + c.upvt[2] - c.pvt[2] };
             if (!gie_in_loc(c, nl[0], nl[1], nl[2]) && gie_in_wr(c, nw[0], nw[1], nw[2])) {
                 const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
                 if (d < cd) {
-                    c.pair[id] = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+                    seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
                     cur_in_q = 1;
                 }
             }
@@ -395,7 +473,7 @@ GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
             if (!n_local && n_valid) {
                 const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
                 if (d < cd) {
-                    c.pair[id] = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+                    seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
                     cur_in_q = 1;
                 }
             }
@@ -417,9 +495,17 @@ GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
             }
         }
     }
-    if (cur_in_q) c.wl[id] = GIE_WL_SEED(c);
+    if (cur_in_q) { c.wl[id] = GIE_WL_SEED(c); c.cand[1][id] = seed; }   /* the pair the seed enters wave C with */
     if (ty == GIE_VOX_FREE && has_unknown) c.glb_type[id] = GIE_VOX_FNT;
     return cur_in_q;
+}
+GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return 0;
+    gie_frontier_st s;
+    gie_frontier_load1(c, id, x, y, z, s);
+    return gie_frontier_finish(c, id, x, y, z, s);
 }
 
 /* ================================================================== wave A (raise_outside) */
@@ -441,6 +527,7 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, const uint64_t *cur, int e)
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     int mask = 0, lowered = 0;
     uint64_t newcoc = GIE_KEY_EMPTY, newpair = GIE_NOPROP;
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
         if (gie_in_loc(c, ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2])) continue;
@@ -494,6 +581,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
     gie_unpack_wr(lpar, &lw[0], &lw[1], &lw[2]);
     const int lc[3] = { lw[0] + c.upvt[0], lw[1] + c.upvt[1], lw[2] + c.upvt[2] };
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         if (!(mask & (1 << k))) continue;
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
@@ -540,6 +628,7 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
     const int32_t stamp = (int32_t)(c.stamp_base + 8u + (uint32_t)(level % 4000));
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     int mask = 0;
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
         const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
@@ -580,6 +669,7 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
     gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
     const uint64_t par = c.rec0[e];
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         if (!(mask & (1 << k))) continue;
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
@@ -588,7 +678,7 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
         const uint64_t key = gie_pair_make(cand, par);
         if (gie_acas64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], key, GIE_NOPROP) != key) continue;
         const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
-        gie_st(&c.pair[nid], key);                         /* the reference's plain store, wave_core.cuh:338-341 */
+        gie_st(&c.cand[1][nid], key);                      /* the reference's plain store (wave_core.cuh:338-341), applied when wave C starts */
         const uint32_t w = gie_ld(&c.wl[nid]);
         if (w == GIE_WL_SEED(c) || w == GIE_WL_PUSHED(c)) continue;
         gie_st(&c.wl[nid], GIE_WL_PUSHED(c));              /* this thread is the only writer of nid in this phase */
@@ -612,12 +702,14 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
 GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, int e, int nid_out[6])
 {
     const int id = gie_ld(&cur[e]);
-    uint64_t pr = gie_ld(&c.pair[id]);
-    if (level > 0) {
+    uint64_t pr;
+    {
+        /* level 0: the seed pairs written by obtainFrontiers / wave B are assignments
+         * (unify_helper.cuh:334-335, wave_core.cuh:338-341); later levels: strict improvement */
         uint64_t *slot = &c.cand[(level - 1) & 1][id];
         const uint64_t cd = gie_ld(slot);
         gie_st(slot, (uint64_t)GIE_NOPROP);
-        if (!(gie_pair_dist(cd) < gie_pair_dist(pr))) return 0;
+        if (level > 0 && !(gie_pair_dist(cd) < gie_pair_dist(gie_ld(&c.pair[id])))) return 0;
         pr = cd;
         gie_st(&c.pair[id], pr);
     }
@@ -630,6 +722,7 @@ GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, in
     int cand[6];
     uint64_t seen[6];
     /* stage 1: six independent reads */
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
         nid_out[k] = -1;
@@ -638,10 +731,12 @@ GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, in
         if (d >= c.empty_value) continue;
         nid_out[k] = gie_lid(c, nx, ny, nz); cand[k] = d;
     }
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) seen[k] = nid_out[k] >= 0 ? gie_ld(&c.pair[nid_out[k]]) : 0ull;
     /* stage 2: candidates that can still improve */
     uint64_t *plane = c.cand[level & 1];
     int mask = 64;
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         if (nid_out[k] < 0 || !(cand[k] < gie_pair_dist(seen[k]))) continue;
         if (gie_amin64(&plane[nid_out[k]], gie_pair_make(cand[k], par)) == GIE_NOPROP) mask |= 1 << k;
@@ -654,24 +749,32 @@ GIE_DEV int gie_wave_c_step(const gie_ctx &c, const int32_t *cur, int32_t *next,
 {
     int nid[6];
     const int m = gie_wave_c_relax(c, cur, level, e, nid);
+    GIE_UNROLL6
     for (int k = 0; k < 6; k++) if (m & (1 << k)) gie_push32(c, next, next_cnt, c.qcap_c, nid[k]);
     return m >> 6;
 }
 
 /* ================================================================== commit */
 /* UpdateHashBatch, unify_helper.cuh:448-523 */
-GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
+struct gie_commit_st { int8_t ty; uint64_t pr; int a; };
+
+GIE_DEV void gie_commit_load1(const gie_ctx &c, int id, int x, int y, int z, gie_commit_st &s)
 {
-    const int id = gie_lid(c, x, y, z);
-    const int8_t ty = c.glb_type[id];
+    s.ty = c.glb_type[id];
+    s.pr = c.pair[id];
+    s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+}
+GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
+{
+    const int8_t ty = s.ty;
     if (ty == GIE_VOX_UNKNOWN) return;
-    const uint64_t pr = c.pair[id];
+    const uint64_t pr = s.pr;
     const int d = gie_pair_dist(pr);
     if (d == c.empty_value) {
         if (gie_pair_par(pr) == GIE_PAR_NONE) c.edt[id] = (float)c.max_loc_dist_sq;
         return;
     }
-    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    const int a = s.a;
     if (a < 0) return;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
@@ -680,6 +783,13 @@ GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
     c.edt[id] = sqrtf((float)d);
     c.g_pair[a] = pr;
     if (ty == GIE_VOX_FNT) c.g_type[a] = GIE_VOX_FNT;
+}
+GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    gie_commit_st s;
+    gie_commit_load1(c, id, x, y, z, s);
+    gie_commit_finish(c, id, s);
 }
 
 /* ================================================================== export for the readers */

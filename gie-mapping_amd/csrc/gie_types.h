@@ -85,8 +85,9 @@ typedef struct gie_ctx {
     int32_t *bdist;         /* untouched copy of the batch dist² (parity reads) */
     uint32_t *bcoc;         /* _coc_idx_aux: batch closest obstacle, local, packed */
     uint64_t *pair;         /* _dist_id_pair (persists across frames by local index) */
-    uint64_t *pair0;        /* Mark-time copy = the reference's _g/_coc_idx "read-only backups" */
     uint32_t *wl;           /* _loc_wave_layer as frame-stamped marks */
+    uint8_t *tflag;         /* per local 8x8x8 tile: some voxel's Mark-time closest obstacle lies outside the volume */
+    int tfd[3];             /* tile grid dims */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
     uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */
@@ -118,6 +119,7 @@ typedef struct gie_ctx {
     int32_t *qc[2];
     int qcap_ab, qcap_c;
     int32_t *cnt;           /* device counters, see GIE_CNT_* */
+    int32_t *lvl_next, *lvl_vis; /* wave C: next-frontier size / visits per BFS level (GIE_MAX_LEVELS words each) */
     /* per-entry scratch of the wave phases */
     uint64_t *rec0, *rec1, *rec2;
     int32_t *rec3;
@@ -139,6 +141,7 @@ enum {
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
     GIE_CNT_NUM = 40
 };
+#define GIE_MAX_LEVELS 4096
 #define GIE_ERRF_POOL 1
 #define GIE_ERRF_QUEUE 2
 #define GIE_ERRF_HASH 4
@@ -152,6 +155,7 @@ enum {
 GIE_HD int gie_in_loc(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.X && y >= 0 && y < c.Y && z >= 0 && z < c.Z; }
 GIE_HD int gie_in_wr(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.wr[0] && y >= 0 && y < c.wr[1] && z >= 0 && z < c.wr[2]; }
 GIE_HD int gie_lid(const gie_ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+GIE_HD int gie_tile_index(const gie_ctx &c, int x, int y, int z) { return ((z >> 3) * c.tfd[1] + (y >> 3)) * c.tfd[0] + (x >> 3); }
 GIE_HD int gie_vox_in_blk(int gx, int gy, int gz) { return ((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7); }
 GIE_HD int gie_d2(int ax, int ay, int az, int bx, int by, int bz)
 {

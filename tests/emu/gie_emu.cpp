@@ -32,6 +32,7 @@ static void be_prof_collect(be_state *, float *ms, int *n, int num) { for (int i
 static void be_times(be_state *, float *a, float *b, float *c, float *d) { *a = *b = *c = *d = 0.f; }
 template <class F> static void be_vox(be_state *, const gie_ctx &c, const F &f)
 { for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) f(c, x, y, z); }
+template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell)
