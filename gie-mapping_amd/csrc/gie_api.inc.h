@@ -83,12 +83,13 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.edt = gie_dalloc<float>(m, N);
     c.cy1 = gie_dalloc<uint16_t>(m, N);
     c.cxy2 = gie_dalloc<uint32_t>(m, N);
-    c.aux = gie_dalloc<int32_t>(m, N);
     c.bcoc = gie_dalloc<uint32_t>(m, N);
     c.pair = gie_dalloc<uint64_t>(m, N);      /* zero-initialised: SURVEY App. B #3 */
     c.wl = gie_dalloc<uint32_t>(m, N);
     for (int i = 0; i < 3; i++) c.tfd[i] = (cfg->local_size[i] + 7) / 8;
-    c.tflag = gie_dalloc<uint8_t>(m, (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2]);
+    const size_t ntile = (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2];
+    c.tflag = gie_dalloc<uint8_t>(m, 4 * ntile);     /* tflag | tknown | tunk | tsum, cleared together */
+    c.tknown = c.tflag + ntile; c.tunk = c.tflag + 2 * ntile; c.tsum = c.tflag + 3 * ntile;
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -347,9 +348,12 @@ extern "C" int gie_merge(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
-    be_memset(&m->be, m->c.tflag, 0, (size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]);
+    const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
+    be_memset(&m->be, m->c.tflag, 0, 3 * (size_t)ntile);
     be_prof(&m->be, GIE_K_MARK, 0); be_vox(&m->be, m->c, op_mark()); be_prof(&m->be, GIE_K_MARK, 1);
-    be_prof(&m->be, GIE_K_FRONTIER, 0); be_vox(&m->be, m->c, op_frontier());   /* staged variants of this op measured slower */ be_prof(&m->be, GIE_K_FRONTIER, 1);
+    be_prof(&m->be, GIE_K_FRONTIER, 0);
+    be_lin(&m->be, m->c, op_tile_summary(), ntile);
+    be_vox(&m->be, m->c, op_frontier());   /* staged variants of this op measured slower */ be_prof(&m->be, GIE_K_FRONTIER, 1);
     if (!m->c.fast_mode) {
         be_prof(&m->be, GIE_K_WAVE_A, 0); be_wave_a(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_A, 1);
         be_prof(&m->be, GIE_K_WAVE_B, 0); be_wave_b(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_B, 1);
@@ -418,12 +422,13 @@ extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
 {
     if (!m) { gie_set_err("gie_read_batch_edt: null handle"); return GIE_ERR_INVALID; }
     const size_t N = (size_t)m->c.N;
-    if (dist_sq) be_d2h(&m->be, dist_sq, m->c.aux, N * 4);
-    if (coc) {
-        int32_t *dc = (int32_t *)be_alloc(&m->be, N * 12, false);
-        op_export_bcoc op; op.coc = dc;
+    if (dist_sq || coc) {
+        int32_t *dd = dist_sq ? (int32_t *)be_alloc(&m->be, N * 4, false) : nullptr;
+        int32_t *dc = coc ? (int32_t *)be_alloc(&m->be, N * 12, false) : nullptr;
+        op_export_bcoc op; op.d = dd; op.coc = dc;
         be_lin(&m->be, m->c, op, m->c.N);
-        be_d2h(&m->be, coc, dc, N * 12); be_free(&m->be, dc);
+        if (dd) { be_d2h(&m->be, dist_sq, dd, N * 4); be_free(&m->be, dd); }
+        if (dc) { be_d2h(&m->be, coc, dc, N * 12); be_free(&m->be, dc); }
     }
     return gie_sync(m);
 }

@@ -52,6 +52,12 @@ struct op_fuse {
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_fuse_voxel(c, x, y, z); } };
 struct op_mark {
     typedef gie_mark_st st;
+    /* per z-column (8 voxels of one 8x8x8 tile): which of them are known */
+    GIE_DEVM void column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid) const {
+        const int t = gie_tile_index(c, x, y, z0);
+        if (known) c.tknown[t] = 1;                 /* all writers store 1 */
+        if (known != valid) c.tunk[t] = 1;
+    }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_mark_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_mark_load2(c, s); }
@@ -68,8 +74,9 @@ struct op_commit {
 /* obtainFrontiers with wave64 ballot compaction of the C seeds: one atomicAdd per wave */
 struct op_frontier {
     typedef gie_frontier_st st;
-    /* the ballot inside finish() works on whatever lanes are active, so skipping is safe */
-    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    /* the ballot inside finish() works on whatever lanes are active, so skipping is safe.
+     * tsum == 0: nothing in or around this 8x8x8 tile can make obtainFrontiers act. */
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const { return c.tsum[gie_tile_index(c, x, y, z)] == 0 || c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_frontier_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
     GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { push_seed(c, gie_frontier_finish(c, id, x, y, z, s), id); }
@@ -95,11 +102,27 @@ struct op_frontier {
     }
 };
 
+/* tile summary for obtainFrontiers: a voxel of tile t can only act (C seed, A/B seed, FNT flip)
+ * when t touches the volume faces, or t / a face-adjacent tile holds an unknown voxel or a
+ * voxel whose Mark-time closest obstacle lies outside the volume */
+struct op_tile_summary { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
+        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+        uint8_t v = 0;
+        if (c.tknown[t]) {
+            if (tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1) v = 1;
+            else {
+                const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
+                v = c.tunk[t] | c.tflag[t] | c.tunk[t - sx] | c.tflag[t - sx] | c.tunk[t + sx] | c.tflag[t + sx] | c.tunk[t - sy] | c.tflag[t - sy]
+                  | c.tunk[t + sy] | c.tflag[t + sy] | c.tunk[t - sz] | c.tflag[t - sz] | c.tunk[t + sz] | c.tflag[t + sz];
+            }
+        }
+        c.tsum[t] = v;
+    } };
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
 struct op_export_pair { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_pair(c, i, d, coc); } };
-struct op_export_bcoc { int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_bcoc(c, i, coc); } };
+struct op_export_bcoc { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_bcoc(c, i, d, coc); } };
 struct op_costmap { gie_seendist *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const {
         gie_seendist s; s.d = c.edt[i]; s.s = 0; s.o = (uint8_t)c.glb_type[i]; s.pad[0] = s.pad[1] = 0; out[i] = s; } };
 

@@ -35,6 +35,18 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_vox(const gie_ctx c,
  * mostly-unknown volume are bound by workgroup dispatch and exposed latency, not by HBM), and
  * the skip tests of the whole column are issued back to back before any voxel is processed. */
 #define GIE_VOX_ZPER 8
+/* optional per-column hook (only op_mark has one: tile known/unknown summaries) */
+template <class F> __device__ __forceinline__ auto gie_column_hook_impl(const F &f, const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int)
+    -> decltype(f.column(c, x, y, z0, known, valid), void()) { f.column(c, x, y, z0, known, valid); }
+template <class F> __device__ __forceinline__ void gie_column_hook_impl(const F &, const gie_ctx &, int, int, int, unsigned, unsigned, long) {}
+template <class F> __device__ __forceinline__ void gie_column_hook(const F &f, const gie_ctx &c, int x, int y, int z0, bool in, const bool *sk)
+{
+    if (!in) return;
+    unsigned known = 0, valid = 0;
+#pragma unroll
+    for (int k = 0; k < GIE_VOX_ZPER; k++) if (z0 + k < c.Z) { valid |= 1u << k; if (!sk[k]) known |= 1u << k; }
+    gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
+}
 template <class F>
 __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c, const F f)
 {
@@ -48,6 +60,7 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c
         const int z = z0 + k;
         sk[k] = !in || z >= c.Z || f.skip(c, in && z < c.Z ? gie_lid(c, x, y, z) : 0, x, y, z);
     }
+    gie_column_hook(f, c, x, y, z0, in, sk);
 #pragma unroll
     for (int k = 0; k < GIE_VOX_ZPER; k++)
         if (!sk[k]) f(c, x, y, z0 + k);
@@ -268,8 +281,8 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
 /* ------------------------------------------------------------------ EDT pass Z */
 /* one workgroup per (y, tile of TX columns): the tile [Z][TX] of pass-X results is staged in
  * LDS with coalesced loads, each wave runs the envelope along z for its columns and overwrites
- * the column in place with the packed closest obstacle; dist² is recomputed from it at the
- * coalesced write-out. */
+ * the column in place with the packed closest obstacle, written back with coalesced stores
+ * (dist² is a function of it and is never stored). */
 /* TX columns per workgroup (TX*4-byte row segments in HBM), padded LDS row stride TX+1 so that
  * column walks hit distinct banks, WAVES waves per workgroup. */
 template <int CP, int TX, int WAVES>
@@ -329,20 +342,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c)
         gie_wave_sync();
     }
     __syncthreads();
-    const int32_t mw2 = c.max_width * c.max_width;
     for (int z = tz; z < Z; z += (64 * WAVES) / TX) {
         const int x = x0 + tx;
-        if (x < X) {
-            const size_t o = (size_t)z * plane + (size_t)y * X + x;
-            const uint32_t bc = tile[z * TS + tx];
-            int32_t d = mw2;
-            if (bc != GIE_BCOC_NONE) {
-                const int dx = x - (int)(bc & 1023u), dy = y - (int)((bc >> 10) & 1023u), dz = z - (int)(bc >> 20);
-                d = dx * dx + dy * dy + dz * dz;
-            }
-            c.aux[o] = d;
-            c.bcoc[o] = bc;
-        }
+        if (x < X) c.bcoc[(size_t)z * plane + (size_t)y * X + x] = tile[z * TS + tx];
     }
 }
 

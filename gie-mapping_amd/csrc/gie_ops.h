@@ -343,12 +343,11 @@ GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
 /* Split in stages so that a thread can keep the loads of several voxels in flight (the sweep is
  * latency-bound): load1 = independent reads, load2 = reads that need load1's block slot,
  * finish = arithmetic + writes.  gie_mark_voxel chains them for one voxel. */
-struct gie_mark_st { uint32_t bc; int dn; uint64_t pr; int a; int dold; uint64_t ococ; };
+struct gie_mark_st { uint32_t bc; uint64_t pr; int a; int dold; uint64_t ococ; };
 
 GIE_DEV void gie_mark_load1(const gie_ctx &c, int id, int x, int y, int z, gie_mark_st &s)
 {
     s.bc = c.bcoc[id];
-    s.dn = c.aux[id];
     s.pr = c.pair[id];
     s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
 }
@@ -363,7 +362,7 @@ GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, cons
     if (s.a < 0) return;
     const uint32_t bc = s.bc;
     int cn[3];
-    const int dn = s.dn;
+    const int dn = gie_bcoc_dist(bc, x, y, z, c.max_width * c.max_width);   /* `_aux` after the batch EDT */
     int auxv = dn;
     uint64_t pr = s.pr;
     const int batch_invalid = (bc == GIE_BCOC_NONE);
@@ -390,7 +389,6 @@ GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         flag_tile = !gie_in_loc(c, cn[0], cn[1], cn[2]);
     }
     if (flag_tile) c.tflag[gie_tile_index(c, x, y, z)] = 1;         /* all writers store 1 */
-    if (auxv != dn) c.aux[id] = auxv;
     c.pair[id] = pr;
 }
 GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
@@ -540,7 +538,9 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, const uint64_t *cur, int e)
         if (gie_ld(&c.g_wl[na]) == -c.map_ct) continue;
         if (nc[0] == lc[0] && nc[1] == lc[1] && nc[2] == lc[2]) continue;
         const int nl[3] = { nc[0] - c.pvt[0], nc[1] - c.pvt[1], nc[2] - c.pvt[2] };
-        if (gie_in_loc(c, nl[0], nl[1], nl[2]) && c.aux[gie_lid(c, nl[0], nl[1], nl[2])] != 0) {
+        /* `_aux[coc] != 0` (wave_core.cuh:177-178): the batch distance of a voxel is 0 iff it is
+         * OCCUPIED, and Mark never turns a non-zero value into 0 */
+        if (gie_in_loc(c, nl[0], nl[1], nl[2]) && c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
             const int d = gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
             gie_amin64(&c.g_prop[na], gie_pair_make(d, lpar));
             mask |= 1 << k;
@@ -650,7 +650,12 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
             }
         } else {
             const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
-            if (c.aux[nid] > cand) {
+            /* `_aux[n]` (wave_core.cuh:334): for an observed voxel Mark left it equal to the pair's
+             * distance (nothing writes `pair` between Mark and wave B); for an unknown voxel it is
+             * still the batch distance */
+            const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? gie_pair_dist(gie_ld(&c.pair[nid]))
+                                                                  : gie_bcoc_dist(c.bcoc[nid], nb[0], nb[1], nb[2], c.max_width * c.max_width);
+            if (ref > cand) {
                 gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand, par));
                 mask |= 1 << k;
             }
@@ -808,9 +813,11 @@ GIE_DEV void gie_export_pair(const gie_ctx &c, int id, int32_t *dist_sq, int32_t
         }
     }
 }
-GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *coc_xyz)
+GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *dist_sq, int32_t *coc_xyz)
 {
     const uint32_t bc = c.bcoc[id];
+    if (dist_sq) dist_sq[id] = gie_bcoc_dist(bc, id % c.X, (id / c.X) % c.Y, id / (c.X * c.Y), c.max_width * c.max_width);
+    if (!coc_xyz) return;
     if (bc == GIE_BCOC_NONE) { coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = -1; }
     else { coc_xyz[3 * id] = (int)(bc & 1023u); coc_xyz[3 * id + 1] = (int)((bc >> 10) & 1023u); coc_xyz[3 * id + 2] = (int)(bc >> 20); }
 }

@@ -54,6 +54,14 @@ GIE_HD void gie_unpack_crd(uint64_t k, int *x, int *y, int *z)
 /* batch-EDT closest obstacle in local coordinates, 10 bits per axis (dims <= 1024) */
 #define GIE_BCOC_NONE 0xffffffffu
 GIE_HD uint32_t gie_pack_bcoc(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
+/* batch dist² of local voxel (x,y,z) from its packed closest obstacle — the reference's `_aux`
+ * plane after batchEDTUpdate is never stored: it is a function of `_coc_idx_aux` */
+GIE_HD int gie_bcoc_dist(uint32_t bc, int x, int y, int z, int none_value)
+{
+    if (bc == GIE_BCOC_NONE) return none_value;
+    const int dx = x - (int)(bc & 1023u), dy = y - (int)((bc >> 10) & 1023u), dz = z - (int)(bc >> 20);
+    return dx * dx + dy * dy + dz * dz;
+}
 
 typedef struct gie_ctx {
     /* ---- configuration (LocMap members, local_batch.h:523-568) */
@@ -81,13 +89,13 @@ typedef struct gie_ctx {
     float *edt;             /* _edt_D     */
     uint16_t *cy1;          /* EDT pass Y: closest y in the column, 0xffff none */
     uint32_t *cxy2;         /* EDT pass X: cx | cy<<16, 0xffffffff none */
-    int32_t *aux;           /* _aux: batch dist², then Mark-edited */
-    int32_t *bdist;         /* untouched copy of the batch dist² (parity reads) */
     uint32_t *bcoc;         /* _coc_idx_aux: batch closest obstacle, local, packed */
     uint64_t *pair;         /* _dist_id_pair (persists across frames by local index) */
     uint32_t *wl;           /* _loc_wave_layer as frame-stamped marks */
     uint8_t *tflag;         /* per local 8x8x8 tile: some voxel's Mark-time closest obstacle lies outside the volume */
     int tfd[3];             /* tile grid dims */
+    uint8_t *tknown, *tunk; /* per tile: holds a known / an unknown voxel (written by the Mark sweep) */
+    uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
     uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */

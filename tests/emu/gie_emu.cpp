@@ -31,7 +31,16 @@ static void be_prof_enable(be_state *, int) {}
 static void be_prof_collect(be_state *, float *ms, int *n, int num) { for (int i = 0; i < num; i++) { ms[i] = 0; n[i] = 0; } }
 static void be_times(be_state *, float *a, float *b, float *c, float *d) { *a = *b = *c = *d = 0.f; }
 template <class F> static void be_vox(be_state *, const gie_ctx &c, const F &f)
-{ for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) f(c, x, y, z); }
+{ for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) if (!f.skip(c, gie_lid(c, x, y, z), x, y, z)) f(c, x, y, z); }
+/* the Mark sweep also records the per-tile known/unknown summaries (column hook on the device) */
+static void be_vox(be_state *, const gie_ctx &c, const op_mark &f)
+{
+    for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) {
+        const bool unk = c.glb_type[gie_lid(c, x, y, z)] == GIE_VOX_UNKNOWN;
+        f.column(c, x, y, z & ~7, unk ? 0u : 1u, 1u);
+        if (!unk) f(c, x, y, z);
+    }
+}
 template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }
@@ -69,8 +78,8 @@ static void be_edt(be_state *, const gie_ctx &c)
             const int dx = x - (int)(v & 0xffff), dy = y - (int)(v >> 16);
             const long long f = (long long)(u - i) * (u - i) + dx * dx + dy * dy; if (f < bf) { bf = f; bs = i; } }
         const int id = gie_lid(c, x, y, u);
-        if (bs < 0) { c.aux[id] = c.max_width * c.max_width; c.bcoc[id] = GIE_BCOC_NONE; }
-        else { const uint32_t v = c.cxy2[gie_lid(c, x, y, bs)]; c.aux[id] = (int32_t)bf; c.bcoc[id] = gie_pack_bcoc((int)(v & 0xffff), (int)(v >> 16), bs); }
+        if (bs < 0) c.bcoc[id] = GIE_BCOC_NONE;
+        else { const uint32_t v = c.cxy2[gie_lid(c, x, y, bs)]; c.bcoc[id] = gie_pack_bcoc((int)(v & 0xffff), (int)(v >> 16), bs); }
     }
 }
 static void be_wave_a(be_state *, const gie_ctx &c)
