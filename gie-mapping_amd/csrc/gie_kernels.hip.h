@@ -61,9 +61,18 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c
         sk[k] = !in || z >= c.Z || f.skip(c, in && z < c.Z ? gie_lid(c, x, y, z) : 0, x, y, z);
     }
     gie_column_hook(f, c, x, y, z0, in, sk);
+    if (F::rolled) {            /* big bodies: keep one copy of the code (instruction cache) */
+        unsigned m = 0;
 #pragma unroll
-    for (int k = 0; k < GIE_VOX_ZPER; k++)
-        if (!sk[k]) f(c, x, y, z0 + k);
+        for (int k = 0; k < GIE_VOX_ZPER; k++) m |= (sk[k] ? 0u : 1u) << k;
+#pragma unroll 1
+        for (int k = 0; k < GIE_VOX_ZPER; k++)
+            if ((m >> k) & 1u) f(c, x, y, z0 + k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < GIE_VOX_ZPER; k++)
+            if (!sk[k]) f(c, x, y, z0 + k);
+    }
 }
 
 /* staged form: the loads of the whole z-column are in flight before anything is consumed */

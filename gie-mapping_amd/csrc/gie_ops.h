@@ -38,7 +38,9 @@ __device__ __forceinline__ int32_t gie_aor32(int32_t *p, int32_t v) { return __h
 
 #if defined(GIE_HOST_EMU)
 #define GIE_UNROLL6
+#define GIE_DEV_COLD static
 #else
+#define GIE_DEV_COLD __device__ __forceinline__   /* (a real call would push the kernarg context through scratch: measured 5x slower) */
 #define GIE_UNROLL6 _Pragma("unroll 6")
 #endif
 
@@ -404,12 +406,67 @@ GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
 /* ================================================================== obtainFrontiers */
 /* obtainFrontiers, unify_helper.cuh:275-446.  Returns a bit mask of what this voxel did so
  * that the kernel can compact the C-queue append with a wave ballot: bit0 = push to C. */
-struct gie_frontier_st { uint64_t p0; int8_t ty; };
+/* obtainFrontiers' branch for a 6-neighbour outside the local volume (unify_helper.cuh:346-438).
+ * Returns bit0 = the voxel became a C seed (*seed set), bit1 = the neighbour is unknown. */
+GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int nx, int ny, int nz,
+                                      const int cl[3], const int cw[3], int cd, uint64_t *seed)
+{
+    int cur_in_q = 0;
+    const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
+    const int a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
+    if (a < 0) return 2;
+    if (c.g_type[a] == GIE_VOX_UNKNOWN) return 2;
+    const int nd = c.g_dist[a];
+    if (gie_invalid_dist(c, nd)) return 0;
+    int ncx, ncy, ncz;
+    gie_unpack_crd(c.g_coc[a], &ncx, &ncy, &ncz);
+    if (gie_invalid_coc(ncx, ncy, ncz)) return 0;
+    const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
+    const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
+    const int n_valid = gie_in_wr(c, nw[0], nw[1], nw[2]);
+    const int n_local = gie_in_loc(c, nl[0], nl[1], nl[2]);
+    if (!n_local && n_valid) {
+        const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
+        if (d < cd) {
+            *seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+            cur_in_q = 1;
+        }
+    }
+    if (c.fast_mode) return cur_in_q;
+    const int c2n = gie_d2(nx, ny, nz, cl[0], cl[1], cl[2]);
+    if (c2n < nd) {                                       /* lower out → frontier B */
+        c.g_wl[a] = 1;
+        c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
+        gie_push64(c, c.qb[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+    } else if (c2n > nd && n_local) {                     /* raise out → frontier A */
+        /* the reference reads the live _glb_type here; FNT never aliases OCCUPIED */
+        if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
+            c.g_dist[a] = c2n;
+            c.g_coc[a] = gie_pack_crd(cl[0] + c.pvt[0], cl[1] + c.pvt[1], cl[2] + c.pvt[2]);
+            c.g_wl[a] = -c.map_ct;
+            c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
+            gie_push64(c, c.qa[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+        }
+    }
+    return cur_in_q;
+}
 
+struct gie_frontier_st { uint64_t p0; int8_t ty; int8_t ntys[6]; uint8_t ntf[6]; };
+
+/* every read that does not depend on another one is issued together — own pair + type, six
+ * neighbour types, six tile flags: one memory round trip per voxel (the sweep is latency-bound) */
 GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, gie_frontier_st &s)
 {
     s.ty = c.glb_type[id];
     s.p0 = c.pair[id];      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        const int inl = gie_in_loc(c, nx, ny, nz);
+        s.ntys[k] = c.glb_type[inl ? gie_lid(c, nx, ny, nz) : id];
+        s.ntf[k] = c.tflag[inl ? gie_tile_index(c, nx, ny, nz) : 0];
+    }
 }
 
 GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s)
@@ -425,15 +482,8 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
     int cur_in_q = 0, has_unknown = 0;
     uint64_t seed = 0;
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    /* six neighbour types + six tile flags issued together */
-    int8_t ntys[6]; uint8_t ntf[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
-        const int inl = gie_in_loc(c, nx, ny, nz);
-        ntys[k] = c.glb_type[inl ? gie_lid(c, nx, ny, nz) : id];
-        ntf[k] = c.tflag[inl ? gie_tile_index(c, nx, ny, nz) : 0];
-    }
+    const int8_t *ntys = s.ntys;
+    const uint8_t *ntf = s.ntf;
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
@@ -455,42 +505,10 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
                 }
             }
         } else {
-            const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
-            const int a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
-            if (a < 0) { has_unknown = 1; continue; }
-            if (c.g_type[a] == GIE_VOX_UNKNOWN) { has_unknown = 1; continue; }
-            const int nd = c.g_dist[a];
-            if (gie_invalid_dist(c, nd)) continue;
-            int ncx, ncy, ncz;
-            gie_unpack_crd(c.g_coc[a], &ncx, &ncy, &ncz);
-            if (gie_invalid_coc(ncx, ncy, ncz)) continue;
-            const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
-            const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
-            const int n_valid = gie_in_wr(c, nw[0], nw[1], nw[2]);
-            const int n_local = gie_in_loc(c, nl[0], nl[1], nl[2]);
-            if (!n_local && n_valid) {
-                const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
-                if (d < cd) {
-                    seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
-                    cur_in_q = 1;
-                }
-            }
-            if (c.fast_mode) continue;
-            const int c2n = gie_d2(nx, ny, nz, cl[0], cl[1], cl[2]);
-            if (c2n < nd) {                                       /* lower out → frontier B */
-                c.g_wl[a] = 1;
-                c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
-                gie_push64(c, c.qb[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
-            } else if (c2n > nd && n_local) {                     /* raise out → frontier A */
-                /* the reference reads the live _glb_type here; FNT never aliases OCCUPIED */
-                if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
-                    c.g_dist[a] = c2n;
-                    c.g_coc[a] = gie_pack_crd(cl[0] + c.pvt[0], cl[1] + c.pvt[1], cl[2] + c.pvt[2]);
-                    c.g_wl[a] = -c.map_ct;
-                    c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
-                    gie_push64(c, c.qa[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
-                }
-            }
+            /* a neighbour outside the volume (only voxels on the six faces get here): kept out of
+             * line so that the hot interior path stays small */
+            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed);
+            cur_in_q |= r & 1; has_unknown |= (r >> 1) & 1;
         }
     }
     if (cur_in_q) { c.wl[id] = GIE_WL_SEED(c); c.cand[1][id] = seed; }   /* the pair the seed enters wave C with */
