@@ -17,7 +17,8 @@
 
 struct be_state {
     int device;
-    int num_cu;
+    int num_cu;     /* workgroups of the persistent wave kernels */
+    int cu_total;   /* CUs of the device */
     hipStream_t stream;
     hipEvent_t ev[GIE_NEV];
     int ev_set[GIE_NEV];
@@ -45,6 +46,7 @@ static int be_init(be_state *b, int device)
     b->device = device;
     if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
     { hipDeviceProp_t pr; b->num_cu = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 64; }
+    b->cu_total = b->num_cu;
     b->num_cu = b->num_cu >= 64 ? b->num_cu / 4 : b->num_cu;   /* wave grids: 64 workgroups measured best (barrier fan-in vs parallelism) */
     { const char *e = getenv("GIE_WAVE_WGS"); if (e && atoi(e) > 0 && atoi(e) <= 256) b->num_cu = atoi(e); }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
@@ -181,7 +183,11 @@ template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, c
         GIE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_z<CP, TX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_edt_z<CP, TX, WAVES>), dim3((c.X + TX - 1) / TX, c.Y), dim3(64 * WAVES), lds, b->stream, c);
+    const int ntx = (c.X + TX - 1) / TX, ntiles = ntx * c.Y;
+    int wgs = (int)((160 * 1024) / (lds + 256));            /* workgroups that fit one CU's LDS */
+    if (wgs < 1) wgs = 1; if (wgs > 4) wgs = 4;
+    int grid = wgs * b->cu_total; if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((k_edt_z<CP, TX, WAVES>), dim3(grid), dim3(64 * WAVES), lds, b->stream, c, ntx, ntiles);
 }
 template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass)
 {
@@ -205,11 +211,11 @@ static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass)
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
 static void be_edt(be_state *b, const gie_ctx &c)
 {
-    dim3 gy((c.X + 255) / 256, c.Z);
+    dim3 gy((c.X + GIE_EDTY_COLS - 1) / GIE_EDTY_COLS, c.Z);
     be_prof(b, 6, 0);   /* GIE_K_EDT_Y */
-    if (c.Y <= 256) hipLaunchKernelGGL(k_edt_y<8>, gy, dim3(256), 0, b->stream, c);
-    else if (c.Y <= 512) hipLaunchKernelGGL(k_edt_y<16>, gy, dim3(256), 0, b->stream, c);
-    else hipLaunchKernelGGL(k_edt_y<32>, gy, dim3(256), 0, b->stream, c);
+    if (c.Y <= 256) hipLaunchKernelGGL(k_edt_y<8>, gy, dim3(GIE_EDTY_COLS, 4), 0, b->stream, c);
+    else if (c.Y <= 512) hipLaunchKernelGGL(k_edt_y<16>, gy, dim3(GIE_EDTY_COLS, 4), 0, b->stream, c);
+    else hipLaunchKernelGGL(k_edt_y<32>, gy, dim3(GIE_EDTY_COLS, 4), 0, b->stream, c);
     be_prof(b, 6, 1);
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
