@@ -33,6 +33,7 @@ struct gie_mapper {
     int32_t *d_rank;
     std::vector<void *> allocs;
     int32_t h_cnt[GIE_CNT_NUM];
+    int32_t next_off[3], next_whole[3];
     float us[4];
 };
 
@@ -59,6 +60,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
     m->has_pose = m->has_ogm = 0;
+    for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
     memset(m->h_cnt, 0, sizeof(m->h_cnt)); memset(m->us, 0, sizeof(m->us));
@@ -167,7 +169,10 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
     for (int i = 0; i < 3; i++) {
         c.origin[i] = pos[i];
         const int crd = gie_pos2coord(pos[i], c.voxel_width);
-        c.pvt[i] = crd - sz[i] / 2;                       /* calculate_pivot_origin, local_batch.h:128-142 */
+        c.pvt[i] = crd - sz[i] / 2 + m->next_off[i];      /* calculate_pivot_origin, local_batch.h:128-142 (+ tile offset) */
+        c.tile_off[i] = m->next_off[i];
+        c.whole_lo[i] = -(m->next_whole[i] / 2) + sz[i] / 2 - m->next_off[i];
+        c.whole_hi[i] = c.whole_lo[i] + m->next_whole[i];
         m->msg_origin[i] = (float)c.pvt[i] * c.voxel_width;
         c.upvt[i] = crd - c.wr[i] / 2;                    /* calculate_update_pivot, :159-166 */
         c.tb0[i] = (c.pvt[i] - 1) >> 3;
@@ -484,6 +489,69 @@ extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])
     if (!m || !pvt) { gie_set_err("gie_get_pivot: bad arguments"); return GIE_ERR_INVALID; }
     pvt[0] = m->c.pvt[0]; pvt[1] = m->c.pvt[1]; pvt[2] = m->c.pvt[2];
     return GIE_OK;
+}
+
+/* ---- tiling: halo exchange + refinement (include/gie.h) */
+extern "C" int gie_set_tile(gie_mapper *m, const int32_t off[3], const int32_t whole[3])
+{
+    if (!m || !off || !whole) { gie_set_err("gie_set_tile: bad arguments"); return GIE_ERR_INVALID; }
+    for (int i = 0; i < 3; i++) {
+        if (whole[i] < m->cfg.local_size[i]) { gie_set_err("gie_set_tile: whole volume smaller than the tile"); return GIE_ERR_INVALID; }
+        m->next_off[i] = off[i]; m->next_whole[i] = whole[i];
+    }
+    return GIE_OK;
+}
+extern "C" int gie_halo_count(gie_mapper *m, int face)
+{
+    if (!m || face < 0 || face > 5) { gie_set_err("gie_halo_count: bad arguments"); return -1; }
+    return gie_face_count(m->c, face);
+}
+extern "C" int gie_halo_export(gie_mapper *m, int face, gie_halo_voxel *out)
+{
+    int rc = gie_need_pose(m, "gie_halo_export"); if (rc) return rc;
+    if (face < 0 || face > 5 || !out) { gie_set_err("gie_halo_export: bad arguments"); return GIE_ERR_INVALID; }
+    const int n = gie_face_count(m->c, face);
+    gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
+    op_halo_export op; op.face = face; op.out = d;
+    be_lin(&m->be, m->c, op, n);
+    be_d2h(&m->be, out, d, (size_t)n * sizeof(gie_halo_voxel));
+    be_free(&m->be, d);
+    return GIE_OK;
+}
+extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in)
+{
+    int rc = gie_need_pose(m, "gie_halo_import"); if (rc) return rc;
+    if (face < 0 || face > 5 || !in) { gie_set_err("gie_halo_import: bad arguments"); return GIE_ERR_INVALID; }
+    const int n = gie_face_count(m->c, face);
+    gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
+    be_h2d(&m->be, d, in, (size_t)n * sizeof(gie_halo_voxel));
+    /* ghost voxels need their blocks: same allocation path as gie_fuse */
+    op_halo_need nd; nd.face = face; nd.in = d;
+    be_lin(&m->be, m->c, nd, n);
+    be_lin(&m->be, m->c, op_cell_flag(), m->ncell);
+    be_exclusive_scan(&m->be, m->c.blk_new, m->d_rank, m->ncell);
+    op_cell_insert ins; ins.flag = m->c.blk_new; ins.rank = m->d_rank;
+    be_lin(&m->be, m->c, ins, m->ncell);
+    be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
+    be_lin(&m->be, m->c, op_cell_table(), m->ncell);
+    op_halo_import im; im.face = face; im.in = d;
+    be_lin(&m->be, m->c, im, n);
+    be_sync(&m->be);
+    be_free(&m->be, d);
+    return GIE_OK;
+}
+extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
+{
+    int rc = gie_need_pose(m, "gie_refine"); if (rc) return rc;
+    gie_ctx &c = m->c;
+    be_memset(&m->be, c.cnt + GIE_CNT_C, 0, sizeof(int32_t));
+    const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
+    be_lin(&m->be, c, op_refine(), nb);
+    be_wave_c(&m->be, c, 0);
+    be_vox_staged(&m->be, c, op_commit());
+    rc = gie_sync(m);
+    if (seeded) *seeded = m->h_cnt[GIE_CNT_FRONT_C];
+    return rc;
 }
 
 extern "C" int gie_profile_enable(gie_mapper *m, int on)

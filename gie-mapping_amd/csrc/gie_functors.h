@@ -118,6 +118,13 @@ struct op_tile_summary { GIE_DEVM void operator()(const gie_ctx &c, int t) const
         }
         c.tsum[t] = v;
     } };
+struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
+struct op_halo_need { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_need_voxel(c, face, i, in); } };
+struct op_halo_import { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_import_voxel(c, face, i, in); } };
+struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
+        const int id = gie_refine_entry(c, j);
+        if (id >= 0 && gie_refine_voxel(c, id)) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, id);
+    } };
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };

@@ -73,7 +73,7 @@ GIE_DEV int gie_gvox_hash(const gie_ctx &c, int gx, int gy, int gz)
 GIE_DEV int gie_robot_sphere(const gie_ctx &c, int x, int y, int z)
 {   /* pntcld_raycast.cu:33-41, vlp16_fast.cu:30-40: |crd - _half_shift|² <= rbt_r2_grids */
     if (!c.for_motion_planner) return 0;
-    const int cx = x - c.X / 2, cy = y - c.Y / 2, cz = z - c.Z / 2;
+    const int cx = x - (c.X / 2 - c.tile_off[0]), cy = y - (c.Y / 2 - c.tile_off[1]), cz = z - (c.Z / 2 - c.tile_off[2]);
     return cx * cx + cy * cy + cz * cz <= c.robot_r2;
 }
 GIE_DEV int gie_pos_mod(int i, int n) { return (i % n + n) % n; }
@@ -377,7 +377,9 @@ GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, cons
     int ox, oy, oz;
     gie_unpack_crd(s.ococ, &ox, &oy, &oz);
     const int ol[3] = { ox - c.pvt[0], oy - c.pvt[1], oz - c.pvt[2] };
-    if (dn > dold && !gie_in_loc(c, ol[0], ol[1], ol[2])) { cn[0] = ol[0]; cn[1] = ol[1]; cn[2] = ol[2]; auxv = dold; }
+    /* limited observation: the old closest obstacle is out of sight (outside the volume; with
+     * tiling: outside the union of all tiles) */
+    if (dn > dold && !gie_in_whole(c, ol[0], ol[1], ol[2])) { cn[0] = ol[0]; cn[1] = ol[1]; cn[2] = ol[2]; auxv = dold; }
     const long long wx = (long long)cn[0] + c.pvt[0] - c.upvt[0];
     const long long wy = (long long)cn[1] + c.pvt[1] - c.upvt[1];
     const long long wz = (long long)cn[2] + c.pvt[2] - c.upvt[2];
@@ -813,6 +815,105 @@ GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
     gie_commit_st s;
     gie_commit_load1(c, id, x, y, z, s);
     gie_commit_finish(c, id, s);
+}
+
+/* ================================================================== halo exchange between tiles */
+/* face f: axis f/2, side f%2.  Layer index i ↔ the two remaining axes (a fastest). */
+GIE_DEV void gie_face_coord(const gie_ctx &c, int face, int i, int depth_off, int *x, int *y, int *z)
+{
+    const int axis = face >> 1, hi = face & 1;
+    const int sz[3] = { c.X, c.Y, c.Z };
+    const int along = hi ? sz[axis] - 1 + depth_off : -depth_off;   /* depth_off 0: own face layer, 1: just outside */
+    if (axis == 0) { *x = along; *y = i % c.Y; *z = i / c.Y; }
+    else if (axis == 1) { *x = i % c.X; *y = along; *z = i / c.X; }
+    else { *x = i % c.X; *y = i / c.X; *z = along; }
+}
+GIE_HD int gie_face_count(const gie_ctx &c, int face)
+{ const int axis = face >> 1; return axis == 0 ? c.Y * c.Z : (axis == 1 ? c.X * c.Z : c.X * c.Y); }
+
+/* committed state of the voxels on one face of the local volume */
+GIE_DEV void gie_halo_export_voxel(const gie_ctx &c, int face, int i, gie_halo_voxel *out)
+{
+    int x, y, z;
+    gie_face_coord(c, face, i, 0, &x, &y, &z);
+    gie_halo_voxel h;
+    h.pad[0] = h.pad[1] = 0; h.occ_val = 0;
+    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    if (a < 0 || c.g_type[a] == GIE_VOX_UNKNOWN) {
+        h.vox_type = GIE_VOX_UNKNOWN; h.dist_sq = c.empty_value; h.coc[0] = h.coc[1] = h.coc[2] = GIE_EMPTY_VALUE;
+    } else {
+        h.vox_type = c.g_type[a]; h.dist_sq = c.g_dist[a]; h.occ_val = c.g_occ[a];
+        gie_unpack_crd(c.g_coc[a], &h.coc[0], &h.coc[1], &h.coc[2]);
+    }
+    out[i] = h;
+}
+/* ghost voxels just outside `face`: mark the blocks they need … */
+GIE_DEV void gie_halo_need_voxel(const gie_ctx &c, int face, int i, const gie_halo_voxel *in)
+{
+    if (in[i].vox_type == GIE_VOX_UNKNOWN) return;
+    int x, y, z;
+    gie_face_coord(c, face, i, 1, &x, &y, &z);
+    c.blk_need[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])] = 1;
+}
+/* … and store them (type / dist² / coc of the owning tile) */
+GIE_DEV void gie_halo_import_voxel(const gie_ctx &c, int face, int i, const gie_halo_voxel *in)
+{
+    if (in[i].vox_type == GIE_VOX_UNKNOWN) return;
+    int x, y, z;
+    gie_face_coord(c, face, i, 1, &x, &y, &z);
+    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    if (a < 0) return;
+    c.g_type[a] = in[i].vox_type;
+    c.g_occ[a] = in[i].occ_val;
+    c.g_dist[a] = in[i].dist_sq;
+    c.g_coc[a] = gie_pack_crd(in[i].coc[0], in[i].coc[1], in[i].coc[2]);
+}
+/* obtainFrontiers' C-seed rule (unify_helper.cuh:365-399) for a face voxel against its ghost
+ * neighbours, on the committed state: a ghost whose closest obstacle lies outside this tile and
+ * is closer than the voxel's own makes the voxel a wave-C seed.  Voxel index v = local id. */
+GIE_DEV int gie_refine_voxel(const gie_ctx &c, int id)
+{
+    const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return 0;
+    const int cd = gie_pair_dist(c.pair[id]);
+    uint64_t seed = 0;
+    int hit = 0;
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        if (gie_in_loc(c, nx, ny, nz)) continue;
+        const int a = gie_gvox_tab(c, nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]);
+        if (a < 0 || c.g_type[a] == GIE_VOX_UNKNOWN) continue;
+        if (gie_invalid_dist(c, c.g_dist[a])) continue;
+        int ncx, ncy, ncz;
+        gie_unpack_crd(c.g_coc[a], &ncx, &ncy, &ncz);
+        if (gie_invalid_coc(ncx, ncy, ncz)) continue;
+        const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
+        const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
+        if (gie_in_loc(c, nl[0], nl[1], nl[2]) || !gie_in_wr(c, nw[0], nw[1], nw[2])) continue;
+        const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
+        if (d < cd) { seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2])); hit = 1; }
+    }
+    if (hit) c.cand[1][id] = seed;
+    return hit;
+}
+/* boundary voxel enumeration: j in [0, 2(XY+YZ+XZ)) → face voxel, each voxel taken once (at its
+ * first face in the order -x,+x,-y,+y,-z,+z) */
+GIE_DEV int gie_refine_entry(const gie_ctx &c, int j)
+{
+    int face = 0, i = j;
+    for (; face < 6; face++) { const int n = gie_face_count(c, face); if (i < n) break; i -= n; }
+    if (face >= 6) return -1;
+    int x, y, z;
+    gie_face_coord(c, face, i, 0, &x, &y, &z);
+    /* skip voxels that an earlier face already covers */
+    if (face >= 1 && x == 0) return -1;
+    if (face >= 2 && x == c.X - 1) return -1;
+    if (face >= 3 && y == 0) return -1;
+    if (face >= 4 && y == c.Y - 1) return -1;
+    if (face >= 5 && z == 0) return -1;
+    return gie_lid(c, x, y, z);
 }
 
 /* ================================================================== export for the readers */

@@ -78,6 +78,8 @@ typedef struct gie_ctx {
     /* ---- per frame */
     int map_ct;
     int pvt[3], upvt[3];
+    int tile_off[3];        /* volume centre minus sensor voxel (tiling); 0 in the reference */
+    int whole_lo[3], whole_hi[3]; /* union of all tiles in local coordinates; = [0,size) without tiling */
     float origin[3];
     gie_se3 L2G, G2L;
     int pntcld_mode;
@@ -161,6 +163,8 @@ enum {
 #define GIE_WL_LEVEL(c, lvl) ((c).stamp_base + 8u + (uint32_t)(lvl))
 
 GIE_HD int gie_in_loc(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.X && y >= 0 && y < c.Y && z >= 0 && z < c.Z; }
+GIE_HD int gie_in_whole(const gie_ctx &c, int x, int y, int z)
+{ return x >= c.whole_lo[0] && x < c.whole_hi[0] && y >= c.whole_lo[1] && y < c.whole_hi[1] && z >= c.whole_lo[2] && z < c.whole_hi[2]; }
 GIE_HD int gie_in_wr(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.wr[0] && y >= 0 && y < c.wr[1] && z >= 0 && z < c.wr[2]; }
 GIE_HD int gie_lid(const gie_ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
 GIE_HD int gie_tile_index(const gie_ctx &c, int x, int y, int z) { return ((z >> 3) * c.tfd[1] + (y >> 3)) * c.tfd[0] + (x >> 3); }

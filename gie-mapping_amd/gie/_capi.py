@@ -94,6 +94,11 @@ SIGNATURES = {
     "query_global": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
     "get_stats": (C.c_int, [_H, C.POINTER(FrameStats)]),
     "get_pivot": (C.c_int, [_H, c_i32p]),
+    "set_tile": (C.c_int, [_H, c_i32p, c_i32p]),
+    "halo_count": (C.c_int, [_H, C.c_int]),
+    "halo_export": (C.c_int, [_H, C.c_int, C.c_void_p]),
+    "halo_import": (C.c_int, [_H, C.c_int, C.c_void_p]),
+    "refine": (C.c_int, [_H, c_i32p]),
 }
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 24), ("total_ms", C.c_float), ("launches", C.c_int32)]

@@ -18,6 +18,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "csrc", "libgie_hip.so")
 
 SEENDIST_DTYPE = np.dtype([("d", "<f4"), ("s", "u1"), ("o", "u1"), ("pad", "u1", (2,))])
+HALO_DTYPE = np.dtype([("dist_sq", "<i4"), ("coc", "<i4", (3,)), ("vox_type", "i1"), ("occ_val", "u1"), ("pad", "i1", (2,))])
 VOXEL_DTYPE = np.dtype([("occ_val", "u1"), ("vox_type", "i1"), ("pad", "<i2"), ("dist_sq", "<i4"),
                         ("coc", "<i4", (3,))])
 
@@ -181,6 +182,28 @@ class MapperBase:
         p = (C.c_int32 * 3)()
         self._chk(self._f["get_pivot"](self._h, p))
         return tuple(p)
+
+    # --- tiling (include/gie.h: halo exchange + refinement) ---------------------------------
+    def set_tile(self, off, whole):
+        o = (C.c_int32 * 3)(*[int(v) for v in off])
+        w = (C.c_int32 * 3)(*[int(v) for v in whole])
+        self._chk(self._f["set_tile"](self._h, o, w))
+
+    def halo_export(self, face):
+        n = self._f["halo_count"](self._h, face)
+        out = np.empty(n, HALO_DTYPE)
+        self._chk(self._f["halo_export"](self._h, face, _ptr(out)))
+        return out
+
+    def halo_import(self, face, layer):
+        layer = np.ascontiguousarray(layer, dtype=HALO_DTYPE)
+        assert layer.shape[0] == self._f["halo_count"](self._h, face)
+        self._chk(self._f["halo_import"](self._h, face, _ptr(layer)))
+
+    def refine(self):
+        n = C.c_int32(0)
+        self._chk(self._f["refine"](self._h, C.byref(n)))
+        return n.value
 
     # --- VOLMAPNODE::publishMap call order (volumetric_mapper.cpp:138-224) -------------
     def update(self, pos, quat_wxyz, sensor_kind, sensor_data, **kw):

@@ -30,6 +30,14 @@ def tile_of_rank(rank, world_size, tile_size):
     return (ix * size[0], iy * size[1], iz * size[2]), size
 
 
+def tile_offset_voxels(rank, world_size, tile_size):
+    """Integer offset (voxels) of the tile centre from the centre of the whole volume — the
+    argument of Mapper.set_tile_offset when all tiles share one sensor pose."""
+    origin, size = tile_of_rank(rank, world_size, tile_size)
+    t = tile_grid(world_size)
+    return tuple(int(origin[i] + size[i] // 2 - (t[i] * size[i]) // 2) for i in range(3))
+
+
 def tile_centre_offset(rank, world_size, tile_size, voxel_width):
     """Metric offset of the tile centre from the centre of the whole volume: the pose a rank
     feeds its mapper is the shared sensor pose shifted by this."""
@@ -51,3 +59,70 @@ def aggregate(dist, seconds, voxels_per_rank, steps):
         world = 1
     t_max = float(t.item())
     return world * voxels_per_rank * steps / t_max / 1e6, t_max
+
+
+# face = 2*axis + side (include/gie.h); the neighbour across my face f imports my layer as its face f^1
+def neighbours(rank, world_size):
+    """{face: neighbour rank} for the tiles that exist around `rank`."""
+    t = tile_grid(world_size)
+    idx = [rank % t[0], (rank // t[0]) % t[1], rank // (t[0] * t[1])]
+    out = {}
+    for axis in range(3):
+        for side in (0, 1):
+            j = list(idx)
+            j[axis] += 1 if side else -1
+            if 0 <= j[axis] < t[axis]:
+                out[2 * axis + side] = j[0] + t[0] * (j[1] + t[1] * j[2])
+    return out
+
+
+def exchange_until_stable_local(mappers, grid, max_rounds=64):
+    """All tiles live in this process (tests, single-GPU checks): export every shared face, hand
+    it to the neighbour, refine, repeat until no tile seeded anything.  Returns the rounds run."""
+    world = grid[0] * grid[1] * grid[2]
+    assert world == len(mappers)
+    rounds = 0
+    for _ in range(max_rounds):
+        layers = {}
+        for r, m in enumerate(mappers):
+            for face, nb in neighbours(r, world).items():
+                layers[(nb, face ^ 1)] = m.halo_export(face)
+        for (r, face), layer in layers.items():
+            mappers[r].halo_import(face, layer)
+        seeded = sum(m.refine() for m in mappers)
+        rounds += 1
+        if seeded == 0:
+            break
+    return rounds
+
+
+def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64):
+    """One tile per rank: face layers travel with torch.distributed point-to-point ops (RCCL over
+    xGMI with backend "nccl", gloo on CPU); a 1-int all-reduce(sum) of the seed counts is the
+    convergence test.  Returns the rounds run."""
+    import torch
+    from .mapper import HALO_DTYPE
+    nbs = neighbours(rank, world_size)
+    rounds = 0
+    for _ in range(max_rounds):
+        sends, recvs, ops = {}, {}, []
+        for face, nb in sorted(nbs.items()):
+            lay = mapper.halo_export(face)
+            t = torch.from_numpy(lay.view(np.uint8).copy())
+            r = torch.empty_like(t)
+            if device is not None:
+                t, r = t.to(device), r.to(device)
+            sends[face], recvs[face] = t, r
+            ops.append(dist.P2POp(dist.isend, t, nb))
+            ops.append(dist.P2POp(dist.irecv, r, nb))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for face in sorted(nbs):
+            mapper.halo_import(face, recvs[face].cpu().numpy().view(HALO_DTYPE))
+        n = torch.tensor([mapper.refine()], dtype=torch.int64, device=device if device is not None else "cpu")
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        rounds += 1
+        if int(n.item()) == 0:
+            break
+    return rounds

@@ -171,6 +171,35 @@ int gie_read_costmap(gie_mapper *h, gie_seendist *payload, gie_costmap_hdr *hdr)
 int gie_query_global(gie_mapper *h, const int32_t *xyz, int n, gie_voxel *out);
 int gie_get_stats(gie_mapper *h, gie_frame_stats *out);
 
+/* ---- spatial tiling across GPUs (no counterpart in the reference, which is single-GPU; SURVEY
+ * §8e).  A large volume is cut into tiles, one mapper per tile/GPU.  After gie_merge every tile
+ * exports the one-voxel layer on each of its faces; the neighbour imports it as "ghost" voxels just
+ * outside its own volume — exactly the role old out-of-volume voxels play in the reference — and
+ * gie_refine lowers inside voxels from them (obtainFrontiers' C seeds restricted to the faces →
+ * wave C → commit).  Rounds of export / exchange / import / refine repeat until no tile changes.
+ * face = 2*axis + side (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z); a layer is indexed b*A + a with (a,b) the
+ * two remaining axes in x<y<z order. */
+typedef struct gie_halo_voxel {
+    int32_t dist_sq;
+    int32_t coc[3];
+    int8_t vox_type;
+    uint8_t occ_val;   /* travels too: a ghost voxel that enters the tile next frame keeps its occupancy state */
+    int8_t pad[2];
+} gie_halo_voxel;
+/* Tile placement: the local volume is centred `off` voxels away from the sensor position
+ * (_pvt = round(pos/w) - size/2 + off); every tile of one robot shares the sensor pose and the
+ * wave-range pivot.  `whole` = size of the union of all tiles (centred on the sensor like an
+ * ordinary local volume): MarkLimitedObserve keeps an old distance only when its closest
+ * obstacle lies outside the WHOLE volume — one inside another tile is re-derived from that
+ * tile's current state through the halo exchange instead of being trusted.  Takes effect at the
+ * next gie_set_pose; default off = 0, whole = local_size = the reference. */
+int gie_set_tile(gie_mapper *h, const int32_t off[3], const int32_t whole[3]);
+int gie_halo_count(gie_mapper *h, int face);
+int gie_halo_export(gie_mapper *h, int face, gie_halo_voxel *out);
+int gie_halo_import(gie_mapper *h, int face, const gie_halo_voxel *in);
+/* returns the number of voxels seeded from ghost neighbours in *seeded (0 = nothing changed) */
+int gie_refine(gie_mapper *h, int32_t *seeded);
+
 /* Per-kernel device time (the reference only has the two std::chrono spans of
  * volumetric_mapper.cpp:153,187-203).  When enabled, every kernel launch of the frame is
  * bracketed by HIP events on the mapper's stream; gie_profile_read synchronises, returns the

@@ -72,6 +72,7 @@ typedef struct gie_oracle {
     gie_se3 L2G, G2L;
     float origin[3];
     int pvt[3], upvt[3];
+    int tile_off[3], next_off[3], next_whole[3], whole_lo[3], whole_hi[3];
     float msg_origin[3];
     int pntcld_mode;    /* last OGM call was the ray-cast one */
     /* LocMap arrays, local_batch.h:541-561 */
@@ -218,6 +219,7 @@ gie_oracle *go_create(const gie_config *cfg)
     o->hcap = 4096; o->htab = (int32_t *)malloc(sizeof(int32_t) * 4096);
     for (int i = 0; i < o->hcap; i++) o->htab[i] = -1;
     o->L2G = gie_se3_from_quat(1, 0, 0, 0, 0, 0, 0); o->G2L = gie_se3_inv(o->L2G);
+    o->next_whole[0] = o->X; o->next_whole[1] = o->Y; o->next_whole[2] = o->Z;
     return o;
 }
 
@@ -248,7 +250,10 @@ int go_set_pose(gie_oracle *o, const float pos[3], const float q[4])
     for (int i = 0; i < 3; i++) {
         o->origin[i] = pos[i];
         const int c = gie_pos2coord(pos[i], w);
-        o->pvt[i] = c - sz[i] / 2;
+        o->tile_off[i] = o->next_off[i];
+        o->whole_lo[i] = -(o->next_whole[i] / 2) + sz[i] / 2 - o->next_off[i];
+        o->whole_hi[i] = o->whole_lo[i] + o->next_whole[i];
+        o->pvt[i] = c - sz[i] / 2 + o->tile_off[i];
         o->msg_origin[i] = (float)o->pvt[i] * w;   /* coord2pos, local_batch.h:259-267 */
         o->upvt[i] = c - o->wr[i] / 2;
     }
@@ -327,7 +332,7 @@ int go_ogm_pointcloud(gie_oracle *o, const float *xyz, int n)
     for (int z = 0; z < o->Z; z++) for (int y = 0; y < o->Y; y++) for (int x = 0; x < o->X; x++) {
         const int id = lid(o, x, y, z);
         if (o->cfg.for_motion_planner) {
-            const int cx = x - o->X / 2, cy = y - o->Y / 2, cz = z - o->Z / 2;
+            const int cx = x - (o->X / 2 - o->tile_off[0]), cy = y - (o->Y / 2 - o->tile_off[1]), cz = z - (o->Z / 2 - o->tile_off[2]);
             if (cx * cx + cy * cy + cz * cz <= o->cfg.robot_r2_grids) o->ray_count[id] = -1;
         }
         const int c = o->ray_count[id];
@@ -340,7 +345,7 @@ int go_ogm_pointcloud(gie_oracle *o, const float *xyz, int n)
 static int robot_sphere(const gie_oracle *o, int x, int y, int z)
 {
     if (!o->cfg.for_motion_planner) return 0;
-    const int cx = x - o->X / 2, cy = y - o->Y / 2, cz = z - o->Z / 2;  /* _half_shift, local_batch.h:49 */
+    const int cx = x - (o->X / 2 - o->tile_off[0]), cy = y - (o->Y / 2 - o->tile_off[1]), cz = z - (o->Z / 2 - o->tile_off[2]);  /* _half_shift, local_batch.h:49 */
     return cx * cx + cy * cy + cz * cz <= o->cfg.robot_r2_grids;
 }
 static int pos_mod(int i, int n) { return (i % n + n) % n; }  /* vlp16_helper.h:11-15 */
@@ -613,7 +618,8 @@ static void mark_limited_observe(gie_oracle *o)
         if (!v) continue; /* the reference asserts: an observed voxel always has its block */
         const int dold = v->dist_sq;
         const int ol[3] = { v->coc[0] - o->pvt[0], v->coc[1] - o->pvt[1], v->coc[2] - o->pvt[2] };
-        const int old_in = in_loc(o, ol[0], ol[1], ol[2]);
+        /* with tiling: inside the union of all tiles (include/gie.h gie_set_tile) */
+        const int old_in = ol[0] >= o->whole_lo[0] && ol[0] < o->whole_hi[0] && ol[1] >= o->whole_lo[1] && ol[1] < o->whole_hi[1] && ol[2] >= o->whole_lo[2] && ol[2] < o->whole_hi[2];
         if (dn > dold && !old_in) { cn[0] = ol[0]; cn[1] = ol[1]; cn[2] = ol[2]; o->aux[id] = dold; } /* limited observation */
         /* loc2wave_range, done in 64-bit because an EMPTY_KEY/invalid coc is far away */
         const long long wx = (long long)cn[0] + o->pvt[0] - o->upvt[0];
@@ -986,6 +992,90 @@ int go_merge(gie_oracle *o)
 }
 
 int go_step(gie_oracle *o) { go_fuse(o); go_batch_edt(o); go_merge(o); return 0; }
+
+/* ------------------------------------------------------------------ tiling: halo exchange + refinement
+ * (no reference counterpart — the reference is single-GPU; semantics documented in include/gie.h) */
+static void face_coord(const gie_oracle *o, int face, int i, int depth_off, int *x, int *y, int *z)
+{
+    const int axis = face >> 1, hi = face & 1;
+    const int sz[3] = { o->X, o->Y, o->Z };
+    const int along = hi ? sz[axis] - 1 + depth_off : -depth_off;
+    if (axis == 0) { *x = along; *y = i % o->Y; *z = i / o->Y; }
+    else if (axis == 1) { *x = i % o->X; *y = along; *z = i / o->X; }
+    else { *x = i % o->X; *y = i / o->X; *z = along; }
+}
+int go_set_tile(gie_oracle *o, const int32_t off[3], const int32_t whole[3])
+{ for (int i = 0; i < 3; i++) { o->next_off[i] = off[i]; o->next_whole[i] = whole[i]; } return 0; }
+int go_halo_count(gie_oracle *o, int face)
+{ const int axis = face >> 1; return axis == 0 ? o->Y * o->Z : (axis == 1 ? o->X * o->Z : o->X * o->Y); }
+
+int go_halo_export(gie_oracle *o, int face, gie_halo_voxel *out)
+{
+    const int n = go_halo_count(o, face);
+    for (int i = 0; i < n; i++) {
+        int x, y, z;
+        face_coord(o, face, i, 0, &x, &y, &z);
+        ovox *v = vox_find(o, x + o->pvt[0], y + o->pvt[1], z + o->pvt[2]);
+        memset(&out[i], 0, sizeof(out[i]));
+        if (!v || v->vox_type == GIE_VOX_UNKNOWN) {
+            out[i].vox_type = GIE_VOX_UNKNOWN; out[i].dist_sq = o->empty_value;
+            out[i].coc[0] = out[i].coc[1] = out[i].coc[2] = GIE_EMPTY_VALUE;
+        } else {
+            out[i].vox_type = v->vox_type; out[i].dist_sq = v->dist_sq; out[i].occ_val = v->occ_val;
+            out[i].coc[0] = v->coc[0]; out[i].coc[1] = v->coc[1]; out[i].coc[2] = v->coc[2];
+        }
+    }
+    return 0;
+}
+
+int go_halo_import(gie_oracle *o, int face, const gie_halo_voxel *in)
+{
+    const int n = go_halo_count(o, face);
+    for (int i = 0; i < n; i++) {
+        if (in[i].vox_type == GIE_VOX_UNKNOWN) continue;
+        int x, y, z;
+        face_coord(o, face, i, 1, &x, &y, &z);
+        const int gx = x + o->pvt[0], gy = y + o->pvt[1], gz = z + o->pvt[2];
+        oblock *b = blk_get_or_alloc(o, fdiv8(gx), fdiv8(gy), fdiv8(gz));
+        ovox *v = &b->v[vox_in_blk(gx, gy, gz)];
+        v->vox_type = in[i].vox_type; v->occ_val = in[i].occ_val; v->dist_sq = in[i].dist_sq;
+        v->coc[0] = in[i].coc[0]; v->coc[1] = in[i].coc[1]; v->coc[2] = in[i].coc[2];
+    }
+    return 0;
+}
+
+int go_refine(gie_oracle *o, int32_t *seeded)
+{
+    queue fc = { 0, 0, 0 };
+    for (int z = 0; z < o->Z; z++) for (int y = 0; y < o->Y; y++) for (int x = 0; x < o->X; x++) {
+        if (!(x == 0 || y == 0 || z == 0 || x == o->X - 1 || y == o->Y - 1 || z == o->Z - 1)) continue;
+        const int id = lid(o, x, y, z);
+        if (o->glb_type[id] == GIE_VOX_UNKNOWN) continue;
+        const int cd = o->pair_dist[id];
+        int hit = 0, sd = 0; int64_t sp = 0;
+        for (int k = 0; k < 6; k++) {
+            const int nx = x + DIRS[k][0], ny = y + DIRS[k][1], nz = z + DIRS[k][2];
+            if (in_loc(o, nx, ny, nz)) continue;
+            ovox *nv = vox_find(o, nx + o->pvt[0], ny + o->pvt[1], nz + o->pvt[2]);
+            if (!nv || nv->vox_type == GIE_VOX_UNKNOWN) continue;
+            if (invalid_dist_glb(o, nv->dist_sq) || invalid_coc_glb(nv->coc)) continue;
+            const int nw[3] = { nv->coc[0] - o->upvt[0], nv->coc[1] - o->upvt[1], nv->coc[2] - o->upvt[2] };
+            const int nl[3] = { nv->coc[0] - o->pvt[0], nv->coc[1] - o->pvt[1], nv->coc[2] - o->pvt[2] };
+            if (in_loc(o, nl[0], nl[1], nl[2]) || !in_wr(o, nw[0], nw[1], nw[2])) continue;
+            const int d = d2i(nl[0], nl[1], nl[2], x, y, z);
+            if (d < cd) { sd = d; sp = pack_wr(nw[0], nw[1], nw[2]); hit = 1; }
+        }
+        if (hit) { o->pair_dist[id] = sd; o->pair_par[id] = sp; q_push(&fc, x, y, z); }
+    }
+    if (seeded) *seeded = fc.n;
+    o->st.visits_c = 0; o->st.levels_c = 0;
+    o->st.front_c = fc.n;
+    wave_c(o, &fc);
+    update_hash_batch(o);
+    o->tot_vis[2] += o->st.visits_c;
+    q_free(&fc);
+    return 0;
+}
 
 /* ------------------------------------------------------------------ readers */
 int go_read_local(gie_oracle *o, float *edt, int8_t *type, int32_t *dist_sq, int32_t *coc_xyz)

@@ -74,6 +74,56 @@ def test_two_ranks_gloo():
     assert p1[0] - p0[0] == 32 and p1[1] == p0[1] and p1[2] == p0[2]   # adjacent, non-overlapping local volumes
 
 
+def _worker_halo(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import gie
+    from gie import tiling
+    from emu_py import EmuMapper
+    import test_tiling_halo as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = gie.make_config(T.W, T.TILE, cutoff_dist=1.0)
+    m = EmuMapper(cfg)
+    m.set_tile(tiling.tile_offset_voxels(rank, world, T.TILE), T.WHOLE)
+    res = []
+    for pos, q, img in T._sensor_frames(4):
+        m.update(pos, q, "multiscan", img, **T.KW)
+        rounds = tiling.exchange_until_stable(m, dist, rank, world)
+        r = m.read_local()
+        res.append((rounds, r["type"].copy(), r["dist_sq"].copy(), r["coc"].copy()))
+    m.close()
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_halo_exchange_matches_in_process_exchange(oracle_lib):
+    """The torch.distributed exchange (isend/irecv + all-reduce of the seed count) must give each
+    rank exactly what the in-process exchange of the oracle gives the corresponding tile."""
+    import test_tiling_halo as T
+    from oracle_py import OracleMapper
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_halo, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = T._run_tiled(OracleMapper)[:4]
+    for k, (reads, rounds, _) in enumerate(ref):
+        for t in range(2):
+            g_rounds, g_type, g_dist, g_coc = got[t][k]
+            assert g_rounds == rounds
+            assert np.array_equal(g_type, reads[t]["type"])
+            assert np.array_equal(g_dist, reads[t]["dist_sq"])
+            assert np.array_equal(g_coc, reads[t]["coc"])
+
+
 def test_tile_layouts():
     from gie import tiling
     assert tiling.tile_grid(1) == (1, 1, 1) and tiling.tile_grid(2) == (2, 1, 1)

@@ -1,0 +1,124 @@
+"""Spatial tiling with halo exchange (include/gie.h "spatial tiling across GPUs"): a 64x32x16
+volume cut into two 32x32x16 tiles along x.  Both tiles see the SAME sensor frame (one robot);
+after every map update they exchange one-voxel face layers and refine until no tile changes.
+
+CPU: the device logic (test-only emulation) must equal the oracle's tiled restatement bit for
+bit; the exchange must carry distance information across the cut; and the stitched tiles must be
+(almost everywhere) the single-volume result.  GPU: the HIP library must equal the oracle the
+same way (two mappers on the one GPU, host-side exchange)."""
+import numpy as np
+import pytest
+
+import gie
+from gie import scenes, tiling
+from oracle_py import OracleMapper
+
+TILE = (32, 32, 16)
+WHOLE = (64, 32, 16)
+W = 0.1
+FR = 8
+
+
+def _sensor_frames(n):
+    world = scenes.BoxWorld(11, extent=(2.8, 1.4, 0.7), n_boxes=24, toggle_frac=0.3, ground_z=-0.6)
+    out = []
+    for k in range(n):
+        pos, q = scenes.pose(k, W, delta_vox=1, yaw_deg=25.0)
+        pts, _ = scenes.lidar_frame(world, k, pos, q, rings=32, az=720, phi_min_deg=-40.0, phi_inc_deg=2.5, max_range=10.0)
+        img = scenes.range_image(pts, scan_num=360, ring_num=32, phi_min_deg=-40.0, phi_inc_deg=2.5)
+        out.append((pos, q, img))
+    return out
+
+
+KW = dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi, phi_inc=np.radians(2.5), phi_min=np.radians(-40.0))
+
+
+def _run_tiled(make, exchange=True):
+    cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
+    ms = [make(cfg), make(cfg)]
+    for r, m in enumerate(ms):
+        m.set_tile(tiling.tile_offset_voxels(r, 2, TILE), WHOLE)
+    hist = []
+    try:
+        for pos, q, img in _sensor_frames(FR):
+            for m in ms:
+                m.update(pos, q, "multiscan", img, **KW)
+            rounds = tiling.exchange_until_stable_local(ms, (2, 1, 1)) if exchange else 0
+            hist.append(([m.read_local() for m in ms], rounds, [m.pivot() for m in ms]))
+    finally:
+        for m in ms:
+            m.close()
+    return hist
+
+
+def _run_whole(make):
+    cfg = gie.make_config(W, WHOLE, cutoff_dist=1.0)
+    m = make(cfg)
+    out = []
+    try:
+        for pos, q, img in _sensor_frames(FR):
+            m.update(pos, q, "multiscan", img, **KW)
+            out.append((m.read_local(), m.pivot()))
+    finally:
+        m.close()
+    return out
+
+
+def _assert_same(ha, hb):
+    assert len(ha) == len(hb)
+    for k, ((ra, na, pa), (rb, nb, pb)) in enumerate(zip(ha, hb)):
+        assert na == nb, "frame %d: %d vs %d refinement rounds" % (k, na, nb)
+        assert pa == pb
+        for t in range(2):
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[t][key], rb[t][key]), "frame %d tile %d: %s differs" % (k, t, key)
+            assert np.allclose(ra[t]["edt"], rb[t]["edt"], rtol=1e-6, atol=0)
+
+
+def test_tiles_are_adjacent_and_share_the_sensor():
+    cfg = gie.make_config(W, TILE)
+    ms = [OracleMapper(cfg), OracleMapper(cfg)]
+    for r, m in enumerate(ms):
+        m.set_tile(tiling.tile_offset_voxels(r, 2, TILE), WHOLE)
+        m.set_pose((0.3, -0.2, 0.1))
+    whole = OracleMapper(gie.make_config(W, WHOLE))
+    whole.set_pose((0.3, -0.2, 0.1))
+    p0, p1, pw = ms[0].pivot(), ms[1].pivot(), whole.pivot()
+    assert p0 == pw and p1 == (pw[0] + TILE[0], pw[1], pw[2])
+    for m in ms + [whole]:
+        m.close()
+
+
+def test_emulated_tiled_matches_oracle_tiled(oracle_lib):
+    from emu_py import EmuMapper
+    _assert_same(_run_tiled(OracleMapper), _run_tiled(EmuMapper))
+
+
+def test_exchange_carries_information_and_approaches_the_single_volume(oracle_lib):
+    with_x = _run_tiled(OracleMapper, exchange=True)
+    without = _run_tiled(OracleMapper, exchange=False)
+    whole = _run_whole(OracleMapper)
+    lowered = 0
+    bad_with = bad_without = total = 0
+    for (ra, na, _), (rb, _, _), (rw, _) in zip(with_x, without, whole):
+        stitched_t = np.concatenate([ra[0]["type"], ra[1]["type"]], axis=2)
+        assert np.array_equal(stitched_t != 0, rw["type"] != 0)             # the same voxels are known
+        for t in range(2):
+            known = (ra[t]["type"] != 0) & (rb[t]["type"] != 0)
+            assert (ra[t]["dist_sq"][known] <= rb[t]["dist_sq"][known]).all()   # exchange only lowers
+            lowered += int((ra[t]["dist_sq"][known] < rb[t]["dist_sq"][known]).sum())
+        sw = np.concatenate([ra[0]["dist_sq"], ra[1]["dist_sq"]], axis=2)
+        so = np.concatenate([rb[0]["dist_sq"], rb[1]["dist_sq"]], axis=2)
+        k = (rw["type"] != 0) & (stitched_t != 0) & (rw["dist_sq"] < 900000)
+        total += int(k.sum())
+        bad_with += int((sw[k] != rw["dist_sq"][k]).sum())
+        bad_without += int((so[k] != rw["dist_sq"][k]).sum())
+    assert lowered > 0
+    assert bad_with < bad_without            # the exchange moves the tiles towards the single-volume field
+    # measured: 30 of 113 000 voxel-frames differ (by <= 0.5 voxel: BFS propagation is not an exact EDT)
+    assert bad_with <= 0.002 * total, (bad_with, bad_without, total)
+
+
+@pytest.mark.gpu
+def test_hip_tiled_matches_oracle_tiled(oracle_lib):
+    _assert_same(_run_tiled(OracleMapper), _run_tiled(gie.Mapper))
