@@ -10,8 +10,9 @@ resident in HBM when the timed region starts.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 every rank owns one independent 512^3 tile (its own world and global map); there is
-no data-path collective yet (halo exchange is the next §8(e) step), so scaling is "weak".
+With N > 1 every rank owns one 512^3 tile of a larger volume around the same robot (2x2x2 tiles =
+1024^3 on 8 GPUs): same sensor stream, one-voxel halo exchange + refinement rounds over RCCL
+point-to-point after every update (gie/tiling.py).  Per-GPU work is fixed: scaling is "weak".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -72,7 +73,7 @@ def cpu_baseline(scenes, voxel, cutoff_dist, sensor):
     from oracle_py import OracleMapper
     import gie
     size = (256, 256, 256)
-    frames = make_frames(scenes, voxel, 3, 5, sensor)
+    frames = make_frames(scenes, voxel, 12, 5, sensor)
     rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
     cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False)
     m = OracleMapper(cfg)
@@ -87,7 +88,7 @@ def cpu_baseline(scenes, voxel, cutoff_dist, sensor):
     m.close()
     n = size[0] * size[1] * size[2] * len(frames)
     return {"value": round(n / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": "256^3 local grid, same scene/%s generator, 3 map updates (%.1f s)" % (sensor, dt)}
+            "sample": "256^3 local grid, same scene/%s generator, %d map updates (%.1f s)" % (sensor, len(frames), dt)}
 
 
 def main():
@@ -122,17 +123,23 @@ def main():
     cutoff_dist = 2.0
     rings, az, phi_min, phi_inc, bins = SENSORS[args.sensor]
     nframes = args.warmup + args.steps
-    # rank r maps tile r of a (2x2x2 for 8 GPUs) arrangement of 512^3 tiles: same world, the
-    # tile's own sensor stream at the tile centre (independent tiles, no exchange yet)
+    # rank r maps tile r of a block-aligned arrangement of 512^3 tiles (2x2x2 = 1024^3 on 8 GPUs):
+    # ONE robot / sensor stream shared by all ranks, each rank's local volume offset to its tile,
+    # one-voxel halo exchange + refinement rounds over RCCL after every map update
     from gie import tiling
-    offset = tiling.tile_centre_offset(rank, world, size, args.voxel)
-    frames = make_frames(scenes, args.voxel, nframes, 5, args.sensor, offset=offset)
+    frames = make_frames(scenes, args.voxel, nframes, 5, args.sensor)
+    tgrid = tiling.tile_grid(world)
+    whole = tuple(tgrid[i] * size[i] for i in range(3))
     dev = torch.device("cuda", local_rank)
     d_pts = [torch.from_numpy(f[2]).to(dev) for f in frames]
     torch.cuda.synchronize()
 
     cfg = gie.make_config(args.voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank)
     m = gie.Mapper(cfg)
+    halo_bufs = {}
+    if world > 1:
+        m.set_tile(tiling.tile_offset_voxels(rank, world, size), whole)
+    rounds_total = [0]
 
     def step(i):
         pos, q = frames[i][0], frames[i][1]
@@ -143,6 +150,8 @@ def main():
             m.ogm_multiscan_dev(d_pts[i].data_ptr(), bins, rings, 2.0 * math.pi / bins, -math.pi,
                                 math.radians(phi_inc), math.radians(phi_min))
         m.step()
+        if world > 1:
+            rounds_total[0] += tiling.exchange_until_stable_device(m, dist, rank, world, dev, halo_bufs)
 
     for i in range(args.warmup):
         step(i)
@@ -195,10 +204,27 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_voxel": ALG_BYTES[dom]}
+        elif dom in ("wave_a", "wave_b", "wave_c"):
+            # BFS wave: algorithmic bytes = 64 B per visited voxel (own record + six 8-byte RMWs)
+            key = "total_visits_" + dom[-1]
+            visits = (st[key] - st0[key]) / float(sweeps[dom][1])
+            achieved = 64.0 * visits / (dom_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4),
+                    "alg_bytes_per_visit": 64, "visits_per_launch": round(visits, 1),
+                    "note": "level-synchronous BFS over %.0f voxels per launch on average: bound by the dependent "
+                            "cross-XCD round trips of each level (grid barrier), not by HBM bandwidth" % visits}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": round(dom_ms, 4),
-                    "note": "dominant kernel is not volume-proportional (ray casting / BFS wave)"}
+                    "note": "dominant kernel is per-point ray casting (atomic/latency bound), not volume-proportional"}
+        # every volume sweep against the same roofline (algorithmic bytes of SURVEY §8d)
+        sweeps_roof = {}
+        for k2, v2 in sweeps.items():
+            if k2 in ALG_BYTES:
+                ms2 = v2[0] / v2[1]
+                sweeps_roof[k2] = {"avg_launch_ms": round(ms2, 4), "achieved_GBps": round(ALG_BYTES[k2] * n_vox / (ms2 * 1e-3) / 1e9, 1),
+                                   "frac": round(ALG_BYTES[k2] * n_vox / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         line = {
             "metric": "edt_map_update_throughput", "value": round(value, 2), "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -210,7 +236,9 @@ def main():
                                       "parallel ray casting" if bins is None else "%dx%d range image (projective OGM)" % (rings, bins),
                                       cutoff_dist),
                        "sensor": args.sensor,
-                       "tiles": "one independent %dx%dx%d tile per GPU" % size, "known_voxel_fraction": known,
+                       "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement (%.1f rounds/step)"
+                                 % (tgrid + size + (rounds_total[0] / float(nframes),))) if world > 1 else "single volume",
+                       "known_voxel_fraction": known,
                        "wave_visits_per_step": [round((st["total_visits_" + k] - st0["total_visits_" + k]) / args.steps, 1) for k in "abc"],
                        "wave_levels_last_step": [st["levels_a"], st["levels_b"], st["levels_c"]],
                        "blocks": st["blocks_total"]},
@@ -218,6 +246,7 @@ def main():
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(sweeps.items(), key=lambda kv: -kv[1][0])},
             "kernel_time_fraction_of_step": round(total_kernel_ms / (1e3 * dt), 3),
             "roofline": roof,
+            "roofline_sweeps": sweeps_roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scenes, args.voxel, cutoff_dist, args.sensor)

@@ -506,25 +506,30 @@ extern "C" int gie_halo_count(gie_mapper *m, int face)
     if (!m || face < 0 || face > 5) { gie_set_err("gie_halo_count: bad arguments"); return -1; }
     return gie_face_count(m->c, face);
 }
+extern "C" int gie_halo_export_dev(gie_mapper *m, int face, gie_halo_voxel *d_out)
+{
+    int rc = gie_need_pose(m, "gie_halo_export"); if (rc) return rc;
+    if (face < 0 || face > 5 || !d_out) { gie_set_err("gie_halo_export: bad arguments"); return GIE_ERR_INVALID; }
+    op_halo_export op; op.face = face; op.out = d_out;
+    be_lin(&m->be, m->c, op, gie_face_count(m->c, face));
+    return GIE_OK;
+}
 extern "C" int gie_halo_export(gie_mapper *m, int face, gie_halo_voxel *out)
 {
     int rc = gie_need_pose(m, "gie_halo_export"); if (rc) return rc;
     if (face < 0 || face > 5 || !out) { gie_set_err("gie_halo_export: bad arguments"); return GIE_ERR_INVALID; }
     const int n = gie_face_count(m->c, face);
     gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
-    op_halo_export op; op.face = face; op.out = d;
-    be_lin(&m->be, m->c, op, n);
+    rc = gie_halo_export_dev(m, face, d);
     be_d2h(&m->be, out, d, (size_t)n * sizeof(gie_halo_voxel));
     be_free(&m->be, d);
-    return GIE_OK;
+    return rc;
 }
-extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in)
+extern "C" int gie_halo_import_dev(gie_mapper *m, int face, const gie_halo_voxel *d)
 {
     int rc = gie_need_pose(m, "gie_halo_import"); if (rc) return rc;
-    if (face < 0 || face > 5 || !in) { gie_set_err("gie_halo_import: bad arguments"); return GIE_ERR_INVALID; }
+    if (face < 0 || face > 5 || !d) { gie_set_err("gie_halo_import: bad arguments"); return GIE_ERR_INVALID; }
     const int n = gie_face_count(m->c, face);
-    gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
-    be_h2d(&m->be, d, in, (size_t)n * sizeof(gie_halo_voxel));
     /* ghost voxels need their blocks: same allocation path as gie_fuse */
     op_halo_need nd; nd.face = face; nd.in = d;
     be_lin(&m->be, m->c, nd, n);
@@ -536,9 +541,19 @@ extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in
     be_lin(&m->be, m->c, op_cell_table(), m->ncell);
     op_halo_import im; im.face = face; im.in = d;
     be_lin(&m->be, m->c, im, n);
+    return GIE_OK;
+}
+extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in)
+{
+    int rc = gie_need_pose(m, "gie_halo_import"); if (rc) return rc;
+    if (face < 0 || face > 5 || !in) { gie_set_err("gie_halo_import: bad arguments"); return GIE_ERR_INVALID; }
+    const int n = gie_face_count(m->c, face);
+    gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
+    be_h2d(&m->be, d, in, (size_t)n * sizeof(gie_halo_voxel));
+    rc = gie_halo_import_dev(m, face, d);
     be_sync(&m->be);
     be_free(&m->be, d);
-    return GIE_OK;
+    return rc;
 }
 extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
 {

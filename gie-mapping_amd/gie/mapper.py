@@ -257,6 +257,15 @@ class Mapper(MapperBase):
             raise RuntimeError(self._err())
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}
 
+    def halo_count(self, face):
+        return self._f["halo_count"](self._h, face)
+
+    def halo_export_dev(self, face, dptr):
+        self._chk(self._f["halo_export_dev"](self._h, face, C.c_void_p(dptr)))
+
+    def halo_import_dev(self, face, dptr):
+        self._chk(self._f["halo_import_dev"](self._h, face, C.c_void_p(dptr)))
+
     # device-resident sensor frames (pointers are raw device addresses, e.g. torch .data_ptr())
     def ogm_depth_dev(self, dptr, rows, cols, cx, cy, fx, fy, valid_nan=False):
         p = CamParam(rows, cols, cx, cy, fx, fy, int(valid_nan))

@@ -96,6 +96,65 @@ def exchange_until_stable_local(mappers, grid, max_rounds=64):
     return rounds
 
 
+def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64):
+    """In-process variant of the device-resident exchange (all tiles on one GPU): the export
+    kernel of one mapper writes the tensor the import kernel of its neighbour reads."""
+    import torch
+    world = grid[0] * grid[1] * grid[2]
+    rounds = 0
+    for _ in range(max_rounds):
+        layers = {}
+        for r, m in enumerate(mappers):
+            for face, nb in neighbours(r, world).items():
+                t = torch.empty(m.halo_count(face) * 20, dtype=torch.uint8, device=device)
+                m.halo_export_dev(face, t.data_ptr())
+                layers[(nb, face ^ 1)] = t
+        for m in mappers:
+            m.sync()
+        for (r, face), t in layers.items():
+            mappers[r].halo_import_dev(face, t.data_ptr())
+        seeded = sum(m.refine() for m in mappers)
+        rounds += 1
+        if seeded == 0:
+            break
+    return rounds
+
+
+def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=None, max_rounds=64):
+    """Device-resident form of exchange_until_stable for backend "nccl" (RCCL over xGMI): the
+    face layers are written by the export kernel straight into the send tensors and read by the
+    import kernel from the receive tensors; nothing crosses PCIe except the seed count."""
+    import torch
+    nbs = neighbours(rank, world_size)
+    if bufs is None:
+        bufs = {}
+    for face in nbs:
+        if face not in bufs:
+            n = mapper.halo_count(face) * 20
+            bufs[face] = (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
+    rounds = 0
+    for _ in range(max_rounds):
+        ops = []
+        for face, nb in sorted(nbs.items()):
+            snd, rcv = bufs[face]
+            mapper.halo_export_dev(face, snd.data_ptr())
+            ops.append(dist.P2POp(dist.isend, snd, nb))
+            ops.append(dist.P2POp(dist.irecv, rcv, nb))
+        mapper.sync()                                   # export kernels ran on the mapper's own stream
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            torch.cuda.synchronize(device)
+        for face in sorted(nbs):
+            mapper.halo_import_dev(face, bufs[face][1].data_ptr())
+        n = torch.tensor([mapper.refine()], dtype=torch.int64, device=device)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        rounds += 1
+        if int(n.item()) == 0:
+            break
+    return rounds
+
+
 def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64):
     """One tile per rank: face layers travel with torch.distributed point-to-point ops (RCCL over
     xGMI with backend "nccl", gloo on CPU); a 1-int all-reduce(sum) of the seed counts is the

@@ -197,6 +197,9 @@ int gie_set_tile(gie_mapper *h, const int32_t off[3], const int32_t whole[3]);
 int gie_halo_count(gie_mapper *h, int face);
 int gie_halo_export(gie_mapper *h, int face, gie_halo_voxel *out);
 int gie_halo_import(gie_mapper *h, int face, const gie_halo_voxel *in);
+/* same with DEVICE buffers (RCCL send/recv tensors), asynchronous on the mapper's stream */
+int gie_halo_export_dev(gie_mapper *h, int face, gie_halo_voxel *d_out);
+int gie_halo_import_dev(gie_mapper *h, int face, const gie_halo_voxel *d_in);
 /* returns the number of voxels seeded from ghost neighbours in *seeded (0 = nothing changed) */
 int gie_refine(gie_mapper *h, int32_t *seeded);
 

@@ -33,7 +33,7 @@ def _sensor_frames(n):
 KW = dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi, phi_inc=np.radians(2.5), phi_min=np.radians(-40.0))
 
 
-def _run_tiled(make, exchange=True):
+def _run_tiled(make, exchange=True, device=None):
     cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
     ms = [make(cfg), make(cfg)]
     for r, m in enumerate(ms):
@@ -43,7 +43,12 @@ def _run_tiled(make, exchange=True):
         for pos, q, img in _sensor_frames(FR):
             for m in ms:
                 m.update(pos, q, "multiscan", img, **KW)
-            rounds = tiling.exchange_until_stable_local(ms, (2, 1, 1)) if exchange else 0
+            if not exchange:
+                rounds = 0
+            elif device is not None:
+                rounds = tiling.exchange_until_stable_local_device(ms, (2, 1, 1), device)
+            else:
+                rounds = tiling.exchange_until_stable_local(ms, (2, 1, 1))
             hist.append(([m.read_local() for m in ms], rounds, [m.pivot() for m in ms]))
     finally:
         for m in ms:
@@ -122,3 +127,10 @@ def test_exchange_carries_information_and_approaches_the_single_volume(oracle_li
 @pytest.mark.gpu
 def test_hip_tiled_matches_oracle_tiled(oracle_lib):
     _assert_same(_run_tiled(OracleMapper), _run_tiled(gie.Mapper))
+
+
+@pytest.mark.gpu
+def test_hip_tiled_device_resident_exchange(oracle_lib):
+    """the *_dev halo entry points (what the RCCL path uses): layers never leave the GPU"""
+    import torch
+    _assert_same(_run_tiled(OracleMapper), _run_tiled(gie.Mapper, device=torch.device("cuda", 0)))
