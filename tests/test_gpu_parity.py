@@ -44,6 +44,8 @@ def test_hip_matches_oracle(oracle_lib, sc):
     ((64, 64, 64), 0.001, 1), ((100, 70, 33), 0.01, 2), ((130, 20, 257), 0.0005, 3), ((16, 300, 16), 0.02, 4),
     ((512, 8, 8), 0.003, 5), ((8, 8, 512), 0.003, 6), ((8, 512, 8), 0.003, 7), ((65, 129, 1), 0.01, 8),
     ((1, 1, 1), 1.0, 9), ((40, 40, 40), 1.0, 10),
+    # the 1024-long axis templates (pass Y with 32 mask words, envelope passes with CP = 16)
+    ((1024, 16, 12), 0.002, 11), ((16, 1024, 12), 0.002, 12), ((12, 16, 1024), 0.002, 13),
 ])
 def test_batch_edt_random_grids(oracle_lib, shape, dens, seed):
     """EDT passes alone on random obstacle fields, through the full C-ABI: types are injected
@@ -111,5 +113,48 @@ def test_costmap_payload(oracle_lib):
         for f in ("x_size", "y_size", "z_size", "x_origin", "y_origin", "z_origin", "width", "type"):
             assert getattr(ha, f) == getattr(hb, f)
         assert pb.dtype.itemsize == 8
+    finally:
+        a.close(); b.close()
+
+
+def test_full_size_512_cube(oracle_lib):
+    """BASELINE size: 512^3 @ 0.05 m (outside the reference's 11/11/10-bit envelope → wide mode).
+    Two map updates against the oracle, every array bit for bit, plus size-independent
+    properties of the result: every finite distance is witnessed by its closest obstacle, and
+    a second update on an unchanged scene and pose changes nothing (idempotence)."""
+    import bench
+    from gie import scenes
+    size = (512, 512, 512)
+    cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
+    frames = bench.make_frames(scenes, 0.05, 2, 5, "vlp16")
+    rings, az, phi_min, phi_inc, bins = bench.SENSORS["vlp16"]
+    kw = dict(theta_inc=2.0 * np.pi / bins, theta_min=-np.pi, phi_inc=np.radians(phi_inc), phi_min=np.radians(phi_min))
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        for pos, q, img, _ in frames:
+            for m in (a, b):
+                m.update(pos, q, "multiscan", img, **kw)
+            ea, eb = a.read_batch_edt(), b.read_batch_edt()
+            assert np.array_equal(ea["dist_sq"], eb["dist_sq"]) and np.array_equal(ea["coc"], eb["coc"])
+            del ea, eb
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), key
+            assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0)
+            sa, sb = a.stats(), b.stats()
+            for key in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_c", "levels_c", "blocks_total"):
+                assert sa[key] == sb[key], key
+        # witness property on the GPU result
+        pv = np.array(b.pivot())
+        known = (rb["type"] != 0) & (rb["dist_sq"] < 4000000)
+        zz, yy, xx = np.nonzero(known)
+        g = np.stack([xx, yy, zz], -1) + pv
+        d = ((rb["coc"][known].astype(np.int64) - g) ** 2).sum(-1)
+        assert np.array_equal(d, rb["dist_sq"][known])
+        # idempotence: same pose, same frame again → same field
+        pos, q, img, _ = frames[-1]
+        b.update(pos, q, "multiscan", img, **kw)
+        rc = b.read_local()
+        assert np.array_equal(rc["dist_sq"][known], rb["dist_sq"][known])
     finally:
         a.close(); b.close()
