@@ -38,10 +38,12 @@ __device__ __forceinline__ int32_t gie_aor32(int32_t *p, int32_t v) { return __h
 
 #if defined(GIE_HOST_EMU)
 #define GIE_UNROLL6
+#define GIE_UNROLL_BATCH
 #define GIE_DEV_COLD static
 #else
 #define GIE_DEV_COLD __device__ __forceinline__   /* (a real call would push the kernarg context through scratch: measured 5x slower) */
 #define GIE_UNROLL6 _Pragma("unroll 6")
+#define GIE_UNROLL_BATCH _Pragma("unroll")
 #endif
 
 /* append to a frontier queue; overflow raises the sticky error flag */
@@ -54,6 +56,30 @@ GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap,
 {
     const int i = gie_aadd32(counter, 1);
     if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+}
+
+/* ray_count[id] += val for every lane with id >= 0, with equal targets inside the wave merged
+ * into ONE atomic (neighbouring rays of a scan share most of their cells; unmerged, thousands of
+ * wave-wide same-address atomics serialise at one L2 slice).  Up to GIE_AGG_ROUNDS distinct
+ * targets are merged, the rest falls back to one atomic per lane.  Safe in divergent code:
+ * ballots and shuffles only involve the lanes that are executing. */
+#define GIE_AGG_ROUNDS 6
+GIE_DEV void gie_wave_add(const gie_ctx &c, int id, int val)
+{
+#if defined(GIE_HOST_EMU)
+    if (id >= 0) c.ray_count[id] += val;
+#else
+    unsigned long long todo = __ballot(id >= 0);
+    const int lane = __lane_id();
+    for (int r = 0; r < GIE_AGG_ROUNDS && todo; r++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lid = __shfl(id, leader);
+        const unsigned long long same = __ballot(id == lid) & todo;
+        if (lane == leader) gie_aadd32(&c.ray_count[lid], val * __popcll(same));
+        todo &= ~same;
+    }
+    if (id >= 0 && ((todo >> lane) & 1ull)) gie_aadd32(&c.ray_count[id], val);
+#endif
 }
 
 /* global voxel address: block slot through the frame's block table (volume +-1 voxel) */
@@ -167,7 +193,7 @@ GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out
         if (gie_in_loc(c, lx, ly, lz)) {
             const int id = gie_lid(c, lx, ly, lz);
             c.inst_type[id] = GIE_VOX_OCCUPIED;      /* all writers store the same value */
-            gie_aadd32(&c.ray_count[id], 1);
+            gie_wave_add(c, id, 1);
         }
     }
 }
@@ -190,7 +216,11 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
     const float max_length = 0.707f * (float)c.X * w;
     int i0[3], i1[3];
     for (int k = 0; k < 3; k++) { i0[k] = gie_pos2coord(p0[k], w); i1[k] = gie_pos2coord(p1[k], w); }
-    gie_clear_ray(c, i0[0] - c.pvt[0], i0[1] - c.pvt[1], i0[2] - c.pvt[2]);
+    {   /* clearRayLoc on the sensor's own cell */
+        const int lx = i0[0] - c.pvt[0], ly = i0[1] - c.pvt[1], lz = i0[2] - c.pvt[2];
+        const int id0 = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
+        gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
+    }
     if (i0[0] == i1[0] && i0[1] == i1[1] && i0[2] == i1[2]) return;
     float dir[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
     const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
@@ -205,19 +235,38 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
             tDelta[k] = w / fabsf(dir[k]);
         } else { tMax[k] = 3.402823466e+38f; tDelta[k] = 3.402823466e+38f; }
     }
+    /* The traversal itself (ray_cast.h:102-142) is a dependent chain "step → read the cell's
+     * type → stop or decrement"; the cells do not depend on what is read, so GIE_RAY_BATCH steps
+     * are generated ahead, their types are fetched together, and the effects are then applied in
+     * the reference's order (a speculative cell beyond the stopping point is simply dropped). */
+#define GIE_RAY_BATCH 8
     for (;;) {
-        int dim;
-        if (tMax[0] < tMax[1]) dim = (tMax[0] < tMax[2]) ? 0 : 2;
-        else dim = (tMax[1] < tMax[2]) ? 1 : 2;
-        /* unrolled select instead of dynamic indexing keeps everything in registers */
-        if (dim == 0) { cur[0] += step[0]; tMax[0] += tDelta[0]; }
-        else if (dim == 1) { cur[1] += step[1]; tMax[1] += tDelta[1]; }
-        else { cur[2] += step[2]; tMax[2] += tDelta[2]; }
-        if (!gie_clear_ray(c, cur[0] - c.pvt[0], cur[1] - c.pvt[1], cur[2] - c.pvt[2])) break;
-        if (cur[0] == i1[0] && cur[1] == i1[1] && cur[2] == i1[2]) break;
-        const float m01 = tMax[0] < tMax[1] ? tMax[0] : tMax[1];
-        const float dist = m01 < tMax[2] ? m01 : tMax[2];
-        if (dist > max_length || dist > len) break;
+        int ids[GIE_RAY_BATCH];            /* local voxel id, -1 = outside the volume */
+        int stop_after[GIE_RAY_BATCH];
+        GIE_UNROLL_BATCH
+        for (int j = 0; j < GIE_RAY_BATCH; j++) {
+            int dim;
+            if (tMax[0] < tMax[1]) dim = (tMax[0] < tMax[2]) ? 0 : 2;
+            else dim = (tMax[1] < tMax[2]) ? 1 : 2;
+            /* unrolled select instead of dynamic indexing keeps everything in registers */
+            if (dim == 0) { cur[0] += step[0]; tMax[0] += tDelta[0]; }
+            else if (dim == 1) { cur[1] += step[1]; tMax[1] += tDelta[1]; }
+            else { cur[2] += step[2]; tMax[2] += tDelta[2]; }
+            const int lx = cur[0] - c.pvt[0], ly = cur[1] - c.pvt[1], lz = cur[2] - c.pvt[2];
+            ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
+            const float m01 = tMax[0] < tMax[1] ? tMax[0] : tMax[1];
+            const float dist = m01 < tMax[2] ? m01 : tMax[2];
+            stop_after[j] = (cur[0] == i1[0] && cur[1] == i1[1] && cur[2] == i1[2]) || dist > max_length || dist > len;
+        }
+        int8_t ty[GIE_RAY_BATCH];
+        GIE_UNROLL_BATCH
+        for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = ids[j] >= 0 ? c.inst_type[ids[j]] : (int8_t)GIE_VOX_UNKNOWN;
+        GIE_UNROLL_BATCH
+        for (int j = 0; j < GIE_RAY_BATCH; j++) {
+            if (ty[j] == GIE_VOX_OCCUPIED) return;                 /* clearRayLoc returned false */
+            gie_wave_add(c, ids[j], -1);
+            if (stop_after[j]) return;
+        }
     }
 }
 
