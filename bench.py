@@ -39,13 +39,17 @@ EDT_UPDATE_BYTES = 124  # V3..V8
 
 # sensor models: name -> (rings, azimuth steps of the synthetic cloud, phi_min_deg, phi_inc_deg, range-image bins or None)
 SENSORS = {
-    # the reference's VLP-16 model MulScanParam(440,16,10,2pi/440,-pi,2deg,-15deg) (volumetric_mapper.cpp:327):
-    # synthetic 16x1800 point cloud → convertPyntCld binning → projective VLP_FAST kernel
-    "vlp16": (16, 1800, -15.0, 2.0, 440),
-    # a denser 64-ring unit, same projective path
-    "lidar64": (64, 1800, -30.0, 60.0 / 64, 1800),
-    # the same 64-ring cloud through the parallel ray-casting path (PNTCLD_RAYCAST)
-    "pointcloud": (64, 1800, -30.0, 60.0 / 64, None),
+    # DEFAULT — BASELINE config "UGV VLP-16 3D LiDAR (ugv_dataset), 512^3 local volume, full wavefront A+B":
+    # launch/ugv_dataset.launch sets data_case=ugv_corridor, i.e. the point cloud goes through
+    # PntcldMapMaker → PNTCLD_RAYCAST (parallel ray casting).  Synthetic 16-ring x 1800 cloud.
+    "vlp16": (16, 1800, -15.0, 2.0, None),
+    # the same cloud through the projective path of launch/ugv_laser3d.launch (data_case=laser3D):
+    # convertPyntCld binning → MulScanParam(440,16,10,2pi/440,-pi,2deg,-15deg) (volumetric_mapper.cpp:327)
+    # → VLP_FAST.  Classifies every voxel of the +-15 deg wedge: dense maps, heavy wavefronts.
+    "vlp16_projective": (16, 1800, -15.0, 2.0, 440),
+    # a denser 64-ring unit through both paths
+    "lidar64": (64, 1800, -30.0, 60.0 / 64, None),
+    "lidar64_projective": (64, 1800, -30.0, 60.0 / 64, 1800),
 }
 
 
@@ -122,6 +126,7 @@ def main():
     n_vox = size[0] * size[1] * size[2]
     cutoff_dist = 2.0
     rings, az, phi_min, phi_inc, bins = SENSORS[args.sensor]
+    ALG_BYTES["fuse"] = 15 if bins is None else 7      # ray-cast fuse also reads/zeroes _ray_count
     nframes = args.warmup + args.steps
     # rank r maps tile r of a block-aligned arrangement of 512^3 tiles (2x2x2 = 1024^3 on 8 GPUs):
     # ONE robot / sensor stream shared by all ranks, each rank's local volume offset to its tile,

@@ -126,8 +126,8 @@ def test_full_size_512_cube(oracle_lib):
     from gie import scenes
     size = (512, 512, 512)
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
-    frames = bench.make_frames(scenes, 0.05, 2, 5, "vlp16")
-    rings, az, phi_min, phi_inc, bins = bench.SENSORS["vlp16"]
+    frames = bench.make_frames(scenes, 0.05, 2, 5, "vlp16_projective")
+    rings, az, phi_min, phi_inc, bins = bench.SENSORS["vlp16_projective"]
     kw = dict(theta_inc=2.0 * np.pi / bins, theta_min=-np.pi, phi_inc=np.radians(phi_inc), phi_min=np.radians(phi_min))
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
     try:
