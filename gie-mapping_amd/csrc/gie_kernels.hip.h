@@ -212,9 +212,12 @@ __device__ __forceinline__ void gie_wave_sync()
 }
 
 template <int CP>
-__device__ __forceinline__ void gie_row_argmin(const uint2 *ce, uint16_t *jsite, const int K, const int L, const int lane)
+__device__ __forceinline__ void gie_row_argmin(const uint2 *ce, const int K, const int L, const int lane, int (&sj)[CP])
 {
+    /* lane owns positions u0 .. u0+CP-1; sj[m] receives the winning RANK of position u0+m.
+     * Everything lives in registers: the only LDS traffic is reading candidate sites. */
     const int u0 = lane * CP;
+    int s0;
     {
         uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
         const int up = u0 << 5;
@@ -231,25 +234,31 @@ __device__ __forceinline__ void gie_row_argmin(const uint2 *ce, uint16_t *jsite,
         }
         for (int j = K4; j < K; j++) { const uint2 v = ce[j]; const int d = up - (int)(v.y & 0xffffu); b0 = min(b0, (uint32_t)__mul24(d, d) + v.x); }
         const uint32_t best = min(min(b0, b1), min(b2, b3));
-        jsite[u0] = (u0 < L) ? (uint16_t)(best & 1023u) : (uint16_t)(K - 1);
-        if (lane == 63) jsite[64 * CP] = (uint16_t)(K - 1);
+        s0 = (u0 < L) ? (int)(best & 1023u) : K - 1;
     }
-    gie_wave_sync();
+    /* upper bound of the chunk = the next lane's first position (monotone argmin) */
+    int sup = __shfl_down(s0, 1);
+    if (lane == 63) sup = K - 1;
+    int sx[CP + 1];
+    sx[0] = s0; sx[CP] = sup;
 #pragma unroll
     for (int step = CP / 2; step >= 1; step >>= 1) {
 #pragma unroll
         for (int m = step; m < CP; m += 2 * step) {
             const int u = u0 + m;
-            const int lo = jsite[u - step], hi = jsite[u + step];
-            uint32_t best = 0xffffffffu;
-            if (u < L) {
+            const int lo = sx[m - step], hi = sx[m + step];
+            int r = lo;
+            if (u < L && hi > lo) {
+                uint32_t best = 0xffffffffu;
                 const int up = u << 5;
                 for (int j = lo; j <= hi; j++) { const uint2 v = ce[j]; const int d = up - (int)(v.y & 0xffffu); best = min(best, (uint32_t)__mul24(d, d) + v.x); }
+                r = (int)(best & 1023u);
             }
-            jsite[u] = (u < L) ? (uint16_t)(best & 1023u) : (uint16_t)(K - 1);
+            sx[m] = (u < L) ? r : K - 1;
         }
-        gie_wave_sync();
     }
+#pragma unroll
+    for (int m = 0; m < CP; m++) sj[m] = sx[m];
 }
 
 /* wave64 stream compaction of the row's real sites; returns K.  `a` = value or ~0u (none),
@@ -265,14 +274,15 @@ __device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const b
 }
 
 /* ------------------------------------------------------------------ EDT pass X */
-/* one wave per (y,z) row; rows are contiguous in memory so loads/stores are coalesced */
+/* one wave per (y,z) row; rows are contiguous in memory so loads/stores are coalesced; every
+ * lane ends up with the CP consecutive results of its chunk in registers and stores them as
+ * 16-byte vectors (the wave covers one contiguous run) */
 #define GIE_EDTX_WAVES 4
 template <int CP>
 __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
 {
     constexpr int LP = 64 * CP;
     __shared__ __attribute__((aligned(16))) uint2 s_ce[GIE_EDTX_WAVES][LP];
-    __shared__ uint16_t s_site[GIE_EDTX_WAVES][LP + 2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * GIE_EDTX_WAVES + wave;        /* row = z*Y + y */
     if (row >= c.Y * c.Z) return;
@@ -280,7 +290,6 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
     const int y = row % c.Y;
     const uint16_t *in = c.cy1 + (size_t)row * X;
     uint2 *ce = s_ce[wave];
-    uint16_t *jsite = s_site[wave];
     int K = 0;
     for (int i0 = 0; i0 < X; i0 += 64) {
         const int i = i0 + lane;
@@ -289,15 +298,28 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
         K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane);
     }
     uint32_t *out = c.cxy2 + (size_t)row * X;
+    const int u0 = lane * CP;
+    uint32_t o[CP];
     if (K == 0) {                                               /* slice without obstacle */
-        for (int i = lane; i < X; i += 64) out[i] = 0xffffffffu;
-        return;
+#pragma unroll
+        for (int m = 0; m < CP; m++) o[m] = 0xffffffffu;
+    } else {
+        gie_wave_sync();
+        int sj[CP];
+        gie_row_argmin<CP>(ce, K, X, lane, sj);
+#pragma unroll
+        for (int m = 0; m < CP; m++) {
+            const uint32_t e = ce[sj[m]].y;
+            o[m] = ((e & 0xffffu) >> 5) | (e & 0xffff0000u);     /* cx | cy << 16 */
+        }
     }
-    gie_wave_sync();
-    gie_row_argmin<CP>(ce, jsite, K, X, lane);
-    for (int i = lane; i < X; i += 64) {
-        const uint32_t e = ce[jsite[i]].y;
-        out[i] = ((e & 0xffffu) >> 5) | (e & 0xffff0000u);       /* cx | cy << 16 */
+    if (CP >= 4 && (X & 3) == 0) {
+#pragma unroll
+        for (int m = 0; m < CP; m += 4)
+            if (u0 + m < X) *reinterpret_cast<uint4 *>(out + u0 + m) = make_uint4(o[m], o[m + 1 < CP ? m + 1 : m], o[m + 2 < CP ? m + 2 : m], o[m + 3 < CP ? m + 3 : m]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < CP; m++) if (u0 + m < X) out[u0 + m] = o[m];
     }
 }
 
@@ -320,20 +342,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
     const int Z = c.Z, X = c.X, Y = c.Y;
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem);                               /* [Z][TS] cx|cy<<16 → bcoc */
     uint2 *s_ce = reinterpret_cast<uint2 *>(tile + (((size_t)Z * TS + 3) & ~(size_t)3));   /* [WAVES][LP] */
-    uint16_t *s_site = reinterpret_cast<uint16_t *>(s_ce + WAVES * LP);                /* [WAVES][LP+2]            */
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = threadIdx.x & (TX - 1), tz = threadIdx.x / TX;
     const size_t plane = (size_t)X * Y;
     uint2 *ce = s_ce + wave * LP;
-    uint16_t *jsite = s_site + wave * (LP + 2);
     /* persistent workgroup: tiles t, t+G, t+2G, …; the NEXT tile is fetched into registers while
      * the envelopes of the current one are computed out of LDS */
     uint32_t pre[NLD];
     int t = blockIdx.x;
+    const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
     if (t < ntiles) {
         const int x = (t % ntiles_x) * TX + tx, y = t / ntiles_x;
+        const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)y * X + x;   /* one 64-bit product per tile, then adds */
 #pragma unroll
-        for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; pre[j] = (z < Z && x < X) ? c.cxy2[(size_t)z * plane + (size_t)y * X + x] : 0xffffffffu; }
+        for (int j = 0; j < NLD; j++) { pre[j] = (tz + j * ZSTEP < Z && x < X) ? *src : 0xffffffffu; src += zstride; }
     }
     for (; t < ntiles; t += gridDim.x) {
         const int x0 = (t % ntiles_x) * TX, y = t / ntiles_x;
@@ -343,8 +365,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
         const int tn = t + gridDim.x;
         if (tn < ntiles) {                                /* prefetch: in flight during the column work */
             const int xn = (tn % ntiles_x) * TX + tx, yn = tn / ntiles_x;
+            const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)yn * X + xn;
 #pragma unroll
-            for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; pre[j] = (z < Z && xn < X) ? c.cxy2[(size_t)z * plane + (size_t)yn * X + xn] : 0xffffffffu; }
+            for (int j = 0; j < NLD; j++) { pre[j] = (tz + j * ZSTEP < Z && xn < X) ? *src : 0xffffffffu; src += zstride; }
         }
         for (int col = wave; col < TX; col += WAVES) {
             const int x = x0 + col;
@@ -360,24 +383,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
             if (K == 0) {                                       /* the whole volume is empty */
                 for (int i = lane; i < Z; i += 64) tile[i * TS + col] = GIE_BCOC_NONE;
             } else {
-                gie_row_argmin<CP>(ce, jsite, K, Z, lane);
+                int sj[CP];
+                gie_row_argmin<CP>(ce, K, Z, lane, sj);
                 /* gather first (own column only), then overwrite the column in place */
+                const int u0 = lane * CP;
                 uint32_t oc[CP];
 #pragma unroll
-                for (int j = 0; j < CP; j++) {
-                    const int i = lane + 64 * j;
-                    if (i < Z) {
-                        const int s = (int)((ce[jsite[i]].y & 0xffffu) >> 5);
+                for (int m = 0; m < CP; m++) {
+                    if (u0 + m < Z) {
+                        const int s = (int)((ce[sj[m]].y & 0xffffu) >> 5);
                         const uint32_t v = tile[s * TS + col];
-                        oc[j] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
+                        oc[m] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
                     }
                 }
                 gie_wave_sync();
 #pragma unroll
-                for (int j = 0; j < CP; j++) {
-                    const int i = lane + 64 * j;
-                    if (i < Z) tile[i * TS + col] = oc[j];
-                }
+                for (int m = 0; m < CP; m++)
+                    if (u0 + m < Z) tile[(u0 + m) * TS + col] = oc[m];
             }
             gie_wave_sync();
         }
@@ -385,8 +407,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
         {
             const int x = x0 + tx;
             if (x < X) {
+                uint32_t *dst = c.bcoc + (size_t)tz * plane + (size_t)y * X + x;
 #pragma unroll
-                for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) c.bcoc[(size_t)z * plane + (size_t)y * X + x] = tile[z * TS + tx]; }
+                for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) *dst = tile[z * TS + tx]; dst += zstride; }
             }
         }
         __syncthreads();                                  /* tile is overwritten by the next trip */
