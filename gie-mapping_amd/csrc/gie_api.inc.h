@@ -31,6 +31,9 @@ struct gie_mapper {
     float *d_pts_g; size_t pts_cap;       /* ray casting: points in the global frame */
     float *d_box_ll, *d_box_ur; uint8_t *d_box_act; int box_cap;
     int32_t *d_rank;
+    /* changed-block streaming: slot list + double-buffered staging (device and pinned host) */
+    int32_t *d_srank, *d_slist;
+    void *d_stage[2], *h_stage[2];
     std::vector<void *> allocs;
     int32_t h_cnt[GIE_CNT_NUM];
     int32_t next_off[3], next_whole[3];
@@ -63,6 +66,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
+    m->d_srank = m->d_slist = nullptr; m->d_stage[0] = m->d_stage[1] = m->h_stage[0] = m->h_stage[1] = nullptr;
     memset(m->h_cnt, 0, sizeof(m->h_cnt)); memset(m->us, 0, sizeof(m->us));
     if (be_init(&m->be, cfg->device_id) != 0) { delete m; return nullptr; }
     gie_ctx &c = m->c;
@@ -119,6 +123,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.g_pair = gie_dalloc<uint64_t>(m, GV, false);
     c.g_prop = gie_dalloc<uint64_t>(m, GV, false);
     c.g_wl = gie_dalloc<int32_t>(m, GV, false);
+    c.g_dirty = gie_dalloc<int32_t>(m, (size_t)mb);
+    c.track = 0;
     long long qab = 16ll * bdr; if (qab < 65536) qab = 65536; if (qab > (16 << 20)) qab = 16 << 20;
     long long qc = (long long)c.N; if (qc < 4096) qc = 4096; if (qc > (16 << 20)) qc = 16 << 20;
     c.qcap_ab = (int)qab; c.qcap_c = (int)qc;
@@ -154,6 +160,8 @@ extern "C" void gie_destroy(gie_mapper *m)
     if (m->d_sensor) be_free(&m->be, m->d_sensor);
     if (m->d_pts_g) be_free(&m->be, m->d_pts_g);
     if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
+    if (m->d_srank) { be_free(&m->be, m->d_srank); be_free(&m->be, m->d_slist); }
+    for (int i = 0; i < 2; i++) { if (m->d_stage[i]) be_free(&m->be, m->d_stage[i]); if (m->h_stage[i]) be_host_free(&m->be, m->h_stage[i]); }
     be_fini(&m->be);
     delete m;
 }
@@ -483,6 +491,68 @@ extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
     be_times(&m->be, &s->us_ogm, &s->us_fuse, &s->us_edt, &s->us_merge);
     memcpy(&s->total_visits_a, &h[GIE_CNT_TOT_A], 8); memcpy(&s->total_visits_b, &h[GIE_CNT_TOT_B], 8); memcpy(&s->total_visits_c, &h[GIE_CNT_TOT_C], 8);
     return rc;
+}
+/* ---- changed-block streaming */
+#define GIE_STREAM_CHUNK 2048                /* blocks per staging buffer: 2048 x (10 KB + 12 B) = 20 MB */
+static const size_t GIE_STREAM_BLK_BYTES = (size_t)GIE_VBSZ * sizeof(gie_voxel);
+
+extern "C" int gie_stream_enable(gie_mapper *m, int on)
+{
+    if (!m) { gie_set_err("gie_stream_enable: null handle"); return GIE_ERR_INVALID; }
+    m->c.track = on ? 1 : 0;
+    return GIE_OK;
+}
+extern "C" int gie_stream_changed(gie_mapper *m, int32_t *keys, gie_voxel *blocks, int max_blocks, int32_t *n_changed)
+{
+    if (!m || max_blocks < 0) { gie_set_err("gie_stream_changed: bad arguments"); return GIE_ERR_INVALID; }
+    gie_ctx &c = m->c;
+    const int cap = c.max_blocks;
+    if (!m->d_srank) {
+        m->d_srank = (int32_t *)be_alloc(&m->be, (size_t)cap * 4, false);
+        m->d_slist = (int32_t *)be_alloc(&m->be, (size_t)cap * 4, false);
+        if (!m->d_srank || !m->d_slist) { gie_set_err("gie_stream_changed: device allocation failed"); return GIE_ERR_DEVICE; }
+    }
+    be_exclusive_scan(&m->be, c.g_dirty, m->d_srank, cap);
+    int32_t last[2] = { 0, 0 };
+    be_d2h(&m->be, &last[0], m->d_srank + (cap - 1), 4);
+    be_d2h(&m->be, &last[1], c.g_dirty + (cap - 1), 4);
+    const int total = last[0] + last[1];
+    if (n_changed) *n_changed = total;
+    if (!keys || !blocks || total == 0 || max_blocks == 0) return gie_sync(m);
+    const int deliver = total < max_blocks ? total : max_blocks;
+    op_stream_list ol; ol.rank = m->d_srank; ol.list = m->d_slist;
+    be_lin(&m->be, c, ol, cap);
+    const size_t chunk_bytes = (size_t)GIE_STREAM_CHUNK * (GIE_STREAM_BLK_BYTES + 12);
+    for (int i = 0; i < 2; i++) {
+        if (!m->d_stage[i]) m->d_stage[i] = be_alloc(&m->be, chunk_bytes, false);
+        if (!m->h_stage[i]) m->h_stage[i] = be_host_alloc(&m->be, chunk_bytes);
+        if (!m->d_stage[i] || !m->h_stage[i]) { gie_set_err("gie_stream_changed: staging allocation failed"); return GIE_ERR_DEVICE; }
+    }
+    /* chunk k: gather on the device → async copy into pinned buffer k&1; meanwhile the host
+     * unpacks chunk k-1 from the other pinned buffer into the caller's arrays */
+    const int nchunk = (deliver + GIE_STREAM_CHUNK - 1) / GIE_STREAM_CHUNK;
+    for (int k = 0; k <= nchunk; k++) {
+        if (k < nchunk) {
+            const int first = k * GIE_STREAM_CHUNK, nb = deliver - first < GIE_STREAM_CHUNK ? deliver - first : GIE_STREAM_CHUNK;
+            char *d = (char *)m->d_stage[k & 1];
+            op_stream_gather og; og.list = m->d_slist; og.first = first;
+            og.out = (gie_voxel *)d; og.keys = (int32_t *)(d + (size_t)GIE_STREAM_CHUNK * GIE_STREAM_BLK_BYTES);
+            be_lin(&m->be, c, og, nb * GIE_VBSZ);
+            op_stream_clear oc; oc.list = m->d_slist; oc.first = first;
+            be_lin(&m->be, c, oc, nb);
+            be_d2h_async(&m->be, m->h_stage[k & 1], d, (size_t)nb * GIE_STREAM_BLK_BYTES, k & 1);
+            be_d2h_async(&m->be, (char *)m->h_stage[k & 1] + (size_t)GIE_STREAM_CHUNK * GIE_STREAM_BLK_BYTES,
+                         d + (size_t)GIE_STREAM_CHUNK * GIE_STREAM_BLK_BYTES, (size_t)nb * 12, k & 1);
+        }
+        if (k > 0) {
+            const int first = (k - 1) * GIE_STREAM_CHUNK, nb = deliver - first < GIE_STREAM_CHUNK ? deliver - first : GIE_STREAM_CHUNK;
+            const char *h = (const char *)m->h_stage[(k - 1) & 1];
+            be_wait(&m->be, (k - 1) & 1);
+            memcpy(blocks + (size_t)first * GIE_VBSZ, h, (size_t)nb * GIE_STREAM_BLK_BYTES);
+            memcpy(keys + 3 * (size_t)first, h + (size_t)GIE_STREAM_CHUNK * GIE_STREAM_BLK_BYTES, (size_t)nb * 12);
+        }
+    }
+    return gie_sync(m);
 }
 extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])
 {

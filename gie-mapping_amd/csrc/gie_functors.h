@@ -128,6 +128,10 @@ struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
+struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };
+struct op_stream_gather { const int32_t *list; int first; int32_t *keys; gie_voxel *out;
+    GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_gather(c, list, first, keys, out, i); } };
+struct op_stream_clear { const int32_t *list; int first; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_clear(c, list, first, i); } };
 struct op_export_pair { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_pair(c, i, d, coc); } };
 struct op_export_bcoc { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_bcoc(c, i, d, coc); } };
 struct op_costmap { gie_seendist *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const {

@@ -23,6 +23,7 @@ struct be_state {
     hipEvent_t ev[GIE_NEV];
     int ev_set[GIE_NEV];
     void *scan_tmp; size_t scan_bytes;
+    hipEvent_t copy_ev[2];              /* completion of the async D2H copies (changed-block streaming) */
     /* per-kernel event profiling */
     int prof_on;
     std::vector<hipEvent_t> *pool;      /* event pool */
@@ -52,6 +53,7 @@ static int be_init(be_state *b, int device)
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
+    for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
     b->prof_on = 0; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
     for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; b->open_start[i] = -1; }
     return 0;
@@ -62,6 +64,7 @@ static void be_fini(be_state *b)
     for (hipEvent_t e : *b->pool) (void)hipEventDestroy(e);
     delete b->pool; delete b->pending;
     for (int i = 0; i < GIE_NEV; i++) (void)hipEventDestroy(b->ev[i]);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(b->copy_ev[i]);
     (void)hipStreamDestroy(b->stream);
 }
 static void *be_alloc(be_state *b, size_t bytes, bool zero)
@@ -84,6 +87,15 @@ static void be_d2h(be_state *b, void *h, const void *d, size_t bytes)
     GIE_HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, b->stream));
     GIE_HIP_OK(hipStreamSynchronize(b->stream));
 }
+/* pinned host memory + asynchronous D2H with a completion event per staging slot */
+static void *be_host_alloc(be_state *b, size_t bytes) { void *p = nullptr; (void)hipSetDevice(b->device); return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+static void be_host_free(be_state *, void *p) { (void)hipHostFree(p); }
+static void be_d2h_async(be_state *b, void *h, const void *d, size_t bytes, int slot)
+{
+    GIE_HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, b->stream));
+    GIE_HIP_OK(hipEventRecord(b->copy_ev[slot], b->stream));
+}
+static void be_wait(be_state *b, int slot) { GIE_HIP_OK(hipEventSynchronize(b->copy_ev[slot])); }
 static int be_sync(be_state *b)
 {
     hipError_t e = hipStreamSynchronize(b->stream);

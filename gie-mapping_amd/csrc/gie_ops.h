@@ -88,6 +88,8 @@ GIE_DEV int gie_gvox_tab(const gie_ctx &c, int gx, int gy, int gz)
     const int s = c.blk_tab[gie_tab_index(c, gx, gy, gz)];
     return s < 0 ? -1 : s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
 }
+/* stream_VB_keys_D bookkeeping as one flag per block (all writers store 1) */
+GIE_DEV void gie_touch(const gie_ctx &c, int a) { if (c.track) gie_st(&c.g_dirty[a >> 9], (int32_t)1); }
 /* … or through the hash (anywhere) */
 GIE_DEV int gie_gvox_hash(const gie_ctx &c, int gx, int gy, int gz)
 {
@@ -376,7 +378,7 @@ GIE_DEV void gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         else if (nt == GIE_VOX_FREE) gie_set_occ(&occ, &ty, 0.f, 0.5f, c.occ_thresh);
     }
     if (occ != occ0) c.g_occ[a] = occ;
-    if (ty != ty0) c.g_type[a] = ty;
+    if (ty != ty0) { c.g_type[a] = ty; gie_touch(c, a); }
     if (gt0 != ty) c.glb_type[id] = ty;
 }
 /* updateHashOGMWithPntCld / updateHashOGMWithSensor, unify_helper.cuh:35-197 */
@@ -494,6 +496,7 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
         if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
             c.g_dist[a] = c2n;
             c.g_coc[a] = gie_pack_crd(cl[0] + c.pvt[0], cl[1] + c.pvt[1], cl[2] + c.pvt[2]);
+            gie_touch(c, a);
             c.g_wl[a] = -c.map_ct;
             c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
             gie_push64(c, c.qa[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
@@ -638,6 +641,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
         const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
         gie_st(&c.g_dist[a], (int32_t)(c.rec3[e] & 0xffffff));
         gie_st(&c.g_coc[a], c.rec0[e]);
+        gie_touch(c, a);
         gie_st(&c.g_wl[a], (int32_t)1);
         if (c.rec1[e] != GIE_NOPROP) {
             gie_st(&c.g_pair[a], c.rec1[e]);
@@ -660,6 +664,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
         if (gie_acas64(&c.g_prop[na], key, GIE_NOPROP) != key) continue;   /* not the (unique) winner */
         gie_st(&c.g_dist[na], (int32_t)d);
         gie_st(&c.g_coc[na], gie_pack_crd(lc[0], lc[1], lc[2]));
+        gie_touch(c, na);
         gie_st(&c.g_wl[na], (int32_t)-c.map_ct);
         gie_st(&c.g_pair[na], key);
         gie_push64(c, next, next_cnt, c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
@@ -683,6 +688,7 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, const uint64_t *cur, int e)
     const uint64_t coc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
     gie_st(&c.g_coc[a], coc);
     gie_st(&c.g_dist[a], (int32_t)gie_pair_dist(pr));
+    gie_touch(c, a);
     c.rec0[e] = gie_pair_par(pr);
     c.rec1[e] = coc;
 }
@@ -852,7 +858,9 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
     if (a < 0) return;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
-    c.g_coc[a] = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
+    const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
+    if (c.track && (c.g_dist[a] != d || c.g_coc[a] != ncoc || (ty == GIE_VOX_FNT && c.g_type[a] != GIE_VOX_FNT))) gie_touch(c, a);
+    c.g_coc[a] = ncoc;
     c.g_dist[a] = d;
     c.edt[id] = sqrtf((float)d);
     c.g_pair[a] = pr;
@@ -916,6 +924,7 @@ GIE_DEV void gie_halo_import_voxel(const gie_ctx &c, int face, int i, const gie_
     c.g_occ[a] = in[i].occ_val;
     c.g_dist[a] = in[i].dist_sq;
     c.g_coc[a] = gie_pack_crd(in[i].coc[0], in[i].coc[1], in[i].coc[2]);
+    gie_touch(c, a);
 }
 /* obtainFrontiers' C-seed rule (unify_helper.cuh:365-399) for a face voxel against its ghost
  * neighbours, on the committed state: a ghost whose closest obstacle lies outside this tile and
@@ -989,6 +998,27 @@ GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *dist_sq, int32_t
     if (bc == GIE_BCOC_NONE) { coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = -1; }
     else { coc_xyz[3 * id] = (int)(bc & 1023u); coc_xyz[3 * id + 1] = (int)((bc >> 10) & 1023u); coc_xyz[3 * id + 2] = (int)(bc >> 20); }
 }
+/* ---- changed-block streaming (streamPipeline / getUpdatedAddr / streamD2H, glb_hash_map.cu:209-247) */
+/* slot list of the flagged blocks in slot order */
+GIE_DEV void gie_stream_list(const gie_ctx &c, const int32_t *rank, int32_t *list, int slot)
+{ if (c.g_dirty[slot]) list[rank[slot]] = slot; }
+/* voxel j (reference in-block order x*64 + y*8 + z) of list entry first + i/512 → staging */
+GIE_DEV void gie_stream_gather(const gie_ctx &c, const int32_t *list, int first, int32_t *keys, gie_voxel *out, int i)
+{
+    const int slot = list[first + (i >> 9)], j = i & 511;
+    const int a = slot * GIE_VBSZ + ((j >> 6) | (((j >> 3) & 7) << 3) | ((j & 7) << 6));
+    gie_voxel v;
+    v.occ_val = c.g_occ[a]; v.vox_type = c.g_type[a]; v.pad = 0; v.dist_sq = c.g_dist[a];
+    gie_unpack_crd(c.g_coc[a], &v.coc[0], &v.coc[1], &v.coc[2]);
+    out[i] = v;
+    if (j < 3) {
+        int k[3];
+        gie_unpack_crd(c.g_key[slot], &k[0], &k[1], &k[2]);
+        keys[3 * (i >> 9) + j] = k[j];
+    }
+}
+GIE_DEV void gie_stream_clear(const gie_ctx &c, const int32_t *list, int first, int i) { c.g_dirty[list[first + i]] = 0; }
+
 GIE_DEV void gie_query_voxel(const gie_ctx &c, const int32_t *xyz, int i, gie_voxel *out)
 {
     const int a = gie_gvox_hash(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);

@@ -120,6 +120,8 @@ typedef struct gie_ctx {
     uint64_t *g_pair;
     uint64_t *g_prop;
     int32_t *g_wl;          /* wave_layer (-map_ct raise stamp / level stamps) */
+    int track;              /* changed-block flags on (gie_stream_enable) */
+    int32_t *g_dirty;       /* per slot: a voxel's type / distance / closest obstacle changed since the last stream */
     /* ---- ext boxes */
     int nbox;
     const float *box_ll, *box_ur;

@@ -99,6 +99,8 @@ SIGNATURES = {
     "halo_export": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "halo_import": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "refine": (C.c_int, [_H, c_i32p]),
+    "stream_enable": (C.c_int, [_H, C.c_int]),
+    "stream_changed": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, c_i32p]),
 }
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 24), ("total_ms", C.c_float), ("launches", C.c_int32)]

@@ -205,6 +205,26 @@ class MapperBase:
         self._chk(self._f["refine"](self._h, C.byref(n)))
         return n.value
 
+    # --- changed-block streaming (GlbHashMap::streamPipeline, glb_hash_map.cu:209-247) --------
+    def stream_enable(self, on=True):
+        self._chk(self._f["stream_enable"](self._h, 1 if on else 0))
+
+    def stream_count(self):
+        n = C.c_int32(0)
+        self._chk(self._f["stream_changed"](self._h, None, None, 0, C.byref(n)))
+        return n.value
+
+    def stream_changed(self, max_blocks=None):
+        """(keys [n,3] int32, blocks [n,512] VOXEL_DTYPE in get_voxID_in_VB order, flagged-before-call)."""
+        total = self.stream_count()
+        n = total if max_blocks is None else min(total, int(max_blocks))
+        keys = np.empty((n, 3), np.int32)
+        blocks = np.empty((n, 512), VOXEL_DTYPE)
+        got = C.c_int32(0)
+        if n:
+            self._chk(self._f["stream_changed"](self._h, _ptr(keys), _ptr(blocks), n, C.byref(got)))
+        return keys, blocks, total
+
     # --- VOLMAPNODE::publishMap call order (volumetric_mapper.cpp:138-224) -------------
     def update(self, pos, quat_wxyz, sensor_kind, sensor_data, **kw):
         self.set_pose(pos, quat_wxyz)

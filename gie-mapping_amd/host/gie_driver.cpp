@@ -16,7 +16,9 @@
  *        5 external obstacle cloud, n_floats = 3 n (world frame) → ExtObstacles::cluster_cloud;
  *                     not a map update
  * Outputs (after the last frame): prefix.edt.f32 prefix.type.i8 prefix.dist.i32 prefix.coc.i32
- * prefix.costmap.bin (when for_motion_planner) prefix.boxes.f32 (ll,ur,active per box).
+ * prefix.costmap.bin (when for_motion_planner) prefix.boxes.f32 (ll,ur,active per box)
+ * prefix.mirror.bin (when display_glb_edt or display_glb_ogm: i32 n, n x (i32 key[3]), then
+ * n x 512 gie_voxel — the CPU mirror built from the changed-block stream).
  * The CSV log starts with the reference's three columns (volumetric_mapper.cpp:121-122,189,202)
  * and adds the per-frame counters.
  */
@@ -62,7 +64,7 @@ int main(int argc, char **argv)
         if (!rd(f, magic, 4) || memcmp(magic, "GIEF", 4) || !rd(f, &ver, 4) || ver != 1 || !rd(f, &count, 4)) throw std::runtime_error("bad frame file header");
 
         CsvLog *csv = log.empty() ? nullptr : new CsvLog(log);
-        if (csv) { *csv << "Occupancy time" << "EDT time" << "RMSE" << "New blocks" << "Visits A" << "Visits B" << "Visits C"; csv->endrow(); }
+        if (csv) { *csv << "Occupancy time" << "EDT time" << "RMSE" << "New blocks" << "Visits A" << "Visits B" << "Visits C" << "Streamed blocks"; csv->endrow(); }
         std::vector<float> data;
         Vlp16Adapter *vlp = nullptr;
         for (uint32_t k = 0; k < count; k++) {
@@ -99,7 +101,7 @@ int main(int argc, char **argv)
                 if (gie_read_local(node.handle(), e.data(), t.data(), nullptr, nullptr) != GIE_OK) throw std::runtime_error(gie_last_error());
                 frame_rms = ground_truth_check(e.data(), t.data(), c.local_size[0], c.local_size[1], c.local_size[2], c.voxel_width).rms;
             }
-            if (csv) { *csv << (float)node.ogm_ms << (float)node.edt_ms << frame_rms << st.blocks_new << st.visits_a << st.visits_b << st.visits_c; csv->endrow(); }
+            if (csv) { *csv << (float)node.ogm_ms << (float)node.edt_ms << frame_rms << st.blocks_new << st.visits_a << st.visits_b << st.visits_c << node.streamed_blocks; csv->endrow(); }
         }
         fclose(f);
         delete csv; delete vlp;
@@ -116,6 +118,14 @@ int main(int argc, char **argv)
                 memcpy(cm.data(), sz, 12); memcpy(cm.data() + 12, og, 16);
                 memcpy(cm.data() + 28, m.payload8.data(), m.payload8.size() * sizeof(gie_seendist));
                 dump(out + ".costmap.bin", cm);
+            }
+            if (p.display_glb_edt || p.display_glb_ogm) {
+                const BlockMirror &mr = node.mirror;
+                const int32_t nb = (int32_t)mr.block_keys.size();
+                std::vector<uint8_t> buf(4 + (size_t)nb * 12 + mr.blocks.size() * sizeof(gie_voxel));
+                memcpy(buf.data(), &nb, 4);
+                if (nb) { memcpy(buf.data() + 4, mr.block_keys.data(), (size_t)nb * 12); memcpy(buf.data() + 4 + (size_t)nb * 12, mr.blocks.data(), mr.blocks.size() * sizeof(gie_voxel)); }
+                dump(out + ".mirror.bin", buf);
             }
             std::vector<float> boxes;
             /* boxes as uploaded for the last frame: 7 floats each */

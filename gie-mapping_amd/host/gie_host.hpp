@@ -9,6 +9,8 @@
  *                         clustering of VOLMAPNODE::clustring, src/volumetric_mapper.cpp:391-491
  *   CsvLog                csvfile, include/simple_logger.h:18-85
  *   GroundTruthCheck      Gnd_truth_checker::cmp_dist, include/gt_checker.h:30-80
+ *   BlockMirror           hash_table_H_std / VB_values_H / VB_keys_H fed by streamPipeline,
+ *                         src/kernel/par_wave/glb_hash_map.cu:209-247, README.md:163-170
  *   VolumetricMapper      VOLMAPNODE ctor + publishMap, src/volumetric_mapper.cpp:6-224, with
  *                         CostMap = msg/CostMap.msg
  * The ROS transport (subscriptions, message_filters, tf broadcast, RViz clouds) is not part of it.
@@ -29,6 +31,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gie.h"
@@ -294,6 +297,50 @@ inline RmsResult ground_truth_check(const float *edt, const int8_t *type, int X,
     return r;
 }
 
+/* ---------------------------------------------------------------- CPU mirror of the global map */
+/* What CPU planners and the RViz publishers read: block key → index into a growing array of
+ * blocks; voxels inside a block in get_voxID_in_VB order.  update() pulls the blocks the device
+ * flagged since the last call. */
+class BlockMirror {
+public:
+    struct Key { int32_t x, y, z; bool operator==(const Key &o) const { return x == o.x && y == o.y && z == o.z; } };
+    struct KeyHash { size_t operator()(const Key &k) const { return ((size_t)(uint32_t)k.x * 73856093u) ^ ((size_t)(uint32_t)k.y * 19349669u) ^ ((size_t)(uint32_t)k.z * 83492791u); } };
+    static int vox_id(int gx, int gy, int gz) { return (gx & 7) * 64 + (gy & 7) * 8 + (gz & 7); }
+    static Key key_of(int gx, int gy, int gz) { return { gx >> 3, gy >> 3, gz >> 3 }; }
+
+    /* returns the number of blocks refreshed */
+    int update(gie_mapper *m)
+    {
+        int32_t n = 0;
+        if (gie_stream_changed(m, nullptr, nullptr, 0, &n) != GIE_OK) throw std::runtime_error(std::string("gie_stream_changed: ") + gie_last_error());
+        if (n == 0) return 0;
+        keys_.resize(3 * (size_t)n); vox_.resize((size_t)n * GIE_BLOCK_VOXELS);
+        int32_t before = 0;
+        if (gie_stream_changed(m, keys_.data(), vox_.data(), n, &before) != GIE_OK) throw std::runtime_error(std::string("gie_stream_changed: ") + gie_last_error());
+        for (int i = 0; i < n; i++) {
+            const Key k{ keys_[3 * i], keys_[3 * i + 1], keys_[3 * i + 2] };
+            auto it = index.find(k);
+            size_t slot;
+            if (it == index.end()) { slot = block_keys.size(); index.emplace(k, slot); block_keys.push_back(k); blocks.resize((slot + 1) * GIE_BLOCK_VOXELS); }
+            else slot = it->second;
+            std::memcpy(&blocks[slot * GIE_BLOCK_VOXELS], &vox_[(size_t)i * GIE_BLOCK_VOXELS], GIE_BLOCK_VOXELS * sizeof(gie_voxel));
+        }
+        return n;
+    }
+    /* nullptr when the block was never streamed */
+    const gie_voxel *find(int gx, int gy, int gz) const
+    {
+        auto it = index.find(key_of(gx, gy, gz));
+        return it == index.end() ? nullptr : &blocks[it->second * GIE_BLOCK_VOXELS + vox_id(gx, gy, gz)];
+    }
+    std::unordered_map<Key, size_t, KeyHash> index;     /* hash_table_H_std */
+    std::vector<Key> block_keys;                        /* VB_keys_H */
+    std::vector<gie_voxel> blocks;                      /* VB_values_H */
+private:
+    std::vector<int32_t> keys_;
+    std::vector<gie_voxel> vox_;
+};
+
 /* ---------------------------------------------------------------- the node's per-frame logic */
 struct CostMap {                        /* msg/CostMap.msg */
     int32_t x_size = 0, y_size = 0, z_size = 0;
@@ -311,6 +358,8 @@ public:
         m_ = gie_create(&cfg_);
         if (!m_) throw std::runtime_error(std::string("gie_create: ") + gie_last_error());
         ext.assign_premap(p.obsbbx_ll, p.obsbbx_ur);
+        streaming_ = p.display_glb_edt || p.display_glb_ogm;       /* volumetric_mapper.cpp:182,196-198 */
+        if (streaming_) chk(gie_stream_enable(m_, 1));
         if (p.for_motion_planner) {
             cost_map.x_size = cfg_.local_size[0]; cost_map.y_size = cfg_.local_size[1]; cost_map.z_size = cfg_.local_size[2];
             cost_map.payload8.resize((size_t)cfg_.local_size[0] * cfg_.local_size[1] * cfg_.local_size[2]);
@@ -351,6 +400,7 @@ public:
         auto t1 = clk::now();
         chk(gie_batch_edt(m_));
         chk(gie_merge(m_));
+        if (streaming_) streamed_blocks = mirror.update(m_);     /* streamPipeline is inside the reference's EDT timing too (:196-202) */
         chk(gie_sync(m_));
         auto t2 = clk::now();
         ogm_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -369,6 +419,8 @@ public:
 
     Parameters param;
     ExtObstacles ext;
+    BlockMirror mirror;
+    int streamed_blocks = 0;
     CostMap cost_map;
     double ogm_ms = 0, edt_ms = 0;
     int frame = 0;
@@ -376,6 +428,7 @@ private:
     static void chk(int rc) { if (rc != GIE_OK) throw std::runtime_error(std::string("gie: ") + gie_last_error()); }
     gie_config cfg_;
     gie_mapper *m_ = nullptr;
+    bool streaming_ = false;
 };
 
 } /* namespace gie_host */

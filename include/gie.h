@@ -171,6 +171,23 @@ int gie_read_costmap(gie_mapper *h, gie_seendist *payload, gie_costmap_hdr *hdr)
 int gie_query_global(gie_mapper *h, const int32_t *xyz, int n, gie_voxel *out);
 int gie_get_stats(gie_mapper *h, gie_frame_stats *out);
 
+/* ---- changed-block streaming: the CPU mirror the reference keeps for RViz and CPU planners.
+ * GlbHashMap::streamPipeline / streamD2H / getUpdatedAddr (glb_hash_map.cu:209-247,
+ * unify_helper.cuh:11-32), fed by the stream_VB_keys_D appends of the fuse / wave / commit kernels
+ * (unify_helper.cuh:103-110,184-191,510-520; wave_core.cuh:129-134), switched by
+ * display_glb_edt / display_glb_ogm (volumetric_mapper.cpp:182,196-198).
+ * gie_stream_enable(1) makes the update kernels flag every block in which a voxel's type,
+ * distance or closest obstacle changes (off by default: README.md:154).  gie_stream_changed
+ * hands over the flagged blocks — key (block coordinate, 3 ints) + GIE_BLOCK_VOXELS voxels in the
+ * reference's in-block order get_voxID_in_VB = (x&7)*64 + (y&7)*8 + (z&7)
+ * (voxmap_utils.cuh:104-109) — and clears their flags.  *n_changed = flagged blocks before the
+ * call; at most max_blocks are delivered (the rest stay flagged), in unspecified order; NULL
+ * keys/blocks only counts.  One gather kernel + one batched copy per chunk instead of the
+ * reference's 20 KB memcpy per block. */
+#define GIE_BLOCK_VOXELS 512
+int gie_stream_enable(gie_mapper *h, int on);
+int gie_stream_changed(gie_mapper *h, int32_t *keys, gie_voxel *blocks, int max_blocks, int32_t *n_changed);
+
 /* ---- spatial tiling across GPUs (no counterpart in the reference, which is single-GPU; SURVEY
  * §8e).  A large volume is cut into tiles, one mapper per tile/GPU.  After gie_merge every tile
  * exports the one-voxel layer on each of its faces; the neighbour imports it as "ghost" voxels just

@@ -52,10 +52,11 @@ typedef struct {
     int32_t pair_dist;
     int64_t pair_par;
     int32_t prop_dist; /* best proposal of the running level (scratch) */
+    int32_t blk;       /* slot of the owning block (for the changed-block flags) */
     int64_t prop_par;
 } ovox;
 
-typedef struct { int32_t key[3]; ovox v[VBSZ]; } oblock;
+typedef struct { int32_t key[3]; int32_t dirty; ovox v[VBSZ]; } oblock;
 
 typedef struct { i3 *d; int n, cap; } queue;
 
@@ -90,6 +91,7 @@ typedef struct gie_oracle {
     int32_t *g1, *cy1, *d2, *cx2, *cy2;
     /* global map */
     oblock **blocks; int nblocks, blocks_cap;
+    int track;         /* changed-block flags on (display_glb_edt / display_glb_ogm) */
     int32_t *htab; int hcap; /* open addressing: index into blocks or -1 */
     /* ext boxes */
     int nbox; float *box_ll, *box_ur; uint8_t *box_act;
@@ -158,14 +160,14 @@ static oblock *blk_get_or_alloc(gie_oracle *o, int bx, int by, int bz)
         for (int i = 0; i < o->nblocks; i++) htab_insert(o, i);
     }
     b = (oblock *)malloc(sizeof(oblock));
-    b->key[0] = bx; b->key[1] = by; b->key[2] = bz;
+    b->key[0] = bx; b->key[1] = by; b->key[2] = bz; b->dirty = 0;
     for (int i = 0; i < VBSZ; i++) { /* GlbVoxel defaults, voxmap_utils.cuh:30-43 */
         ovox *v = &b->v[i];
         v->occ_val = 0; v->vox_type = GIE_VOX_UNKNOWN; v->update_ct = 0;
         v->coc[0] = v->coc[1] = v->coc[2] = EMPTY_KEY_C;
         v->dist_sq = GIE_EMPTY_VALUE; v->wave_layer = -1;
         v->pair_dist = 0; v->pair_par = 0;
-        v->prop_dist = 0x7fffffff; v->prop_par = 0;
+        v->prop_dist = 0x7fffffff; v->prop_par = 0; v->blk = o->nblocks;
     }
     if (o->wide) for (int i = 0; i < VBSZ; i++) b->v[i].dist_sq = o->empty_value;
     o->blocks[o->nblocks] = b;
@@ -174,6 +176,10 @@ static oblock *blk_get_or_alloc(gie_oracle *o, int bx, int by, int bz)
     o->st.blocks_new++;
     return b;
 }
+/* stream_VB_keys_D bookkeeping (unify_helper.cuh:103-110,510-520, wave_core.cuh:129-134) as one
+ * flag per block: set whenever a store changes the type, distance or closest obstacle of a voxel */
+static void touch(gie_oracle *o, const ovox *v) { if (o->track) o->blocks[v->blk]->dirty = 1; }
+
 static ovox *vox_find(const gie_oracle *o, int gx, int gy, int gz)  /* hash lookup + retrive_vox_D */
 {
     oblock *b = blk_find(o, fdiv8(gx), fdiv8(gy), fdiv8(gz));
@@ -489,6 +495,7 @@ int go_fuse(gie_oracle *o)
         if (!v) { o->glb_type[id] = GIE_VOX_UNKNOWN; continue; }
         const float gp[3] = { (float)gx * w, (float)gy * w, (float)gz * w };
         int occ_flag = 0;
+        const int8_t ty_before = v->vox_type;
         if (o->nbox > 0 && o->box_act[0] && !inside_aabb(gp, o->box_ll, o->box_ur)) occ_flag = 1;
         else for (int i = 1; i < o->nbox; i++)
             if (o->box_act[i] && inside_aabb(gp, o->box_ll + 3 * i, o->box_ur + 3 * i)) { occ_flag = 1; break; }
@@ -502,6 +509,7 @@ int go_fuse(gie_oracle *o)
             if (nt == GIE_VOX_OCCUPIED || occ_flag) set_occ(v, 250.f, 0.8f, o->cfg.occupancy_threshold);
             else if (nt == GIE_VOX_FREE) set_occ(v, 0.f, 0.5f, o->cfg.occupancy_threshold);
         }
+        if (v->vox_type != ty_before) touch(o, v);
         o->glb_type[id] = v->vox_type;
     }
     return 0;
@@ -698,6 +706,7 @@ static void obtain_frontiers(gie_oracle *o, queue *fa, queue *fb, queue *fc)
                 } else if (c2n > nd && n_local) {                    /* raise out */
                     if (o->glb_type[lid(o, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
                         nv->dist_sq = c2n; nv->coc[0] = cg[0]; nv->coc[1] = cg[1]; nv->coc[2] = cg[2];
+                        touch(o, nv);
                         nv->wave_layer = -ct;
                         nv->pair_dist = c2n; nv->pair_par = pack_wr(cw[0], cw[1], cw[2]);
                         q_push(fa, ng[0], ng[1], ng[2]);
@@ -771,6 +780,7 @@ static void wave_a(gie_oracle *o, queue *front, queue *fb)
             if (!low[e].lowered) continue;
             ovox *c = vox_find(o, cur.d[e].x, cur.d[e].y, cur.d[e].z);
             c->dist_sq = low[e].dist; c->coc[0] = low[e].coc[0]; c->coc[1] = low[e].coc[1]; c->coc[2] = low[e].coc[2];
+            touch(o, c);
             c->wave_layer = 1; c->update_ct = ct;
             if (low[e].pair_set) {
                 c->pair_dist = low[e].pair_dist; c->pair_par = low[e].pair_par;
@@ -784,6 +794,7 @@ static void wave_a(gie_oracle *o, queue *front, queue *fb)
             int lw[3]; unpack_wr(nv->prop_par, &lw[0], &lw[1], &lw[2]);
             nv->dist_sq = nv->prop_dist;
             nv->coc[0] = lw[0] + o->upvt[0]; nv->coc[1] = lw[1] + o->upvt[1]; nv->coc[2] = lw[2] + o->upvt[2];
+            touch(o, nv);
             nv->wave_layer = -ct; nv->update_ct = -ct;
             nv->pair_dist = nv->prop_dist; nv->pair_par = nv->prop_par;
             nv->prop_dist = 0x7fffffff; nv->prop_par = 0;
@@ -833,6 +844,7 @@ static void wave_b(gie_oracle *o, queue *front, queue *fc)
             int cw[3]; unpack_wr(c->pair_par, &cw[0], &cw[1], &cw[2]);
             c->coc[0] = cw[0] + o->upvt[0]; c->coc[1] = cw[1] + o->upvt[1]; c->coc[2] = cw[2] + o->upvt[2];
             c->dist_sq = c->pair_dist;
+            touch(o, c);
             sn[e].active = 1; sn[e].par = c->pair_par;
             sn[e].coc[0] = c->coc[0]; sn[e].coc[1] = c->coc[1]; sn[e].coc[2] = c->coc[2];
         }
@@ -963,7 +975,10 @@ static void update_hash_batch(gie_oracle *o)
         ovox *v = vox_find(o, x + o->pvt[0], y + o->pvt[1], z + o->pvt[2]);
         if (!v) continue;
         int cw[3]; unpack_wr(o->pair_par[id], &cw[0], &cw[1], &cw[2]);
-        v->coc[0] = cw[0] + o->upvt[0]; v->coc[1] = cw[1] + o->upvt[1]; v->coc[2] = cw[2] + o->upvt[2];
+        const int nc[3] = { cw[0] + o->upvt[0], cw[1] + o->upvt[1], cw[2] + o->upvt[2] };
+        if (v->dist_sq != o->pair_dist[id] || v->coc[0] != nc[0] || v->coc[1] != nc[1] || v->coc[2] != nc[2] ||
+            (ty == GIE_VOX_FNT && v->vox_type != GIE_VOX_FNT)) touch(o, v);
+        v->coc[0] = nc[0]; v->coc[1] = nc[1]; v->coc[2] = nc[2];
         v->dist_sq = o->pair_dist[id];
         o->edt[id] = sqrtf((float)o->pair_dist[id]);
         v->pair_dist = o->pair_dist[id]; v->pair_par = o->pair_par[id];
@@ -1040,6 +1055,7 @@ int go_halo_import(gie_oracle *o, int face, const gie_halo_voxel *in)
         ovox *v = &b->v[vox_in_blk(gx, gy, gz)];
         v->vox_type = in[i].vox_type; v->occ_val = in[i].occ_val; v->dist_sq = in[i].dist_sq;
         v->coc[0] = in[i].coc[0]; v->coc[1] = in[i].coc[1]; v->coc[2] = in[i].coc[2];
+        touch(o, v);
     }
     return 0;
 }
@@ -1133,6 +1149,32 @@ int go_get_stats(gie_oracle *o, gie_frame_stats *s)
 {
     *s = o->st; s->blocks_total = o->nblocks;
     s->total_visits_a = o->tot_vis[0]; s->total_visits_b = o->tot_vis[1]; s->total_visits_c = o->tot_vis[2];
+    return 0;
+}
+/* GlbHashMap::streamPipeline + streamD2H (glb_hash_map.cu:209-247): the blocks flagged since the
+ * last call, each as its key and its 512 voxels in the reference's in-block order
+ * (get_voxID_in_VB, voxmap_utils.cuh:104-109: x*64 + y*8 + z).  Blocks come in slot order; a
+ * NULL output pointer only counts. */
+int go_stream_enable(gie_oracle *o, int on) { o->track = on != 0; return 0; }
+int go_stream_changed(gie_oracle *o, int32_t *keys, gie_voxel *vox, int max_blocks, int32_t *n_changed)
+{
+    int n = 0, w = 0;
+    for (int s = 0; s < o->nblocks; s++) {
+        oblock *b = o->blocks[s];
+        if (!b->dirty) continue;
+        n++;
+        if (!keys || !vox || w >= max_blocks) continue;
+        keys[3 * w] = b->key[0]; keys[3 * w + 1] = b->key[1]; keys[3 * w + 2] = b->key[2];
+        for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+            const ovox *v = &b->v[vox_in_blk(x, y, z)];
+            gie_voxel *d = &vox[(size_t)w * VBSZ + (size_t)(x * 64 + y * 8 + z)];
+            d->occ_val = v->occ_val; d->vox_type = v->vox_type; d->pad = 0; d->dist_sq = v->dist_sq;
+            d->coc[0] = v->coc[0]; d->coc[1] = v->coc[1]; d->coc[2] = v->coc[2];
+        }
+        b->dirty = 0;
+        w++;
+    }
+    if (n_changed) *n_changed = n;
     return 0;
 }
 int go_get_pivot(gie_oracle *o, int32_t p[3]) { p[0] = o->pvt[0]; p[1] = o->pvt[1]; p[2] = o->pvt[2]; return 0; }

@@ -53,7 +53,12 @@ def ring_bin(pts, rings):
     """numpy statement of the ring binning (vlp16_map_maker.cpp:73-147): last writer wins."""
     img = np.full((16, 440), np.inf, np.float32)
     res = np.float32(2.0 * np.pi / 440)
-    ang = np.arctan2(pts[:, 1], pts[:, 0]).astype(np.float32)
+    # the C library's atan2f (what the C++ adapter calls): numpy's float32 arctan2 can differ in the last bit,
+    # which moves points that sit on a bin edge
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.atan2f.restype, libm.atan2f.argtypes = ctypes.c_float, [ctypes.c_float, ctypes.c_float]
+    ang = np.array([libm.atan2f(float(y), float(x)) for x, y in zip(pts[:, 0], pts[:, 1])], np.float32)
     b = ((ang + np.float32(np.pi)) / res).astype(np.int32)
     r = np.sqrt(pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]).astype(np.float32)
     for i in range(len(pts)):
@@ -127,7 +132,19 @@ def _replay_mixed(driver, tmp_path, size):
     rows = open(log).read().strip().split("\n")
     assert rows[0].startswith('"Occupancy time","EDT time","RMSE",')
     assert len(rows) == 1 + len(records)
-    assert all(len(r.rstrip(",").split(",")) == 7 for r in rows)
+    assert all(len(r.rstrip(",").split(",")) == 8 for r in rows)
+    # the CPU mirror built from the changed-block stream (display_glb_* default to true) equals the global map
+    raw = np.fromfile(out + ".mirror.bin", np.uint8)
+    nb = int(np.frombuffer(raw[:4].tobytes(), np.int32)[0])
+    keys = np.frombuffer(raw[4:4 + 12 * nb].tobytes(), np.int32).reshape(nb, 3)
+    blocks = np.frombuffer(raw[4 + 12 * nb:].tobytes(), gie.mapper.VOXEL_DTYPE).reshape(nb, 512)
+    assert nb > 0 and len({tuple(k) for k in keys.tolist()}) == nb
+    j = np.arange(512)
+    for k, blk in list(zip(keys, blocks))[::7]:
+        xyz = np.stack([k[0] * 8 + (j >> 6), k[1] * 8 + ((j >> 3) & 7), k[2] * 8 + (j & 7)], 1).astype(np.int32)
+        g = o.query_global(xyz)
+        for f in ("vox_type", "dist_sq", "coc"):
+            assert np.array_equal(blk[f], g[f]), (tuple(k), f)
     o.close()
 
 
