@@ -94,8 +94,10 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.wl = gie_dalloc<uint32_t>(m, N);
     for (int i = 0; i < 3; i++) c.tfd[i] = (cfg->local_size[i] + 7) / 8;
     const size_t ntile = (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2];
-    c.tflag = gie_dalloc<uint8_t>(m, 4 * ntile);     /* tflag | tknown | tunk | tsum, cleared together */
-    c.tknown = c.tflag + ntile; c.tunk = c.tflag + 2 * ntile; c.tsum = c.tflag + 3 * ntile;
+    c.tflag = gie_dalloc<uint8_t>(m, 6 * ntile);     /* tflag | tunk | tsum | tray | tknown (this frame / previous frame) */
+    c.tunk = c.tflag + ntile; c.tsum = c.tflag + 2 * ntile; c.tray = c.tflag + 3 * ntile;
+    c.tknown = c.tflag + 4 * ntile; c.tknown_prev = c.tflag + 5 * ntile;
+    c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -192,6 +194,7 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
         be_memset(&m->be, c.g_wl, 0xff, (size_t)c.max_blocks * GIE_VBSZ * sizeof(int32_t));
     }
     c.stamp_base = (f + 1u) << 12;
+    be_memset(&m->be, c.tray, 0, (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2]);
     /* per-frame counters (the sticky error flag survives) */
     be_memset(&m->be, c.cnt, 0, GIE_CNT_ERR * sizeof(int32_t));
     be_memset(&m->be, c.cnt + GIE_CNT_ERR + 1, 0, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
@@ -343,6 +346,13 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
     be_lin(&m->be, m->c, op_cell_table(), m->ncell);
     be_prof(&m->be, GIE_K_ALLOC, 1);
+    be_memset(&m->be, m->c.zocc, 0, (size_t)m->c.Z);
+    {   /* per-tile summaries: last frame's "known" flags tell which tiles still hold stale _glb_type */
+        const size_t ntile = (size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
+        uint8_t *t = m->c.tknown; m->c.tknown = m->c.tknown_prev; m->c.tknown_prev = t;
+        be_memset(&m->be, m->c.tknown, 0, ntile);
+        be_memset(&m->be, m->c.tunk, 0, ntile);
+    }
     be_prof(&m->be, GIE_K_FUSE, 0); be_vox_staged(&m->be, m->c, op_fuse()); be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
@@ -362,7 +372,7 @@ extern "C" int gie_merge(gie_mapper *m)
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
     const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-    be_memset(&m->be, m->c.tflag, 0, 3 * (size_t)ntile);
+    be_memset(&m->be, m->c.tflag, 0, (size_t)ntile);
     be_prof(&m->be, GIE_K_MARK, 0); be_vox(&m->be, m->c, op_mark()); be_prof(&m->be, GIE_K_MARK, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_lin(&m->be, m->c, op_tile_summary(), ntile);
@@ -495,6 +505,14 @@ extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
 /* ---- changed-block streaming */
 #define GIE_STREAM_CHUNK 2048                /* blocks per staging buffer: 2048 x (10 KB + 12 B) = 20 MB */
 static const size_t GIE_STREAM_BLK_BYTES = (size_t)GIE_VBSZ * sizeof(gie_voxel);
+/* blocks per trip through the staging buffers; GIE_STREAM_CHUNK_BLOCKS (1..2048) shrinks it so that
+ * small test volumes exercise the multi-chunk pipeline */
+static int gie_stream_chunk_blocks()
+{
+    const char *e = getenv("GIE_STREAM_CHUNK_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= GIE_STREAM_CHUNK) ? v : GIE_STREAM_CHUNK;
+}
 
 extern "C" int gie_stream_enable(gie_mapper *m, int on)
 {
@@ -530,10 +548,11 @@ extern "C" int gie_stream_changed(gie_mapper *m, int32_t *keys, gie_voxel *block
     }
     /* chunk k: gather on the device → async copy into pinned buffer k&1; meanwhile the host
      * unpacks chunk k-1 from the other pinned buffer into the caller's arrays */
-    const int nchunk = (deliver + GIE_STREAM_CHUNK - 1) / GIE_STREAM_CHUNK;
+    const int CH = gie_stream_chunk_blocks();
+    const int nchunk = (deliver + CH - 1) / CH;
     for (int k = 0; k <= nchunk; k++) {
         if (k < nchunk) {
-            const int first = k * GIE_STREAM_CHUNK, nb = deliver - first < GIE_STREAM_CHUNK ? deliver - first : GIE_STREAM_CHUNK;
+            const int first = k * CH, nb = deliver - first < CH ? deliver - first : CH;
             char *d = (char *)m->d_stage[k & 1];
             op_stream_gather og; og.list = m->d_slist; og.first = first;
             og.out = (gie_voxel *)d; og.keys = (int32_t *)(d + (size_t)GIE_STREAM_CHUNK * GIE_STREAM_BLK_BYTES);
@@ -545,7 +564,7 @@ extern "C" int gie_stream_changed(gie_mapper *m, int32_t *keys, gie_voxel *block
                          d + (size_t)GIE_STREAM_CHUNK * GIE_STREAM_BLK_BYTES, (size_t)nb * 12, k & 1);
         }
         if (k > 0) {
-            const int first = (k - 1) * GIE_STREAM_CHUNK, nb = deliver - first < GIE_STREAM_CHUNK ? deliver - first : GIE_STREAM_CHUNK;
+            const int first = (k - 1) * CH, nb = deliver - first < CH ? deliver - first : CH;
             const char *h = (const char *)m->h_stage[(k - 1) & 1];
             be_wait(&m->be, (k - 1) & 1);
             memcpy(blocks + (size_t)first * GIE_VBSZ, h, (size_t)nb * GIE_STREAM_BLK_BYTES);

@@ -15,12 +15,14 @@
 
 /* skip(c, id, x, y, z): cheap test (at most one small load, issued for a whole z-column up
  * front by k_voxz) that is true only when operator() would do nothing for the voxel. */
-struct op_classify_depth { static constexpr bool rolled = false; const float *img; gie_cam_param p;
+struct op_classify_depth { static constexpr bool rolled = false;
+    GIE_DEVM bool tile_skip(const gie_ctx &, int, int, int) const { return false; } const float *img; gie_cam_param p;
     GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_depth(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
-struct op_classify_multiscan { static constexpr bool rolled = false; const float *img; gie_multiscan_param p; float tan_lo, tan_hi; int fov_test;
+struct op_classify_multiscan { static constexpr bool rolled = false;
+    GIE_DEVM bool tile_skip(const gie_ctx &, int, int, int) const { return false; } const float *img; gie_multiscan_param p; float tan_lo, tan_hi; int fov_test;
     /* conservative field-of-view test: elevation surely outside [phi_min - inc/2, phi_max + inc/2]
      * (bounds widened by 1e-3 rad on the host, far above the 2-ulp error of gie_atan2f) */
     GIE_DEVM bool skip(const gie_ctx &c, int, int x, int y, int z) const {
@@ -34,41 +36,43 @@ struct op_classify_multiscan { static constexpr bool rolled = false; const float
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_multiscan(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
-struct op_classify_scan2d { static constexpr bool rolled = false; const float *img; gie_scan_param p;
+struct op_classify_scan2d { static constexpr bool rolled = false;
+    GIE_DEVM bool tile_skip(const gie_ctx &, int, int, int) const { return false; } const float *img; gie_scan_param p;
     GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_scan2d(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
 struct op_raycast_finalize { static constexpr bool rolled = false;
+    /* no ray went through the tile (the robot sphere of for_motion_planner is written without rays) */
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.for_motion_planner && !c.tray[gie_tile_index(c, x, y, z0)]; }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const { return c.ray_count[id] == 0 && !c.for_motion_planner; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_raycast_finalize(c, x, y, z); } };
 /* staged ops (k_voxz_staged): st = per-voxel registers, load1/load2/finish as in gie_ops.h */
 struct op_fuse { static constexpr bool rolled = false;
     typedef gie_fuse_st st;
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return gie_fuse_column_idle(c, x, y, z0) != 0; }
+    /* per z-column (8 voxels of one 8x8x8 tile): which of them ended up known */
+    GIE_DEVM void column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid) const { gie_fuse_column_summary(c, x, y, z0, known, valid); }
     GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_fuse_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_fuse_load2(c, s); }
-    GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_fuse_finish(c, id, x, y, z, s); }
-    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_fuse_voxel(c, x, y, z); } };
+    GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { return gie_fuse_finish(c, id, x, y, z, s); }
+    GIE_DEVM int operator()(const gie_ctx &c, int x, int y, int z) const { return gie_fuse_voxel(c, x, y, z); } };
 struct op_mark { static constexpr bool rolled = false;
     typedef gie_mark_st st;
-    /* per z-column (8 voxels of one 8x8x8 tile): which of them are known */
-    GIE_DEVM void column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid) const {
-        const int t = gie_tile_index(c, x, y, z0);
-        if (known) c.tknown[t] = 1;                 /* all writers store 1 */
-        if (known != valid) c.tunk[t] = 1;
-    }
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.tknown[gie_tile_index(c, x, y, z0)]; }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_mark_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_mark_load2(c, s); }
-    GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_mark_finish(c, id, x, y, z, s); }
+    GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_mark_finish(c, id, x, y, z, s); return 0; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_mark_voxel(c, x, y, z); } };
 struct op_commit { static constexpr bool rolled = false;
     typedef gie_commit_st st;
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.tknown[gie_tile_index(c, x, y, z0)]; }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_commit_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
-    GIE_DEVM void finish(const gie_ctx &c, int id, int, int, int, const st &s) const { gie_commit_finish(c, id, s); }
+    GIE_DEVM int finish(const gie_ctx &c, int id, int, int, int, const st &s) const { gie_commit_finish(c, id, s); return 0; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_commit_voxel(c, x, y, z); } };
 
 /* obtainFrontiers with wave64 ballot compaction of the C seeds: one atomicAdd per wave */
@@ -76,10 +80,11 @@ struct op_frontier { static constexpr bool rolled = false;
     typedef gie_frontier_st st;
     /* the ballot inside finish() works on whatever lanes are active, so skipping is safe.
      * tsum == 0: nothing in or around this 8x8x8 tile can make obtainFrontiers act. */
-    GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const { return c.tsum[gie_tile_index(c, x, y, z)] == 0 || c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return c.tsum[gie_tile_index(c, x, y, z0)] == 0; }
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_frontier_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
-    GIE_DEVM void finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { push_seed(c, gie_frontier_finish(c, id, x, y, z, s), id); }
+    GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { push_seed(c, gie_frontier_finish(c, id, x, y, z, s), id); return 0; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { push_seed(c, gie_frontier_voxel(c, x, y, z), gie_lid(c, x, y, z)); }
     GIE_DEVM void push_seed(const gie_ctx &c, const int push, const int id) const {
 #if defined(GIE_HOST_EMU)

@@ -35,18 +35,10 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_vox(const gie_ctx c,
  * mostly-unknown volume are bound by workgroup dispatch and exposed latency, not by HBM), and
  * the skip tests of the whole column are issued back to back before any voxel is processed. */
 #define GIE_VOX_ZPER 8
-/* optional per-column hook (only op_mark has one: tile known/unknown summaries) */
+/* optional per-column hook of the staged sweep (only op_fuse has one: tile known/unknown summaries) */
 template <class F> __device__ __forceinline__ auto gie_column_hook_impl(const F &f, const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int)
     -> decltype(f.column(c, x, y, z0, known, valid), void()) { f.column(c, x, y, z0, known, valid); }
 template <class F> __device__ __forceinline__ void gie_column_hook_impl(const F &, const gie_ctx &, int, int, int, unsigned, unsigned, long) {}
-template <class F> __device__ __forceinline__ void gie_column_hook(const F &f, const gie_ctx &c, int x, int y, int z0, bool in, const bool *sk)
-{
-    if (!in) return;
-    unsigned known = 0, valid = 0;
-#pragma unroll
-    for (int k = 0; k < GIE_VOX_ZPER; k++) if (z0 + k < c.Z) { valid |= 1u << k; if (!sk[k]) known |= 1u << k; }
-    gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
-}
 template <class F>
 __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c, const F f)
 {
@@ -54,13 +46,13 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c
     const int y = blockIdx.y * GIE_VOX_BY + threadIdx.y;
     const int z0 = blockIdx.z * GIE_VOX_ZPER;
     const bool in = (x < c.X && y < c.Y);
+    if (!in || f.tile_skip(c, x, y, z0)) return;            /* one flag for the thread's whole z-column (one 8x8x8 tile) */
     bool sk[GIE_VOX_ZPER];
 #pragma unroll
     for (int k = 0; k < GIE_VOX_ZPER; k++) {
         const int z = z0 + k;
-        sk[k] = !in || z >= c.Z || f.skip(c, in && z < c.Z ? gie_lid(c, x, y, z) : 0, x, y, z);
+        sk[k] = z >= c.Z || f.skip(c, z < c.Z ? gie_lid(c, x, y, z) : 0, x, y, z);
     }
-    gie_column_hook(f, c, x, y, z0, in, sk);
     if (F::rolled) {            /* big bodies: keep one copy of the code (instruction cache) */
         unsigned m = 0;
 #pragma unroll
@@ -82,22 +74,29 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz_staged(const gi
     const int x = blockIdx.x * GIE_VOX_BX + threadIdx.x;
     const int y = blockIdx.y * GIE_VOX_BY + threadIdx.y;
     const int z0 = blockIdx.z * ZP;
+    static_assert(ZP == GIE_VOX_ZPER, "a thread's z-column is one tile high");
     const bool in = (x < c.X && y < c.Y);
+    if (!in || f.tile_skip(c, x, y, z0)) return;
     bool sk[ZP];
     int id[ZP];
     typename F::st s[ZP];
 #pragma unroll
     for (int k = 0; k < ZP; k++) {
         const int z = z0 + k;
-        id[k] = (in && z < c.Z) ? gie_lid(c, x, y, z) : 0;
-        sk[k] = !in || z >= c.Z || f.skip(c, id[k], x, y, z);
+        id[k] = (z < c.Z) ? gie_lid(c, x, y, z) : 0;
+        sk[k] = z >= c.Z || f.skip(c, id[k], x, y, z);
     }
 #pragma unroll
     for (int k = 0; k < ZP; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
 #pragma unroll
     for (int k = 0; k < ZP; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
+    unsigned known = 0, valid = 0;
 #pragma unroll
-    for (int k = 0; k < ZP; k++) if (!sk[k]) f.finish(c, id[k], x, y, z0 + k, s[k]);
+    for (int k = 0; k < ZP; k++) {
+        if (z0 + k < c.Z) valid |= 1u << k;
+        if (!sk[k]) known |= (unsigned)(f.finish(c, id[k], x, y, z0 + k, s[k]) != 0) << k;
+    }
+    gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
 }
 
 template <class F>
@@ -142,6 +141,7 @@ __global__ __launch_bounds__(GIE_EDTY_COLS * 4) void k_edt_y(const gie_ctx c)
     const int col = threadIdx.x, q = threadIdx.y;
     const int x = blockIdx.x * GIE_EDTY_COLS + col;
     const int z = blockIdx.y;
+    if (!c.zocc[z]) return;                              /* plane without obstacle: passes X/Z never read its cy1 */
     const int X = c.X, Y = c.Y;
     const bool in = x < X;
     const int8_t *t = c.glb_type + (size_t)z * X * Y + (in ? x : 0);
@@ -211,6 +211,24 @@ __device__ __forceinline__ void gie_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* min key of position `up` (= u << 5) over the sites lo..hi.  The loop is bound by the LDS round
+ * trip, not by ALU work, so four independent reads are issued per trip; indices past `hi` are
+ * clamped to it (a repeated candidate does not change a minimum). */
+__device__ __forceinline__ uint32_t gie_scan_sites(const uint2 *ce, const int up, const int lo, const int hi)
+{
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
+    for (int j = lo; j <= hi; j += 4) {
+        const uint2 v0 = ce[j], v1 = ce[min(j + 1, hi)], v2 = ce[min(j + 2, hi)], v3 = ce[min(j + 3, hi)];
+        const int d0 = up - (int)(v0.y & 0xffffu), d1 = up - (int)(v1.y & 0xffffu);
+        const int d2 = up - (int)(v2.y & 0xffffu), d3 = up - (int)(v3.y & 0xffffu);
+        b0 = min(b0, (uint32_t)__mul24(d0, d0) + v0.x);
+        b1 = min(b1, (uint32_t)__mul24(d1, d1) + v1.x);
+        b2 = min(b2, (uint32_t)__mul24(d2, d2) + v2.x);
+        b3 = min(b3, (uint32_t)__mul24(d3, d3) + v3.x);
+    }
+    return min(min(b0, b1), min(b2, b3));
+}
+
 template <int CP>
 __device__ __forceinline__ void gie_row_argmin(const uint2 *ce, const int K, const int L, const int lane, int (&sj)[CP])
 {
@@ -219,22 +237,35 @@ __device__ __forceinline__ void gie_row_argmin(const uint2 *ce, const int K, con
     const int u0 = lane * CP;
     int s0;
     {
+        /* first position of every lane, in two steps (the argmin rank is monotone in u):
+         * (1) the eight positions owned by lanes 0, 8, .. 56: the eight lanes of a group split
+         *     the K sites between them (site j goes to lane j mod 8) and min-reduce;
+         * (2) every other lane searches only between its group's result and the next group's. */
+        const int g8 = lane & ~7, r = lane & 7;
+        const int ug = g8 * CP;
         uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
-        const int up = u0 << 5;
-        const int K4 = K & ~3;
-        const uint4 *ce2 = reinterpret_cast<const uint4 *>(ce);     /* two sites per 16-byte read */
-        for (int j = 0; j < K4; j += 4) {
-            const uint4 v0 = ce2[j >> 1], v1 = ce2[(j >> 1) + 1];
-            const int d0 = up - (int)(v0.y & 0xffffu), d1 = up - (int)(v0.w & 0xffffu);
-            const int d2 = up - (int)(v1.y & 0xffffu), d3 = up - (int)(v1.w & 0xffffu);
-            b0 = min(b0, (uint32_t)__mul24(d0, d0) + v0.x);
-            b1 = min(b1, (uint32_t)__mul24(d1, d1) + v0.z);
-            b2 = min(b2, (uint32_t)__mul24(d2, d2) + v1.x);
-            b3 = min(b3, (uint32_t)__mul24(d3, d3) + v1.z);
+        {
+            const int up = ug << 5, kl = K - 1;
+            for (int j = r; j < K; j += 32) {                  /* clamped repeats are harmless for a minimum */
+                const uint2 v0 = ce[j], v1 = ce[min(j + 8, kl)], v2 = ce[min(j + 16, kl)], v3 = ce[min(j + 24, kl)];
+                const int d0 = up - (int)(v0.y & 0xffffu), d1 = up - (int)(v1.y & 0xffffu);
+                const int d2 = up - (int)(v2.y & 0xffffu), d3 = up - (int)(v3.y & 0xffffu);
+                b0 = min(b0, (uint32_t)__mul24(d0, d0) + v0.x);
+                b1 = min(b1, (uint32_t)__mul24(d1, d1) + v1.x);
+                b2 = min(b2, (uint32_t)__mul24(d2, d2) + v2.x);
+                b3 = min(b3, (uint32_t)__mul24(d3, d3) + v3.x);
+            }
         }
-        for (int j = K4; j < K; j++) { const uint2 v = ce[j]; const int d = up - (int)(v.y & 0xffffu); b0 = min(b0, (uint32_t)__mul24(d, d) + v.x); }
-        const uint32_t best = min(min(b0, b1), min(b2, b3));
-        s0 = (u0 < L) ? (int)(best & 1023u) : K - 1;
+        uint32_t bg = min(min(b0, b1), min(b2, b3));
+        bg = min(bg, (uint32_t)__shfl_xor((int)bg, 1));
+        bg = min(bg, (uint32_t)__shfl_xor((int)bg, 2));
+        bg = min(bg, (uint32_t)__shfl_xor((int)bg, 4));
+        const int sg = (ug < L) ? (int)(bg & 1023u) : K - 1;
+        int sn = __shfl_down(sg, 8);
+        if (lane >= 56) sn = K - 1;
+        s0 = sg;
+        if (r != 0 && u0 < L && sn > sg) s0 = (int)(gie_scan_sites(ce, u0 << 5, sg, sn) & 1023u);
+        if (u0 >= L) s0 = K - 1;
     }
     /* upper bound of the chunk = the next lane's first position (monotone argmin) */
     int sup = __shfl_down(s0, 1);
@@ -248,12 +279,7 @@ __device__ __forceinline__ void gie_row_argmin(const uint2 *ce, const int K, con
             const int u = u0 + m;
             const int lo = sx[m - step], hi = sx[m + step];
             int r = lo;
-            if (u < L && hi > lo) {
-                uint32_t best = 0xffffffffu;
-                const int up = u << 5;
-                for (int j = lo; j <= hi; j++) { const uint2 v = ce[j]; const int d = up - (int)(v.y & 0xffffu); best = min(best, (uint32_t)__mul24(d, d) + v.x); }
-                r = (int)(best & 1023u);
-            }
+            if (u < L && hi > lo) r = (int)(gie_scan_sites(ce, u << 5, lo, hi) & 1023u);
             sx[m] = (u < L) ? r : K - 1;
         }
     }
@@ -286,6 +312,7 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * GIE_EDTX_WAVES + wave;        /* row = z*Y + y */
     if (row >= c.Y * c.Z) return;
+    if (!c.zocc[row / c.Y]) return;                             /* empty plane: pass Z does not read its cxy2 */
     const int X = c.X;
     const int y = row % c.Y;
     const uint16_t *in = c.cy1 + (size_t)row * X;
@@ -349,13 +376,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
     /* persistent workgroup: tiles t, t+G, t+2G, …; the NEXT tile is fetched into registers while
      * the envelopes of the current one are computed out of LDS */
     uint32_t pre[NLD];
+    unsigned zmask = 0;                                   /* this thread's z rows that lie in a plane with obstacles */
+#pragma unroll
+    for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && c.zocc[z]) zmask |= 1u << j; }
     int t = blockIdx.x;
     const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
     if (t < ntiles) {
         const int x = (t % ntiles_x) * TX + tx, y = t / ntiles_x;
         const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)y * X + x;   /* one 64-bit product per tile, then adds */
 #pragma unroll
-        for (int j = 0; j < NLD; j++) { pre[j] = (tz + j * ZSTEP < Z && x < X) ? *src : 0xffffffffu; src += zstride; }
+        for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && x < X) ? *src : 0xffffffffu; src += zstride; }
     }
     for (; t < ntiles; t += gridDim.x) {
         const int x0 = (t % ntiles_x) * TX, y = t / ntiles_x;
@@ -367,12 +397,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
             const int xn = (tn % ntiles_x) * TX + tx, yn = tn / ntiles_x;
             const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)yn * X + xn;
 #pragma unroll
-            for (int j = 0; j < NLD; j++) { pre[j] = (tz + j * ZSTEP < Z && xn < X) ? *src : 0xffffffffu; src += zstride; }
+            for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && xn < X) ? *src : 0xffffffffu; src += zstride; }
         }
         for (int col = wave; col < TX; col += WAVES) {
             const int x = x0 + col;
             if (x >= X) break;
             int K = 0;
+#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 3
+            continue;                                           /* measurement only: no column work at all */
+#endif
             for (int i0 = 0; i0 < Z; i0 += 64) {
                 const int i = i0 + lane;
                 const uint32_t v = (i < Z) ? tile[i * TS + col] : 0xffffffffu;
@@ -384,7 +417,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
                 for (int i = lane; i < Z; i += 64) tile[i * TS + col] = GIE_BCOC_NONE;
             } else {
                 int sj[CP];
+#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE >= 1
+                for (int m = 0; m < CP; m++) sj[m] = (lane * CP + m) % K;      /* measurement only: no argmin */
+#else
                 gie_row_argmin<CP>(ce, K, Z, lane, sj);
+#endif
+#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 2
+                if (sj[0] >= 0) continue;                       /* measurement only: compaction, nothing else */
+#endif
                 /* gather first (own column only), then overwrite the column in place */
                 const int u0 = lane * CP;
                 uint32_t oc[CP];

@@ -82,6 +82,14 @@ GIE_DEV void gie_wave_add(const gie_ctx &c, int id, int val)
 #endif
 }
 
+/* every cell whose _ray_count changes flags its tile, so that getAllocKeys (ray_finalize) only
+ * looks at tiles a ray went through; `last` spares the store while the ray stays in one tile */
+GIE_DEV void gie_ray_touch(const gie_ctx &c, int lx, int ly, int lz, int *last)
+{
+    const int t = gie_tile_index(c, lx, ly, lz);
+    if (t != *last) { c.tray[t] = 1; *last = t; }
+}
+
 /* global voxel address: block slot through the frame's block table (volume +-1 voxel) */
 GIE_DEV int gie_gvox_tab(const gie_ctx &c, int gx, int gy, int gz)
 {
@@ -195,6 +203,8 @@ GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out
         if (gie_in_loc(c, lx, ly, lz)) {
             const int id = gie_lid(c, lx, ly, lz);
             c.inst_type[id] = GIE_VOX_OCCUPIED;      /* all writers store the same value */
+            int lt = -1;
+            gie_ray_touch(c, lx, ly, lz, &lt);
             gie_wave_add(c, id, 1);
         }
     }
@@ -205,7 +215,7 @@ GIE_DEV int gie_clear_ray(const gie_ctx &c, int lx, int ly, int lz)
 {
     if (!gie_in_loc(c, lx, ly, lz)) return 1;
     const int id = gie_lid(c, lx, ly, lz);
-    if (c.inst_type[id] != GIE_VOX_OCCUPIED) { gie_aadd32(&c.ray_count[id], -1); return 1; }
+    if (c.inst_type[id] != GIE_VOX_OCCUPIED) { int lt = -1; gie_ray_touch(c, lx, ly, lz, &lt); gie_aadd32(&c.ray_count[id], -1); return 1; }
     return 0;
 }
 
@@ -217,10 +227,12 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
     const float p1[3] = { g[3 * i], g[3 * i + 1], g[3 * i + 2] };
     const float max_length = 0.707f * (float)c.X * w;
     int i0[3], i1[3];
+    int last_tile = -1;
     for (int k = 0; k < 3; k++) { i0[k] = gie_pos2coord(p0[k], w); i1[k] = gie_pos2coord(p1[k], w); }
     {   /* clearRayLoc on the sensor's own cell */
         const int lx = i0[0] - c.pvt[0], ly = i0[1] - c.pvt[1], lz = i0[2] - c.pvt[2];
         const int id0 = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
+        if (id0 >= 0) gie_ray_touch(c, lx, ly, lz, &last_tile);
         gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
     }
     if (i0[0] == i1[0] && i0[1] == i1[1] && i0[2] == i1[2]) return;
@@ -256,6 +268,7 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
             else { cur[2] += step[2]; tMax[2] += tDelta[2]; }
             const int lx = cur[0] - c.pvt[0], ly = cur[1] - c.pvt[1], lz = cur[2] - c.pvt[2];
             ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
+            if (ids[j] >= 0) gie_ray_touch(c, lx, ly, lz, &last_tile);      /* speculative cells may over-flag: harmless */
             const float m01 = tMax[0] < tMax[1] ? tMax[0] : tMax[1];
             const float dist = m01 < tMax[2] ? m01 : tMax[2];
             stop_after[j] = (cur[0] == i1[0] && cur[1] == i1[1] && cur[2] == i1[2]) || dist > max_length || dist > len;
@@ -348,7 +361,8 @@ GIE_DEV void gie_fuse_load2(const gie_ctx &c, gie_fuse_st &s)
     s.occ = c.g_occ[s.a];
     s.ty = c.g_type[s.a];
 }
-GIE_DEV void gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_fuse_st &s)
+/* returns 1 when the voxel ends up known (feeds the per-tile known/unknown summaries) */
+GIE_DEV int gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_fuse_st &s)
 {
     const int count = s.count;
     if (count != 0) c.ray_count[id] = 0;                                 /* write only what changes */
@@ -356,7 +370,7 @@ GIE_DEV void gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, cons
     if (nt != GIE_VOX_UNKNOWN) c.inst_type[id] = GIE_VOX_UNKNOWN;
     const int8_t gt0 = s.gt0;
     const int a = s.a;
-    if (a < 0) { if (gt0 != GIE_VOX_UNKNOWN) c.glb_type[id] = GIE_VOX_UNKNOWN; return; }
+    if (a < 0) { if (gt0 != GIE_VOX_UNKNOWN) c.glb_type[id] = GIE_VOX_UNKNOWN; return 0; }
     const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz = z + c.pvt[2];
     int occ_flag = 0;
     if (c.nbox > 0) {
@@ -380,15 +394,36 @@ GIE_DEV void gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, cons
     if (occ != occ0) c.g_occ[a] = occ;
     if (ty != ty0) { c.g_type[a] = ty; gie_touch(c, a); }
     if (gt0 != ty) c.glb_type[id] = ty;
+    if (ty == GIE_VOX_OCCUPIED) c.zocc[z] = 1;                           /* all writers store 1 */
+    return ty != GIE_VOX_UNKNOWN;
+}
+/* A z-column of 8 voxels (x, y, z0..z0+7: one tile, at most two blocks) has nothing to fuse when
+ * neither block exists — a voxel the scan observed always has its block by now — and the tile's
+ * _glb_type is still all UNKNOWN from the frames before.  Such a column is all-unknown. */
+GIE_DEV int gie_fuse_column_idle(const gie_ctx &c, int x, int y, int z0)
+{
+    const int t = gie_tile_index(c, x, y, z0);
+    if (c.tknown_prev[t]) return 0;
+    const int z1 = (z0 + 7 < c.Z) ? z0 + 7 : c.Z - 1;
+    const int gx = x + c.pvt[0], gy = y + c.pvt[1];
+    if (c.blk_tab[gie_tab_index(c, gx, gy, z0 + c.pvt[2])] >= 0 || c.blk_tab[gie_tab_index(c, gx, gy, z1 + c.pvt[2])] >= 0) return 0;
+    c.tunk[t] = 1;
+    return 1;
+}
+GIE_DEV void gie_fuse_column_summary(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid)
+{
+    const int t = gie_tile_index(c, x, y, z0);
+    if (known) c.tknown[t] = 1;                 /* all writers store 1 */
+    if (known != valid) c.tunk[t] = 1;
 }
 /* updateHashOGMWithPntCld / updateHashOGMWithSensor, unify_helper.cuh:35-197 */
-GIE_DEV void gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
+GIE_DEV int gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
 {
     const int id = gie_lid(c, x, y, z);
     gie_fuse_st s;
     gie_fuse_load1(c, id, x, y, z, s);
     gie_fuse_load2(c, s);
-    gie_fuse_finish(c, id, x, y, z, s);
+    return gie_fuse_finish(c, id, x, y, z, s);
 }
 
 /* ================================================================== Mark */

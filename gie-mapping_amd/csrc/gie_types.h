@@ -96,8 +96,11 @@ typedef struct gie_ctx {
     uint32_t *wl;           /* _loc_wave_layer as frame-stamped marks */
     uint8_t *tflag;         /* per local 8x8x8 tile: some voxel's Mark-time closest obstacle lies outside the volume */
     int tfd[3];             /* tile grid dims */
-    uint8_t *tknown, *tunk; /* per tile: holds a known / an unknown voxel (written by the Mark sweep) */
+    uint8_t *tknown, *tunk; /* per tile: holds a known / an unknown voxel after this frame's fuse */
+    uint8_t *tknown_prev;   /* tknown of the previous frame = "_glb_type of the tile is not all UNKNOWN yet" */
+    uint8_t *tray;          /* per tile: a ray touched it this scan (ray-casting OGM) */
     uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
+    uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
     uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */

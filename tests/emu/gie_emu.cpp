@@ -34,15 +34,23 @@ static void be_prof(be_state *, int, int) {}
 static void be_prof_enable(be_state *, int) {}
 static void be_prof_collect(be_state *, float *ms, int *n, int num) { for (int i = 0; i < num; i++) { ms[i] = 0; n[i] = 0; } }
 static void be_times(be_state *, float *a, float *b, float *c, float *d) { *a = *b = *c = *d = 0.f; }
+/* a device thread owns the z-column (x, y, z0..z0+7) of one 8x8x8 tile: same order here, so that the
+ * per-tile skip flags are exercised exactly as on the device */
 template <class F> static void be_vox(be_state *, const gie_ctx &c, const F &f)
-{ for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) if (!f.skip(c, gie_lid(c, x, y, z), x, y, z)) f(c, x, y, z); }
-/* the Mark sweep also records the per-tile known/unknown summaries (column hook on the device) */
-static void be_vox(be_state *, const gie_ctx &c, const op_mark &f)
 {
-    for (int z = 0; z < c.Z; z++) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) {
-        const bool unk = c.glb_type[gie_lid(c, x, y, z)] == GIE_VOX_UNKNOWN;
-        f.column(c, x, y, z & ~7, unk ? 0u : 1u, 1u);
-        if (!unk) f(c, x, y, z);
+    for (int z0 = 0; z0 < c.Z; z0 += 8) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) {
+        if (f.tile_skip(c, x, y, z0)) continue;
+        for (int z = z0; z < z0 + 8 && z < c.Z; z++) if (!f.skip(c, gie_lid(c, x, y, z), x, y, z)) f(c, x, y, z);
+    }
+}
+/* the fuse sweep also records the per-tile known/unknown summaries (column hook on the device) */
+static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
+{
+    for (int z0 = 0; z0 < c.Z; z0 += 8) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) {
+        if (f.tile_skip(c, x, y, z0)) continue;
+        unsigned known = 0, valid = 0;
+        for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f(c, x, y, z)) known |= 1u << (z - z0); }
+        f.column(c, x, y, z0, known, valid);
     }
 }
 template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }

@@ -104,13 +104,21 @@ def test_partial_delivery_and_off():
         m.close()
 
 
+def test_stream_in_several_chunks(monkeypatch):
+    """more flagged blocks than one trip through the staging buffers carries"""
+    monkeypatch.setenv("GIE_STREAM_CHUNK_BLOCKS", "7")
+    sc = Scenario("stream_chunks", (40, 40, 16), sensor="depth", frames=3)
+    flagged = _run(EmuMapper, sc)
+    assert max(flagged) > 3 * 7
+
+
 @pytest.mark.gpu
-def test_stream_on_gpu_matches_oracle():
-    # 20 x 20 x 8 = 3200 blocks in the first frame: more than one staging chunk (2048 blocks)
+def test_stream_on_gpu_matches_oracle(monkeypatch):
+    monkeypatch.setenv("GIE_STREAM_CHUNK_BLOCKS", "500")      # several chunks: exercises the double-buffered copy
     sc = Scenario("stream_gpu", (160, 160, 64), sensor="mixed", frames=4, cutoff_dist=2.0, img=(240, 320, 260.0), max_depth=10.0,
                   extent=(7.0, 7.0, 2.5))
     flagged = _run(gie.Mapper, sc)
-    assert max(flagged) > 2048
+    assert max(flagged) > 1000
 
 
 @pytest.mark.gpu
