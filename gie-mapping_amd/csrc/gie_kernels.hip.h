@@ -287,6 +287,55 @@ __device__ __forceinline__ void gie_row_argmin(const uint2 *ce, const int K, con
     for (int m = 0; m < CP; m++) sj[m] = sx[m];
 }
 
+/* The same argmin for rows with few real sites, organised in BANDS: lane owns the positions
+ * lane, 64 + lane, 128 + lane, ...; sj[m] = winning rank of position 64 m + lane.  The argmin at
+ * the band starts 0, 64, 128, ... is found first (the 64/CP lanes of a group split the K sites);
+ * the 64 positions of band m can then only be won by the sites sa[m] .. sa[m+1], a range that is
+ * the same for the whole wave: a uniform loop with broadcast reads and no divergence.  Every
+ * lane evaluates K + CP candidates in total (the divide & conquer form above evaluates fewer
+ * when K is large, but pays per-lane loop set-up for every position). */
+#define GIE_BAND_MAXK 160
+template <int CP>
+__device__ __forceinline__ void gie_row_argmin_banded(const uint2 *ce, const int K, const int L, const int lane, int (&sj)[CP])
+{
+    constexpr int G = 64 / CP;                            /* lanes per band start */
+    const int b = lane / G, r = lane % G;
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu;
+    {
+        const int up = (64 * b) << 5, kl = K - 1;
+        for (int j = r; j < K; j += 2 * G) {
+            const uint2 v0 = ce[j], v1 = ce[min(j + G, kl)];
+            const int d0 = up - (int)(v0.y & 0xffffu), d1 = up - (int)(v1.y & 0xffffu);
+            b0 = min(b0, (uint32_t)__mul24(d0, d0) + v0.x);
+            b1 = min(b1, (uint32_t)__mul24(d1, d1) + v1.x);
+        }
+    }
+    uint32_t bg = min(b0, b1);
+#pragma unroll
+    for (int w = 1; w < G; w <<= 1) bg = min(bg, (uint32_t)__shfl_xor((int)bg, w));
+    const int sg = (64 * b < L) ? (int)(bg & 1023u) : K - 1;
+    int sa[CP + 1];
+#pragma unroll
+    for (int m = 0; m < CP; m++) sa[m] = __builtin_amdgcn_readlane(sg, m * G);
+    sa[CP] = K - 1;
+#pragma unroll
+    for (int m = 0; m < CP; m++) {
+        const int lo = sa[m], hi = sa[m + 1];             /* wave-uniform */
+        const int up = (64 * m + lane) << 5;
+        uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu, c3 = 0xffffffffu;
+        for (int j = lo; j <= hi; j += 4) {
+            const uint2 v0 = ce[j], v1 = ce[min(j + 1, hi)], v2 = ce[min(j + 2, hi)], v3 = ce[min(j + 3, hi)];
+            const int d0 = up - (int)(v0.y & 0xffffu), d1 = up - (int)(v1.y & 0xffffu);
+            const int d2 = up - (int)(v2.y & 0xffffu), d3 = up - (int)(v3.y & 0xffffu);
+            c0 = min(c0, (uint32_t)__mul24(d0, d0) + v0.x);
+            c1 = min(c1, (uint32_t)__mul24(d1, d1) + v1.x);
+            c2 = min(c2, (uint32_t)__mul24(d2, d2) + v2.x);
+            c3 = min(c3, (uint32_t)__mul24(d3, d3) + v3.x);
+        }
+        sj[m] = (int)(min(min(c0, c1), min(c2, c3)) & 1023u);
+    }
+}
+
 /* wave64 stream compaction of the row's real sites; returns K.  `a` = value or ~0u (none),
  * `hi16` is carried in the upper half of ce[].y (pass X keeps the site's closest y there). */
 __device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const bool valid, const uint32_t a, const int i, const uint32_t hi16, const int lane)
@@ -417,20 +466,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
                 for (int i = lane; i < Z; i += 64) tile[i * TS + col] = GIE_BCOC_NONE;
             } else {
                 int sj[CP];
+                const bool banded = K <= GIE_BAND_MAXK;         /* wave-uniform: few sites → banded form */
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE >= 1
                 for (int m = 0; m < CP; m++) sj[m] = (lane * CP + m) % K;      /* measurement only: no argmin */
 #else
-                gie_row_argmin<CP>(ce, K, Z, lane, sj);
+                if (banded) gie_row_argmin_banded<CP>(ce, K, Z, lane, sj);
+                else gie_row_argmin<CP>(ce, K, Z, lane, sj);
 #endif
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 2
                 if (sj[0] >= 0) continue;                       /* measurement only: compaction, nothing else */
 #endif
-                /* gather first (own column only), then overwrite the column in place */
-                const int u0 = lane * CP;
+                /* gather first (own column only), then overwrite the column in place.
+                 * position of result m: 64 m + lane (banded) or lane CP + m */
+                const int ub = banded ? lane : lane * CP, us = banded ? 64 : 1;
                 uint32_t oc[CP];
 #pragma unroll
                 for (int m = 0; m < CP; m++) {
-                    if (u0 + m < Z) {
+                    if (ub + m * us < Z) {
                         const int s = (int)((ce[sj[m]].y & 0xffffu) >> 5);
                         const uint32_t v = tile[s * TS + col];
                         oc[m] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
@@ -439,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
                 gie_wave_sync();
 #pragma unroll
                 for (int m = 0; m < CP; m++)
-                    if (u0 + m < Z) tile[(u0 + m) * TS + col] = oc[m];
+                    if (ub + m * us < Z) tile[(ub + m * us) * TS + col] = oc[m];
             }
             gie_wave_sync();
         }

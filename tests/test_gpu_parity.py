@@ -46,6 +46,8 @@ def test_hip_matches_oracle(oracle_lib, sc):
     ((1, 1, 1), 1.0, 9), ((40, 40, 40), 1.0, 10),
     # the 1024-long axis templates (pass Y with 32 mask words, envelope passes with CP = 16)
     ((1024, 16, 12), 0.002, 11), ((16, 1024, 12), 0.002, 12), ((12, 16, 1024), 0.002, 13),
+    # pass Z picks its argmin form by the number of planes with obstacles: banded (<= 160) or divide & conquer
+    ((8, 8, 1000), 0.001, 14), ((24, 24, 400), 0.02, 15), ((20, 20, 200), 0.05, 16), ((16, 16, 130), 0.003, 17),
 ])
 def test_batch_edt_random_grids(oracle_lib, shape, dens, seed):
     """EDT passes alone on random obstacle fields, through the full C-ABI: types are injected
