@@ -295,8 +295,7 @@ extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
     if (n > 0) {
         op_register_point r; r.xyz = d_xyz; r.g = m->d_pts_g;
         be_prof(&m->be, GIE_K_RAY_REGISTER, 0); be_lin(&m->be, m->c, r, n); be_prof(&m->be, GIE_K_RAY_REGISTER, 1);   /* registerLocObs */
-        op_free_ray fr; fr.g = m->d_pts_g;
-        be_prof(&m->be, GIE_K_RAY_FREE, 0); be_lin(&m->be, m->c, fr, n); be_prof(&m->be, GIE_K_RAY_FREE, 1);           /* freeLocObs */
+        be_prof(&m->be, GIE_K_RAY_FREE, 0); be_free_rays(&m->be, m->c, m->d_pts_g, n); be_prof(&m->be, GIE_K_RAY_FREE, 1);   /* freeLocObs */
     }
     be_prof(&m->be, GIE_K_RAY_FINAL, 0); be_vox(&m->be, m->c, op_raycast_finalize()); be_prof(&m->be, GIE_K_RAY_FINAL, 1);   /* getAllocKeys */
     be_time(&m->be, 1);

@@ -169,6 +169,12 @@ template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f,
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, b->stream, c, f, n);
 }
+static void be_free_rays(be_state *b, const gie_ctx &c, const float *g, int n)
+{
+    if (n <= 0) return;
+    const int seg_steps = (gie_ray_max_steps(c) + GIE_RAY_SEGS - 1) / GIE_RAY_SEGS;
+    hipLaunchKernelGGL(k_free_rays, dim3((n + 63) / 64), dim3(64 * GIE_RAY_SEGS), 0, b->stream, c, g, n, seg_steps);
+}
 static void be_exclusive_scan(be_state *b, const int32_t *flag, int32_t *rank, int n)
 {
     size_t bytes = 0;

@@ -106,6 +106,77 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
     if (i < n) f(c, i);
 }
 
+/* ------------------------------------------------------------------ ray casting, segmented */
+/* freeLocObs with the walk of every ray cut into GIE_RAY_SEGS segments: lane = ray (64 rays
+ * adjacent in the cloud per workgroup, so that the wave aggregation of the _ray_count atomics
+ * still sees rays crossing the same near-sensor cells), wave = segment.  A ray walk is a chain of
+ * dependent memory round trips and one thread per ray leaves the GPU almost empty (a 16 x 1800
+ * cloud is 450 waves); the DDA arithmetic is cheap, so every thread replays it (registers only)
+ * up to its segment and only then touches memory.  Phase 1 finds where the ray stops (first
+ * OCCUPIED cell or the walk's end) as a minimum over the segments in LDS, phase 2 applies the
+ * decrements of the cells before that point — the same set of cells as the sequential walk. */
+#define GIE_RAY_SEGS 16
+__global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int seg_steps)
+{
+    __shared__ int s_stop[64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const bool ray = i < n;
+    if (seg == 0) s_stop[lane] = 0x7fffffff;
+    gie_dda d;
+    int s0[3] = { 0, 0, 0 };
+    int last_tile = -1;
+    bool walk = ray && gie_dda_init(c, g, i, d, s0);
+    if (seg == 0) {   /* clearRayLoc on the sensor's own cell */
+        const int id0 = (ray && gie_in_loc(c, s0[0], s0[1], s0[2])) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
+        if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
+        gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
+    }
+    /* replay up to the segment's first step; a walk that ended earlier leaves nothing to do */
+    const int first = seg * seg_steps;
+    for (int k = 0; k < first && walk; k++) if (gie_dda_step(d)) walk = false;
+    const gie_dda at_start = d;
+    __syncthreads();
+    /* phase 1: types of the segment's cells → where does the ray stop? (exclusive step index) */
+    if (walk) {
+        int stop = 0x7fffffff;
+        for (int k0 = 0; k0 < seg_steps && stop == 0x7fffffff; k0 += GIE_RAY_BATCH) {
+            int ids[GIE_RAY_BATCH], end[GIE_RAY_BATCH];
+#pragma unroll
+            for (int j = 0; j < GIE_RAY_BATCH; j++) {
+                end[j] = gie_dda_step(d);
+                const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
+                ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
+            }
+            int8_t ty[GIE_RAY_BATCH];
+#pragma unroll
+            for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = ids[j] >= 0 ? c.inst_type[ids[j]] : (int8_t)GIE_VOX_UNKNOWN;
+#pragma unroll
+            for (int j = 0; j < GIE_RAY_BATCH; j++) {
+                if (stop != 0x7fffffff || k0 + j >= seg_steps) continue;
+                if (ty[j] == GIE_VOX_OCCUPIED) stop = first + k0 + j;          /* this cell is not cleared */
+                else if (end[j]) stop = first + k0 + j + 1;                     /* this cell is the last one cleared */
+            }
+        }
+        if (stop != 0x7fffffff) atomicMin(&s_stop[lane], stop);
+    }
+    __syncthreads();
+    /* phase 2: clear the segment's cells that lie before the stop (all lanes take part in the
+     * wave aggregation; lanes without work pass -1) */
+    const int stop = s_stop[lane];
+    d = at_start;
+    for (int k = 0; k < seg_steps; k++) {
+        int id = -1;
+        if (walk && first + k < stop) {
+            gie_dda_step(d);
+            const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
+            if (gie_in_loc(c, lx, ly, lz)) { id = gie_lid(c, lx, ly, lz); gie_ray_touch(c, lx, ly, lz, &last_tile); }
+        }
+        if (__ballot(id >= 0) == 0ull) { if (__ballot(walk && first + k + 1 < stop) == 0ull) break; continue; }
+        gie_wave_add(c, id, -1);
+    }
+}
+
 /* one workgroup per table cell: initialise the 512 voxels of a block created this frame */
 __global__ __launch_bounds__(256) void k_block_init(const gie_ctx c, const int32_t *flag, const int32_t *rank)
 {

@@ -219,36 +219,65 @@ GIE_DEV int gie_clear_ray(const gie_ctx &c, int lx, int ly, int lz)
     return 0;
 }
 
-/* freeLocObs (pntcld_raycast.cu:67-80) → RAY::rayCastLoc (ray_cast.h:57-144) */
-GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
+/* freeLocObs (pntcld_raycast.cu:67-80) → RAY::rayCastLoc (ray_cast.h:57-144).
+ * The 3-D DDA itself, shared by the sequential walk below and by the segmented kernel
+ * (k_free_rays): same float operations in the same order, so a replayed walk visits the same cells. */
+struct gie_dda { int cur[3], step[3], i1[3]; float tMax[3], tDelta[3]; float len, max_length; };
+/* returns 0 when origin and end point share a cell (nothing to walk); sensor cell (local) in s0 */
+GIE_DEV int gie_dda_init(const gie_ctx &c, const float *g, int i, gie_dda &d, int s0[3])
 {
     const float w = c.voxel_width;
     const float p0[3] = { c.origin[0], c.origin[1], c.origin[2] };
     const float p1[3] = { g[3 * i], g[3 * i + 1], g[3 * i + 2] };
-    const float max_length = 0.707f * (float)c.X * w;
-    int i0[3], i1[3];
+    d.max_length = 0.707f * (float)c.X * w;
+    int i0[3];
+    for (int k = 0; k < 3; k++) { i0[k] = gie_pos2coord(p0[k], w); d.i1[k] = gie_pos2coord(p1[k], w); d.cur[k] = i0[k]; s0[k] = i0[k] - c.pvt[k]; }
+    if (i0[0] == d.i1[0] && i0[1] == d.i1[1] && i0[2] == d.i1[2]) return 0;
+    float dir[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
+    d.len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    for (int k = 0; k < 3; k++) dir[k] = dir[k] / d.len;
+    for (int k = 0; k < 3; k++) {
+        if (dir[k] > 0.0f) d.step[k] = 1; else if (dir[k] < 0.0f) d.step[k] = -1; else d.step[k] = 0;
+        if (d.step[k] != 0) {
+            const float border = (float)d.cur[k] * w + (float)d.step[k] * w * 0.5f;
+            d.tMax[k] = (border - p0[k]) / dir[k];
+            d.tDelta[k] = w / fabsf(dir[k]);
+        } else { d.tMax[k] = 3.402823466e+38f; d.tDelta[k] = 3.402823466e+38f; }
+    }
+    return 1;
+}
+/* one cell forward; returns the reference's stop test for the NEW cell (end cell reached or
+ * past the ray / the maximum length): that cell is still cleared, the walk ends after it */
+GIE_DEV int gie_dda_step(gie_dda &d)
+{
+    int dim;
+    if (d.tMax[0] < d.tMax[1]) dim = (d.tMax[0] < d.tMax[2]) ? 0 : 2;
+    else dim = (d.tMax[1] < d.tMax[2]) ? 1 : 2;
+    /* unrolled select instead of dynamic indexing keeps everything in registers */
+    if (dim == 0) { d.cur[0] += d.step[0]; d.tMax[0] += d.tDelta[0]; }
+    else if (dim == 1) { d.cur[1] += d.step[1]; d.tMax[1] += d.tDelta[1]; }
+    else { d.cur[2] += d.step[2]; d.tMax[2] += d.tDelta[2]; }
+    const float m01 = d.tMax[0] < d.tMax[1] ? d.tMax[0] : d.tMax[1];
+    const float dist = m01 < d.tMax[2] ? m01 : d.tMax[2];
+    return (d.cur[0] == d.i1[0] && d.cur[1] == d.i1[1] && d.cur[2] == d.i1[2]) || dist > d.max_length || dist > d.len;
+}
+/* upper bound of the cells one ray can visit: max_length / w voxels along the ray, at most
+ * |dx|+|dy|+|dz| <= sqrt(3) cell changes per voxel of length */
+GIE_HD int gie_ray_max_steps(const gie_ctx &c) { return (int)(0.707f * (float)c.X * 1.7321f) + 8; }
+
+/* sequential walk of one ray (one thread per ray) */
+GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
+{
+    gie_dda d;
+    int s0[3];
     int last_tile = -1;
-    for (int k = 0; k < 3; k++) { i0[k] = gie_pos2coord(p0[k], w); i1[k] = gie_pos2coord(p1[k], w); }
+    const int walk = gie_dda_init(c, g, i, d, s0);
     {   /* clearRayLoc on the sensor's own cell */
-        const int lx = i0[0] - c.pvt[0], ly = i0[1] - c.pvt[1], lz = i0[2] - c.pvt[2];
-        const int id0 = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
-        if (id0 >= 0) gie_ray_touch(c, lx, ly, lz, &last_tile);
+        const int id0 = gie_in_loc(c, s0[0], s0[1], s0[2]) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
+        if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
         gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
     }
-    if (i0[0] == i1[0] && i0[1] == i1[1] && i0[2] == i1[2]) return;
-    float dir[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
-    const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    for (int k = 0; k < 3; k++) dir[k] = dir[k] / len;
-    int step[3]; float tMax[3], tDelta[3];
-    int cur[3] = { i0[0], i0[1], i0[2] };
-    for (int k = 0; k < 3; k++) {
-        if (dir[k] > 0.0f) step[k] = 1; else if (dir[k] < 0.0f) step[k] = -1; else step[k] = 0;
-        if (step[k] != 0) {
-            const float border = (float)cur[k] * w + (float)step[k] * w * 0.5f;
-            tMax[k] = (border - p0[k]) / dir[k];
-            tDelta[k] = w / fabsf(dir[k]);
-        } else { tMax[k] = 3.402823466e+38f; tDelta[k] = 3.402823466e+38f; }
-    }
+    if (!walk) return;
     /* The traversal itself (ray_cast.h:102-142) is a dependent chain "step → read the cell's
      * type → stop or decrement"; the cells do not depend on what is read, so GIE_RAY_BATCH steps
      * are generated ahead, their types are fetched together, and the effects are then applied in
@@ -259,19 +288,10 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
         int stop_after[GIE_RAY_BATCH];
         GIE_UNROLL_BATCH
         for (int j = 0; j < GIE_RAY_BATCH; j++) {
-            int dim;
-            if (tMax[0] < tMax[1]) dim = (tMax[0] < tMax[2]) ? 0 : 2;
-            else dim = (tMax[1] < tMax[2]) ? 1 : 2;
-            /* unrolled select instead of dynamic indexing keeps everything in registers */
-            if (dim == 0) { cur[0] += step[0]; tMax[0] += tDelta[0]; }
-            else if (dim == 1) { cur[1] += step[1]; tMax[1] += tDelta[1]; }
-            else { cur[2] += step[2]; tMax[2] += tDelta[2]; }
-            const int lx = cur[0] - c.pvt[0], ly = cur[1] - c.pvt[1], lz = cur[2] - c.pvt[2];
+            stop_after[j] = gie_dda_step(d);
+            const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
             ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
             if (ids[j] >= 0) gie_ray_touch(c, lx, ly, lz, &last_tile);      /* speculative cells may over-flag: harmless */
-            const float m01 = tMax[0] < tMax[1] ? tMax[0] : tMax[1];
-            const float dist = m01 < tMax[2] ? m01 : tMax[2];
-            stop_after[j] = (cur[0] == i1[0] && cur[1] == i1[1] && cur[2] == i1[2]) || dist > max_length || dist > len;
         }
         int8_t ty[GIE_RAY_BATCH];
         GIE_UNROLL_BATCH

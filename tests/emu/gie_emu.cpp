@@ -55,6 +55,7 @@ static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
 }
 template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
+static void be_free_rays(be_state *, const gie_ctx &c, const float *g, int n) { for (int i = 0; i < n; i++) gie_free_ray(c, g, i); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell)
 {
