@@ -194,10 +194,6 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
         be_memset(&m->be, c.g_wl, 0xff, (size_t)c.max_blocks * GIE_VBSZ * sizeof(int32_t));
     }
     c.stamp_base = (f + 1u) << 12;
-    be_memset(&m->be, c.tray, 0, (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2]);
-    /* per-frame counters (the sticky error flag survives) */
-    be_memset(&m->be, c.cnt, 0, GIE_CNT_ERR * sizeof(int32_t));
-    be_memset(&m->be, c.cnt + GIE_CNT_ERR + 1, 0, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
     m->has_pose = 1;
     return GIE_OK;
 }
@@ -338,20 +334,25 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
     be_prof(&m->be, GIE_K_ALLOC, 0);
-    be_lin(&m->be, m->c, op_cell_flag(), m->ncell);
-    be_exclusive_scan(&m->be, m->c.blk_new, m->d_rank, m->ncell);
-    op_cell_insert ins; ins.flag = m->c.blk_new; ins.rank = m->d_rank;
-    be_lin(&m->be, m->c, ins, m->ncell);
-    be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
-    be_lin(&m->be, m->c, op_cell_table(), m->ncell);
-    be_prof(&m->be, GIE_K_ALLOC, 1);
-    be_memset(&m->be, m->c.zocc, 0, (size_t)m->c.Z);
-    {   /* per-tile summaries: last frame's "known" flags tell which tiles still hold stale _glb_type */
-        const size_t ntile = (size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-        uint8_t *t = m->c.tknown; m->c.tknown = m->c.tknown_prev; m->c.tknown_prev = t;
-        be_memset(&m->be, m->c.tknown, 0, ntile);
-        be_memset(&m->be, m->c.tunk, 0, ntile);
+    {   /* everything that has to be zero for this map update, in one launch.  Per-tile summaries:
+         * last frame's "known" flags (tknown_prev) tell which tiles still hold stale _glb_type; the
+         * ray-touch flags were consumed by the OGM stage and are cleared for the next scan. */
+        gie_ctx &c = m->c;
+        const size_t ntile = (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2];
+        uint8_t *t = c.tknown; c.tknown = c.tknown_prev; c.tknown_prev = t;
+        gie_clear_list l; l.n = 0;
+        auto add = [&l](void *p, size_t bytes) { l.p[l.n] = p; l.bytes[l.n] = (uint32_t)bytes; l.n++; };
+        add(c.tflag, 4 * ntile);                                   /* tflag | tunk | tsum | tray */
+        add(c.tknown, ntile);
+        add(c.zocc, (size_t)c.Z);
+        add(c.cnt, GIE_CNT_ERR * sizeof(int32_t));                 /* per-frame counters (the sticky error flag survives) */
+        add(c.cnt + GIE_CNT_ERR + 1, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
+        add(c.cnt + GIE_CNT_BAR_B, (GIE_CNT_AUX_END - GIE_CNT_BAR_B) * sizeof(int32_t));
+        add(c.lvl_next, 2 * GIE_MAX_LEVELS * sizeof(int32_t));
+        be_clear(&m->be, l);
     }
+    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0);
+    be_prof(&m->be, GIE_K_ALLOC, 1);
     be_prof(&m->be, GIE_K_FUSE, 0); be_vox_staged(&m->be, m->c, op_fuse()); be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
@@ -371,7 +372,6 @@ extern "C" int gie_merge(gie_mapper *m)
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
     const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-    be_memset(&m->be, m->c.tflag, 0, (size_t)ntile);
     be_prof(&m->be, GIE_K_MARK, 0); be_vox(&m->be, m->c, op_mark()); be_prof(&m->be, GIE_K_MARK, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_lin(&m->be, m->c, op_tile_summary(), ntile);
@@ -380,7 +380,7 @@ extern "C" int gie_merge(gie_mapper *m)
         be_prof(&m->be, GIE_K_WAVE_A, 0); be_wave_a(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_A, 1);
         be_prof(&m->be, GIE_K_WAVE_B, 0); be_wave_b(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_B, 1);
     }
-    be_prof(&m->be, GIE_K_WAVE_C, 0); be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
+    be_prof(&m->be, GIE_K_WAVE_C, 0); be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     be_prof(&m->be, GIE_K_COMMIT, 0); be_vox_staged(&m->be, m->c, op_commit()); be_prof(&m->be, GIE_K_COMMIT, 1);
     be_time(&m->be, 7);
     return GIE_OK;
@@ -621,12 +621,7 @@ extern "C" int gie_halo_import_dev(gie_mapper *m, int face, const gie_halo_voxel
     /* ghost voxels need their blocks: same allocation path as gie_fuse */
     op_halo_need nd; nd.face = face; nd.in = d;
     be_lin(&m->be, m->c, nd, n);
-    be_lin(&m->be, m->c, op_cell_flag(), m->ncell);
-    be_exclusive_scan(&m->be, m->c.blk_new, m->d_rank, m->ncell);
-    op_cell_insert ins; ins.flag = m->c.blk_new; ins.rank = m->d_rank;
-    be_lin(&m->be, m->c, ins, m->ncell);
-    be_block_init(&m->be, m->c, m->c.blk_new, m->d_rank, m->ncell);
-    be_lin(&m->be, m->c, op_cell_table(), m->ncell);
+    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 1);
     op_halo_import im; im.face = face; im.in = d;
     be_lin(&m->be, m->c, im, n);
     return GIE_OK;
@@ -650,7 +645,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     be_memset(&m->be, c.cnt + GIE_CNT_C, 0, sizeof(int32_t));
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
-    be_wave_c(&m->be, c, 0);
+    be_wave_c(&m->be, c, 0, 1);
     be_vox_staged(&m->be, c, op_commit());
     rc = gie_sync(m);
     if (seeded) *seeded = m->h_cnt[GIE_CNT_FRONT_C];

@@ -169,6 +169,17 @@ template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f,
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, b->stream, c, f, n);
 }
+static void be_clear(be_state *b, const gie_clear_list &l)
+{
+    if (l.n > 0) hipLaunchKernelGGL(k_clear, dim3(32, l.n), dim3(256), 0, b->stream, l);
+}
+/* allocHashTB + block table (see k_cell_alloc) */
+static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, int clear_list)
+{
+    if (clear_list) GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_NEWLIST], 0, sizeof(int32_t), b->stream));
+    hipLaunchKernelGGL(k_cell_alloc, dim3((ncell + 255) / 256), dim3(256), 0, b->stream, c, ncell);
+    hipLaunchKernelGGL(k_block_init_list, dim3(b->cu_total * 4), dim3(256), 0, b->stream, c);
+}
 static void be_free_rays(be_state *b, const gie_ctx &c, const float *g, int n)
 {
     if (n <= 0) return;
@@ -241,18 +252,20 @@ static void be_edt(be_state *b, const gie_ctx &c)
 /* one workgroup per CU: co-resident by construction (1024 threads, < 72 VGPRs, 16 B of LDS) */
 static void be_wave_a(be_state *b, const gie_ctx &c)
 {
-    GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
     hipLaunchKernelGGL(k_wave_a, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c);
 }
 static void be_wave_b(be_state *b, const gie_ctx &c)
 {
-    GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
     hipLaunchKernelGGL(k_wave_b, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c);
 }
-static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds)
+/* the frame clear has zeroed the barrier words and the per-level arrays; a second wave C inside
+ * the same map update (gie_refine) clears them itself */
+static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds, int clear_first)
 {
-    GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR], 0, sizeof(int32_t), b->stream));
-    GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
+    if (clear_first) {
+        GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
+        GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
+    }
     hipLaunchKernelGGL(k_wave_c, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, record_seeds);
 }
 

@@ -177,6 +177,72 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     }
 }
 
+/* ------------------------------------------------------------------ frame clear */
+/* every small array that has to be zero when a map update starts, in one launch (blockIdx.y = region) */
+__global__ __launch_bounds__(256) void k_clear(const gie_clear_list l)
+{
+    const int r = blockIdx.y;
+    if (r >= l.n) return;
+    unsigned char *p = (unsigned char *)l.p[r];
+    const uint32_t bytes = l.bytes[r];
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) < bytes ? (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) : bytes;
+    const uint32_t nvec = (bytes - head) / 16u, tail0 = head + nvec * 16u;
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    for (uint32_t i = tid; i < head; i += nth) p[i] = 0;
+    uint4 *v = (uint4 *)(p + head);
+    for (uint32_t i = tid; i < nvec; i += nth) v[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tail0 + tid; i < bytes; i += nth) p[i] = 0;
+}
+
+/* ------------------------------------------------------------------ block allocation */
+/* allocHashTB (glb_hash_map.cu:58-113) + the frame's block table in one sweep over the table
+ * cells: look the block up; a cell the scan observed without a block gets a slot (one atomic per
+ * wave on the pool counter), is inserted and queued for initialisation; either way the table
+ * entry is final when the thread ends (nobody else handles this key in this launch, and inserts
+ * of other keys cannot break a probe sequence). */
+__global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int ncell)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int found = -1;
+    bool isnew = false;
+    if (i < ncell) {
+        const int bx = i % c.tdim[0], by = (i / c.tdim[0]) % c.tdim[1], bz = i / (c.tdim[0] * c.tdim[1]);
+        found = gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]);
+        isnew = found < 0 && c.blk_need[i];
+        c.blk_need[i] = 0;
+    }
+    const unsigned long long m = __ballot(isnew);
+    if (m) {
+        const int lane = __lane_id(), leader = __ffsll((long long)m) - 1, cnt = __popcll(m);
+        int base = 0, lbase = 0;
+        if (lane == leader) {
+            base = atomicAdd(c.pool_count, cnt);
+            lbase = atomicAdd(&c.cnt[GIE_CNT_NEWLIST], cnt);
+            atomicAdd(&c.cnt[GIE_CNT_NEWBLK], cnt);
+        }
+        base = __shfl(base, leader); lbase = __shfl(lbase, leader);
+        if (isnew) {
+            const int r = __popcll(m & ((1ull << lane) - 1ull));
+            const int slot = base + r;
+            if (slot >= c.max_blocks) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_POOL); c.blk_new[lbase + r] = -1; }
+            else { gie_cell_insert(c, i, slot); c.blk_new[lbase + r] = slot; found = slot; }
+        }
+    }
+    if (i < ncell) c.blk_tab[i] = found;
+}
+/* initialise the 512 voxels of every block on the list (one workgroup per block, grid-stride) */
+__global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c)
+{
+    const int n = c.cnt[GIE_CNT_NEWLIST];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *c.pool_count > c.max_blocks) *c.pool_count = c.max_blocks;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const int slot = c.blk_new[e];
+        if (slot < 0) continue;
+        gie_init_voxel(c, slot, threadIdx.x);
+        gie_init_voxel(c, slot, threadIdx.x + 256);
+    }
+}
+
 /* one workgroup per table cell: initialise the 512 voxels of a block created this frame */
 __global__ __launch_bounds__(256) void k_block_init(const gie_ctx c, const int32_t *flag, const int32_t *rank)
 {
@@ -650,7 +716,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_b(const gie_ctx c)
 {
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0, &s_fail };
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_B], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
@@ -726,7 +792,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, co
     __shared__ gie_wg_scratch s_wg;
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0, &s_fail };
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;

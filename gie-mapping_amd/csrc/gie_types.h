@@ -150,10 +150,13 @@ enum {
     GIE_CNT_LVL_A, GIE_CNT_LVL_B, GIE_CNT_LVL_C,
     GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
-    GIE_CNT_BAR,                                /* grid-barrier word, zeroed before every wave launch */
+    GIE_CNT_BAR,                                /* grid-barrier word of wave A (B and C have their own, below): zeroed by the frame clear */
     GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (n, cur, level) published after a solo episode */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
+    GIE_CNT_BAR_B = 34, GIE_CNT_BAR_C = 35,     /* grid-barrier words of waves B and C */
+    GIE_CNT_NEWLIST = 36,                       /* entries in the list of blocks to initialise (blk_new) */
+    GIE_CNT_AUX_END = 37,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 40
 };
 #define GIE_MAX_LEVELS 4096
@@ -161,6 +164,10 @@ enum {
 #define GIE_ERRF_QUEUE 2
 #define GIE_ERRF_HASH 4
 #define GIE_ERRF_BARRIER 8
+
+/* regions zeroed by one launch at the start of a map update */
+#define GIE_CLEAR_MAX 8
+typedef struct gie_clear_list { void *p[GIE_CLEAR_MAX]; uint32_t bytes[GIE_CLEAR_MAX]; int n; } gie_clear_list;
 
 /* stamps in ctx.wl (local) */
 #define GIE_WL_SEED(c) ((c).stamp_base + 1u)

@@ -55,6 +55,19 @@ static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
 }
 template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
+static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
+static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
+static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell);
+/* sequential allocHashTB: flag → rank → insert → initialise → table */
+static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *rank, int)
+{
+    be_lin(b, c, op_cell_flag(), ncell);
+    be_exclusive_scan(b, c.blk_new, rank, ncell);
+    op_cell_insert ins; ins.flag = c.blk_new; ins.rank = rank;
+    be_lin(b, c, ins, ncell);
+    be_block_init(b, c, c.blk_new, rank, ncell);
+    be_lin(b, c, op_cell_table(), ncell);
+}
 static void be_free_rays(be_state *, const gie_ctx &c, const float *g, int n) { for (int i = 0; i < n; i++) gie_free_ray(c, g, i); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell)
@@ -118,7 +131,7 @@ static void be_wave_b(be_state *, const gie_ctx &c)
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
     }
 }
-static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds)
+static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
 {
     int n = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c, cur = 0, level = 0;
     c.cnt[GIE_CNT_FRONT_C] = n;
