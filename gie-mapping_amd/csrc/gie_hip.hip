@@ -48,7 +48,7 @@ static int be_init(be_state *b, int device)
     if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
     { hipDeviceProp_t pr; b->num_cu = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 64; }
     b->cu_total = b->num_cu;
-    b->num_cu = b->num_cu >= 64 ? b->num_cu / 4 : b->num_cu;   /* wave grids: 64 workgroups measured best (barrier fan-in vs parallelism) */
+    b->num_cu = b->num_cu >= 64 ? b->num_cu / 2 : b->num_cu;   /* wave grids: 128 workgroups measured best (64: 20.6, 128: 17.7, 256: 20.0 us per BFS level — a compute unit's request queue vs barrier fan-in) */
     { const char *e = getenv("GIE_WAVE_WGS"); if (e && atoi(e) > 0 && atoi(e) <= 256) b->num_cu = atoi(e); }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }

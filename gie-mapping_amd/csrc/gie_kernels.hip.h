@@ -660,14 +660,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
 
 struct gie_gridbar { int32_t *word; int epoch; int failed; int solo; int *s_fail; };
 
+/* Everything the wave kernels share between workgroups is read and written with agent-scope
+ * (write-through, L1-bypassing) accesses — gie_ld / gie_st / atomics — so the barrier needs no
+ * cache write-back or invalidate (each costs microseconds per level): every wave drains its own
+ * stores, the workgroup meets, one lane arrives on the counter and polls it. */
 __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (gb.solo) return;                 /* one workgroup left: its waves share the CU's L2 path */
     gb.epoch += 1;
     if (threadIdx.x == 0 && !gb.failed) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int target = gb.epoch * (int)gridDim.x;
         __hip_atomic_fetch_add(gb.word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
@@ -675,7 +678,6 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
             __builtin_amdgcn_s_sleep(2);
             if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         /* a timed-out barrier poisons the launch: this block leaves; the others time out at their
          * next barrier (bounded spin), so nobody hangs */
         if (spins > GIE_BAR_SPIN_LIMIT) *gb.s_fail = 1;
@@ -746,17 +748,27 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_b(const gie_ctx c)
  * to six same-address atomics per thread. */
 struct gie_wg_scratch { int32_t tot[GIE_WAVE_THREADS / 64]; int32_t vis[GIE_WAVE_THREADS / 64]; int32_t base; };
 
-__device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cur, int level, int wg_first, int stride, gie_wg_scratch *sc)
+/* entries [first, last) belong to this workgroup (the frontier is split EVENLY over the
+ * workgroups: every entry costs a dozen scattered 8-byte transactions, and a compute unit's path
+ * to the fabric, not the fabric, is what a level waits for) */
+__device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int level, int first, int last, gie_wg_scratch *sc)
 {
     int32_t *next_cnt = &c.lvl_next[level];
     int32_t *next = c.qc[cur ^ 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int b0 = wg_first; b0 < n; b0 += stride) {
+#if defined(GIE_WAVE_TIMING)
+#define GIE_TS(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && level < 4000) c.edt[level * 8 + (k)] = (float)(wall_clock64() & 0xffffff); } while (0)
+#else
+#define GIE_TS(k) do { } while (0)
+#endif
+    GIE_TS(0);
+    for (int b0 = first; b0 < last; b0 += GIE_WAVE_THREADS) {
         const int e = b0 + (int)threadIdx.x;
         int nid[6];
         int m = 0;
-        if (e < n) m = gie_wave_c_relax(c, c.qc[cur], level, e, nid);
+        if (e < last) m = gie_wave_c_relax(c, c.qc[cur], level, e, nid);
+        GIE_TS(1);
         int off[6], wtot = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -767,6 +779,7 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cu
         const int wvis = __popcll(__ballot((m >> 6) & 1));
         if (lane == 0) { sc->tot[wave] = wtot; sc->vis[wave] = wvis; }
         __syncthreads();
+        GIE_TS(2);
         if (threadIdx.x == 0) {
             int t = 0, v = 0;
             for (int w = 0; w < GIE_WAVE_THREADS / 64; w++) { t += sc->tot[w]; v += sc->vis[w]; }
@@ -774,6 +787,7 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cu
             if (v) gie_aadd32(&c.lvl_vis[level], v);
         }
         __syncthreads();
+        GIE_TS(3);
         int wbase = sc->base;
         for (int w = 0; w < wave; w++) wbase += sc->tot[w];
 #pragma unroll
@@ -785,6 +799,7 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int n, int cu
             }
         }
         __syncthreads();                       /* scratch is reused by the next trip */
+        GIE_TS(4);
     }
 }
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, const int record_seeds)
@@ -809,7 +824,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, co
              * small, the others wait at ONE grid barrier and then pick up the published state */
             if (blockIdx.x == 0) {
                 do {
-                    gie_wave_c_level(c, n, cur, level, 0, GIE_WAVE_THREADS, &s_wg);
+                    gie_wave_c_level(c, cur, level, 0, n, &s_wg);
                     __syncthreads();
                     n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c); cur ^= 1; level++;
                 } while (n > 0 && n <= GIE_WAVE_SOLO && level < GIE_MAX_LEVELS - 1);
@@ -819,9 +834,14 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, co
             n = gie_ld(&c.cnt[GIE_CNT_STATE]); cur = gie_ld(&c.cnt[GIE_CNT_STATE + 1]); level = gie_ld(&c.cnt[GIE_CNT_STATE + 2]);
             gie_grid_sync(gb, c);              /* everybody has read the state before it can be republished */
         } else {
-            gie_wave_c_level(c, n, cur, level, (int)blockIdx.x * GIE_WAVE_THREADS, gsz, &s_wg);
+            const int share = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;      /* whole waves */
+            const int first = (int)blockIdx.x * share;
+            gie_wave_c_level(c, cur, level, first < n ? first : n, first + share < n ? first + share : n, &s_wg);
             gie_grid_sync(gb, c);
-            n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c); cur ^= 1; level++;
+            GIE_TS(5);
+            n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c);
+            GIE_TS(6);
+            cur ^= 1; level++;
         }
     }
     if (n > 0 && level >= GIE_MAX_LEVELS - 1 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);

@@ -837,37 +837,38 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
 GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, int e, int nid_out[6])
 {
     const int id = gie_ld(&cur[e]);
-    uint64_t pr;
-    {
-        /* level 0: the seed pairs written by obtainFrontiers / wave B are assignments
-         * (unify_helper.cuh:334-335, wave_core.cuh:338-341); later levels: strict improvement */
-        uint64_t *slot = &c.cand[(level - 1) & 1][id];
-        const uint64_t cd = gie_ld(slot);
-        gie_st(slot, (uint64_t)GIE_NOPROP);
-        if (level > 0 && !(gie_pair_dist(cd) < gie_pair_dist(gie_ld(&c.pair[id])))) return 0;
-        pr = cd;
-        gie_st(&c.pair[id], pr);
-    }
     const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    /* every read of this entry is issued in ONE batch (each is a round trip through the fabric:
+     * own candidate, own pair and the six neighbours' pairs only depend on the voxel id) */
+    uint64_t *slot = &c.cand[(level - 1) & 1][id];
+    const uint64_t cd = gie_ld(slot);
+    const uint64_t own = gie_ld(&c.pair[id]);
+    uint64_t seen[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+        nid_out[k] = gie_in_loc(c, nx, ny, nz) ? gie_lid(c, nx, ny, nz) : -1;
+        seen[k] = nid_out[k] >= 0 ? gie_ld(&c.pair[nid_out[k]]) : 0ull;
+    }
+    /* level 0: the seed pairs written by obtainFrontiers / wave B are assignments
+     * (unify_helper.cuh:334-335, wave_core.cuh:338-341); later levels: strict improvement */
+    gie_st(slot, (uint64_t)GIE_NOPROP);
+    if (level > 0 && !(gie_pair_dist(cd) < gie_pair_dist(own))) return 0;
+    const uint64_t pr = cd;
+    gie_st(&c.pair[id], pr);
     const uint64_t par = gie_pair_par(pr);
     int cw[3];
     gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
     const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     int cand[6];
-    uint64_t seen[6];
-    /* stage 1: six independent reads */
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
-        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
-        nid_out[k] = -1;
-        if (!gie_in_loc(c, nx, ny, nz)) continue;
-        const int d = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
-        if (d >= c.empty_value) continue;
-        nid_out[k] = gie_lid(c, nx, ny, nz); cand[k] = d;
+        if (nid_out[k] < 0) continue;
+        const int d = gie_d2(cl[0], cl[1], cl[2], x + dx[k], y + dy[k], z + dz[k]);
+        if (d >= c.empty_value) { nid_out[k] = -1; continue; }
+        cand[k] = d;
     }
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) seen[k] = nid_out[k] >= 0 ? gie_ld(&c.pair[nid_out[k]]) : 0ull;
     /* stage 2: candidates that can still improve */
     uint64_t *plane = c.cand[level & 1];
     int mask = 64;
