@@ -26,6 +26,7 @@ struct gie_mapper {
     be_state be;
     int ncell;
     int has_pose, has_ogm;
+    int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
     float msg_origin[3];
     float *d_sensor; size_t sensor_cap;   /* device copy of the last sensor frame */
     float *d_pts_g; size_t pts_cap;       /* ray casting: points in the global frame */
@@ -62,7 +63,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0;
+    m->has_pose = m->has_ogm = 0; m->edt_partial = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -98,6 +99,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tunk = c.tflag + ntile; c.tsum = c.tflag + 2 * ntile; c.tray = c.tflag + 3 * ntile;
     c.tknown = c.tflag + 4 * ntile; c.tknown_prev = c.tflag + 5 * ntile;
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
+    c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -362,7 +364,10 @@ extern "C" int gie_batch_edt(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_batch_edt"); if (rc) return rc;
     be_time(&m->be, 4);
-    be_edt(&m->be, m->c);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z) */
+    be_lin(&m->be, m->c, op_zneed(), m->c.tfd[0] * m->c.tfd[1]);
+    const int partial = m->c.tfd[2] <= 64;
+    be_edt(&m->be, m->c, partial ? 0 : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
+    m->edt_partial = partial;
     be_time(&m->be, 5);
     return GIE_OK;
 }
@@ -444,6 +449,10 @@ extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
 {
     if (!m) { gie_set_err("gie_read_batch_edt: null handle"); return GIE_ERR_INVALID; }
     const size_t N = (size_t)m->c.N;
+    if (m->edt_partial && !getenv("GIE_EDT_EXPORT_PARTIAL")) {   /* complete the tiles the map update itself never reads */
+        be_edt_z(&m->be, m->c, 1);
+        m->edt_partial = 0;
+    }
     if (dist_sq || coc) {
         int32_t *dd = dist_sq ? (int32_t *)be_alloc(&m->be, N * 4, false) : nullptr;
         int32_t *dc = coc ? (int32_t *)be_alloc(&m->be, N * 12, false) : nullptr;

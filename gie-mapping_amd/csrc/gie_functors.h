@@ -133,6 +133,7 @@ struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
+struct op_zneed { GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_zneed_column(c, i); } };
 struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };
 struct op_stream_gather { const int32_t *list; int first; int32_t *keys; gie_voxel *out;
     GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_gather(c, list, first, keys, out, i); } };

@@ -202,7 +202,7 @@ static void be_block_init(be_state *b, const gie_ctx &c, const int32_t *flag, co
     hipLaunchKernelGGL(k_pool_advance, dim3(1), dim3(1), 0, b->stream, c, flag, rank, ncell);
 }
 
-template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, const gie_ctx &c)
+template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, const gie_ctx &c, int full)
 {
     constexpr int LP = 64 * CP;
     const size_t tile = ((size_t)c.Z * (TX + 1) + 3) & ~(size_t)3;
@@ -216,29 +216,29 @@ template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, c
     int wgs = (int)((160 * 1024) / (lds + 256));            /* workgroups that fit one CU's LDS */
     if (wgs < 1) wgs = 1; if (wgs > 4) wgs = 4;
     int grid = wgs * b->cu_total; if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((k_edt_z<CP, TX, WAVES>), dim3(grid), dim3(64 * WAVES), lds, b->stream, c, ntx, ntiles);
+    hipLaunchKernelGGL((k_edt_z<CP, TX, WAVES>), dim3(grid), dim3(64 * WAVES), lds, b->stream, c, ntx, ntiles, full);
 }
-template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass)
+template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass, int full)
 {
     if (!zpass) {
         const int rows = c.Y * c.Z;
         hipLaunchKernelGGL(k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, b->stream, c);
-    } else if (CP <= 8) {
-        gie_launch_edt_z<CP, 16, 8>(b, c);      /* 2 workgroups per CU overlap load / envelope / store phases */
     } else {
-        gie_launch_edt_z<CP, 16, 8>(b, c);      /* Z up to 1024 */
+        gie_launch_edt_z<CP, 16, 8>(b, c, full);      /* 2 workgroups per CU overlap load / envelope / store phases */
     }
 }
-static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass)
+static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass, int full)
 {
-    if (L <= 64) gie_launch_edt_xz<1>(b, c, zpass);
-    else if (L <= 128) gie_launch_edt_xz<2>(b, c, zpass);
-    else if (L <= 256) gie_launch_edt_xz<4>(b, c, zpass);
-    else if (L <= 512) gie_launch_edt_xz<8>(b, c, zpass);
-    else gie_launch_edt_xz<16>(b, c, zpass);
+    if (L <= 64) gie_launch_edt_xz<1>(b, c, zpass, full);
+    else if (L <= 128) gie_launch_edt_xz<2>(b, c, zpass, full);
+    else if (L <= 256) gie_launch_edt_xz<4>(b, c, zpass, full);
+    else if (L <= 512) gie_launch_edt_xz<8>(b, c, zpass, full);
+    else gie_launch_edt_xz<16>(b, c, zpass, full);
 }
+/* pass Z again over the whole volume (the passes before it are complete either way) */
+static void be_edt_z(be_state *b, const gie_ctx &c, int full) { gie_launch_edt_dim(b, c, c.Z, true, full); }
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
-static void be_edt(be_state *b, const gie_ctx &c)
+static void be_edt(be_state *b, const gie_ctx &c, int full)
 {
     dim3 gy((c.X + GIE_EDTY_COLS - 1) / GIE_EDTY_COLS, c.Z);
     be_prof(b, 6, 0);   /* GIE_K_EDT_Y */
@@ -246,8 +246,8 @@ static void be_edt(be_state *b, const gie_ctx &c)
     else if (c.Y <= 512) hipLaunchKernelGGL(k_edt_y<16>, gy, dim3(GIE_EDTY_COLS, 4), 0, b->stream, c);
     else hipLaunchKernelGGL(k_edt_y<32>, gy, dim3(GIE_EDTY_COLS, 4), 0, b->stream, c);
     be_prof(b, 6, 1);
-    be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
-    be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
+    be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
+    be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true, full); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
 }
 /* one workgroup per CU: co-resident by construction (1024 threads, < 72 VGPRs, 16 B of LDS) */
 static void be_wave_a(be_state *b, const gie_ctx &c)

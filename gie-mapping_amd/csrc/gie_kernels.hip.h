@@ -433,7 +433,7 @@ __device__ __forceinline__ void gie_row_argmin(const uint2 *ce, const int K, con
  * when K is large, but pays per-lane loop set-up for every position). */
 #define GIE_BAND_MAXK 160
 template <int CP>
-__device__ __forceinline__ void gie_row_argmin_banded(const uint2 *ce, const int K, const int L, const int lane, int (&sj)[CP])
+__device__ __forceinline__ void gie_row_argmin_banded(const uint2 *ce, const int K, const int L, const int lane, int (&sj)[CP], const unsigned bandneed = ~0u)
 {
     constexpr int G = 64 / CP;                            /* lanes per band start */
     const int b = lane / G, r = lane % G;
@@ -457,6 +457,7 @@ __device__ __forceinline__ void gie_row_argmin_banded(const uint2 *ce, const int
     sa[CP] = K - 1;
 #pragma unroll
     for (int m = 0; m < CP; m++) {
+        if (!((bandneed >> m) & 1u)) { sj[m] = 0; continue; }      /* nobody reads this band (wave-uniform) */
         const int lo = sa[m], hi = sa[m + 1];             /* wave-uniform */
         const int up = (64 * m + lane) << 5;
         uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu, c2 = 0xffffffffu, c3 = 0xffffffffu;
@@ -543,9 +544,13 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
  * (dist² is a function of it and is never stored). */
 /* TX columns per workgroup (TX*4-byte row segments in HBM), padded LDS row stride TX+1 so that
  * column walks hit distinct banks, WAVES waves per workgroup. */
+/* `full` = 0: only the tiles somebody reads are produced (c.zneed: tiles with a known voxel or on
+ * a face of the volume); whole workgroup tiles, columns, 64-position bands and output rows
+ * without a reader are skipped.  `full` = 1 (gie_read_batch_edt): every voxel. */
 template <int CP, int TX, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int ntiles_x, const int ntiles)
+__global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const gie_ctx c, const int ntiles_x, const int ntiles, const int full)
 {
+    static_assert(TX == 16 && WAVES == 8, "a workgroup tile spans two 8-voxel tile columns, one column per wave and half");
     constexpr int LP = 64 * CP;
     constexpr int TS = TX + 1;
     constexpr int NT = 64 * WAVES;
@@ -567,27 +572,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
     for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && c.zocc[z]) zmask |= 1u << j; }
     int t = blockIdx.x;
     const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
+    /* reader masks of the two 8-wide tile columns a workgroup tile spans (workgroup-uniform) */
+    uint64_t nd0, nd1, ndn0 = 0, ndn1 = 0;               /* bit tz: tile (tx, ty, tz) has a reader */
+#define GIE_LOAD_NEED(tt, o0, o1) do { \
+        const int txc_ = (((tt) % ntiles_x) * TX) >> 3, tyc_ = ((tt) / ntiles_x) >> 3; \
+        const uint64_t *p_ = c.zneed + ((size_t)tyc_ * c.tfd[0] + txc_); \
+        o0 = full ? ~0ull : p_[0]; \
+        o1 = full ? ~0ull : ((txc_ + 1 < c.tfd[0]) ? p_[1] : 0ull); } while (0)
     if (t < ntiles) {
+        GIE_LOAD_NEED(t, ndn0, ndn1);
         const int x = (t % ntiles_x) * TX + tx, y = t / ntiles_x;
         const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)y * X + x;   /* one 64-bit product per tile, then adds */
+        if ((ndn0 | ndn1) != 0ull) {
 #pragma unroll
-        for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && x < X) ? *src : 0xffffffffu; src += zstride; }
+            for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && x < X) ? *src : 0xffffffffu; src += zstride; }
+        }
     }
     for (; t < ntiles; t += gridDim.x) {
         const int x0 = (t % ntiles_x) * TX, y = t / ntiles_x;
+        nd0 = ndn0; nd1 = ndn1;
+        const bool work = (nd0 | nd1) != 0ull;            /* workgroup-uniform */
+        if (work) {
 #pragma unroll
-        for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) tile[z * TS + tx] = pre[j]; }
+            for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) tile[z * TS + tx] = pre[j]; }
+        }
         __syncthreads();
         const int tn = t + gridDim.x;
         if (tn < ntiles) {                                /* prefetch: in flight during the column work */
-            const int xn = (tn % ntiles_x) * TX + tx, yn = tn / ntiles_x;
-            const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)yn * X + xn;
+            GIE_LOAD_NEED(tn, ndn0, ndn1);
+            if ((ndn0 | ndn1) != 0ull) {
+                const int xn = (tn % ntiles_x) * TX + tx, yn = tn / ntiles_x;
+                const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)yn * X + xn;
 #pragma unroll
-            for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && xn < X) ? *src : 0xffffffffu; src += zstride; }
+                for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && xn < X) ? *src : 0xffffffffu; src += zstride; }
+            }
         }
-        for (int col = wave; col < TX; col += WAVES) {
+        if (!work) continue;                              /* nobody reads this tile: nothing loaded, nothing stored */
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const int col = wave + 8 * half;
             const int x = x0 + col;
             if (x >= X) break;
+            const uint64_t nc = half ? nd1 : nd0;
+            if (nc == 0ull) continue;                     /* this 8-wide tile column has no reader */
             int K = 0;
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 3
             continue;                                           /* measurement only: no column work at all */
@@ -602,12 +629,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
             if (K == 0) {                                       /* the whole volume is empty */
                 for (int i = lane; i < Z; i += 64) tile[i * TS + col] = GIE_BCOC_NONE;
             } else {
+                /* 64-position bands (8 z tiles each) with a reader */
+                unsigned bandneed = 0;
+#pragma unroll
+                for (int m = 0; m < CP && m < 8; m++) if ((nc >> (8 * m)) & 0xffull) bandneed |= 1u << m;
+                if (full) bandneed = ~0u;                       /* also covers Z > 512 (more than 64 z tiles) */
                 int sj[CP];
                 const bool banded = K <= GIE_BAND_MAXK;         /* wave-uniform: few sites → banded form */
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE >= 1
                 for (int m = 0; m < CP; m++) sj[m] = (lane * CP + m) % K;      /* measurement only: no argmin */
 #else
-                if (banded) gie_row_argmin_banded<CP>(ce, K, Z, lane, sj);
+                if (banded) gie_row_argmin_banded<CP>(ce, K, Z, lane, sj, bandneed);
                 else gie_row_argmin<CP>(ce, K, Z, lane, sj);
 #endif
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 2
@@ -619,7 +651,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
                 uint32_t oc[CP];
 #pragma unroll
                 for (int m = 0; m < CP; m++) {
-                    if (ub + m * us < Z) {
+                    if (ub + m * us < Z && (!banded || ((bandneed >> m) & 1u))) {
                         const int s = (int)((ce[sj[m]].y & 0xffffu) >> 5);
                         const uint32_t v = tile[s * TS + col];
                         oc[m] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
@@ -628,7 +660,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
                 gie_wave_sync();
 #pragma unroll
                 for (int m = 0; m < CP; m++)
-                    if (ub + m * us < Z) tile[(ub + m * us) * TS + col] = oc[m];
+                    if (ub + m * us < Z && (!banded || ((bandneed >> m) & 1u))) tile[(ub + m * us) * TS + col] = oc[m];
             }
             gie_wave_sync();
         }
@@ -638,7 +670,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_edt_z(const gie_ctx c, const int
             if (x < X) {
                 uint32_t *dst = c.bcoc + (size_t)tz * plane + (size_t)y * X + x;
 #pragma unroll
-                for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) *dst = tile[z * TS + tx]; dst += zstride; }
+                for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && (full || ((((tx >> 3) ? nd1 : nd0) >> ((z >> 3) & 63)) & 1ull))) *dst = tile[z * TS + tx]; dst += zstride; }
             }
         }
         __syncthreads();                                  /* tile is overwritten by the next trip */

@@ -1054,6 +1054,22 @@ GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *dist_sq, int32_t
     if (bc == GIE_BCOC_NONE) { coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = -1; }
     else { coc_xyz[3 * id] = (int)(bc & 1023u); coc_xyz[3 * id + 1] = (int)((bc >> 10) & 1023u); coc_xyz[3 * id + 2] = (int)(bc >> 20); }
 }
+/* Who reads the batch EDT (`_aux` / `_coc_idx_aux`)?  Mark reads it at known voxels, wave B at unknown
+ * voxels on the faces of the volume (wave_core.cuh:334), nobody anywhere else: pass Z only has
+ * to produce the tiles that hold a known voxel or touch a face.  One 64-bit z mask per (x,y)
+ * tile column; volumes taller than 64 tiles (Z > 512) run pass Z in full. */
+GIE_DEV void gie_zneed_column(const gie_ctx &c, int col)
+{
+    const int tx = col % c.tfd[0], ty = col / c.tfd[0];
+    const bool side = tx == 0 || ty == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1;
+    uint64_t m = 0;
+    for (int tz = 0; tz < c.tfd[2] && tz < 64; tz++) {
+        const bool need = side || tz == 0 || tz == c.tfd[2] - 1 || c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx];
+        if (need) m |= 1ull << tz;
+    }
+    c.zneed[col] = m;
+}
+
 /* ---- changed-block streaming (streamPipeline / getUpdatedAddr / streamD2H, glb_hash_map.cu:209-247) */
 /* slot list of the flagged blocks in slot order */
 GIE_DEV void gie_stream_list(const gie_ctx &c, const int32_t *rank, int32_t *list, int slot)

@@ -84,7 +84,8 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
 }
 /* plain restatement of the closed form the HIP EDT kernels implement (see
  * tests/test_oracle_edt.py::test_meijster_tie_rule) */
-static void be_edt(be_state *, const gie_ctx &c)
+static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
+static void be_edt(be_state *, const gie_ctx &c, int)
 {
     const int X = c.X, Y = c.Y, Z = c.Z;
     for (int z = 0; z < Z; z++) for (int x = 0; x < X; x++) for (int y = 0; y < Y; y++) {

@@ -160,3 +160,36 @@ def test_full_size_512_cube(oracle_lib):
         assert np.array_equal(rc["dist_sq"][known], rb["dist_sq"][known])
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
+    """The map update only produces the batch EDT where it is read (tiles with a known voxel or on
+    a face of the volume).  Exported without completion, it must equal the oracle on exactly those
+    tiles; the completed export equals it everywhere (checked by every other parity test)."""
+    sc = parity.Scenario("partial_z", (96, 80, 72), sensor="lidar_points", frames=3, lidar_az=360, extent=(4.0, 3.5, 3.0))
+    cfg = sc.config()
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        monkeypatch.setenv("GIE_EDT_EXPORT_PARTIAL", "1")
+        for pos, q, kind, data, kw in sc.frames_iter():
+            for m in (a, b):
+                m.set_pose(pos, q); m.ogm_pointcloud(data); m.fuse(); m.batch_edt()
+            ea, eb = a.read_batch_edt(), b.read_batch_edt()
+            ty = a.read_local(edt=False, dist_sq=False, coc=False)["type"]
+            Z, Y, X = ty.shape
+            kn = np.zeros(((Z + 7) // 8, (Y + 7) // 8, (X + 7) // 8), bool)
+            zz, yy, xx = np.nonzero(ty != 0)
+            kn[zz // 8, yy // 8, xx // 8] = True
+            kn[0] = kn[-1] = True; kn[:, 0] = kn[:, -1] = True; kn[:, :, 0] = kn[:, :, -1] = True
+            need = np.repeat(np.repeat(np.repeat(kn, 8, 0), 8, 1), 8, 2)[:Z, :Y, :X]
+            assert 0.05 < need.mean() < 0.9
+            assert np.array_equal(ea["dist_sq"][need], eb["dist_sq"][need])
+            assert np.array_equal(ea["coc"][need], eb["coc"][need])
+            for m in (a, b):
+                m.merge()
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), key
+    finally:
+        a.close(); b.close()
