@@ -677,6 +677,47 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     }
 }
 
+/* The two faces z = 0 and z = Z-1 of the batch EDT (read by wave B at unknown face voxels) for
+ * every column, without running the whole column: thread = (x, y) column, loop over the planes
+ * that hold obstacles (the only real sites of any column), two running minima.  Ties go to the
+ * smaller z like the envelope (strict '<' while z ascends).  Reads K x X x Y x 4 bytes coalesced. */
+__global__ __launch_bounds__(256) void k_edt_z_faces(const gie_ctx c)
+{
+    __shared__ uint16_t s_z[1024];
+    __shared__ int s_k;
+    const int Z = c.Z, X = c.X, Y = c.Y;
+    if (threadIdx.x < 64) {                               /* plane list, once per workgroup */
+        int k = 0;
+        for (int z0 = 0; z0 < Z; z0 += 64) {
+            const int z = z0 + (int)threadIdx.x;
+            const bool v = z < Z && c.zocc[z];
+            const unsigned long long m = __ballot(v);
+            if (v) s_z[k + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (uint16_t)z;
+            k += __popcll(m);
+        }
+        if (threadIdx.x == 0) s_k = k;
+    }
+    __syncthreads();
+    const int K = s_k;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= X * Y) return;
+    const int x = i % X, y = i / X;
+    const size_t plane = (size_t)X * Y;
+    uint32_t best0 = 0xffffffffu, best1 = 0xffffffffu, w0 = GIE_BCOC_NONE, w1 = GIE_BCOC_NONE;
+    for (int j = 0; j < K; j++) {
+        const int z = s_z[j];
+        const uint32_t v = c.cxy2[(size_t)z * plane + i];
+        const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
+        const uint32_t a = (uint32_t)(dx * dx + dy * dy);
+        const uint32_t k0 = a + (uint32_t)(z * z), k1 = a + (uint32_t)((Z - 1 - z) * (Z - 1 - z));
+        const uint32_t pk = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), z);
+        if (k0 < best0) { best0 = k0; w0 = pk; }
+        if (k1 < best1) { best1 = k1; w1 = pk; }
+    }
+    c.bcoc[i] = w0;
+    c.bcoc[(size_t)(Z - 1) * plane + i] = w1;
+}
+
 /* ------------------------------------------------------------------ persistent BFS waves */
 /* One launch per wave type, one workgroup per CU, all co-resident; BFS levels and the phases
  * inside a level are separated by a grid barrier (monotonic counter, agent-scope release /

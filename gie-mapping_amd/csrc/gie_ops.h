@@ -1064,7 +1064,7 @@ GIE_DEV void gie_zneed_column(const gie_ctx &c, int col)
     const bool side = tx == 0 || ty == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1;
     uint64_t m = 0;
     for (int tz = 0; tz < c.tfd[2] && tz < 64; tz++) {
-        const bool need = side || tz == 0 || tz == c.tfd[2] - 1 || c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx];
+        const bool need = side || c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx];    /* the z = 0 and z = Z-1 faces have their own kernel */
         if (need) m |= 1ull << tz;
     }
     c.zneed[col] = m;
