@@ -247,10 +247,12 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     else hipLaunchKernelGGL(k_edt_y<32>, gy, dim3(GIE_EDTY_COLS, 4), 0, b->stream, c);
     be_prof(b, 6, 1);
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
-    be_prof(b, 8, 0);                                                              /* GIE_K_EDT_Z */
-    gie_launch_edt_dim(b, c, c.Z, true, full);
-    if (!full) hipLaunchKernelGGL(k_edt_z_faces, dim3((c.X * c.Y + 255) / 256), dim3(256), 0, b->stream, c);
-    be_prof(b, 8, 1);
+    be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true, full); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
+    if (!full) {                                                                     /* GIE_K_EDT_ZFACES (with the reader masks) */
+        be_prof(b, 15, 0);
+        hipLaunchKernelGGL(k_edt_z_faces, dim3((c.X * c.Y + 255) / 256), dim3(256), 0, b->stream, c);
+        be_prof(b, 15, 1);
+    }
 }
 /* one workgroup per CU: co-resident by construction (1024 threads, < 72 VGPRs, 16 B of LDS) */
 static void be_wave_a(be_state *b, const gie_ctx &c)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the rocprofv3 evidence behind bench.py's roofline object.
+#   pass 1  --kernel-trace --stats   (per-kernel durations of the same command)
+#   pass 2  --pmc FETCH_SIZE         (own run, kernel-trace only: PMC passes never share a run with other traces)
+#   pass 3  --pmc WRITE_SIZE
+# Summaries land in gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r01}
+ARGS=${2:-"--steps 10 --warmup 3 --no-cpu-baseline --no-secondary"}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/write.err
+cd $ROOT
+T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1)
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (MI355X)"; python tools/rocpd_summary.py stats "$T"; echo; echo "# bench.py line of the same (profiled) run:"; cat $OUT/bench_trace.json; } > $OUT/kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes) -- python bench.py $ARGS"; python tools/rocpd_summary.py pmc "$F" "$W" $OUT/traffic.json; } > $OUT/hbm_traffic.txt
+rm -rf $OUT/trace $OUT/fetch $OUT/write      # the databases are large; the summaries are what travels back
+ls -la $OUT
