@@ -30,6 +30,7 @@ struct be_state {
     std::vector<int> *pending;          /* triples (kernel id, start event idx, stop event idx) */
     int pool_used;
     int open_start[32];
+    int last_end;                       /* event that closed the previous bracket of this stage (-1: none): the next bracket starts there */
     double acc_ms[32]; int acc_n[32];
 };
 #include <vector>
@@ -54,7 +55,7 @@ static int be_init(be_state *b, int device)
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
     for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
-    b->prof_on = 0; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
+    b->prof_on = 0; b->last_end = -1; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
     for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; b->open_start[i] = -1; }
     return 0;
 }
@@ -104,7 +105,14 @@ static int be_sync(be_state *b)
     if (e != hipSuccess) { gie_set_err(std::string("HIP error: ") + hipGetErrorString(e)); return 1; }
     return 0;
 }
-static void be_time(be_state *b, int i) { GIE_HIP_OK(hipEventRecord(b->ev[i], b->stream)); b->ev_set[i] = 1; }
+/* stage boundaries (us_ogm .. us_merge of gie_frame_stats): recorded while profiling is on — every
+ * event is a marker packet the next kernel has to wait for */
+static void be_time(be_state *b, int i)
+{
+    if (!b->prof_on) { b->ev_set[i] = 0; return; }
+    GIE_HIP_OK(hipEventRecord(b->ev[i], b->stream)); b->ev_set[i] = 1;
+    if ((i & 1) == 0) b->last_end = -1;               /* a stage starts: the host may have left the stream idle before it */
+}
 static void be_times(be_state *b, float *ogm, float *fuse, float *edt, float *merge)
 {
     float *out[4] = { ogm, fuse, edt, merge };
@@ -124,7 +132,7 @@ static int be_prof_event(be_state *b)
 }
 static void be_prof_resolve(be_state *b)
 {
-    if (b->pending->empty()) { b->pool_used = 0; return; }
+    if (b->pending->empty()) { b->pool_used = 0; b->last_end = -1; return; }
     GIE_HIP_OK(hipStreamSynchronize(b->stream));
     for (size_t i = 0; i + 2 < b->pending->size(); i += 3) {
         float ms = 0.f;
@@ -132,19 +140,24 @@ static void be_prof_resolve(be_state *b)
             b->acc_ms[(*b->pending)[i]] += ms; b->acc_n[(*b->pending)[i]] += 1;
         }
     }
-    b->pending->clear(); b->pool_used = 0;
+    b->pending->clear(); b->pool_used = 0; b->last_end = -1;
 }
 static void be_prof(be_state *b, int id, int end)
 {
     if (!b->prof_on) return;
-    if (!end) { if (b->pool_used > 4000) be_prof_resolve(b); b->open_start[id] = be_prof_event(b); }
-    else if (b->open_start[id] >= 0) {
+    /* brackets inside a stage follow each other on the stream: the event that closed one opens
+     * the next (half the marker packets; a kernel's time then includes its dispatch gap) */
+    if (!end) {
+        if (b->pool_used > 4000) { be_prof_resolve(b); b->last_end = -1; }
+        b->open_start[id] = b->last_end >= 0 ? b->last_end : be_prof_event(b);
+    } else if (b->open_start[id] >= 0) {
         const int e1 = be_prof_event(b);
         b->pending->push_back(id); b->pending->push_back(b->open_start[id]); b->pending->push_back(e1);
         b->open_start[id] = -1;
+        b->last_end = e1;
     }
 }
-static void be_prof_enable(be_state *b, int on) { be_prof_resolve(b); b->prof_on = on; }
+static void be_prof_enable(be_state *b, int on) { be_prof_resolve(b); b->prof_on = on; b->last_end = -1; }
 static void be_prof_collect(be_state *b, float *ms, int *n, int num)
 {
     be_prof_resolve(b);

@@ -107,7 +107,7 @@ typedef struct gie_frame_stats {
     int32_t front_b, front_c; /* |B| after wave A, |C| after wave B              */
     int32_t visits_a, visits_b, visits_c; /* frontier entries expanded          */
     int32_t levels_a, levels_b, levels_c;
-    float us_ogm, us_fuse, us_edt, us_merge; /* device time of the last step    */
+    float us_ogm, us_fuse, us_edt, us_merge; /* device time of the last step's stages; filled while gie_profile_enable is on, else 0 */
     int64_t total_visits_a, total_visits_b, total_visits_c; /* since gie_create */
 } gie_frame_stats;
 
