@@ -72,12 +72,12 @@ def make_frames(scenes, voxel, nframes, seed, sensor, delta_vox=8, yaw_deg=2.0, 
 
 def cpu_baseline(scenes, voxel, cutoff_dist, sensor):
     """The CPU oracle (a scalar port of the reference's algorithm) on a bounded sample of the
-    same workload: same scene generator / sensor, 256^3 local grid, 3 frames."""
+    same workload: same scene generator / sensor, 256^3 local grid, 24 map updates (≈ 12 s)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_py import OracleMapper
     import gie
     size = (256, 256, 256)
-    frames = make_frames(scenes, voxel, 12, 5, sensor)
+    frames = make_frames(scenes, voxel, 24, 5, sensor)
     rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
     cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False)
     m = OracleMapper(cfg)
