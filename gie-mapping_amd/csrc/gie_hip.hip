@@ -219,7 +219,7 @@ template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, c
 {
     constexpr int LP = 64 * CP;
     const size_t tile = ((size_t)c.Z * (TX + 1) + 3) & ~(size_t)3;
-    const size_t lds = tile * 4 + (size_t)WAVES * LP * 8;
+    const size_t lds = tile * 4 + (size_t)WAVES * LP * 8 + (size_t)LP * 2 + 16;      /* column tile + per-wave sites + plane list */
     static bool attr_done = false;
     if (!attr_done) {
         GIE_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edt_z<CP, TX, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

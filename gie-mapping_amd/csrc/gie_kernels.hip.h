@@ -560,6 +560,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     const int Z = c.Z, X = c.X, Y = c.Y;
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem);                               /* [Z][TS] cx|cy<<16 → bcoc */
     uint2 *s_ce = reinterpret_cast<uint2 *>(tile + (((size_t)Z * TS + 3) & ~(size_t)3));   /* [WAVES][LP] */
+    uint16_t *s_zl = reinterpret_cast<uint16_t *>(s_ce + WAVES * LP);                       /* [LP] planes with obstacles, ascending */
+    int *s_K = reinterpret_cast<int *>(s_zl + LP);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = threadIdx.x & (TX - 1), tz = threadIdx.x / TX;
     const size_t plane = (size_t)X * Y;
@@ -570,6 +572,21 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     unsigned zmask = 0;                                   /* this thread's z rows that lie in a plane with obstacles */
 #pragma unroll
     for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && c.zocc[z]) zmask |= 1u << j; }
+    /* the real sites of EVERY column are the planes with obstacles (a plane that holds one gives
+     * every voxel of the plane a closest obstacle): one list for the whole launch */
+    if (wave == 0) {
+        int k = 0;
+        for (int z0 = 0; z0 < Z; z0 += 64) {
+            const int z = z0 + lane;
+            const bool v = z < Z && c.zocc[z];
+            const unsigned long long m = __ballot(v);
+            if (v) s_zl[k + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)z;
+            k += __popcll(m);
+        }
+        if (lane == 0) *s_K = k;
+    }
+    __syncthreads();
+    const int K = *s_K;
     int t = blockIdx.x;
     const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
     /* reader masks of the two 8-wide tile columns a workgroup tile spans (workgroup-uniform) */
@@ -594,7 +611,7 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
         const bool work = (nd0 | nd1) != 0ull;            /* workgroup-uniform */
         if (work) {
 #pragma unroll
-            for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) tile[z * TS + tx] = pre[j]; }
+            for (int j = 0; j < NLD; j++) { if ((zmask >> j) & 1u) tile[(tz + j * ZSTEP) * TS + tx] = pre[j]; }   /* only site rows are ever read */
         }
         __syncthreads();
         const int tn = t + gridDim.x;
@@ -615,15 +632,14 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             if (x >= X) break;
             const uint64_t nc = half ? nd1 : nd0;
             if (nc == 0ull) continue;                     /* this 8-wide tile column has no reader */
-            int K = 0;
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 3
             continue;                                           /* measurement only: no column work at all */
 #endif
-            for (int i0 = 0; i0 < Z; i0 += 64) {
-                const int i = i0 + lane;
-                const uint32_t v = (i < Z) ? tile[i * TS + col] : 0xffffffffu;
+            for (int j = lane; j < K; j += 64) {                /* site j = plane s_zl[j]: value = in-plane distance² */
+                const int i = s_zl[j];
+                const uint32_t v = tile[i * TS + col];
                 const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
-                K = gie_row_compact_push(ce, K, v != 0xffffffffu, (uint32_t)(dx * dx + dy * dy), i, 0u, lane);
+                ce[j] = make_uint2(((uint32_t)(dx * dx + dy * dy) << 10) | (uint32_t)j, (uint32_t)i << 5);
             }
             gie_wave_sync();
             if (K == 0) {                                       /* the whole volume is empty */
