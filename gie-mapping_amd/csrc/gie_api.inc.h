@@ -14,7 +14,7 @@
 enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, GIE_K_ALLOC, GIE_K_FUSE, GIE_K_EDT_Y, GIE_K_EDT_X,
        GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_EDT_ZFACES, GIE_K_NUM };
 static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
-       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "wave_c", "commit", "edt_z_faces" };
+       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "wave_c", "commit", "edt_prep" };
 
 static thread_local std::string g_gie_err;
 static void gie_set_err(const std::string &s) { g_gie_err = s; }
@@ -100,6 +100,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tknown = c.tflag + 4 * ntile; c.tknown_prev = c.tflag + 5 * ntile;
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
+    c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
+    c.zcount = gie_dalloc<int32_t>(m, 4);
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -365,7 +367,7 @@ extern "C" int gie_batch_edt(gie_mapper *m)
     int rc = gie_need_pose(m, "gie_batch_edt"); if (rc) return rc;
     be_time(&m->be, 4);
     be_prof(&m->be, GIE_K_EDT_ZFACES, 0);
-    be_lin(&m->be, m->c, op_zneed(), m->c.tfd[0] * m->c.tfd[1]);
+    be_edt_prep(&m->be, m->c);          /* plane list + reader masks */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 1);
     const int partial = m->c.tfd[2] <= 64;
     be_edt(&m->be, m->c, partial ? 0 : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */

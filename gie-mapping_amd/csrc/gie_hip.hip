@@ -251,6 +251,11 @@ static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass,
 /* pass Z again over the whole volume (the passes before it are complete either way) */
 static void be_edt_z(be_state *b, const gie_ctx &c, int full) { gie_launch_edt_dim(b, c, c.Z, true, full); }
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
+static void be_edt_prep(be_state *b, const gie_ctx &c)
+{
+    const int ncol = c.tfd[0] * c.tfd[1];
+    hipLaunchKernelGGL(k_edt_prep, dim3((ncol + 3) / 4), dim3(256), 0, b->stream, c, ncol);
+}
 static void be_edt(be_state *b, const gie_ctx &c, int full)
 {
     dim3 gy((c.X + GIE_EDTY_COLS - 1) / GIE_EDTY_COLS, c.Z);
@@ -261,11 +266,7 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 6, 1);
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0); gie_launch_edt_dim(b, c, c.Z, true, full); be_prof(b, 8, 1);    /* GIE_K_EDT_Z */
-    if (!full) {                                                                     /* GIE_K_EDT_ZFACES (with the reader masks) */
-        be_prof(b, 15, 0);
-        hipLaunchKernelGGL(k_edt_z_faces, dim3((c.X * c.Y + 255) / 256), dim3(256), 0, b->stream, c);
-        be_prof(b, 15, 1);
-    }
+
 }
 /* one workgroup per CU: co-resident by construction (1024 threads, < 72 VGPRs, 16 B of LDS) */
 static void be_wave_a(be_state *b, const gie_ctx &c)

@@ -561,7 +561,6 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem);                               /* [Z][TS] cx|cy<<16 → bcoc */
     uint2 *s_ce = reinterpret_cast<uint2 *>(tile + (((size_t)Z * TS + 3) & ~(size_t)3));   /* [WAVES][LP] */
     uint16_t *s_zl = reinterpret_cast<uint16_t *>(s_ce + WAVES * LP);                       /* [LP] planes with obstacles, ascending */
-    int *s_K = reinterpret_cast<int *>(s_zl + LP);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = threadIdx.x & (TX - 1), tz = threadIdx.x / TX;
     const size_t plane = (size_t)X * Y;
@@ -573,20 +572,11 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
 #pragma unroll
     for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && c.zocc[z]) zmask |= 1u << j; }
     /* the real sites of EVERY column are the planes with obstacles (a plane that holds one gives
-     * every voxel of the plane a closest obstacle): one list for the whole launch */
-    if (wave == 0) {
-        int k = 0;
-        for (int z0 = 0; z0 < Z; z0 += 64) {
-            const int z = z0 + lane;
-            const bool v = z < Z && c.zocc[z];
-            const unsigned long long m = __ballot(v);
-            if (v) s_zl[k + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)z;
-            k += __popcll(m);
-        }
-        if (lane == 0) *s_K = k;
-    }
+     * every voxel of the plane a closest obstacle): one list for the whole launch (k_edt_prep) */
+    const int K = *c.zcount;
+    for (int j = threadIdx.x; j < K; j += NT) s_zl[j] = c.zlist[j];
     __syncthreads();
-    const int K = *s_K;
+
     int t = blockIdx.x;
     const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
     /* reader masks of the two 8-wide tile columns a workgroup tile spans (workgroup-uniform) */
@@ -693,45 +683,28 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     }
 }
 
-/* The two faces z = 0 and z = Z-1 of the batch EDT (read by wave B at unknown face voxels) for
- * every column, without running the whole column: thread = (x, y) column, loop over the planes
- * that hold obstacles (the only real sites of any column), two running minima.  Ties go to the
- * smaller z like the envelope (strict '<' while z ascends).  Reads K x X x Y x 4 bytes coalesced. */
-__global__ __launch_bounds__(256) void k_edt_z_faces(const gie_ctx c)
+/* Before the EDT passes: the list of planes that hold obstacles (workgroup 0, wave 0) and the
+ * reader masks of pass Z (one thread per (x,y) tile column). */
+__global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int ncol)
 {
-    __shared__ uint16_t s_z[1024];
-    __shared__ int s_k;
-    const int Z = c.Z, X = c.X, Y = c.Y;
-    if (threadIdx.x < 64) {                               /* plane list, once per workgroup */
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
         int k = 0;
-        for (int z0 = 0; z0 < Z; z0 += 64) {
+        for (int z0 = 0; z0 < c.Z; z0 += 64) {
             const int z = z0 + (int)threadIdx.x;
-            const bool v = z < Z && c.zocc[z];
+            const bool v = z < c.Z && c.zocc[z];
             const unsigned long long m = __ballot(v);
-            if (v) s_z[k + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (uint16_t)z;
+            if (v) c.zlist[k + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (uint16_t)z;
             k += __popcll(m);
         }
-        if (threadIdx.x == 0) s_k = k;
+        if (threadIdx.x == 0) *c.zcount = k;
     }
-    __syncthreads();
-    const int K = s_k;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= X * Y) return;
-    const int x = i % X, y = i / X;
-    const size_t plane = (size_t)X * Y;
-    uint32_t best0 = 0xffffffffu, best1 = 0xffffffffu, w0 = GIE_BCOC_NONE, w1 = GIE_BCOC_NONE;
-    for (int j = 0; j < K; j++) {
-        const int z = s_z[j];
-        const uint32_t v = c.cxy2[(size_t)z * plane + i];
-        const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
-        const uint32_t a = (uint32_t)(dx * dx + dy * dy);
-        const uint32_t k0 = a + (uint32_t)(z * z), k1 = a + (uint32_t)((Z - 1 - z) * (Z - 1 - z));
-        const uint32_t pk = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), z);
-        if (k0 < best0) { best0 = k0; w0 = pk; }
-        if (k1 < best1) { best1 = k1; w1 = pk; }
-    }
-    c.bcoc[i] = w0;
-    c.bcoc[(size_t)(Z - 1) * plane + i] = w1;
+    /* one wave per (x,y) tile column, lane = z tile: the ballot IS the mask */
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6), tz = threadIdx.x & 63;
+    if (col >= ncol) return;
+    const int tx = col % c.tfd[0], ty = col / c.tfd[0];
+    const bool k = tz < c.tfd[2] && c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx];
+    const unsigned long long m = __ballot(k);
+    if (tz == 0) c.zneed[col] = m;
 }
 
 /* ------------------------------------------------------------------ persistent BFS waves */

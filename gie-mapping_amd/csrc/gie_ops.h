@@ -726,6 +726,27 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
     }
 }
 
+/* batch EDT distance of ONE voxel straight from the pass-X planes: min over the planes with
+ * obstacles of (in-plane distance)² + (z - plane)².  A few dozen reads — for rare lookups only. */
+GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
+{
+#if defined(GIE_HOST_EMU)
+    return gie_bcoc_dist(c.bcoc[gie_lid(c, x, y, z)], x, y, z, c.max_width * c.max_width);   /* the emulation fills the whole plane */
+#else
+    const int K = *c.zcount;
+    const size_t plane = (size_t)c.X * c.Y, o = (size_t)y * c.X + x;
+    int best = c.max_width * c.max_width;
+    for (int j = 0; j < K; j++) {
+        const int zj = c.zlist[j];
+        const uint32_t v = c.cxy2[(size_t)zj * plane + o];
+        const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16), dz = z - zj;
+        const int d = dx * dx + dy * dy + dz * dz;
+        best = d < best ? d : best;
+    }
+    return best;
+#endif
+}
+
 /* ================================================================== wave B (lower_outside) */
 /* wave_core.cuh:229-350, three phases per level. rec0[e] = snapshot parent (GIE_NOPROP =
  * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask. */
@@ -784,7 +805,7 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
              * distance (nothing writes `pair` between Mark and wave B); for an unknown voxel it is
              * still the batch distance */
             const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? gie_pair_dist(gie_ld(&c.pair[nid]))
-                                                                  : gie_bcoc_dist(c.bcoc[nid], nb[0], nb[1], nb[2], c.max_width * c.max_width);
+                                                                  : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
             if (ref > cand) {
                 gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand, par));
                 mask |= 1 << k;
@@ -1054,19 +1075,17 @@ GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *dist_sq, int32_t
     if (bc == GIE_BCOC_NONE) { coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = -1; }
     else { coc_xyz[3 * id] = (int)(bc & 1023u); coc_xyz[3 * id + 1] = (int)((bc >> 10) & 1023u); coc_xyz[3 * id + 2] = (int)(bc >> 20); }
 }
-/* Who reads the batch EDT (`_aux` / `_coc_idx_aux`)?  Mark reads it at known voxels, wave B at unknown
- * voxels on the faces of the volume (wave_core.cuh:334), nobody anywhere else: pass Z only has
- * to produce the tiles that hold a known voxel or touch a face.  One 64-bit z mask per (x,y)
- * tile column; volumes taller than 64 tiles (Z > 512) run pass Z in full. */
+/* Who reads the batch EDT (`_aux` / `_coc_idx_aux`)?  Mark reads it at known voxels; wave B needs the
+ * batch DISTANCE of the occasional unknown voxel on a face of the volume (wave_core.cuh:334) and
+ * computes it on demand (gie_batch_dist_direct); nobody else: pass Z only has to produce the
+ * tiles that hold a known voxel.  One 64-bit z mask per (x,y) tile column; volumes taller than
+ * 64 tiles (Z > 512) run pass Z in full. */
 GIE_DEV void gie_zneed_column(const gie_ctx &c, int col)
 {
     const int tx = col % c.tfd[0], ty = col / c.tfd[0];
-    const bool side = tx == 0 || ty == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1;
     uint64_t m = 0;
-    for (int tz = 0; tz < c.tfd[2] && tz < 64; tz++) {
-        const bool need = side || c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx];    /* the z = 0 and z = Z-1 faces have their own kernel */
-        if (need) m |= 1ull << tz;
-    }
+    for (int tz = 0; tz < c.tfd[2] && tz < 64; tz++)
+        if (c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx]) m |= 1ull << tz;
     c.zneed[col] = m;
 }
 

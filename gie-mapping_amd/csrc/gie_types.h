@@ -102,6 +102,8 @@ typedef struct gie_ctx {
     uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
     uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */
     uint64_t *zneed;        /* per (x,y) tile column: bit tz set = somebody reads the batch EDT of tile (tx,ty,tz) */
+    uint16_t *zlist;        /* the planes with obstacles, ascending; zlist[Z] .. = count as int32 behind it (zcount) */
+    int32_t *zcount;
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
     uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */

@@ -84,6 +84,7 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
 }
 /* plain restatement of the closed form the HIP EDT kernels implement (see
  * tests/test_oracle_edt.py::test_meijster_tie_rule) */
+static void be_edt_prep(be_state *, const gie_ctx &) {}            /* plane list / reader masks: device-only shortcuts */
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
 static void be_edt(be_state *, const gie_ctx &c, int)
 {

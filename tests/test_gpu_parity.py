@@ -164,9 +164,10 @@ def test_full_size_512_cube(oracle_lib):
 
 @pytest.mark.gpu
 def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
-    """The map update only produces the batch EDT where it is read (tiles with a known voxel or on
-    a side face of the volume, plus the planes z = 0 and z = Z-1).  Exported without completion, it must equal the oracle on exactly those
-    tiles; the completed export equals it everywhere (checked by every other parity test)."""
+    """The map update only produces the batch EDT where Mark reads it (tiles with a known voxel; wave B
+    computes the distance of an unknown face voxel on demand).  Exported without completion, it
+    must equal the oracle on exactly those tiles; the completed export equals it everywhere
+    (checked by every other parity test)."""
     sc = parity.Scenario("partial_z", (96, 80, 72), sensor="lidar_points", frames=3, lidar_az=360, extent=(4.0, 3.5, 3.0))
     cfg = sc.config()
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
@@ -181,10 +182,8 @@ def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
             kn = np.zeros(((Z + 7) // 8, (Y + 7) // 8, (X + 7) // 8), bool)
             zz, yy, xx = np.nonzero(ty != 0)
             kn[zz // 8, yy // 8, xx // 8] = True
-            kn[:, 0] = kn[:, -1] = True; kn[:, :, 0] = kn[:, :, -1] = True      # side faces: whole tile columns
             need = np.repeat(np.repeat(np.repeat(kn, 8, 0), 8, 1), 8, 2)[:Z, :Y, :X]
-            need[0] = need[-1] = True                                             # bottom / top face: the two planes
-            assert 0.05 < need.mean() < 0.9
+            assert 0.01 < need.mean() < 0.9
             assert np.array_equal(ea["dist_sq"][need], eb["dist_sq"][need])
             assert np.array_equal(ea["coc"][need], eb["coc"][need])
             for m in (a, b):
