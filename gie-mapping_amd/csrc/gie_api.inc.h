@@ -27,6 +27,8 @@ struct gie_mapper {
     int ncell;
     int has_pose, has_ogm;
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
+    int list_mode;                        /* this map update visits tile lists instead of sweeping the volume */
+    int32_t *pub_h;                       /* pinned words written by the device: [0] = known tiles of a recent map update */
     float msg_origin[3];
     float *d_sensor; size_t sensor_cap;   /* device copy of the last sensor frame */
     float *d_pts_g; size_t pts_cap;       /* ray casting: points in the global frame */
@@ -63,7 +65,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->edt_partial = 0;
+    m->has_pose = m->has_ogm = 0; m->edt_partial = 0; m->list_mode = 0; m->pub_h = nullptr;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -102,6 +104,10 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
     c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
     c.zcount = gie_dalloc<int32_t>(m, 4);
+    c.tl_known = gie_dalloc<int32_t>(m, ntile);
+    c.tl_front = gie_dalloc<int32_t>(m, ntile);
+    m->pub_h = be_pub_alloc(&m->be, &c.pub);
+    if (!m->pub_h) { gie_set_err("gie_create: pinned allocation failed"); gie_destroy(m); return nullptr; }
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -168,6 +174,7 @@ extern "C" void gie_destroy(gie_mapper *m)
     if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
     if (m->d_srank) { be_free(&m->be, m->d_srank); be_free(&m->be, m->d_slist); }
     for (int i = 0; i < 2; i++) { if (m->d_stage[i]) be_free(&m->be, m->d_stage[i]); if (m->h_stage[i]) be_host_free(&m->be, m->h_stage[i]); }
+    be_pub_free(&m->be, m->pub_h);
     be_fini(&m->be);
     delete m;
 }
@@ -369,8 +376,16 @@ extern "C" int gie_batch_edt(gie_mapper *m)
     be_prof(&m->be, GIE_K_EDT_ZFACES, 0);
     be_edt_prep(&m->be, m->c);          /* plane list + reader masks */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 1);
+    /* Sparse or dense?  The device publishes how many tiles hold a known voxel; the value the host
+     * sees is a map update or two old, which is all a heuristic needs.  Few known tiles: Mark,
+     * obtainFrontiers, commit and pass Z walk tile lists; many: they sweep the volume (wide
+     * coalesced rows).  Results are identical (GIE_TILE_LIST=0/1 forces a mode for the tests). */
+    const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
+    static const char *force = getenv("GIE_TILE_LIST");
+    m->list_mode = force ? atoi(force) != 0 : (long long)m->pub_h[0] * 8 <= (long long)ntile;
+    if (getenv("GIE_DEBUG_MODE")) fprintf(stderr, "gie: frame %d known tiles (published) %d of %d -> %s\n", m->c.map_ct, m->pub_h[0], ntile, m->list_mode ? "lists" : "sweeps");
     const int partial = m->c.tfd[2] <= 64;
-    be_edt(&m->be, m->c, partial ? 0 : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
+    be_edt(&m->be, m->c, partial ? (m->list_mode ? 2 : 0) : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
     m->edt_partial = partial;
     be_time(&m->be, 5);
     return GIE_OK;
@@ -381,16 +396,23 @@ extern "C" int gie_merge(gie_mapper *m)
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
     const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-    be_prof(&m->be, GIE_K_MARK, 0); be_vox(&m->be, m->c, op_mark()); be_prof(&m->be, GIE_K_MARK, 1);
+    be_prof(&m->be, GIE_K_MARK, 0);
+    if (m->list_mode) be_vox_list(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false); else be_vox(&m->be, m->c, op_mark());
+    be_prof(&m->be, GIE_K_MARK, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_lin(&m->be, m->c, op_tile_summary(), ntile);
-    be_vox(&m->be, m->c, op_frontier());   /* staged variants of this op measured slower */ be_prof(&m->be, GIE_K_FRONTIER, 1);
+    /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
+     * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
+    be_vox_list(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, false);
+    be_prof(&m->be, GIE_K_FRONTIER, 1);
     if (!m->c.fast_mode) {
         be_prof(&m->be, GIE_K_WAVE_A, 0); be_wave_a(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_A, 1);
         be_prof(&m->be, GIE_K_WAVE_B, 0); be_wave_b(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_B, 1);
     }
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
-    be_prof(&m->be, GIE_K_COMMIT, 0); be_vox_staged(&m->be, m->c, op_commit()); be_prof(&m->be, GIE_K_COMMIT, 1);
+    be_prof(&m->be, GIE_K_COMMIT, 0);
+    if (m->list_mode) be_vox_list(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, true); else be_vox_staged(&m->be, m->c, op_commit());
+    be_prof(&m->be, GIE_K_COMMIT, 1);
     be_time(&m->be, 7);
     return GIE_OK;
 }
@@ -659,7 +681,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
     be_wave_c(&m->be, c, 0, 1);
-    be_vox_staged(&m->be, c, op_commit());
+    if (m->list_mode) be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true); else be_vox_staged(&m->be, c, op_commit());
     rc = gie_sync(m);
     if (seeded) *seeded = m->h_cnt[GIE_CNT_FRONT_C];
     return rc;

@@ -122,6 +122,19 @@ struct op_tile_summary { GIE_DEVM void operator()(const gie_ctx &c, int t) const
             }
         }
         c.tsum[t] = v;
+        /* the tiles with something to look at, as a list (order is irrelevant) */
+#if defined(GIE_HOST_EMU)
+        if (v) c.tl_front[c.cnt[GIE_CNT_TL_FRONT]++] = t;
+#else
+        const unsigned long long bm = __ballot(v != 0);
+        if (bm) {
+            const int lane = __lane_id(), leader = __ffsll((long long)bm) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&c.cnt[GIE_CNT_TL_FRONT], __popcll(bm));
+            base = __shfl(base, leader);
+            if (v) c.tl_front[base + __popcll(bm & ((1ull << lane) - 1ull))] = t;
+        }
+#endif
     } };
 struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
 struct op_halo_need { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_need_voxel(c, face, i, in); } };

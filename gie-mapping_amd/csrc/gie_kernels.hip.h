@@ -270,14 +270,18 @@ __global__ void k_pool_advance(const gie_ctx c, const int32_t *flag, const int32
  * holds the whole mask in registers and writes the answers of its own quarter — 4x the waves
  * in flight of a thread-per-column scan, same HBM traffic (1 B read + 2 B written per voxel). */
 #define GIE_EDTY_COLS 64
-template <int YW>
-__global__ __launch_bounds__(GIE_EDTY_COLS * 4) void k_edt_y(const gie_ctx c)
+template <int YW, int TPC>
+__global__ __launch_bounds__(GIE_EDTY_COLS * TPC) void k_edt_y(const gie_ctx c)
 {
-    constexpr int QW = YW / 4;                           /* mask words per quarter */
+    constexpr int QW = YW / TPC;                         /* mask words per thread (TPC threads share a column) */
     __shared__ uint32_t s_bits[YW][GIE_EDTY_COLS];
     const int col = threadIdx.x, q = threadIdx.y;
     const int x = blockIdx.x * GIE_EDTY_COLS + col;
     const int z = blockIdx.y;
+    /* the list of known tiles is complete (previous launch): publish its length in pinned host
+     * memory for the host's sparse / dense choice in a LATER map update */
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0)
+        __hip_atomic_store(c.pub, c.cnt[GIE_CNT_TL_KNOWN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!c.zocc[z]) return;                              /* plane without obstacle: passes X/Z never read its cy1 */
     const int X = c.X, Y = c.Y;
     const bool in = x < X;
@@ -702,10 +706,94 @@ __global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int nco
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6), tz = threadIdx.x & 63;
     if (col >= ncol) return;
     const int tx = col % c.tfd[0], ty = col / c.tfd[0];
-    const bool k = tz < c.tfd[2] && c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx];
+    const int t = (tz * c.tfd[1] + ty) * c.tfd[0] + tx;
+    const bool k = tz < c.tfd[2] && c.tknown[t];
     const unsigned long long m = __ballot(k);
     if (tz == 0) c.zneed[col] = m;
+    /* the same tiles as a list (mark / commit / pass Z visit only these when they are few) */
+    int base = 0;
+    if (tz == 0 && m) base = atomicAdd(&c.cnt[GIE_CNT_TL_KNOWN], __popcll(m));
+    base = __shfl(base, 0);
+    if (k) c.tl_known[base + __popcll(m & ((1ull << tz) - 1ull))] = t;
 }
+
+/* ------------------------------------------------------------------ sweeps over a tile list */
+/* The same per-voxel operations as k_voxz / k_voxz_staged, but only over the tiles on a list:
+ * one wave per 8x8x8 tile (lane = (x,y) column of the tile, 8 voxels along z per lane), a fixed
+ * grid strides through the list whose length lives in device memory.  For sparsely observed
+ * volumes this replaces 65 536 workgroups that each find out they have nothing to do. */
+template <class F, bool STAGED>
+__global__ __launch_bounds__(256) void k_voxt(const gie_ctx c, const F f, const int32_t *list, const int count_idx)
+{
+    const int n = c.cnt[count_idx];
+    const int lane = threadIdx.x & 63;
+    const int waves = gridDim.x * 4;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+        const int t = list[e];
+        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+        const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3), z0 = tz * 8;
+        if (x >= c.X || y >= c.Y || f.tile_skip(c, x, y, z0)) continue;
+        bool sk[8];
+        int id[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int z = z0 + k;
+            id[k] = (z < c.Z) ? gie_lid(c, x, y, z) : 0;
+            sk[k] = z >= c.Z || f.skip(c, id[k], x, y, z);
+        }
+        if (STAGED) {
+            typename F::st s[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (!sk[k]) f.finish(c, id[k], x, y, z0 + k, s[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (!sk[k]) f(c, x, y, z0 + k);
+        }
+    }
+}
+
+/* pass Z for the tiles on tl_known, straight from the pass-X planes: lane = (x,y) column of the
+ * tile, loop over the planes with obstacles, eight running minima (the tile's z range).  Ties go
+ * to the smaller z like the envelope (strict '<' while z ascends).  Cheaper than the column
+ * kernel while the known tiles are few: K reads per column instead of a whole column's work. */
+__global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
+{
+    const int n = c.cnt[GIE_CNT_TL_KNOWN];
+    const int K = *c.zcount;
+    const int lane = threadIdx.x & 63;
+    const int waves = gridDim.x * 4;
+    const size_t plane = (size_t)c.X * c.Y;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+        const int t = c.tl_known[e];
+        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+        const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3), z0 = tz * 8;
+        if (x >= c.X || y >= c.Y) continue;
+        const size_t o = (size_t)y * c.X + x;
+        uint32_t best[8], win[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { best[k] = 0xffffffffu; win[k] = GIE_BCOC_NONE; }
+        for (int j = 0; j < K; j++) {
+            const int zj = c.zlist[j];
+            const uint32_t v = c.cxy2[(size_t)zj * plane + o];
+            const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
+            const uint32_t a = (uint32_t)(dx * dx + dy * dy);
+            const uint32_t pk = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), zj);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int dz = z0 + k - zj;
+                const uint32_t key = a + (uint32_t)(dz * dz);
+                if (key < best[k]) { best[k] = key; win[k] = pk; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (z0 + k < c.Z) c.bcoc[(size_t)(z0 + k) * plane + o] = win[k];
+    }
+}
+
 
 /* ------------------------------------------------------------------ persistent BFS waves */
 /* One launch per wave type, one workgroup per CU, all co-resident; BFS levels and the phases

@@ -102,8 +102,11 @@ typedef struct gie_ctx {
     uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
     uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */
     uint64_t *zneed;        /* per (x,y) tile column: bit tz set = somebody reads the batch EDT of tile (tx,ty,tz) */
-    uint16_t *zlist;        /* the planes with obstacles, ascending; zlist[Z] .. = count as int32 behind it (zcount) */
-    int32_t *zcount;
+    uint16_t *zlist;        /* the planes with obstacles, ascending */
+    int32_t *zcount;        /* how many */
+    int32_t *tl_known;      /* tiles that hold a known voxel (built by k_edt_prep); count in cnt[GIE_CNT_TL_KNOWN] */
+    int32_t *tl_front;      /* tiles obtainFrontiers has to look at (tsum); count in cnt[GIE_CNT_TL_FRONT] */
+    int32_t *pub;           /* pinned host words the device publishes for the host's next-frame heuristics: [0] = known tiles */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
     uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */
@@ -159,8 +162,10 @@ enum {
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
     GIE_CNT_BAR_B = 34, GIE_CNT_BAR_C = 35,     /* grid-barrier words of waves B and C */
     GIE_CNT_NEWLIST = 36,                       /* entries in the list of blocks to initialise (blk_new) */
-    GIE_CNT_AUX_END = 37,                       /* [BAR_B, AUX_END) is zeroed every frame too */
-    GIE_CNT_NUM = 40
+    GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
+    GIE_CNT_TL_DONE = 39,                       /* tile columns that have appended to tl_known (the last one publishes the count) */
+    GIE_CNT_AUX_END = 40,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096
 #define GIE_ERRF_POOL 1

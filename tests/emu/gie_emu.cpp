@@ -54,6 +54,8 @@ static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
     }
 }
 template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }
+/* the list form visits a subset of the tiles the sweep would not skip anyway */
+template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *, int, bool) { be_vox(b, c, f); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
@@ -84,7 +86,9 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
 }
 /* plain restatement of the closed form the HIP EDT kernels implement (see
  * tests/test_oracle_edt.py::test_meijster_tie_rule) */
-static void be_edt_prep(be_state *, const gie_ctx &) {}            /* plane list / reader masks: device-only shortcuts */
+static void be_edt_prep(be_state *, const gie_ctx &) {}            /* plane list / reader masks / tile lists: device-only shortcuts */
+static int32_t *be_pub_alloc(be_state *, int32_t **dev) { int32_t *h = (int32_t *)calloc(16, 4); *dev = h; return h; }
+static void be_pub_free(be_state *, int32_t *h) { free(h); }
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
 static void be_edt(be_state *, const gie_ctx &c, int)
 {

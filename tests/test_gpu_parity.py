@@ -193,3 +193,26 @@ def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
                 assert np.array_equal(ra[key], rb[key]), key
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_tile_list_and_sweep_modes_agree_with_the_oracle(oracle_lib, monkeypatch, mode):
+    """Mark, obtainFrontiers, commit and pass Z either sweep the volume or walk the lists of tiles
+    that hold something (chosen per map update from the number of known tiles).  Both forms must
+    be bit-exact; GIE_TILE_LIST forces one.  The library reads the variable once per process, so
+    each mode runs in its own interpreter."""
+    import subprocess, sys, os
+    code = (
+        "import sys; sys.path[:0] = [%r, %r, %r]\n"
+        "import gie, parity\n"
+        "from oracle_py import OracleMapper\n"
+        "for sensor, fast in (('mixed', False), ('lidar_points', False), ('depth', True)):\n"
+        "    sc = parity.Scenario('modes_' + sensor, (72, 64, 40), sensor=sensor, frames=5, fast_mode=fast, lidar_az=360)\n"
+        "    parity.run_and_compare(sc, OracleMapper, gie.Mapper)\n"
+        "print('ok')\n"
+    ) % (os.path.join(parity.__file__.rsplit('/', 2)[0]), os.path.join(parity.__file__.rsplit('/', 2)[0], 'gie-mapping_amd'),
+         os.path.dirname(parity.__file__))
+    env = dict(os.environ, GIE_TILE_LIST=mode)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
