@@ -521,6 +521,18 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
     if (K == 0) {                                               /* slice without obstacle */
 #pragma unroll
         for (int m = 0; m < CP; m++) o[m] = 0xffffffffu;
+    } else if (K <= GIE_BAND_MAXK) {
+        /* few sites (the usual case: a handful of obstacle columns per row): banded form, results
+         * for positions lane, 64 + lane, ... — stored as 4-byte coalesced rows */
+        gie_wave_sync();
+        int sj[CP];
+        gie_row_argmin_banded<CP>(ce, K, X, lane, sj);
+#pragma unroll
+        for (int m = 0; m < CP; m++) {
+            const uint32_t e = ce[sj[m]].y;
+            if (64 * m + lane < X) out[64 * m + lane] = ((e & 0xffffu) >> 5) | (e & 0xffff0000u);
+        }
+        return;
     } else {
         gie_wave_sync();
         int sj[CP];
