@@ -111,33 +111,57 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
  * adjacent in the cloud per workgroup, so that the wave aggregation of the _ray_count atomics
  * still sees rays crossing the same near-sensor cells), wave = segment.  A ray walk is a chain of
  * dependent memory round trips and one thread per ray leaves the GPU almost empty (a 16 x 1800
- * cloud is 450 waves); the DDA arithmetic is cheap, so every thread replays it (registers only)
- * up to its segment and only then touches memory.  Phase 1 finds where the ray stops (first
- * OCCUPIED cell or the walk's end) as a minimum over the segments in LDS, phase 2 applies the
- * decrements of the cells before that point — the same set of cells as the sequential walk. */
+ * cloud is 450 waves).  The DDA state at a segment's start is handed from wave to wave through
+ * LDS: wave s waits for wave s-1, advances its own steps in registers (no memory), publishes the
+ * state for wave s+1 and only then starts on memory — the arithmetic chain is walked once per
+ * ray, the memory chains of the sixteen segments run side by side.  Phase 1 finds where the ray
+ * stops (first OCCUPIED cell or the walk's end) as a minimum over the segments in LDS, phase 2
+ * applies the decrements of the cells before that point — the same set of cells as the
+ * sequential walk. */
 #define GIE_RAY_SEGS 16
 __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int seg_steps)
 {
     __shared__ int s_stop[64];
+    __shared__ int s_cur[GIE_RAY_SEGS][3][64];
+    __shared__ float s_tmax[GIE_RAY_SEGS][3][64];
+    __shared__ int s_walk[GIE_RAY_SEGS][64];
+    __shared__ int s_ready[GIE_RAY_SEGS];
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     const bool ray = i < n;
     if (seg == 0) s_stop[lane] = 0x7fffffff;
+    if (threadIdx.x < GIE_RAY_SEGS) s_ready[threadIdx.x] = 0;
     gie_dda d;
     int s0[3] = { 0, 0, 0 };
     int last_tile = -1;
-    bool walk = ray && gie_dda_init(c, g, i, d, s0);
+    bool walk = ray && gie_dda_init(c, g, i, d, s0);      /* constants of the ray (direction, deltas, end cell) in every wave */
+    __syncthreads();
     if (seg == 0) {   /* clearRayLoc on the sensor's own cell */
         const int id0 = (ray && gie_in_loc(c, s0[0], s0[1], s0[2])) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
         if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
         gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
+    } else {
+        /* state at the end of segment seg-1 = at the start of mine */
+        volatile int *rdy = &s_ready[seg - 1];
+        while (*rdy == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int k = 0; k < 3; k++) { d.cur[k] = s_cur[seg - 1][k][lane]; d.tMax[k] = s_tmax[seg - 1][k][lane]; }
+        walk = s_walk[seg - 1][lane] != 0;                /* a walk that ended earlier leaves nothing to do */
     }
-    /* replay up to the segment's first step; a walk that ended earlier leaves nothing to do */
     const int first = seg * seg_steps;
-    for (int k = 0; k < first && walk; k++) if (gie_dda_step(d)) walk = false;
     const gie_dda at_start = d;
-    __syncthreads();
-    /* phase 1: types of the segment's cells → where does the ray stop? (exclusive step index) */
+    const bool walk_start = walk;
+    if (seg + 1 < GIE_RAY_SEGS) {                         /* my steps in registers only, for the next wave */
+        for (int k = 0; k < seg_steps && walk; k++) if (gie_dda_step(d)) walk = false;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { s_cur[seg][k][lane] = d.cur[k]; s_tmax[seg][k][lane] = d.tMax[k]; }
+        s_walk[seg][lane] = walk ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) { volatile int *w = &s_ready[seg]; *w = 1; }
+    }
+    d = at_start; walk = walk_start;
+    /* phase 1 (starts as soon as this wave has its state; no workgroup barrier before it): types of the segment's cells → where does the ray stop? (exclusive step index) */
     if (walk) {
         int stop = 0x7fffffff;
         for (int k0 = 0; k0 < seg_steps && stop == 0x7fffffff; k0 += GIE_RAY_BATCH) {
@@ -150,7 +174,11 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
             }
             int8_t ty[GIE_RAY_BATCH];
 #pragma unroll
+#if defined(GIE_RAY_ABLATE) && GIE_RAY_ABLATE == 2
+            for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = (int8_t)GIE_VOX_UNKNOWN;      /* measurement only: no type reads */
+#else
             for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = ids[j] >= 0 ? c.inst_type[ids[j]] : (int8_t)GIE_VOX_UNKNOWN;
+#endif
 #pragma unroll
             for (int j = 0; j < GIE_RAY_BATCH; j++) {
                 if (stop != 0x7fffffff || k0 + j >= seg_steps) continue;
@@ -173,7 +201,9 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
             if (gie_in_loc(c, lx, ly, lz)) { id = gie_lid(c, lx, ly, lz); gie_ray_touch(c, lx, ly, lz, &last_tile); }
         }
         if (__ballot(id >= 0) == 0ull) { if (__ballot(walk && first + k + 1 < stop) == 0ull) break; continue; }
+#if !defined(GIE_RAY_ABLATE) || GIE_RAY_ABLATE != 1
         gie_wave_add(c, id, -1);
+#endif
     }
 }
 
