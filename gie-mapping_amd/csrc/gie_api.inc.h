@@ -97,9 +97,9 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.wl = gie_dalloc<uint32_t>(m, N);
     for (int i = 0; i < 3; i++) c.tfd[i] = (cfg->local_size[i] + 7) / 8;
     const size_t ntile = (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2];
-    c.tflag = gie_dalloc<uint8_t>(m, 6 * ntile);     /* tflag | tunk | tsum | tray | tknown (this frame / previous frame) */
-    c.tunk = c.tflag + ntile; c.tsum = c.tflag + 2 * ntile; c.tray = c.tflag + 3 * ntile;
-    c.tknown = c.tflag + 4 * ntile; c.tknown_prev = c.tflag + 5 * ntile;
+    c.tflag = gie_dalloc<uint8_t>(m, 7 * ntile);     /* tflag | tunk | tsum | tray | tact | tknown (this frame / previous frame) */
+    c.tunk = c.tflag + ntile; c.tsum = c.tflag + 2 * ntile; c.tray = c.tflag + 3 * ntile; c.tact = c.tflag + 4 * ntile;
+    c.tknown = c.tflag + 5 * ntile; c.tknown_prev = c.tflag + 6 * ntile;
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
     c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
@@ -353,7 +353,7 @@ extern "C" int gie_fuse(gie_mapper *m)
         uint8_t *t = c.tknown; c.tknown = c.tknown_prev; c.tknown_prev = t;
         gie_clear_list l; l.n = 0;
         auto add = [&l](void *p, size_t bytes) { l.p[l.n] = p; l.bytes[l.n] = (uint32_t)bytes; l.n++; };
-        add(c.tflag, 4 * ntile);                                   /* tflag | tunk | tsum | tray */
+        add(c.tflag, 5 * ntile);                                   /* tflag | tunk | tsum | tray | tact */
         add(c.tknown, ntile);
         add(c.zocc, (size_t)c.Z);
         add(c.cnt, GIE_CNT_ERR * sizeof(int32_t));                 /* per-frame counters (the sticky error flag survives) */
@@ -363,8 +363,19 @@ extern "C" int gie_fuse(gie_mapper *m)
         be_clear(&m->be, l);
     }
     be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0);
+    /* the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
+     * earlier frames); the same choice between lists and volume sweeps as the later stages */
+    be_lin(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     be_prof(&m->be, GIE_K_ALLOC, 1);
-    be_prof(&m->be, GIE_K_FUSE, 0); be_vox_staged(&m->be, m->c, op_fuse()); be_prof(&m->be, GIE_K_FUSE, 1);
+    {
+        const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
+        static const char *force = getenv("GIE_TILE_LIST");
+        m->list_mode = force ? atoi(force) != 0 : (long long)m->pub_h[0] * 8 <= (long long)ntile;
+        if (getenv("GIE_DEBUG_MODE")) fprintf(stderr, "gie: frame %d known tiles (published) %d of %d -> %s\n", m->c.map_ct, m->pub_h[0], ntile, m->list_mode ? "lists" : "sweeps");
+    }
+    be_prof(&m->be, GIE_K_FUSE, 0);
+    if (m->list_mode) be_vox_list(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, true); else be_vox_staged(&m->be, m->c, op_fuse());
+    be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
 }
@@ -376,14 +387,10 @@ extern "C" int gie_batch_edt(gie_mapper *m)
     be_prof(&m->be, GIE_K_EDT_ZFACES, 0);
     be_edt_prep(&m->be, m->c);          /* plane list + reader masks */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 1);
-    /* Sparse or dense?  The device publishes how many tiles hold a known voxel; the value the host
-     * sees is a map update or two old, which is all a heuristic needs.  Few known tiles: Mark,
-     * obtainFrontiers, commit and pass Z walk tile lists; many: they sweep the volume (wide
+    /* Sparse or dense (decided in gie_fuse)?  The device publishes how many tiles hold a known voxel;
+     * the value the host sees is a map update or two old, which is all a heuristic needs.  Few
+     * known tiles: fuse, Mark, commit and pass Z walk tile lists; many: they sweep the volume (wide
      * coalesced rows).  Results are identical (GIE_TILE_LIST=0/1 forces a mode for the tests). */
-    const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-    static const char *force = getenv("GIE_TILE_LIST");
-    m->list_mode = force ? atoi(force) != 0 : (long long)m->pub_h[0] * 8 <= (long long)ntile;
-    if (getenv("GIE_DEBUG_MODE")) fprintf(stderr, "gie: frame %d known tiles (published) %d of %d -> %s\n", m->c.map_ct, m->pub_h[0], ntile, m->list_mode ? "lists" : "sweeps");
     const int partial = m->c.tfd[2] <= 64;
     be_edt(&m->be, m->c, partial ? (m->list_mode ? 2 : 0) : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
     m->edt_partial = partial;

@@ -110,15 +110,18 @@ struct op_frontier { static constexpr bool rolled = false;
 /* tile summary for obtainFrontiers: a voxel of tile t can only act (C seed, A/B seed, FNT flip)
  * when t touches the volume faces, or t / a face-adjacent tile holds an unknown voxel or a
  * voxel whose Mark-time closest obstacle lies outside the volume */
-struct op_tile_summary { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
+struct op_tile_summary {
+    /* tile holds an unknown voxel: fuse said so, or fuse never looked at it (then it is all-unknown) */
+    GIE_DEVM static int unk(const gie_ctx &c, int t) { return c.tunk[t] | (c.tact[t] ^ 1); }
+    GIE_DEVM void operator()(const gie_ctx &c, int t) const {
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
         uint8_t v = 0;
         if (c.tknown[t]) {
             if (tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1) v = 1;
             else {
                 const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
-                v = c.tunk[t] | c.tflag[t] | c.tunk[t - sx] | c.tflag[t - sx] | c.tunk[t + sx] | c.tflag[t + sx] | c.tunk[t - sy] | c.tflag[t - sy]
-                  | c.tunk[t + sy] | c.tflag[t + sy] | c.tunk[t - sz] | c.tflag[t - sz] | c.tunk[t + sz] | c.tflag[t + sz];
+                v = (uint8_t)(unk(c, t) | c.tflag[t] | unk(c, t - sx) | c.tflag[t - sx] | unk(c, t + sx) | c.tflag[t + sx] | unk(c, t - sy) | c.tflag[t - sy]
+                  | unk(c, t + sy) | c.tflag[t + sy] | unk(c, t - sz) | c.tflag[t - sz] | unk(c, t + sz) | c.tflag[t + sz]);
             }
         }
         c.tsum[t] = v;
@@ -146,6 +149,22 @@ struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
+/* the fuse tile list (thread per tile; device: one atomic per wave) */
+struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
+        const int v = gie_fuse_tile_listed(c, t);
+#if defined(GIE_HOST_EMU)
+        if (v) c.tl_front[c.cnt[GIE_CNT_TL_FUSE]++] = t;
+#else
+        const unsigned long long bm = __ballot(v != 0);
+        if (bm) {
+            const int lane = __lane_id(), leader = __ffsll((long long)bm) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&c.cnt[GIE_CNT_TL_FUSE], __popcll(bm));
+            base = __shfl(base, leader);
+            if (v) c.tl_front[base + __popcll(bm & ((1ull << lane) - 1ull))] = t;
+        }
+#endif
+    } };
 struct op_zneed { GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_zneed_column(c, i); } };
 struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };
 struct op_stream_gather { const int32_t *list; int first; int32_t *keys; gie_voxel *out;

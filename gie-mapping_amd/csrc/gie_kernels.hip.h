@@ -258,7 +258,10 @@ __global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int n
             else { gie_cell_insert(c, i, slot); c.blk_new[lbase + r] = slot; found = slot; }
         }
     }
-    if (i < ncell) c.blk_tab[i] = found;
+    if (i < ncell) {
+        c.blk_tab[i] = found;
+        if (found >= 0) gie_cell_mark_tiles(c, i);
+    }
 }
 /* initialise the 512 voxels of every block on the list (one workgroup per block, grid-stride) */
 __global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c)
@@ -789,8 +792,13 @@ __global__ __launch_bounds__(256) void k_voxt(const gie_ctx c, const F f, const 
             for (int k = 0; k < 8; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
 #pragma unroll
             for (int k = 0; k < 8; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
+            unsigned known = 0, valid = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) if (!sk[k]) f.finish(c, id[k], x, y, z0 + k, s[k]);
+            for (int k = 0; k < 8; k++) {
+                if (z0 + k < c.Z) valid |= 1u << k;
+                if (!sk[k]) known |= (unsigned)(f.finish(c, id[k], x, y, z0 + k, s[k]) != 0) << k;
+            }
+            gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; k++) if (!sk[k]) f(c, x, y, z0 + k);

@@ -350,6 +350,30 @@ GIE_DEV void gie_init_voxel(const gie_ctx &c, int slot, int i)
     c.g_pair[a] = 0; c.g_prop[a] = GIE_NOPROP; c.g_wl[a] = -1;
 }
 
+/* an existing block makes the (up to eight) local tiles it overlaps interesting for fuse */
+GIE_DEV void gie_cell_mark_tiles(const gie_ctx &c, int cell)
+{
+    const int bx = cell % c.tdim[0] + c.tb0[0], by = (cell / c.tdim[0]) % c.tdim[1] + c.tb0[1], bz = cell / (c.tdim[0] * c.tdim[1]) + c.tb0[2];
+    const int l0[3] = { bx * 8 - c.pvt[0], by * 8 - c.pvt[1], bz * 8 - c.pvt[2] };
+    int t0[3], t1[3];
+    for (int a = 0; a < 3; a++) {
+        t0[a] = l0[a] >> 3; t1[a] = (l0[a] + 7) >> 3;              /* arithmetic shifts: floor */
+        if (t0[a] < 0) t0[a] = 0;
+        if (t1[a] > c.tfd[a] - 1) t1[a] = c.tfd[a] - 1;
+        if (t0[a] > t1[a]) return;                                  /* the block lies outside the volume */
+    }
+    for (int tz = t0[2]; tz <= t1[2]; tz++) for (int ty = t0[1]; ty <= t1[1]; ty++) for (int tx = t0[0]; tx <= t1[0]; tx++)
+        c.tact[(tz * c.tfd[1] + ty) * c.tfd[0] + tx] = 1;          /* all writers store 1 */
+}
+/* fuse looks at a tile when a block overlaps it or its _glb_type is not all-UNKNOWN yet; a tile
+ * that is not listed stays all-unknown */
+GIE_DEV int gie_fuse_tile_listed(const gie_ctx &c, int t)
+{
+    const int v = c.tact[t] | c.tknown_prev[t];
+    c.tact[t] = (uint8_t)v;                                         /* from here on: "fuse looked at this tile" */
+    return v;
+}
+
 /* ================================================================== fuse */
 GIE_DEV int gie_inside_aabb(float px, float py, float pz, const float *ll, const float *ur)
 { return px >= ll[0] && py >= ll[1] && pz >= ll[2] && px <= ur[0] && py <= ur[1] && pz <= ur[2]; }

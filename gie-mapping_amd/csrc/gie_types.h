@@ -99,6 +99,7 @@ typedef struct gie_ctx {
     uint8_t *tknown, *tunk; /* per tile: holds a known / an unknown voxel after this frame's fuse */
     uint8_t *tknown_prev;   /* tknown of the previous frame = "_glb_type of the tile is not all UNKNOWN yet" */
     uint8_t *tray;          /* per tile: a ray touched it this scan (ray-casting OGM) */
+    uint8_t *tact;          /* per tile: fuse has to look at it (overlaps an existing block, or held a known voxel last frame) */
     uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
     uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */
     uint64_t *zneed;        /* per (x,y) tile column: bit tz set = somebody reads the batch EDT of tile (tx,ty,tz) */
@@ -164,7 +165,8 @@ enum {
     GIE_CNT_NEWLIST = 36,                       /* entries in the list of blocks to initialise (blk_new) */
     GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
     GIE_CNT_TL_DONE = 39,                       /* tile columns that have appended to tl_known (the last one publishes the count) */
-    GIE_CNT_AUX_END = 40,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
+    GIE_CNT_AUX_END = 41,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096

@@ -54,8 +54,28 @@ static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
     }
 }
 template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox(b, c, f); }
-/* the list form visits a subset of the tiles the sweep would not skip anyway */
-template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *, int, bool) { be_vox(b, c, f); }
+/* the list form: only the listed tiles, one (x,y) column of a tile at a time like a device lane */
+template <class F> static void be_vox_list_col(const gie_ctx &c, const F &f, int x, int y, int z0)
+{ for (int z = z0; z < z0 + 8 && z < c.Z; z++) if (!f.skip(c, gie_lid(c, x, y, z), x, y, z)) f(c, x, y, z); }
+static void be_vox_list_col(const gie_ctx &c, const op_fuse &f, int x, int y, int z0)
+{
+    unsigned known = 0, valid = 0;
+    for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f(c, x, y, z)) known |= 1u << (z - z0); }
+    f.column(c, x, y, z0, known, valid);
+}
+template <class F> static void be_vox_list(be_state *, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool)
+{
+    const int n = c.cnt[count_idx];
+    for (int e = 0; e < n; e++) {
+        const int t = list[e];
+        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+        for (int ly = 0; ly < 8; ly++) for (int lx = 0; lx < 8; lx++) {
+            const int x = tx * 8 + lx, y = ty * 8 + ly, z0 = tz * 8;
+            if (x >= c.X || y >= c.Y || f.tile_skip(c, x, y, z0)) continue;
+            be_vox_list_col(c, f, x, y, z0);
+        }
+    }
+}
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
@@ -69,6 +89,7 @@ static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *ra
     be_lin(b, c, ins, ncell);
     be_block_init(b, c, c.blk_new, rank, ncell);
     be_lin(b, c, op_cell_table(), ncell);
+    for (int cell = 0; cell < ncell; cell++) if (c.blk_tab[cell] >= 0) gie_cell_mark_tiles(c, cell);
 }
 static void be_free_rays(be_state *, const gie_ctx &c, const float *g, int n) { for (int i = 0; i < n; i++) gie_free_ray(c, g, i); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }
@@ -86,7 +107,13 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
 }
 /* plain restatement of the closed form the HIP EDT kernels implement (see
  * tests/test_oracle_edt.py::test_meijster_tie_rule) */
-static void be_edt_prep(be_state *, const gie_ctx &) {}            /* plane list / reader masks / tile lists: device-only shortcuts */
+/* the list of tiles that hold a known voxel (the plane list and the reader masks are device-only shortcuts) */
+static void be_edt_prep(be_state *, const gie_ctx &c)
+{
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    for (int t = 0; t < ntile; t++) if (c.tknown[t]) c.tl_known[c.cnt[GIE_CNT_TL_KNOWN]++] = t;
+    *c.pub = c.cnt[GIE_CNT_TL_KNOWN];
+}
 static int32_t *be_pub_alloc(be_state *, int32_t **dev) { int32_t *h = (int32_t *)calloc(16, 4); *dev = h; return h; }
 static void be_pub_free(be_state *, int32_t *h) { free(h); }
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */

@@ -1,0 +1,31 @@
+"""Tile lists vs volume sweeps (fuse, Mark, obtainFrontiers, commit): the host picks per map
+update; GIE_TILE_LIST forces one.  The library reads the variable once per process, so every
+mode runs in its own interpreter.  CPU: the test-only emulation (which walks the same lists);
+GPU: tests/test_gpu_parity.py::test_tile_list_and_sweep_modes_agree_with_the_oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+CODE = (
+    "import sys; sys.path[:0] = [%r, %r, %r]\n"
+    "import parity\n"
+    "from emu_py import EmuMapper\n"
+    "from oracle_py import OracleMapper\n"
+    "for sensor, fast, size in (('mixed', False, (56, 48, 24)), ('lidar_points', False, (48, 48, 40)), ('depth', True, (40, 40, 16))):\n"
+    "    sc = parity.Scenario('lists_' + sensor, size, sensor=sensor, frames=5, fast_mode=fast, lidar_az=360, delta_vox=6)\n"
+    "    parity.run_and_compare(sc, OracleMapper, EmuMapper)\n"
+    "print('ok')\n"
+) % (ROOT, os.path.join(ROOT, "gie-mapping_amd"), HERE)
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_both_modes_match_the_oracle_on_cpu(mode):
+    from emu_py import load
+    load()                                            # build the emulation once, outside the children
+    r = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, GIE_TILE_LIST=mode), capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
