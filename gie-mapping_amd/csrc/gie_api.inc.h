@@ -28,6 +28,7 @@ struct gie_mapper {
     int has_pose, has_ogm;
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
     int list_mode;                        /* this map update visits tile lists instead of sweeping the volume */
+    int ogm_unlabelled;                   /* ray-cast scan whose _inst_type labels have not been written (gie_read_ogm does it) */
     int32_t *pub_h;                       /* pinned words written by the device: [0] = known tiles of a recent map update */
     float msg_origin[3];
     float *d_sensor; size_t sensor_cap;   /* device copy of the last sensor frame */
@@ -65,7 +66,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->edt_partial = 0; m->list_mode = 0; m->pub_h = nullptr;
+    m->has_pose = m->has_ogm = 0; m->edt_partial = 0; m->list_mode = 0; m->ogm_unlabelled = 0; m->pub_h = nullptr;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -304,7 +305,11 @@ extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
         be_prof(&m->be, GIE_K_RAY_REGISTER, 0); be_lin(&m->be, m->c, r, n); be_prof(&m->be, GIE_K_RAY_REGISTER, 1);   /* registerLocObs */
         be_prof(&m->be, GIE_K_RAY_FREE, 0); be_free_rays(&m->be, m->c, m->d_pts_g, n); be_prof(&m->be, GIE_K_RAY_FREE, 1);   /* freeLocObs */
     }
-    be_prof(&m->be, GIE_K_RAY_FINAL, 0); be_vox(&m->be, m->c, op_raycast_finalize()); be_prof(&m->be, GIE_K_RAY_FINAL, 1);   /* getAllocKeys */
+    /* getAllocKeys: the ray kernels already flag the block of every cell they count in; what is left
+     * is the scan label of those cells — which only gie_read_ogm looks at (fuse works from the
+     * counts) — and the robot sphere of for_motion_planner */
+    if (m->c.for_motion_planner) { be_prof(&m->be, GIE_K_RAY_FINAL, 0); be_vox(&m->be, m->c, op_raycast_finalize()); be_prof(&m->be, GIE_K_RAY_FINAL, 1); }
+    else m->ogm_unlabelled = 1;
     be_time(&m->be, 1);
     m->has_ogm = 1;
     return GIE_OK;
@@ -341,6 +346,7 @@ extern "C" int gie_set_ext_boxes(gie_mapper *m, const float *ll, const float *ur
 extern "C" int gie_fuse(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_fuse"); if (rc) return rc;
+    m->ogm_unlabelled = 0;                /* fuse consumes the scan */
     be_time(&m->be, 2);
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
@@ -474,6 +480,7 @@ extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *
 extern "C" int gie_read_ogm(gie_mapper *m, int8_t *inst_type, int32_t *ray_count)
 {
     if (!m) { gie_set_err("gie_read_ogm: null handle"); return GIE_ERR_INVALID; }
+    if (m->ogm_unlabelled) { be_vox(&m->be, m->c, op_raycast_finalize()); m->ogm_unlabelled = 0; }   /* the scan labels of a ray-cast scan, on demand */
     if (inst_type) be_d2h(&m->be, inst_type, m->c.inst_type, (size_t)m->c.N);
     if (ray_count) be_d2h(&m->be, ray_count, m->c.ray_count, (size_t)m->c.N * 4);
     return gie_sync(m);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     if (threadIdx.x < GIE_RAY_SEGS) s_ready[threadIdx.x] = 0;
     gie_dda d;
     int s0[3] = { 0, 0, 0 };
-    int last_tile = -1;
+    gie_ray_marks last_tile = { -1, -1 };
     bool walk = ray && gie_dda_init(c, g, i, d, s0);      /* constants of the ray (direction, deltas, end cell) in every wave */
     __syncthreads();
     if (seg == 0) {   /* clearRayLoc on the sensor's own cell */

@@ -84,10 +84,15 @@ GIE_DEV void gie_wave_add(const gie_ctx &c, int id, int val)
 
 /* every cell whose _ray_count changes flags its tile, so that getAllocKeys (ray_finalize) only
  * looks at tiles a ray went through; `last` spares the store while the ray stays in one tile */
-GIE_DEV void gie_ray_touch(const gie_ctx &c, int lx, int ly, int lz, int *last)
+struct gie_ray_marks { int tile, blk; };
+GIE_DEV void gie_ray_touch(const gie_ctx &c, int lx, int ly, int lz, gie_ray_marks *last)
 {
     const int t = gie_tile_index(c, lx, ly, lz);
-    if (t != *last) { c.tray[t] = 1; *last = t; }
+    if (t != last->tile) { c.tray[t] = 1; last->tile = t; }
+    /* a touched cell needs its block (getAllocKeys, pntcld_raycast.cu:21-63: every cell whose count
+     * is not zero — hits and misses never cancel: a free ray stops in front of a hit cell) */
+    const int b = gie_tab_index(c, lx + c.pvt[0], ly + c.pvt[1], lz + c.pvt[2]);
+    if (b != last->blk) { c.blk_need[b] = 1; last->blk = b; }
 }
 
 /* global voxel address: block slot through the frame's block table (volume +-1 voxel) */
@@ -203,7 +208,7 @@ GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out
         if (gie_in_loc(c, lx, ly, lz)) {
             const int id = gie_lid(c, lx, ly, lz);
             c.inst_type[id] = GIE_VOX_OCCUPIED;      /* all writers store the same value */
-            int lt = -1;
+            gie_ray_marks lt = { -1, -1 };
             gie_ray_touch(c, lx, ly, lz, &lt);
             gie_wave_add(c, id, 1);
         }
@@ -215,7 +220,7 @@ GIE_DEV int gie_clear_ray(const gie_ctx &c, int lx, int ly, int lz)
 {
     if (!gie_in_loc(c, lx, ly, lz)) return 1;
     const int id = gie_lid(c, lx, ly, lz);
-    if (c.inst_type[id] != GIE_VOX_OCCUPIED) { int lt = -1; gie_ray_touch(c, lx, ly, lz, &lt); gie_aadd32(&c.ray_count[id], -1); return 1; }
+    if (c.inst_type[id] != GIE_VOX_OCCUPIED) { gie_ray_marks lt = { -1, -1 }; gie_ray_touch(c, lx, ly, lz, &lt); gie_aadd32(&c.ray_count[id], -1); return 1; }
     return 0;
 }
 
@@ -270,7 +275,7 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
 {
     gie_dda d;
     int s0[3];
-    int last_tile = -1;
+    gie_ray_marks last_tile = { -1, -1 };
     const int walk = gie_dda_init(c, g, i, d, s0);
     {   /* clearRayLoc on the sensor's own cell */
         const int id0 = gie_in_loc(c, s0[0], s0[1], s0[2]) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
@@ -286,12 +291,13 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
     for (;;) {
         int ids[GIE_RAY_BATCH];            /* local voxel id, -1 = outside the volume */
         int stop_after[GIE_RAY_BATCH];
+        int loc[GIE_RAY_BATCH][3];
         GIE_UNROLL_BATCH
         for (int j = 0; j < GIE_RAY_BATCH; j++) {
             stop_after[j] = gie_dda_step(d);
             const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
             ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
-            if (ids[j] >= 0) gie_ray_touch(c, lx, ly, lz, &last_tile);      /* speculative cells may over-flag: harmless */
+            loc[j][0] = lx; loc[j][1] = ly; loc[j][2] = lz;
         }
         int8_t ty[GIE_RAY_BATCH];
         GIE_UNROLL_BATCH
@@ -299,6 +305,7 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
         GIE_UNROLL_BATCH
         for (int j = 0; j < GIE_RAY_BATCH; j++) {
             if (ty[j] == GIE_VOX_OCCUPIED) return;                 /* clearRayLoc returned false */
+            if (ids[j] >= 0) gie_ray_touch(c, loc[j][0], loc[j][1], loc[j][2], &last_tile);   /* only cells that are really cleared */
             gie_wave_add(c, ids[j], -1);
             if (stop_after[j]) return;
         }
