@@ -127,7 +127,7 @@ def secondary_run(gie, scenes, torch, dev, sensor, size, voxel, cutoff_dist, war
     m.close()
     n_vox = size[0] * size[1] * size[2]
     visits = {k: (st["total_visits_" + k] - st0["total_visits_" + k]) / float(steps) for k in "abc"}
-    wave_ms = sum(prof[k][0] for k in ("wave_a", "wave_b", "wave_c") if k in prof) / steps
+    wave_ms = sum(prof[k][0] for k in ("waves",) if k in prof) / steps
     return {"sensor": sensor, "ms_per_step": round(1e3 * dt / steps, 4), "hz": round(steps / dt, 3),
             "value": round(n_vox * steps / dt / 1e6, 2), "unit": "Mvoxels/s", "known_voxel_fraction": round(known, 4),
             "wave_visits_per_step": [round(visits[k], 1) for k in "abc"],
@@ -266,10 +266,9 @@ def main():
                     "note": "achieved = the reference's per-voxel bytes for the WHOLE volume / launch time (SURVEY 8d); the kernels skip "
                             "tiles and planes that hold nothing to do, so the measured HBM bytes (traffic, rocprofv3 PMC) are far below "
                             "the algorithmic bytes on a sparsely observed volume"}
-        elif dom in ("wave_a", "wave_b", "wave_c"):
-            # BFS wave: algorithmic bytes = 64 B per visited voxel (own record + six 8-byte RMWs)
-            key = "total_visits_" + dom[-1]
-            visits = (st[key] - st0[key]) / float(sweeps[dom][1])
+        elif dom == "waves":
+            # BFS waves A+B+C (one launch): algorithmic bytes = 64 B per visited voxel (own record + six 8-byte RMWs)
+            visits = sum(st["total_visits_" + k] - st0["total_visits_" + k] for k in "abc") / float(sweeps[dom][1])
             achieved = 64.0 * visits / (dom_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4),

@@ -14,7 +14,7 @@
 enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, GIE_K_ALLOC, GIE_K_FUSE, GIE_K_EDT_Y, GIE_K_EDT_X,
        GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_EDT_ZFACES, GIE_K_NUM };
 static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
-       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "wave_c", "commit", "edt_prep" };
+       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "waves", "commit", "edt_prep" };
 
 static thread_local std::string g_gie_err;
 static void gie_set_err(const std::string &s) { g_gie_err = s; }
@@ -418,11 +418,7 @@ extern "C" int gie_merge(gie_mapper *m)
      * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
     be_vox_list(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, false);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
-    if (!m->c.fast_mode) {
-        be_prof(&m->be, GIE_K_WAVE_A, 0); be_wave_a(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_A, 1);
-        be_prof(&m->be, GIE_K_WAVE_B, 0); be_wave_b(&m->be, m->c); be_prof(&m->be, GIE_K_WAVE_B, 1);
-    }
-    be_prof(&m->be, GIE_K_WAVE_C, 0); be_wave_c(&m->be, m->c, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
+    be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     be_prof(&m->be, GIE_K_COMMIT, 0);
     if (m->list_mode) be_vox_list(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, true); else be_vox_staged(&m->be, m->c, op_commit());
     be_prof(&m->be, GIE_K_COMMIT, 1);
@@ -694,7 +690,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     be_memset(&m->be, c.cnt + GIE_CNT_C, 0, sizeof(int32_t));
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
-    be_wave_c(&m->be, c, 0, 1);
+    be_waves(&m->be, c, 0, 0, 1);
     if (m->list_mode) be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true); else be_vox_staged(&m->be, c, op_commit());
     rc = gie_sync(m);
     if (seeded) *seeded = m->h_cnt[GIE_CNT_FRONT_C];

@@ -296,24 +296,16 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 8, 1);
 
 }
-/* one workgroup per CU: co-resident by construction (1024 threads, < 72 VGPRs, 16 B of LDS) */
-static void be_wave_a(be_state *b, const gie_ctx &c)
-{
-    hipLaunchKernelGGL(k_wave_a, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c);
-}
-static void be_wave_b(be_state *b, const gie_ctx &c)
-{
-    hipLaunchKernelGGL(k_wave_b, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c);
-}
-/* the frame clear has zeroed the barrier words and the per-level arrays; a second wave C inside
- * the same map update (gie_refine) clears them itself */
-static void be_wave_c(be_state *b, const gie_ctx &c, int record_seeds, int clear_first)
+/* waves A, B and C in one launch; workgroups are co-resident by construction (1024 threads each,
+ * at most one per compute unit).  The frame clear has zeroed the barrier word and the per-level
+ * arrays; a second launch inside the same map update (gie_refine) clears them itself. */
+static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
     if (clear_first) {
         GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
         GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     }
-    hipLaunchKernelGGL(k_wave_c, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, record_seeds);
+    hipLaunchKernelGGL(k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, with_ab, record_seeds);
 }
 
 #include "gie_api.inc.h"

@@ -888,11 +888,12 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
 
 __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : hi; }
 
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_a(const gie_ctx c)
+/* The three waves run inside ONE launch (k_waves), separated by grid barriers: a wave without
+ * seeds costs a counter read instead of a launch.  Every workgroup executes the same number of
+ * grid barriers: a small wave is run by workgroup 0 alone (block barriers only, gb.solo) while
+ * the others fall through to the barrier that separates it from the next wave. */
+__device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb)
 {
-    __shared__ int s_fail;
-    if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab), cur = 0, level = 0;
@@ -914,11 +915,8 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_a(const gie_ctx c)
     }
 }
 
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_b(const gie_ctx c)
+__device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb)
 {
-    __shared__ int s_fail;
-    if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_B], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
@@ -1002,12 +1000,8 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int 
         GIE_TS(4);
     }
 }
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, const int record_seeds)
+__device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb, const int record_seeds, gie_wg_scratch &s_wg)
 {
-    __shared__ gie_wg_scratch s_wg;
-    __shared__ int s_fail;
-    if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, 0, &s_fail };
     const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;
@@ -1052,6 +1046,25 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_wave_c(const gie_ctx c, co
         c.cnt[GIE_CNT_VIS_C] = (int)vis; c.cnt[GIE_CNT_LVL_C] = lv;
         *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += vis;
     }
+}
+
+/* waves A, B (unless fast_mode / refinement) and C in one launch */
+__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds)
+{
+    __shared__ gie_wg_scratch s_wg;
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, 0, &s_fail };
+    __syncthreads();
+    if (with_ab) {
+        gie_wave_a_run(c, gb);
+        gb.solo = 0;
+        gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
+        gie_wave_b_run(c, gb);
+        gb.solo = 0;
+        gie_grid_sync(gb, c);
+    }
+    gie_wave_c_run(c, gb, record_seeds, s_wg);
 }
 
 #endif /* GIE_KERNELS_HIP_H */

@@ -177,5 +177,10 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_c ? c.cnt[GIE_CNT_NEXT] : c.qcap_c; cur ^= 1; level++;
     }
 }
+static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
+{
+    if (with_ab) { be_wave_a(b, c); be_wave_b(b, c); }
+    be_wave_c(b, c, record_seeds, clear_first);
+}
 
 #include "../../gie-mapping_amd/csrc/gie_api.inc.h"

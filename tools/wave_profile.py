@@ -23,10 +23,10 @@ for i, (pos, q, pts, _) in enumerate(frames):
     st = m.stats(); prof = m.profile_read()
     row = {"frame": i, "seeds": [st["seeds_a"], st["seeds_b"], st["seeds_c"]], "visits": [st["visits_a"], st["visits_b"], st["visits_c"]],
            "levels": [st["levels_a"], st["levels_b"], st["levels_c"]]}
-    for k in ("wave_a", "wave_b", "wave_c", "frontiers", "mark", "commit"):
+    for k in ("waves", "frontiers", "mark", "commit"):
         t = prof[k][0] - prev.get(k, 0.0); prev[k] = prof[k][0]
         row[k + "_ms"] = round(t, 3)
     if st["levels_c"]:
-        row["us_per_level_c"] = round(1e3 * row["wave_c_ms"] / st["levels_c"], 2)
+        row["us_per_level_c"] = round(1e3 * row["waves_ms"] / st["levels_c"], 2)
         row["visits_per_level_c"] = round(st["visits_c"] / st["levels_c"], 1)
     print(json.dumps(row))
