@@ -196,6 +196,7 @@ def main():
     if world > 1:
         m.set_tile(tiling.tile_offset_voxels(rank, world, size), whole)
     rounds_total = [0]
+    ray_cells = [None]
 
     def step(i):
         pos, q = frames[i][0], frames[i][1]
@@ -205,6 +206,10 @@ def main():
         else:
             m.ogm_multiscan_dev(d_pts[i].data_ptr(), bins, rings, 2.0 * math.pi / bins, -math.pi,
                                 math.radians(phi_inc), math.radians(phi_min))
+        if ray_cells[0] is None and bins is None and rank == 0:
+            # once, in the warm-up: how many cells does a scan's ray casting count in?  (|_ray_count| summed over
+            # the volume: every hit and every cleared cell is one visit = the algorithmic unit of the ray kernels)
+            ray_cells[0] = int(np.abs(m.read_ogm()["ray_count"].astype(np.int64)).sum())
         m.step()
         if world > 1:
             if backend == "nccl":
@@ -275,10 +280,26 @@ def main():
                     "alg_bytes_per_visit": 64, "visits_per_launch": round(visits, 1),
                     "note": "level-synchronous BFS over %.0f voxels per launch on average: bound by the dependent "
                             "cross-XCD round trips of each level (grid barrier), not by HBM bandwidth" % visits}
+        elif dom in ("ray_free", "ray_register") and ray_cells[0]:
+            # ray casting: algorithmic bytes = 13 B per visited cell (1 B scan label read + one 4-byte atomic
+            # read-modify-write + its 4-byte return path + 4 B of the ray's own state amortised), SURVEY §8d row R
+            achieved = 13.0 * ray_cells[0] / (dom_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(dom_ms, 4),
+                    "alg_bytes_per_cell": 13, "cells_per_launch": ray_cells[0],
+                    "note": "per-ray 3-D DDA: a chain of dependent cell visits with one atomic each; bound by that latency chain "
+                            "(16 segments of a ray run side by side, 64 adjacent rays share atomics), not by HBM bandwidth"}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": round(dom_ms, 4),
-                    "note": "dominant kernel is per-point ray casting (atomic/latency bound), not volume-proportional"}
+                    "note": "dominant kernel is not volume-proportional"}
         # every volume sweep against the same roofline (algorithmic bytes of SURVEY §8d)
         sweeps_roof = {}
         for k2, v2 in sweeps.items():
