@@ -163,6 +163,41 @@ def test_full_size_512_cube(oracle_lib):
 
 
 @pytest.mark.gpu
+def test_full_size_512_cube_ray_casting(oracle_lib):
+    """The bench's default workload at full size: 512^3 @ 0.05 m, VLP-16 cloud through parallel
+    ray casting (sparse observation: tile lists, direct pass Z, scan labels on demand).  Three map
+    updates against the oracle, every array bit for bit, and the scan (labels + counts) of the
+    last one."""
+    import bench
+    from gie import scenes
+    size = (512, 512, 512)
+    cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
+    frames = bench.make_frames(scenes, 0.05, 3, 5, "vlp16")
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        for k, (pos, q, pts, _) in enumerate(frames):
+            for m in (a, b):
+                m.set_pose(pos, q)
+                m.ogm_pointcloud(pts)
+            if k == len(frames) - 1:
+                oa, ob = a.read_ogm(), b.read_ogm()
+                assert np.array_equal(oa["ray_count"], ob["ray_count"]) and np.array_equal(oa["inst_type"], ob["inst_type"])
+                del oa, ob
+            for m in (a, b):
+                m.fuse(); m.batch_edt(); m.merge()
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), (k, key)
+            assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0)
+            sa, sb = a.stats(), b.stats()
+            for key in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_c", "levels_c", "blocks_total"):
+                assert sa[key] == sb[key], (k, key)
+            del ra, rb
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
     """The map update only produces the batch EDT where Mark reads it (tiles with a known voxel; wave B
     computes the distance of an unknown face voxel on demand).  Exported without completion, it
