@@ -27,9 +27,7 @@ struct gie_mapper {
     int ncell;
     int has_pose, has_ogm;
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
-    int list_mode;                        /* this map update visits tile lists instead of sweeping the volume */
     int ogm_unlabelled;                   /* ray-cast scan whose _inst_type labels have not been written (gie_read_ogm does it) */
-    int32_t *pub_h;                       /* pinned words written by the device: [0] = known tiles of a recent map update */
     float msg_origin[3];
     float *d_sensor; size_t sensor_cap;   /* device copy of the last sensor frame */
     float *d_pts_g; size_t pts_cap;       /* ray casting: points in the global frame */
@@ -66,7 +64,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->edt_partial = 0; m->list_mode = 0; m->ogm_unlabelled = 0; m->pub_h = nullptr;
+    m->has_pose = m->has_ogm = 0; m->edt_partial = 0; m->ogm_unlabelled = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -107,8 +105,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.zcount = gie_dalloc<int32_t>(m, 4);
     c.tl_known = gie_dalloc<int32_t>(m, ntile);
     c.tl_front = gie_dalloc<int32_t>(m, ntile);
-    m->pub_h = be_pub_alloc(&m->be, &c.pub);
-    if (!m->pub_h) { gie_set_err("gie_create: pinned allocation failed"); gie_destroy(m); return nullptr; }
+    { const char *force = getenv("GIE_TILE_LIST"); c.force_lists = force ? (atoi(force) != 0) : -1; }   /* tests force lists / sweeps */
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -175,7 +172,6 @@ extern "C" void gie_destroy(gie_mapper *m)
     if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
     if (m->d_srank) { be_free(&m->be, m->d_srank); be_free(&m->be, m->d_slist); }
     for (int i = 0; i < 2; i++) { if (m->d_stage[i]) be_free(&m->be, m->d_stage[i]); if (m->h_stage[i]) be_host_free(&m->be, m->h_stage[i]); }
-    be_pub_free(&m->be, m->pub_h);
     be_fini(&m->be);
     delete m;
 }
@@ -370,17 +366,12 @@ extern "C" int gie_fuse(gie_mapper *m)
     }
     be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0);
     /* the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
-     * earlier frames); the same choice between lists and volume sweeps as the later stages */
+     * earlier frames); fuse, Mark, commit and pass Z walk their list or sweep the volume — each kernel
+     * decides from the length of its list (gie_use_lists) */
     be_lin(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     be_prof(&m->be, GIE_K_ALLOC, 1);
-    {
-        const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-        static const char *force = getenv("GIE_TILE_LIST");
-        m->list_mode = force ? atoi(force) != 0 : (long long)m->pub_h[0] * 8 <= (long long)ntile;
-        if (getenv("GIE_DEBUG_MODE")) fprintf(stderr, "gie: frame %d known tiles (published) %d of %d -> %s\n", m->c.map_ct, m->pub_h[0], ntile, m->list_mode ? "lists" : "sweeps");
-    }
     be_prof(&m->be, GIE_K_FUSE, 0);
-    if (m->list_mode) be_vox_list(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, true); else be_vox_staged(&m->be, m->c, op_fuse());
+    be_vox_list(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, true, false);
     be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
@@ -393,12 +384,8 @@ extern "C" int gie_batch_edt(gie_mapper *m)
     be_prof(&m->be, GIE_K_EDT_ZFACES, 0);
     be_edt_prep(&m->be, m->c);          /* plane list + reader masks */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 1);
-    /* Sparse or dense (decided in gie_fuse)?  The device publishes how many tiles hold a known voxel;
-     * the value the host sees is a map update or two old, which is all a heuristic needs.  Few
-     * known tiles: fuse, Mark, commit and pass Z walk tile lists; many: they sweep the volume (wide
-     * coalesced rows).  Results are identical (GIE_TILE_LIST=0/1 forces a mode for the tests). */
     const int partial = m->c.tfd[2] <= 64;
-    be_edt(&m->be, m->c, partial ? (m->list_mode ? 2 : 0) : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
+    be_edt(&m->be, m->c, partial ? 0 : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
     m->edt_partial = partial;
     be_time(&m->be, 5);
     return GIE_OK;
@@ -410,17 +397,17 @@ extern "C" int gie_merge(gie_mapper *m)
     be_time(&m->be, 6);
     const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
     be_prof(&m->be, GIE_K_MARK, 0);
-    if (m->list_mode) be_vox_list(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false); else be_vox(&m->be, m->c, op_mark());
+    be_vox_list(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false, false);
     be_prof(&m->be, GIE_K_MARK, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_lin(&m->be, m->c, op_tile_summary(), ntile);
     /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
      * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
-    be_vox_list(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, false);
+    be_vox_list(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, false, true);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     be_prof(&m->be, GIE_K_COMMIT, 0);
-    if (m->list_mode) be_vox_list(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, true); else be_vox_staged(&m->be, m->c, op_commit());
+    be_vox_list(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, true, false);
     be_prof(&m->be, GIE_K_COMMIT, 1);
     be_time(&m->be, 7);
     return GIE_OK;
@@ -691,7 +678,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
     be_waves(&m->be, c, 0, 0, 1);
-    if (m->list_mode) be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true); else be_vox_staged(&m->be, c, op_commit());
+    be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true, false);
     rc = gie_sync(m);
     if (seeded) *seeded = m->h_cnt[GIE_CNT_FRONT_C];
     return rc;

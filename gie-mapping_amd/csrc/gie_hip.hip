@@ -89,18 +89,6 @@ static void be_d2h(be_state *b, void *h, const void *d, size_t bytes)
     GIE_HIP_OK(hipStreamSynchronize(b->stream));
 }
 /* pinned host memory + asynchronous D2H with a completion event per staging slot */
-/* a few pinned host words the device can write (zero-copy) */
-static int32_t *be_pub_alloc(be_state *b, int32_t **dev)
-{
-    void *h = nullptr, *d = nullptr;
-    (void)hipSetDevice(b->device);
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
-    memset(h, 0, 64);
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
-    *dev = (int32_t *)d;
-    return (int32_t *)h;
-}
-static void be_pub_free(be_state *, int32_t *h) { if (h) (void)hipHostFree(h); }
 static void *be_host_alloc(be_state *b, size_t bytes) { void *p = nullptr; (void)hipSetDevice(b->device); return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 static void be_host_free(be_state *, void *p) { (void)hipHostFree(p); }
 static void be_d2h_async(be_state *b, void *h, const void *d, size_t bytes, int slot)
@@ -263,12 +251,16 @@ static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass,
 /* pass Z again over the whole volume (the passes before it are complete either way) */
 static void be_edt_z(be_state *b, const gie_ctx &c, int full) { gie_launch_edt_dim(b, c, c.Z, true, full); }
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
-/* sweep over a tile list (k_voxt); staged = the functor's load1/load2/finish form */
-template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool staged)
+/* adaptive sweep (k_voxa): the kernel walks the list or sweeps the volume, whichever the list's
+ * length calls for; staged = the functor's load1/load2/finish form; always_list = never sweep */
+template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool staged, bool always_list)
 {
-    const int grid = b->cu_total * 8;
-    if (staged) hipLaunchKernelGGL((k_voxt<F, true>), dim3(grid), dim3(256), 0, b->stream, c, f, list, count_idx);
-    else hipLaunchKernelGGL((k_voxt<F, false>), dim3(grid), dim3(256), 0, b->stream, c, f, list, count_idx);
+    /* workgroups per compute unit: 8 / 16 / 32 / 64 measured 0.33 / 0.27 / 0.25 / 0.25 ms for Mark on a densely known
+     * volume (sweep side); the list side does not care */
+    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
+    const int grid = b->cu_total * mult;
+    if (staged) hipLaunchKernelGGL((k_voxa<F, true>), dim3(grid), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
+    else hipLaunchKernelGGL((k_voxa<F, false>), dim3(grid), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
 }
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {
@@ -279,7 +271,9 @@ static void be_edt_prep(be_state *b, const gie_ctx &c)
     const int ncol = c.tfd[0] * c.tfd[1];
     hipLaunchKernelGGL(k_edt_prep, dim3((ncol + 3) / 4), dim3(256), 0, b->stream, c, ncol);
 }
-/* full = 1: whole volume; 0: the column kernel where somebody reads; 2: the direct kernel over tl_known */
+/* full = 1: whole volume (column kernel); 0: only where Mark reads — the direct kernel over tl_known
+ * and the column kernel are both launched and the one the known-tile count does not call for
+ * returns at once */
 static void be_edt(be_state *b, const gie_ctx &c, int full)
 {
     dim3 gy((c.X + GIE_EDTY_COLS - 1) / GIE_EDTY_COLS, c.Z);
@@ -292,7 +286,8 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 6, 1);
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0);                                                              /* GIE_K_EDT_Z */
-    if (full == 2) be_edt_z_direct(b, c); else gie_launch_edt_dim(b, c, c.Z, true, full);
+    if (!full) be_edt_z_direct(b, c);
+    gie_launch_edt_dim(b, c, c.Z, true, full);
     be_prof(b, 8, 1);
 
 }

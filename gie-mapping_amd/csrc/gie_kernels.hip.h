@@ -311,10 +311,6 @@ __global__ __launch_bounds__(GIE_EDTY_COLS * TPC) void k_edt_y(const gie_ctx c)
     const int col = threadIdx.x, q = threadIdx.y;
     const int x = blockIdx.x * GIE_EDTY_COLS + col;
     const int z = blockIdx.y;
-    /* the list of known tiles is complete (previous launch): publish its length in pinned host
-     * memory for the host's sparse / dense choice in a LATER map update */
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0)
-        __hip_atomic_store(c.pub, c.cnt[GIE_CNT_TL_KNOWN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!c.zocc[z]) return;                              /* plane without obstacle: passes X/Z never read its cy1 */
     const int X = c.X, Y = c.Y;
     const bool in = x < X;
@@ -600,6 +596,7 @@ template <int CP, int TX, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const gie_ctx c, const int ntiles_x, const int ntiles, const int full)
 {
     static_assert(TX == 16 && WAVES == 8, "a workgroup tile spans two 8-voxel tile columns, one column per wave and half");
+    if (full == 0 && gie_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) return;   /* few known tiles: k_edt_z_direct (launched next to this one) does the pass */
     constexpr int LP = 64 * CP;
     constexpr int TS = TX + 1;
     constexpr int NT = 64 * WAVES;
@@ -762,47 +759,59 @@ __global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int nco
     if (k) c.tl_known[base + __popcll(m & ((1ull << tz) - 1ull))] = t;
 }
 
-/* ------------------------------------------------------------------ sweeps over a tile list */
-/* The same per-voxel operations as k_voxz / k_voxz_staged, but only over the tiles on a list:
- * one wave per 8x8x8 tile (lane = (x,y) column of the tile, 8 voxels along z per lane), a fixed
- * grid strides through the list whose length lives in device memory.  For sparsely observed
- * volumes this replaces 65 536 workgroups that each find out they have nothing to do. */
+/* ------------------------------------------------------------------ adaptive sweeps */
+/* The per-voxel functors of fuse / Mark / obtainFrontiers / commit over either the tiles on a list
+ * (one wave per 8x8x8 tile, lane = (x,y) column of the tile) or the whole volume (the geometry of
+ * k_voxz: 64 x 4 columns per virtual workgroup), chosen by the kernel itself from the length of
+ * the list (gie_use_lists).  A fixed grid strides through the work either way: for a sparsely
+ * observed volume this replaces 65 536 workgroups that each find out they have nothing to do. */
 template <class F, bool STAGED>
-__global__ __launch_bounds__(256) void k_voxt(const gie_ctx c, const F f, const int32_t *list, const int count_idx)
+__device__ __forceinline__ void gie_vox_column(const gie_ctx &c, const F &f, const int x, const int y, const int z0)
+{
+    if (x >= c.X || y >= c.Y || f.tile_skip(c, x, y, z0)) return;
+    bool sk[8];
+    int id[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int z = z0 + k;
+        id[k] = (z < c.Z) ? gie_lid(c, x, y, z) : 0;
+        sk[k] = z >= c.Z || f.skip(c, id[k], x, y, z);
+    }
+    if (STAGED) {
+        typename F::st s[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
+        unsigned known = 0, valid = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (z0 + k < c.Z) valid |= 1u << k;
+            if (!sk[k]) known |= (unsigned)(f.finish(c, id[k], x, y, z0 + k, s[k]) != 0) << k;
+        }
+        gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (!sk[k]) f(c, x, y, z0 + k);
+    }
+}
+template <class F, bool STAGED>
+__global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const int32_t *list, const int count_idx, const int always_list)
 {
     const int n = c.cnt[count_idx];
     const int lane = threadIdx.x & 63;
-    const int waves = gridDim.x * 4;
-    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
-        const int t = list[e];
-        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
-        const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3), z0 = tz * 8;
-        if (x >= c.X || y >= c.Y || f.tile_skip(c, x, y, z0)) continue;
-        bool sk[8];
-        int id[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int z = z0 + k;
-            id[k] = (z < c.Z) ? gie_lid(c, x, y, z) : 0;
-            sk[k] = z >= c.Z || f.skip(c, id[k], x, y, z);
+    if (always_list || gie_use_lists(c, n)) {
+        const int waves = gridDim.x * 4;
+        for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+            const int t = list[e];
+            const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+            gie_vox_column<F, STAGED>(c, f, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8);
         }
-        if (STAGED) {
-            typename F::st s[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
-            unsigned known = 0, valid = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (z0 + k < c.Z) valid |= 1u << k;
-                if (!sk[k]) known |= (unsigned)(f.finish(c, id[k], x, y, z0 + k, s[k]) != 0) << k;
-            }
-            gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (!sk[k]) f(c, x, y, z0 + k);
-        }
+    } else {
+        const int gx = (c.X + 63) / 64, gy = (c.Y + 3) / 4, gz = (c.Z + 7) / 8;
+        const int nv = gx * gy * gz;
+        for (int v = blockIdx.x; v < nv; v += gridDim.x)
+            gie_vox_column<F, STAGED>(c, f, (v % gx) * 64 + lane, ((v / gx) % gy) * 4 + (int)(threadIdx.x >> 6), (v / (gx * gy)) * 8);
     }
 }
 
@@ -813,6 +822,7 @@ __global__ __launch_bounds__(256) void k_voxt(const gie_ctx c, const F f, const 
 __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
+    if (!gie_use_lists(c, n)) return;                     /* many known tiles: the column kernel (launched next to this one) does the pass */
     const int K = *c.zcount;
     const int lane = threadIdx.x & 63;
     const int waves = gridDim.x * 4;

@@ -107,7 +107,7 @@ typedef struct gie_ctx {
     int32_t *zcount;        /* how many */
     int32_t *tl_known;      /* tiles that hold a known voxel (built by k_edt_prep); count in cnt[GIE_CNT_TL_KNOWN] */
     int32_t *tl_front;      /* tiles obtainFrontiers has to look at (tsum); count in cnt[GIE_CNT_TL_FRONT] */
-    int32_t *pub;           /* pinned host words the device publishes for the host's next-frame heuristics: [0] = known tiles */
+    int force_lists;        /* -1: every kernel chooses lists or a volume sweep from its list's length; 0 / 1: forced (tests) */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
     uint64_t *cand[2];      /* wave C candidate planes (BFS level parity), all-ones = none */
     /* ---- block table of the frame: slot of every block overlapping the volume +-1 voxel */
@@ -189,6 +189,14 @@ GIE_HD int gie_in_whole(const gie_ctx &c, int x, int y, int z)
 { return x >= c.whole_lo[0] && x < c.whole_hi[0] && y >= c.whole_lo[1] && y < c.whole_hi[1] && z >= c.whole_lo[2] && z < c.whole_hi[2]; }
 GIE_HD int gie_in_wr(const gie_ctx &c, int x, int y, int z) { return x >= 0 && x < c.wr[0] && y >= 0 && y < c.wr[1] && z >= 0 && z < c.wr[2]; }
 GIE_HD int gie_lid(const gie_ctx &c, int x, int y, int z) { return (z * c.Y + y) * c.X + x; }
+/* few listed tiles: walk the list; many (more than 1/8 of the volume): sweep the volume, whose
+ * 64-voxel rows coalesce better.  Decided on the device from the list's length, so it is right
+ * for THIS map update however far the host has run ahead. */
+GIE_HD int gie_use_lists(const gie_ctx &c, int listed)
+{
+    if (c.force_lists >= 0) return c.force_lists;
+    return (long long)listed * 8 <= (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
+}
 GIE_HD int gie_tile_index(const gie_ctx &c, int x, int y, int z) { return ((z >> 3) * c.tfd[1] + (y >> 3)) * c.tfd[0] + (x >> 3); }
 GIE_HD int gie_vox_in_blk(int gx, int gy, int gz) { return ((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7); }
 GIE_HD int gie_d2(int ax, int ay, int az, int bx, int by, int bz)

@@ -63,9 +63,10 @@ static void be_vox_list_col(const gie_ctx &c, const op_fuse &f, int x, int y, in
     for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f(c, x, y, z)) known |= 1u << (z - z0); }
     f.column(c, x, y, z0, known, valid);
 }
-template <class F> static void be_vox_list(be_state *, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool)
+template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool, bool always_list)
 {
     const int n = c.cnt[count_idx];
+    if (!always_list && !gie_use_lists(c, n)) { be_vox(b, c, f); return; }        /* the same choice the device kernel makes */
     for (int e = 0; e < n; e++) {
         const int t = list[e];
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
@@ -112,10 +113,7 @@ static void be_edt_prep(be_state *, const gie_ctx &c)
 {
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     for (int t = 0; t < ntile; t++) if (c.tknown[t]) c.tl_known[c.cnt[GIE_CNT_TL_KNOWN]++] = t;
-    *c.pub = c.cnt[GIE_CNT_TL_KNOWN];
 }
-static int32_t *be_pub_alloc(be_state *, int32_t **dev) { int32_t *h = (int32_t *)calloc(16, 4); *dev = h; return h; }
-static void be_pub_free(be_state *, int32_t *h) { free(h); }
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
 static void be_edt(be_state *, const gie_ctx &c, int)
 {

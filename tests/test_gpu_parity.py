@@ -234,7 +234,7 @@ def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_tile_list_and_sweep_modes_agree_with_the_oracle(oracle_lib, monkeypatch, mode):
     """Mark, obtainFrontiers, commit and pass Z either sweep the volume or walk the lists of tiles
-    that hold something (chosen per map update from the number of known tiles).  Both forms must
+    that hold something (chosen by each kernel from the length of its list).  Both forms must
     be bit-exact; GIE_TILE_LIST forces one.  The library reads the variable once per process, so
     each mode runs in its own interpreter."""
     import subprocess, sys, os

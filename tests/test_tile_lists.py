@@ -1,5 +1,5 @@
-"""Tile lists vs volume sweeps (fuse, Mark, obtainFrontiers, commit): the host picks per map
-update; GIE_TILE_LIST forces one.  The library reads the variable once per process, so every
+"""Tile lists vs volume sweeps (fuse, Mark, obtainFrontiers, commit): every kernel picks per map
+update from the length of its list; GIE_TILE_LIST forces one.  The library reads the variable once per process, so every
 mode runs in its own interpreter.  CPU: the test-only emulation (which walks the same lists);
 GPU: tests/test_gpu_parity.py::test_tile_list_and_sweep_modes_agree_with_the_oracle."""
 import os
