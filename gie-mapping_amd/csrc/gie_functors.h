@@ -47,7 +47,7 @@ struct op_raycast_finalize { static constexpr bool rolled = false;
     GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.for_motion_planner && !c.tray[gie_tile_index(c, x, y, z0)]; }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const { return c.ray_count[id] == 0 && !c.for_motion_planner; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_raycast_finalize(c, x, y, z); } };
-/* staged ops (k_voxz_staged): st = per-voxel registers, load1/load2/finish as in gie_ops.h */
+/* staged ops (k_voxa<F, true>): st = per-voxel registers, load1/load2/finish as in gie_ops.h */
 struct op_fuse { static constexpr bool rolled = false;
     typedef gie_fuse_st st;
     GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return gie_fuse_column_idle(c, x, y, z0) != 0; }

@@ -170,13 +170,6 @@ template <class F> static void be_vox(be_state *b, const gie_ctx &c, const F &f)
     dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, (c.Z + GIE_VOX_ZPER - 1) / GIE_VOX_ZPER);
     hipLaunchKernelGGL(k_voxz<F>, grd, blk, 0, b->stream, c, f);
 }
-template <int ZP, class F> static void be_vox_staged_z(be_state *b, const gie_ctx &c, const F &f)
-{
-    dim3 blk(GIE_VOX_BX, GIE_VOX_BY, 1);
-    dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, (c.Z + ZP - 1) / ZP);
-    hipLaunchKernelGGL((k_voxz_staged<F, ZP>), grd, blk, 0, b->stream, c, f);
-}
-template <class F> static void be_vox_staged(be_state *b, const gie_ctx &c, const F &f) { be_vox_staged_z<8>(b, c, f); }
 template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f, int n)
 {
     if (n <= 0) return;
@@ -208,11 +201,6 @@ static void be_exclusive_scan(be_state *b, const int32_t *flag, int32_t *rank, i
         GIE_HIP_OK(hipMalloc(&b->scan_tmp, bytes)); b->scan_bytes = bytes;
     }
     GIE_HIP_OK(rocprim::exclusive_scan(b->scan_tmp, bytes, flag, rank, 0, (size_t)n, rocprim::plus<int32_t>(), b->stream));
-}
-static void be_block_init(be_state *b, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell)
-{
-    hipLaunchKernelGGL(k_block_init, dim3(ncell), dim3(256), 0, b->stream, c, flag, rank);
-    hipLaunchKernelGGL(k_pool_advance, dim3(1), dim3(1), 0, b->stream, c, flag, rank, ncell);
 }
 
 template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, const gie_ctx &c, int full)

@@ -1,8 +1,10 @@
 /*
  * gie_kernels.hip.h — gfx950 kernels of the map update.  HIP only (never built for the host).
  *
- *  k_vox<F>           streaming per-voxel sweeps (classify, fuse, Mark, frontiers, commit):
+ *  k_voxz<F>          streaming per-voxel sweep of the whole volume (projective OGM classify):
  *                     one wave = 64 consecutive x → every plane access is a coalesced segment.
+ *  k_voxa<F>          the same functors over a tile list or the volume, chosen on the device
+ *                     (fuse, Mark, obtainFrontiers, commit).
  *  k_edt_y            EDT pass Y (EDTphase1, local_edt_core.h:14-82): the column's occupancy
  *                     lives in registers as a bit mask; one read of _glb_type, one 2-byte write.
  *  k_edt_x / k_edt_z  EDT passes X/Z (EDTphase2/3, :84-193): the Meijster lower envelope is
@@ -22,18 +24,9 @@
 #define GIE_VOX_BX 64
 #define GIE_VOX_BY 4
 
-template <class F>
-__global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_vox(const gie_ctx c, const F f)
-{
-    const int x = blockIdx.x * GIE_VOX_BX + threadIdx.x;
-    const int y = blockIdx.y * GIE_VOX_BY + threadIdx.y;
-    const int z = blockIdx.z;
-    if (x < c.X && y < c.Y) f(c, x, y, z);
-}
-
-/* same sweep with a short z-column per thread: 16x fewer workgroups than k_vox (the sweeps over a
- * mostly-unknown volume are bound by workgroup dispatch and exposed latency, not by HBM), and
- * the skip tests of the whole column are issued back to back before any voxel is processed. */
+/* volume sweep with a short z-column per thread (the sweeps over a mostly-unknown volume are bound
+ * by workgroup dispatch and exposed latency, not by HBM); the skip tests of the whole column are
+ * issued back to back before any voxel is processed. */
 #define GIE_VOX_ZPER 8
 /* optional per-column hook of the staged sweep (only op_fuse has one: tile known/unknown summaries) */
 template <class F> __device__ __forceinline__ auto gie_column_hook_impl(const F &f, const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int)
@@ -65,38 +58,6 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c
         for (int k = 0; k < GIE_VOX_ZPER; k++)
             if (!sk[k]) f(c, x, y, z0 + k);
     }
-}
-
-/* staged form: the loads of the whole z-column are in flight before anything is consumed */
-template <class F, int ZP>
-__global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz_staged(const gie_ctx c, const F f)
-{
-    const int x = blockIdx.x * GIE_VOX_BX + threadIdx.x;
-    const int y = blockIdx.y * GIE_VOX_BY + threadIdx.y;
-    const int z0 = blockIdx.z * ZP;
-    static_assert(ZP == GIE_VOX_ZPER, "a thread's z-column is one tile high");
-    const bool in = (x < c.X && y < c.Y);
-    if (!in || f.tile_skip(c, x, y, z0)) return;
-    bool sk[ZP];
-    int id[ZP];
-    typename F::st s[ZP];
-#pragma unroll
-    for (int k = 0; k < ZP; k++) {
-        const int z = z0 + k;
-        id[k] = (z < c.Z) ? gie_lid(c, x, y, z) : 0;
-        sk[k] = z >= c.Z || f.skip(c, id[k], x, y, z);
-    }
-#pragma unroll
-    for (int k = 0; k < ZP; k++) if (!sk[k]) f.load1(c, id[k], x, y, z0 + k, s[k]);
-#pragma unroll
-    for (int k = 0; k < ZP; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
-    unsigned known = 0, valid = 0;
-#pragma unroll
-    for (int k = 0; k < ZP; k++) {
-        if (z0 + k < c.Z) valid |= 1u << k;
-        if (!sk[k]) known |= (unsigned)(f.finish(c, id[k], x, y, z0 + k, s[k]) != 0) << k;
-    }
-    gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
 }
 
 template <class F>
@@ -274,25 +235,6 @@ __global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c)
         gie_init_voxel(c, slot, threadIdx.x);
         gie_init_voxel(c, slot, threadIdx.x + 256);
     }
-}
-
-/* one workgroup per table cell: initialise the 512 voxels of a block created this frame */
-__global__ __launch_bounds__(256) void k_block_init(const gie_ctx c, const int32_t *flag, const int32_t *rank)
-{
-    const int cell = blockIdx.x;
-    if (!flag[cell]) return;
-    const int slot = *c.pool_count + rank[cell];
-    if (slot >= c.max_blocks) return;
-    gie_init_voxel(c, slot, threadIdx.x);
-    gie_init_voxel(c, slot, threadIdx.x + 256);
-}
-__global__ void k_pool_advance(const gie_ctx c, const int32_t *flag, const int32_t *rank, int ncell)
-{
-    const int total = rank[ncell - 1] + flag[ncell - 1];
-    int pc = *c.pool_count + total;
-    if (pc > c.max_blocks) pc = c.max_blocks;
-    *c.pool_count = pc;
-    c.cnt[GIE_CNT_NEWBLK] = total;
 }
 
 /* ------------------------------------------------------------------ EDT pass Y */
