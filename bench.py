@@ -196,6 +196,9 @@ def main():
     if world > 1:
         m.set_tile(tiling.tile_offset_voxels(rank, world, size), whole)
     rounds_total = [0]
+    hr = os.environ.get("GIE_HALO_ROUNDS", "1")
+    halo_mode = ["stable" if hr == "stable" else "stream"]
+    halo_rounds = 1 if hr == "stable" else max(1, int(hr))
     ray_cells = [None]
 
     def step(i):
@@ -212,10 +215,19 @@ def main():
             ray_cells[0] = int(np.abs(m.read_ogm()["ray_count"].astype(np.int64)).sum())
         m.step()
         if world > 1:
-            if backend == "nccl":
-                rounds_total[0] += tiling.exchange_until_stable_device(m, dist, rank, world, dev, halo_bufs)
-            else:
+            if backend != "nccl":
                 rounds_total[0] += tiling.exchange_until_stable(m, dist, rank, world)
+            elif halo_mode[0] == "stream":
+                # one exchange round per map update, enqueued on the mapper's own stream (RCCL included): the host never waits.
+                # Information crosses one tile boundary per map update.  GIE_HALO_ROUNDS=stable: rounds until no tile changes.
+                try:
+                    rounds_total[0] += tiling.exchange_rounds_device(m, dist, rank, world, dev, halo_bufs, rounds=halo_rounds)
+                except Exception as e:                                  # e.g. no external-stream support: host-synchronised rounds
+                    sys.stderr.write("bench: stream-ordered exchange failed (%s); falling back to synchronised rounds\n" % e)
+                    halo_mode[0] = "stable"
+                    rounds_total[0] += tiling.exchange_until_stable_device(m, dist, rank, world, dev, halo_bufs)
+            else:
+                rounds_total[0] += tiling.exchange_until_stable_device(m, dist, rank, world, dev, halo_bufs)
 
     for i in range(args.warmup):
         step(i)
@@ -318,8 +330,9 @@ def main():
                                       "parallel ray casting" if bins is None else "%dx%d range image (projective OGM)" % (rings, bins),
                                       cutoff_dist),
                        "sensor": args.sensor,
-                       "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement (%.1f rounds/step)"
-                                 % (tgrid + size + (rounds_total[0] / float(nframes),))) if world > 1 else "single volume",
+                       "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement (%.1f rounds/step, %s)"
+                                 % (tgrid + size + (rounds_total[0] / float(nframes),
+                                                    "stream-ordered, fixed" if (halo_mode[0] == "stream" and backend == "nccl") else "until no tile changes"))) if world > 1 else "single volume",
                        "known_voxel_fraction": known,
                        "wave_visits_per_step": [round((st["total_visits_" + k] - st0["total_visits_" + k]) / args.steps, 1) for k in "abc"],
                        "wave_levels_last_step": [st["levels_a"], st["levels_b"], st["levels_c"]],

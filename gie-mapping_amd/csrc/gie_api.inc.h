@@ -679,9 +679,16 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     be_lin(&m->be, c, op_refine(), nb);
     be_waves(&m->be, c, 0, 0, 1);
     be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true, false);
+    if (!seeded) return GIE_OK;          /* enqueue only: a fixed number of exchange rounds needs no answer */
     rc = gie_sync(m);
-    if (seeded) *seeded = m->h_cnt[GIE_CNT_FRONT_C];
+    *seeded = m->h_cnt[GIE_CNT_FRONT_C];
     return rc;
+}
+extern "C" int gie_get_stream(gie_mapper *m, void **stream)
+{
+    if (!m || !stream) { gie_set_err("gie_get_stream: bad arguments"); return GIE_ERR_INVALID; }
+    *stream = be_stream_handle(&m->be);
+    return GIE_OK;
 }
 
 extern "C" int gie_profile_enable(gie_mapper *m, int on)

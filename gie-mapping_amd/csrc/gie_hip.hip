@@ -97,6 +97,7 @@ static void be_d2h_async(be_state *b, void *h, const void *d, size_t bytes, int 
     GIE_HIP_OK(hipEventRecord(b->copy_ev[slot], b->stream));
 }
 static void be_wait(be_state *b, int slot) { GIE_HIP_OK(hipEventSynchronize(b->copy_ev[slot])); }
+static void *be_stream_handle(be_state *b) { return (void *)b->stream; }
 static int be_sync(be_state *b)
 {
     hipError_t e = hipStreamSynchronize(b->stream);

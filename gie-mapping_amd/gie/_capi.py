@@ -112,6 +112,7 @@ DEVICE_ONLY = {
     "profile_read": (C.c_int, [_H, C.POINTER(KernelTime), C.c_int]),
     "last_error": (C.c_char_p, []),
     "sync": (C.c_int, [_H]),
+    "get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "ogm_pointcloud_dev": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "halo_export_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "halo_import_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),

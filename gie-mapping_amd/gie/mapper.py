@@ -277,6 +277,15 @@ class Mapper(MapperBase):
             raise RuntimeError(self._err())
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}
 
+    def stream_handle(self):
+        """The mapper's HIP stream as an integer (for torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        self._chk(self._f["get_stream"](self._h, C.byref(p)))
+        return p.value or 0
+
+    def refine_async(self):
+        self._chk(self._f["refine"](self._h, None))
+
     def halo_count(self, face):
         return self._f["halo_count"](self._h, face)
 

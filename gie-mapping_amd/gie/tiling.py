@@ -155,6 +155,59 @@ def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=No
     return rounds
 
 
+def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=1):
+    """A fixed number of exchange rounds, ordered ON THE MAPPER'S STREAM: export kernels, the RCCL
+    send / receive of the face layers, ghost import and refinement are enqueued back to back and
+    the host never waits (no seed count comes back, so there is no convergence test: information
+    crosses one tile boundary per round, the rest follows with the next map update)."""
+    import torch
+    nbs = neighbours(rank, world_size)
+    for face in nbs:
+        if face not in bufs:
+            n = mapper.halo_count(face) * 20
+            bufs[face] = (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
+    if "stream" not in bufs:
+        bufs["stream"] = torch.cuda.ExternalStream(mapper.stream_handle(), device=device)
+    with torch.cuda.stream(bufs["stream"]):
+        for _ in range(rounds):
+            ops = []
+            for face, nb in sorted(nbs.items()):
+                snd, rcv = bufs[face]
+                mapper.halo_export_dev(face, snd.data_ptr())
+                ops.append(dist.P2POp(dist.isend, snd, nb))
+                ops.append(dist.P2POp(dist.irecv, rcv, nb))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()                              # stream-level: the current (= the mapper's) stream waits for RCCL
+            for face in sorted(nbs):
+                mapper.halo_import_dev(face, bufs[face][1].data_ptr())
+            mapper.refine_async()
+    return rounds
+
+
+def exchange_rounds_local_device(mappers, grid, device, rounds=1):
+    """The same stream-ordered rounds with all tiles in this process (one GPU): the neighbour's
+    stream waits for an event on the exporter's stream instead of an RCCL transfer."""
+    import torch
+    world = grid[0] * grid[1] * grid[2]
+    streams = [torch.cuda.ExternalStream(m.stream_handle(), device=device) for m in mappers]
+    for _ in range(rounds):
+        layers = {}
+        for r, m in enumerate(mappers):
+            for face, nb in neighbours(r, world).items():
+                t = torch.empty(m.halo_count(face) * 20, dtype=torch.uint8, device=device)
+                m.halo_export_dev(face, t.data_ptr())
+                ev = torch.cuda.Event()
+                ev.record(streams[r])
+                layers[(nb, face ^ 1)] = (t, ev)
+        for (r, face), (t, ev) in layers.items():
+            streams[r].wait_event(ev)
+            mappers[r].halo_import_dev(face, t.data_ptr())
+        for m in mappers:
+            m.refine_async()
+    return rounds
+
+
 def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64):
     """One tile per rank: face layers travel with torch.distributed point-to-point ops (RCCL over
     xGMI with backend "nccl", gloo on CPU); a 1-int all-reduce(sum) of the seed counts is the

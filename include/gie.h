@@ -218,7 +218,11 @@ int gie_halo_import(gie_mapper *h, int face, const gie_halo_voxel *in);
 int gie_halo_export_dev(gie_mapper *h, int face, gie_halo_voxel *d_out);
 int gie_halo_import_dev(gie_mapper *h, int face, const gie_halo_voxel *d_in);
 /* returns the number of voxels seeded from ghost neighbours in *seeded (0 = nothing changed) */
-int gie_refine(gie_mapper *h, int32_t *seeded);
+int gie_refine(gie_mapper *h, int32_t *seeded);   /* seeded == NULL: enqueue only (no synchronisation) */
+/* The HIP stream all work of this mapper is enqueued on (a hipStream_t), so that a caller can order
+ * its own device work — e.g. the RCCL transfers of the halo layers — with it instead of
+ * synchronising the host.  NULL for implementations without streams. */
+int gie_get_stream(gie_mapper *h, void **stream);
 
 /* Per-kernel device time (the reference only has the two std::chrono spans of
  * volumetric_mapper.cpp:153,187-203).  When enabled, every kernel launch of the frame is

@@ -33,7 +33,7 @@ def _sensor_frames(n):
 KW = dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi, phi_inc=np.radians(2.5), phi_min=np.radians(-40.0))
 
 
-def _run_tiled(make, exchange=True, device=None):
+def _run_tiled(make, exchange=True, device=None, fixed_rounds=0):
     cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
     ms = [make(cfg), make(cfg)]
     for r, m in enumerate(ms):
@@ -45,6 +45,9 @@ def _run_tiled(make, exchange=True, device=None):
                 m.update(pos, q, "multiscan", img, **KW)
             if not exchange:
                 rounds = 0
+            elif device is not None and fixed_rounds:
+                tiling.exchange_rounds_local_device(ms, (2, 1, 1), device, rounds=fixed_rounds)
+                rounds = -1
             elif device is not None:
                 rounds = tiling.exchange_until_stable_local_device(ms, (2, 1, 1), device)
             else:
@@ -134,3 +137,19 @@ def test_hip_tiled_device_resident_exchange(oracle_lib):
     """the *_dev halo entry points (what the RCCL path uses): layers never leave the GPU"""
     import torch
     _assert_same(_run_tiled(OracleMapper), _run_tiled(gie.Mapper, device=torch.device("cuda", 0)))
+
+
+@pytest.mark.gpu
+def test_hip_tiled_stream_ordered_rounds(oracle_lib):
+    """The exchange the multi-GPU bench uses: a fixed number of rounds enqueued on the mappers' own
+    streams (gie_get_stream, gie_refine without a seed count), the host never waits.  Rounds
+    beyond convergence change nothing, so four rounds must equal "until stable" of the oracle."""
+    import torch
+    want = _run_tiled(OracleMapper)
+    assert max(n for _, n, _ in want) <= 4
+    got = _run_tiled(gie.Mapper, device=torch.device("cuda", 0), fixed_rounds=4)
+    for k, ((ra, _, pa), (rb, _, pb)) in enumerate(zip(want, got)):
+        assert pa == pb
+        for t in range(2):
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[t][key], rb[t][key]), (k, t, key)
