@@ -78,6 +78,17 @@ def pmc(fetch_db, write_db):
         total = (2.0 * fk + wk) * 1024.0
         js[k] = round(total)
         out.append("%-16s %8d %16.0f %18.1f %16.0f %18.1f" % (k, n, fk, 2.0 * fk * 1024 / 1e6, wk, total / 1e6))
+    steps = f.get("edt_pass_y", (0, 0))[1] or w.get("edt_pass_y", (0, 0))[1]        # one launch per map update
+    if steps:
+        tot = 0.0
+        for k in set(f) | set(w):
+            if k.startswith("__"):
+                continue
+            fk, n = f.get(k, (0.0, 0)); wk, n2 = w.get(k, (0.0, 0))
+            tot += (2.0 * fk * n + wk * n2) * 1024.0
+        js["_per_step_total_bytes"] = round(tot / steps)
+        out.append("")
+        out.append("all kernels of one map update together: %.1f MB (%d map updates in the run)" % (tot / steps / 1e6, steps))
     out.append("")
     out.append("per launch = mean over the launches of the run; fetch_corrected = 2 x FETCH_SIZE (gfx950 wide-stream correction,")
     out.append("MI355X_MICROARCH.md §HBM; uncalibrated for scattered 4/8-byte accesses); hbm_bytes = fetch_corrected + WRITE_SIZE.")
