@@ -670,14 +670,54 @@ extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in
     be_free(&m->be, d);
     return rc;
 }
+/* several faces per call: one launch per step instead of one per face and step, and ONE block
+ * allocation for all ghost layers (a 2x2x2 tile has three shared faces; the exchange is bound by
+ * the number of small launches) */
+static int gie_face_set_of(const gie_ctx &c, const void *const p[6], gie_face_set *fs)
+{
+    int n = 0;
+    for (int f = 0; f < 6; f++) { fs->off[f] = n; if (p[f]) n += gie_face_count(c, f); }
+    fs->off[6] = n;
+    return n;
+}
+extern "C" int gie_halo_export_all_dev(gie_mapper *m, gie_halo_voxel *const d_out[6])
+{
+    int rc = gie_need_pose(m, "gie_halo_export_all"); if (rc) return rc;
+    if (!d_out) { gie_set_err("gie_halo_export_all: bad arguments"); return GIE_ERR_INVALID; }
+    op_halo_export_all op;
+    const int n = gie_face_set_of(m->c, (const void *const *)d_out, &op.fs);
+    for (int f = 0; f < 6; f++) op.out[f] = d_out[f];
+    be_lin(&m->be, m->c, op, n);
+    return GIE_OK;
+}
+extern "C" int gie_halo_import_all_dev(gie_mapper *m, const gie_halo_voxel *const d_in[6])
+{
+    int rc = gie_need_pose(m, "gie_halo_import_all"); if (rc) return rc;
+    if (!d_in) { gie_set_err("gie_halo_import_all: bad arguments"); return GIE_ERR_INVALID; }
+    op_halo_need_all nd; op_halo_import_all im;
+    const int n = gie_face_set_of(m->c, (const void *const *)d_in, &nd.fs);
+    im.fs = nd.fs;
+    for (int f = 0; f < 6; f++) { nd.in[f] = d_in[f]; im.in[f] = d_in[f]; }
+    if (n == 0) return GIE_OK;
+    be_lin(&m->be, m->c, nd, n);
+    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 1);
+    be_lin(&m->be, m->c, im, n);
+    return GIE_OK;
+}
 extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
 {
     int rc = gie_need_pose(m, "gie_refine"); if (rc) return rc;
     gie_ctx &c = m->c;
-    be_memset(&m->be, c.cnt + GIE_CNT_C, 0, sizeof(int32_t));
+    {   /* what the second waves launch of this map update needs zeroed, in one launch */
+        gie_clear_list l; l.n = 0;
+        l.p[l.n] = c.cnt + GIE_CNT_C; l.bytes[l.n++] = sizeof(int32_t);
+        l.p[l.n] = c.cnt + GIE_CNT_BAR_C; l.bytes[l.n++] = sizeof(int32_t);
+        l.p[l.n] = c.lvl_next; l.bytes[l.n++] = 2 * GIE_MAX_LEVELS * sizeof(int32_t);
+        be_clear(&m->be, l);
+    }
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
-    be_waves(&m->be, c, 0, 0, 1);
+    be_waves(&m->be, c, 0, 0, 0);
     be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true, false);
     if (!seeded) return GIE_OK;          /* enqueue only: a fixed number of exchange rounds needs no answer */
     rc = gie_sync(m);

@@ -142,6 +142,15 @@ struct op_tile_summary {
 struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
 struct op_halo_need { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_need_voxel(c, face, i, in); } };
 struct op_halo_import { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_import_voxel(c, face, i, in); } };
+/* the same three operations for several faces in one launch: item i belongs to the face whose
+ * [off[f], off[f+1]) range holds it (faces without a buffer have an empty range) */
+struct gie_face_set { int off[7]; GIE_DEVM int face_of(int i) const { int f = 0; while (f < 5 && i >= off[f + 1]) f++; return f; } };
+struct op_halo_export_all { gie_face_set fs; gie_halo_voxel *out[6];
+    GIE_DEVM void operator()(const gie_ctx &c, int i) const { const int f = fs.face_of(i); gie_halo_export_voxel(c, f, i - fs.off[f], out[f]); } };
+struct op_halo_need_all { gie_face_set fs; const gie_halo_voxel *in[6];
+    GIE_DEVM void operator()(const gie_ctx &c, int i) const { const int f = fs.face_of(i); gie_halo_need_voxel(c, f, i - fs.off[f], in[f]); } };
+struct op_halo_import_all { gie_face_set fs; const gie_halo_voxel *in[6];
+    GIE_DEVM void operator()(const gie_ctx &c, int i) const { const int f = fs.face_of(i); gie_halo_import_voxel(c, f, i - fs.off[f], in[f]); } };
 struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
         const int id = gie_refine_entry(c, j);
         if (id >= 0 && gie_refine_voxel(c, id)) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, id);

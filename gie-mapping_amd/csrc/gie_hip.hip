@@ -283,13 +283,28 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
 /* waves A, B and C in one launch; workgroups are co-resident by construction (1024 threads each,
  * at most one per compute unit).  The frame clear has zeroed the barrier word and the per-level
  * arrays; a second launch inside the same map update (gie_refine) clears them itself. */
+/* The waves kernel synchronises its workgroups with a grid barrier, so ALL of them have to be
+ * resident at once.  One launch is (128 workgroups on 256 compute units); two launches from
+ * different mappers on the same device at the same time need not be.  Waves launches of one
+ * device are therefore chained through an event: a launch waits for the previous one, whichever
+ * mapper (stream) it came from. */
+#include <mutex>
+static std::mutex g_waves_mutex;
+static hipEvent_t g_waves_event[64];
+static bool g_waves_event_set[64];
 static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
+    std::lock_guard<std::mutex> lock(g_waves_mutex);
+    const int dv = b->device & 63;
+    (void)hipSetDevice(b->device);
+    if (g_waves_event_set[dv]) GIE_HIP_OK(hipStreamWaitEvent(b->stream, g_waves_event[dv], 0));
+    else { GIE_HIP_OK(hipEventCreateWithFlags(&g_waves_event[dv], hipEventDisableTiming)); g_waves_event_set[dv] = true; }
     if (clear_first) {
         GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
         GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     }
     hipLaunchKernelGGL(k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, with_ab, record_seeds);
+    GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
 }
 
 #include "gie_api.inc.h"

@@ -115,6 +115,8 @@ DEVICE_ONLY = {
     "get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "ogm_pointcloud_dev": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "halo_export_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
+    "halo_export_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "halo_import_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "halo_import_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "ogm_multiscan_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(MultiScanParam)]),
     "ogm_depth_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(CamParam)]),

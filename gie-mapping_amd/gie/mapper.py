@@ -8,6 +8,7 @@ libgie_hip.so and fails loudly when it is missing — there is no CPU fallback i
 import ctypes as C
 import math
 import os
+import sys
 
 import numpy as np
 
@@ -255,6 +256,15 @@ def load_library(path=None):
         if not os.path.exists(p):
             raise RuntimeError("%s not found: build it with __graft_entry__.build() "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64,
+        # and a process that initialises the system runtime first (through this library) leaves torch
+        # without a device ("No HIP GPUs are available").  Loaded the other way round, this library
+        # binds to the runtime torch brought.  So: if torch is installed, let it load first.
+        if "torch" not in sys.modules and not os.environ.get("GIE_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = C.CDLL(p)
         _fns = _capi.bind(_lib, "gie_", _capi.DEVICE_ONLY)
     return _fns
@@ -276,6 +286,15 @@ class Mapper(MapperBase):
         if n < 0:
             raise RuntimeError(self._err())
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}
+
+    def halo_export_all_dev(self, dptrs):
+        """dptrs: {face: device pointer}; all faces in one launch."""
+        arr = (C.c_void_p * 6)(*[dptrs.get(f) for f in range(6)])
+        self._chk(self._f["halo_export_all_dev"](self._h, arr))
+
+    def halo_import_all_dev(self, dptrs):
+        arr = (C.c_void_p * 6)(*[dptrs.get(f) for f in range(6)])
+        self._chk(self._f["halo_import_all_dev"](self._h, arr))
 
     def stream_handle(self):
         """The mapper's HIP stream as an integer (for torch.cuda.ExternalStream)."""

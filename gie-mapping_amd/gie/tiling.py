@@ -171,16 +171,15 @@ def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=
     with torch.cuda.stream(bufs["stream"]):
         for _ in range(rounds):
             ops = []
+            mapper.halo_export_all_dev({face: bufs[face][0].data_ptr() for face in nbs})
             for face, nb in sorted(nbs.items()):
                 snd, rcv = bufs[face]
-                mapper.halo_export_dev(face, snd.data_ptr())
                 ops.append(dist.P2POp(dist.isend, snd, nb))
                 ops.append(dist.P2POp(dist.irecv, rcv, nb))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()                              # stream-level: the current (= the mapper's) stream waits for RCCL
-            for face in sorted(nbs):
-                mapper.halo_import_dev(face, bufs[face][1].data_ptr())
+            mapper.halo_import_all_dev({face: bufs[face][1].data_ptr() for face in nbs})
             mapper.refine_async()
     return rounds
 
@@ -192,18 +191,21 @@ def exchange_rounds_local_device(mappers, grid, device, rounds=1):
     world = grid[0] * grid[1] * grid[2]
     streams = [torch.cuda.ExternalStream(m.stream_handle(), device=device) for m in mappers]
     for _ in range(rounds):
-        layers = {}
+        layers, evs = {}, []
         for r, m in enumerate(mappers):
+            out = {}
             for face, nb in neighbours(r, world).items():
                 t = torch.empty(m.halo_count(face) * 20, dtype=torch.uint8, device=device)
-                m.halo_export_dev(face, t.data_ptr())
-                ev = torch.cuda.Event()
-                ev.record(streams[r])
-                layers[(nb, face ^ 1)] = (t, ev)
-        for (r, face), (t, ev) in layers.items():
-            streams[r].wait_event(ev)
-            mappers[r].halo_import_dev(face, t.data_ptr())
-        for m in mappers:
+                out[face] = t.data_ptr()
+                layers[(nb, face ^ 1)] = t
+            m.halo_export_all_dev(out)
+            ev = torch.cuda.Event()
+            ev.record(streams[r])
+            evs.append(ev)
+        for r, m in enumerate(mappers):
+            for ev in evs:
+                streams[r].wait_event(ev)
+            m.halo_import_all_dev({face: t.data_ptr() for (rr, face), t in layers.items() if rr == r})
             m.refine_async()
     return rounds
 

@@ -218,6 +218,10 @@ int gie_halo_import(gie_mapper *h, int face, const gie_halo_voxel *in);
 int gie_halo_export_dev(gie_mapper *h, int face, gie_halo_voxel *d_out);
 int gie_halo_import_dev(gie_mapper *h, int face, const gie_halo_voxel *d_in);
 /* returns the number of voxels seeded from ghost neighbours in *seeded (0 = nothing changed) */
+/* Several faces in one call (NULL entry = face not exchanged): one launch per step for all of
+ * them and one block allocation for all ghost layers. */
+int gie_halo_export_all_dev(gie_mapper *h, gie_halo_voxel *const d_out[6]);
+int gie_halo_import_all_dev(gie_mapper *h, const gie_halo_voxel *const d_in[6]);
 int gie_refine(gie_mapper *h, int32_t *seeded);   /* seeded == NULL: enqueue only (no synchronisation) */
 /* The HIP stream all work of this mapper is enqueued on (a hipStream_t), so that a caller can order
  * its own device work — e.g. the RCCL transfers of the halo layers — with it instead of

@@ -153,3 +153,41 @@ def test_hip_tiled_stream_ordered_rounds(oracle_lib):
         for t in range(2):
             for key in ("type", "dist_sq", "coc"):
                 assert np.array_equal(ra[t][key], rb[t][key]), (k, t, key)
+
+
+@pytest.mark.gpu
+def test_eight_mappers_share_one_device(oracle_lib):
+    """Eight tiles as eight mappers (eight streams) on ONE GPU: their waves kernels need all their
+    workgroups resident at once, so launches from different mappers must not overlap (they are
+    chained through a per-device event).  Before that, this ran into the grid-barrier time-out."""
+    import torch
+    size = (64, 64, 64)
+    grid = tiling.tile_grid(8)
+    whole = tuple(grid[i] * size[i] for i in range(3))
+    cfg = gie.make_config(0.1, size, cutoff_dist=1.0)
+    world = scenes.BoxWorld(3, extent=(5.0, 5.0, 5.0), n_boxes=60, toggle_frac=0.3)
+    def run(make, device):
+        ms = []
+        for r in range(8):
+            m = make(cfg); m.set_tile(tiling.tile_offset_voxels(r, 8, size), whole); ms.append(m)
+        out = None
+        try:
+            for k in range(4):
+                pos, q = scenes.pose(k, 0.1, delta_vox=1, yaw_deg=10.0)
+                pts, _ = scenes.lidar_frame(world, k, pos, q, rings=32, az=360, phi_min_deg=-40.0, phi_inc_deg=2.5, max_range=10.0)
+                for m in ms:
+                    m.update(pos, q, "pointcloud", pts)
+                if device is None:
+                    tiling.exchange_until_stable_local(ms, grid)
+                else:
+                    tiling.exchange_rounds_local_device(ms, grid, device, rounds=6)
+            out = [m.read_local() for m in ms]
+        finally:
+            for m in ms:
+                m.close()
+        return out
+    want = run(OracleMapper, None)
+    got = run(gie.Mapper, torch.device("cuda", 0))
+    for t in range(8):
+        for key in ("type", "dist_sq", "coc"):
+            assert np.array_equal(want[t][key], got[t][key]), (t, key)

@@ -9,7 +9,7 @@ import numpy as np, torch, bench, gie
 from gie import scenes, tiling
 
 size = tuple(int(v) for v in (sys.argv[1:4] or (512, 512, 512)))
-world = 2
+world = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 sensor = "vlp16"
 rings, az, phi_min, phi_inc, bins = bench.SENSORS[sensor]
 frames = bench.make_frames(scenes, 0.05, 10, 5, sensor)
