@@ -307,7 +307,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(dom_ms, 4),
                     "alg_bytes_per_cell": 13, "cells_per_launch": ray_cells[0],
                     "note": "per-ray 3-D DDA: a chain of dependent cell visits with one atomic each; bound by that latency chain "
-                            "(16 segments of a ray run side by side, 64 adjacent rays share atomics), not by HBM bandwidth"}
+                            "(8 segments of a ray run side by side, 64 adjacent rays share atomics), not by HBM bandwidth"}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": round(dom_ms, 4),

@@ -75,14 +75,20 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
  * cloud is 450 waves).  The DDA state at a segment's start is handed from wave to wave through
  * LDS: wave s waits for wave s-1, advances its own steps in registers (no memory), publishes the
  * state for wave s+1 and only then starts on memory — the arithmetic chain is walked once per
- * ray, the memory chains of the sixteen segments run side by side.  Phase 1 finds where the ray
+ * ray, the memory chains of the segments run side by side.  Phase 1 finds where the ray
  * stops (first OCCUPIED cell or the walk's end) as a minimum over the segments in LDS, phase 2
  * applies the decrements of the cells before that point — the same set of cells as the
  * sequential walk. */
-#define GIE_RAY_SEGS 16
-__global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int seg_steps)
+#ifndef GIE_RAY_SEGS
+#define GIE_RAY_SEGS 8       /* 4 / 8 / 16 measured: 0.108 / 0.080 / 0.083 ms (16 x 1800 cloud), 8 vs 16 on a 64 x 1800 cloud: 0.100 vs 0.166 ms */
+#endif
+#ifndef GIE_RAY_SPIN_SLEEP
+#define GIE_RAY_SPIN_SLEEP 4
+#endif
+__global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int max_seg_steps)
 {
     __shared__ int s_stop[64];
+    __shared__ int s_bound;
     __shared__ int s_cur[GIE_RAY_SEGS][3][64];
     __shared__ float s_tmax[GIE_RAY_SEGS][3][64];
     __shared__ int s_walk[GIE_RAY_SEGS][64];
@@ -92,11 +98,32 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     const bool ray = i < n;
     if (seg == 0) s_stop[lane] = 0x7fffffff;
     if (threadIdx.x < GIE_RAY_SEGS) s_ready[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_bound = 0;
     gie_dda d;
     int s0[3] = { 0, 0, 0 };
     gie_ray_marks last_tile = { -1, -1 };
     bool walk = ray && gie_dda_init(c, g, i, d, s0);      /* constants of the ray (direction, deltas, end cell) in every wave */
     __syncthreads();
+    /* The segment length follows the workgroup's own rays (neighbours in the scan: similar
+     * lengths), so that all waves have work whether the rays end after 40 cells or after
+     * 600.  Bound on the steps of a walk: along axis a at most L / tDelta_a + 1 cell borders lie
+     * within L = min(len, max_length), and the walk ends with the first step past L. */
+    if (seg == 0) {
+        int nb = 0;
+        if (walk) {
+            const float L = d.len < d.max_length ? d.len : d.max_length;
+            float f = 8.0f;                                /* 3 (+1 per axis) + 1 (last step) + rounding margin */
+#pragma unroll
+            for (int k = 0; k < 3; k++) if (d.step[k] != 0) f += L / d.tDelta[k];
+            nb = f < 1.0e6f ? (int)f : 1000000;
+        }
+#pragma unroll
+        for (int w = 1; w < 64; w <<= 1) { const int o = __shfl_xor(nb, w); nb = nb > o ? nb : o; }
+        if (lane == 0) s_bound = nb;
+    }
+    __syncthreads();
+    int seg_steps = (s_bound + GIE_RAY_SEGS - 1) / GIE_RAY_SEGS;
+    seg_steps = seg_steps < 4 ? 4 : (seg_steps > max_seg_steps ? max_seg_steps : seg_steps);
     if (seg == 0) {   /* clearRayLoc on the sensor's own cell */
         const int id0 = (ray && gie_in_loc(c, s0[0], s0[1], s0[2])) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
         if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
@@ -104,23 +131,42 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     } else {
         /* state at the end of segment seg-1 = at the start of mine */
         volatile int *rdy = &s_ready[seg - 1];
-        while (*rdy == 0) __builtin_amdgcn_s_sleep(1);
+        while (*rdy == 0) __builtin_amdgcn_s_sleep(GIE_RAY_SPIN_SLEEP);   /* waiting waves must not eat the issue slots of the one that works */
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
         for (int k = 0; k < 3; k++) { d.cur[k] = s_cur[seg - 1][k][lane]; d.tMax[k] = s_tmax[seg - 1][k][lane]; }
         walk = s_walk[seg - 1][lane] != 0;                /* a walk that ended earlier leaves nothing to do */
     }
+#if defined(GIE_RAY_TIMING)
+#if GIE_RAY_TIMING < 0      /* every workgroup: first and last stamp of wave 0 */
+#define GIE_RTS(k) do { if (seg == 0 && lane == 0 && ((k) == 0 || (k) == 4)) c.edt[blockIdx.x * 2 + ((k) ? 1 : 0)] = (float)(wall_clock64() & 0xffffff); } while (0)
+#else
+#define GIE_RTS(k) do { if (blockIdx.x == GIE_RAY_TIMING && lane == 0) c.edt[seg * 8 + (k)] = (float)(wall_clock64() & 0xffffff); } while (0)
+#endif
+#else
+#define GIE_RTS(k) do { } while (0)
+#endif
+    GIE_RTS(0);
     const int first = seg * seg_steps;
     const gie_dda at_start = d;
     const bool walk_start = walk;
     if (seg + 1 < GIE_RAY_SEGS) {                         /* my steps in registers only, for the next wave */
-        for (int k = 0; k < seg_steps && walk; k++) if (gie_dda_step(d)) walk = false;
+        /* uniform loop, no per-lane masking: a walk that has ended keeps stepping (its state is never
+         * used again: the later segments of an ended walk do nothing), only the flag is kept */
+        int ended = walk ? 0 : 1;
+        for (int k0 = 0; k0 < seg_steps; k0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (k0 + k < seg_steps) ended |= gie_dda_step(d);
+            if (__all(ended)) break;
+        }
+        walk = !ended;
 #pragma unroll
         for (int k = 0; k < 3; k++) { s_cur[seg][k][lane] = d.cur[k]; s_tmax[seg][k][lane] = d.tMax[k]; }
         s_walk[seg][lane] = walk ? 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) { volatile int *w = &s_ready[seg]; *w = 1; }
     }
+    GIE_RTS(1);
     d = at_start; walk = walk_start;
     /* phase 1 (starts as soon as this wave has its state; no workgroup barrier before it): types of the segment's cells → where does the ray stop? (exclusive step index) */
     if (walk) {
@@ -149,7 +195,9 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
         }
         if (stop != 0x7fffffff) atomicMin(&s_stop[lane], stop);
     }
+    GIE_RTS(2);
     __syncthreads();
+    GIE_RTS(3);
     /* phase 2: clear the segment's cells that lie before the stop (all lanes take part in the
      * wave aggregation; lanes without work pass -1) */
     const int stop = s_stop[lane];
@@ -166,6 +214,7 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
         gie_wave_add(c, id, -1);
 #endif
     }
+    GIE_RTS(4);
 }
 
 /* ------------------------------------------------------------------ frame clear */

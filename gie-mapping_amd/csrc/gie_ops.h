@@ -58,27 +58,31 @@ GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap,
     if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
 }
 
-/* ray_count[id] += val for every lane with id >= 0, with equal targets inside the wave merged
- * into ONE atomic (neighbouring rays of a scan share most of their cells; unmerged, thousands of
- * wave-wide same-address atomics serialise at one L2 slice).  Up to GIE_AGG_ROUNDS distinct
- * targets are merged, the rest falls back to one atomic per lane.  Safe in divergent code:
- * ballots and shuffles only involve the lanes that are executing. */
-#define GIE_AGG_ROUNDS 6
+/* ray_count[id] += val for every lane with id >= 0, with equal targets of NEIGHBOURING lanes merged
+ * into one atomic: lanes are rays adjacent in the scan, which cross the same cells at the same
+ * step near the sensor, so equal targets come as contiguous runs of lanes (unmerged, thousands of
+ * wave-wide same-address atomics serialise at one L2 slice).  One shuffle and three ballots: a
+ * lane heads a run when the lane below it does not take part or has another target; the head
+ * adds for the whole run.  Equal targets that are not neighbours simply get their own atomics.
+ * Safe in divergent code: only executing lanes are looked at. */
 GIE_DEV void gie_wave_add(const gie_ctx &c, int id, int val)
 {
 #if defined(GIE_HOST_EMU)
     if (id >= 0) c.ray_count[id] += val;
 #else
-    unsigned long long todo = __ballot(id >= 0);
     const int lane = __lane_id();
-    for (int r = 0; r < GIE_AGG_ROUNDS && todo; r++) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lid = __shfl(id, leader);
-        const unsigned long long same = __ballot(id == lid) & todo;
-        if (lane == leader) gie_aadd32(&c.ray_count[lid], val * __popcll(same));
-        todo &= ~same;
+    const unsigned long long exec = __ballot(1);
+    const unsigned long long valid = __ballot(id >= 0);
+    if (!valid) return;
+    const int below = __builtin_amdgcn_update_dpp(id, id, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);   /* lane-1's id without the LDS crossbar */
+    const bool below_in = lane > 0 && ((exec & valid) >> (lane - 1)) & 1ull;
+    const bool head = id >= 0 && !(below_in && below == id);
+    const unsigned long long heads = __ballot(head);
+    if (head) {
+        const unsigned long long stops = (heads | ~valid) & ~((2ull << lane) - 1ull);   /* where the run above me ends */
+        const int end = (lane == 63 || !stops) ? 64 : __ffsll((long long)stops) - 1;
+        gie_aadd32(&c.ray_count[id], val * (end - lane));
     }
-    if (id >= 0 && ((todo >> lane) & 1ull)) gie_aadd32(&c.ray_count[id], val);
 #endif
 }
 
@@ -255,16 +259,18 @@ GIE_DEV int gie_dda_init(const gie_ctx &c, const float *g, int i, gie_dda &d, in
  * past the ray / the maximum length): that cell is still cleared, the walk ends after it */
 GIE_DEV int gie_dda_step(gie_dda &d)
 {
-    int dim;
-    if (d.tMax[0] < d.tMax[1]) dim = (d.tMax[0] < d.tMax[2]) ? 0 : 2;
-    else dim = (d.tMax[1] < d.tMax[2]) ? 1 : 2;
-    /* unrolled select instead of dynamic indexing keeps everything in registers */
-    if (dim == 0) { d.cur[0] += d.step[0]; d.tMax[0] += d.tDelta[0]; }
-    else if (dim == 1) { d.cur[1] += d.step[1]; d.tMax[1] += d.tDelta[1]; }
-    else { d.cur[2] += d.step[2]; d.tMax[2] += d.tDelta[2]; }
+    /* the axis whose boundary comes first (ray_cast.h:104-118: x if tMax.x < tMax.y and < tMax.z, else y if
+     * tMax.y < tMax.z, else z), written with selects only: as branches this loop body costs several
+     * exec-mask round trips per step, and the walk is a chain of a few hundred dependent steps */
+    const bool c01 = d.tMax[0] < d.tMax[1], c02 = d.tMax[0] < d.tMax[2], c12 = d.tMax[1] < d.tMax[2];
+    const bool is0 = c01 & c02, is1 = (!c01) & c12, is2 = !(is0 | is1);
+    d.cur[0] = is0 ? d.cur[0] + d.step[0] : d.cur[0]; d.tMax[0] = is0 ? d.tMax[0] + d.tDelta[0] : d.tMax[0];
+    d.cur[1] = is1 ? d.cur[1] + d.step[1] : d.cur[1]; d.tMax[1] = is1 ? d.tMax[1] + d.tDelta[1] : d.tMax[1];
+    d.cur[2] = is2 ? d.cur[2] + d.step[2] : d.cur[2]; d.tMax[2] = is2 ? d.tMax[2] + d.tDelta[2] : d.tMax[2];
     const float m01 = d.tMax[0] < d.tMax[1] ? d.tMax[0] : d.tMax[1];
     const float dist = m01 < d.tMax[2] ? m01 : d.tMax[2];
-    return (d.cur[0] == d.i1[0] && d.cur[1] == d.i1[1] && d.cur[2] == d.i1[2]) || dist > d.max_length || dist > d.len;
+    const int at_end = (d.cur[0] == d.i1[0]) & (d.cur[1] == d.i1[1]) & (d.cur[2] == d.i1[2]);
+    return at_end | (int)(dist > d.max_length) | (int)(dist > d.len);
 }
 /* upper bound of the cells one ray can visit: max_length / w voxels along the ray, at most
  * |dx|+|dy|+|dz| <= sqrt(3) cell changes per voxel of length */
