@@ -248,9 +248,22 @@ def main():
     prof = m.profile_read()
     st = m.stats()
     known = None
+    units = {}
     if rank == 0:
         ty = m.read_local(edt=False, dist_sq=False, coc=False)["type"]
-        known = float((ty != 0).mean())
+        kn = ty != 0
+        known = float(kn.mean())
+        # the units a launch processes (per-unit bytes x units of one launch): the sweeps only work on
+        # observed voxels, the EDT passes Y / X on the planes that hold obstacles, pass Z on the tiles Mark reads
+        n_known = int(kn.sum())
+        planes = int((ty == 2).any(axis=(1, 2)).sum())
+        Zs, Ys, Xs = ty.shape
+        pad = [(0, (-Zs) % 8), (0, (-Ys) % 8), (0, (-Xs) % 8)]
+        kt = np.pad(kn, pad).reshape((Zs + pad[0][1]) // 8, 8, (Ys + pad[1][1]) // 8, 8, (Xs + pad[2][1]) // 8, 8).any(axis=(1, 3, 5))
+        units = {"fuse": n_known, "mark": n_known, "frontiers": n_known, "commit": n_known,
+                 "edt_pass_y": planes * Ys * Xs, "edt_pass_x": planes * Ys * Xs, "edt_pass_z": int(kt.sum()) * 512,
+                 "ogm_classify": n_vox}
+        del ty, kn, kt
 
     t_max = dt
     if dist is not None:
@@ -269,20 +282,20 @@ def main():
         dom_ms = sweeps[dom][0] / sweeps[dom][1]
         roof = None
         if dom in ALG_BYTES:
-            achieved = ALG_BYTES[dom] * n_vox / (dom_ms * 1e-3) / 1e9
+            achieved = ALG_BYTES[dom] * units.get(dom, n_vox) / (dom_ms * 1e-3) / 1e9
             traffic = None
             tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(dom)
+                    traffic = sum(v for k3, v in json.load(open(tp)).items() if k3 == dom or k3.startswith(dom + ".")) or None
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_voxel": ALG_BYTES[dom],
-                    "note": "achieved = the reference's per-voxel bytes for the WHOLE volume / launch time (SURVEY 8d); the kernels skip "
-                            "tiles and planes that hold nothing to do, so the measured HBM bytes (traffic, rocprofv3 PMC) are far below "
-                            "the algorithmic bytes on a sparsely observed volume"}
+                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_voxel": ALG_BYTES[dom], "voxels_per_launch": units.get(dom, n_vox),
+                    "note": "achieved = the reference's per-voxel bytes x the voxels one launch works on (observed voxels for the "
+                            "sweeps, the planes that hold obstacles for EDT passes Y/X, the tiles Mark reads for pass Z; state of "
+                            "the last timed map update) / average launch time; traffic = rocprofv3 PMC bytes per launch"}
         elif dom == "waves":
             # BFS waves A+B+C (one launch): algorithmic bytes = 64 B per visited voxel (own record + six 8-byte RMWs)
             visits = sum(st["total_visits_" + k] - st0["total_visits_" + k] for k in "abc") / float(sweeps[dom][1])
@@ -300,7 +313,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(dom)
+                    traffic = sum(v for k3, v in json.load(open(tp)).items() if k3 == dom or k3.startswith(dom + ".")) or None
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -317,8 +330,10 @@ def main():
         for k2, v2 in sweeps.items():
             if k2 in ALG_BYTES:
                 ms2 = v2[0] / v2[1]
-                sweeps_roof[k2] = {"avg_launch_ms": round(ms2, 4), "achieved_GBps": round(ALG_BYTES[k2] * n_vox / (ms2 * 1e-3) / 1e9, 1),
-                                   "frac": round(ALG_BYTES[k2] * n_vox / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                u2 = units.get(k2, n_vox)
+                sweeps_roof[k2] = {"avg_launch_ms": round(ms2, 4), "voxels_per_launch": u2,
+                                   "achieved_GBps": round(ALG_BYTES[k2] * u2 / (ms2 * 1e-3) / 1e9, 1),
+                                   "frac": round(ALG_BYTES[k2] * u2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # HBM bytes one map update really moves: rocprofv3 PMC (FETCH_SIZE corrected + WRITE_SIZE) per launch of the
         # committed profile of this workload, summed over the kernels of a step (None without the profile)
         measured_bytes = None
