@@ -158,10 +158,14 @@ int gie_sync(gie_mapper *h);
  * dist_sq: N (pair distance); coc_xyz: 3N global coords of the closest obstacle
  * (GIE_EMPTY_VALUE x3 when there is none). */
 int gie_read_local(gie_mapper *h, float *edt, int8_t *type, int32_t *dist_sq, int32_t *coc_xyz);
-/* Intermediate state for parity tests: OGM scan labels / hit-miss counters (before fuse). */
+/* Intermediate state for parity tests: OGM scan labels / hit-miss counters (before fuse).  After a
+ * ray-cast scan the FREE / OCCUPIED labels of the counted cells (getAllocKeys) are only written
+ * when this call asks for them: fuse works from the counters. */
 int gie_read_ogm(gie_mapper *h, int8_t *inst_type, int32_t *ray_count);
 /* Batch EDT result before the merge: dist² (_aux) and local closest-obstacle coords
- * (_coc_idx_aux unpacked; -1 x3 when the volume holds no obstacle). */
+ * (_coc_idx_aux unpacked; -1 x3 when the volume holds no obstacle).  The map update itself only
+ * produces this plane where it is read (voxels of tiles that hold a known voxel); this call
+ * completes it over the whole volume first. */
 int gie_read_batch_edt(gie_mapper *h, int32_t *dist_sq, int32_t *coc_xyz_local);
 /* LocMap::convertCostMap (local_batch.h:382-391) + setupEDTmsg4Motion
  * (volumetric_mapper.cpp:375-389). payload: N gie_seendist. */
