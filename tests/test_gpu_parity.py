@@ -251,3 +251,23 @@ def test_tile_list_and_sweep_modes_agree_with_the_oracle(oracle_lib, monkeypatch
     env = dict(os.environ, GIE_TILE_LIST=mode)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_long_run_robot_travels_and_returns(oracle_lib):
+    """Sixty map updates with the robot travelling three volume widths away and back through a
+    changing scene: blocks leave the local volume and come back, tile flags / stamps / lists are
+    reused frame after frame.  Every array bit for bit every frame (parity.run_and_compare)."""
+    sc = parity.Scenario("long_run", (64, 56, 32), sensor="mixed", frames=60, delta_vox=7, yaw_deg=23.0, n_boxes=80,
+                         extent=(10.0, 5.0, 1.5), toggle=0.3)
+    # there and back again: scenes.pose(k) moves along +x; mirror the second half
+    orig = sc.frames_iter
+    def there_and_back():
+        fr = list(orig())
+        half = len(fr) // 2
+        for k, f in enumerate(fr):
+            yield f if k < half else (fr[len(fr) - 1 - k][0], fr[len(fr) - 1 - k][1]) + f[2:]
+    sc.frames_iter = there_and_back
+    out = parity.run_and_compare(sc, OracleMapper, gie.Mapper)
+    assert len(out) == 60
+    assert sum(s["visits_c"] for s in out) > 0 and max(s["blocks_total"] for s in out) > 300

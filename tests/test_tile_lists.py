@@ -29,3 +29,24 @@ def test_both_modes_match_the_oracle_on_cpu(mode):
     load()                                            # build the emulation once, outside the children
     r = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, GIE_TILE_LIST=mode), capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_long_run_there_and_back_on_cpu():
+    """Thirty map updates, the robot travelling away and back (blocks leave and re-enter the local
+    volume, tile flags and lists are reused frame after frame), kernels choosing lists or sweeps
+    themselves: emulation == oracle, every array, every frame."""
+    import parity
+    from emu_py import EmuMapper
+    from oracle_py import OracleMapper
+    sc = parity.Scenario("long_run_cpu", (48, 40, 24), sensor="mixed", frames=30, delta_vox=7, yaw_deg=23.0, n_boxes=60,
+                         extent=(8.0, 4.0, 1.2), toggle=0.3)
+    orig = sc.frames_iter
+
+    def there_and_back():
+        fr = list(orig())
+        half = len(fr) // 2
+        for k, f in enumerate(fr):
+            yield f if k < half else (fr[len(fr) - 1 - k][0], fr[len(fr) - 1 - k][1]) + f[2:]
+    sc.frames_iter = there_and_back
+    out = parity.run_and_compare(sc, OracleMapper, EmuMapper)
+    assert len(out) == 30 and sum(s["visits_c"] for s in out) > 0
