@@ -271,3 +271,17 @@ def test_long_run_robot_travels_and_returns(oracle_lib):
     out = parity.run_and_compare(sc, OracleMapper, gie.Mapper)
     assert len(out) == 60
     assert sum(s["visits_c"] for s in out) > 0 and max(s["blocks_total"] for s in out) > 300
+
+
+@pytest.mark.gpu
+def test_block_pool_overflow_fails_loudly():
+    """A pool that is too small is a sticky, reported error (never a silent wrong map or a crash)."""
+    sc = parity.Scenario("tiny_pool", (64, 64, 32), sensor="depth", frames=3)
+    cfg = gie.make_config(sc.voxel, sc.size, cutoff_dist=1.0, max_blocks=7)
+    m = gie.Mapper(cfg)
+    with pytest.raises(RuntimeError) as e:
+        for pos, q, kind, data, kw in sc.frames_iter():
+            m.update(pos, q, kind, data, **kw)
+            m.sync()
+    assert "block pool" in str(e.value)
+    m.close()

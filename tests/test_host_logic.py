@@ -36,3 +36,19 @@ def test_waves_are_exercised(oracle_lib):
     assert sum(s["visits_a"] for s in stats) > 0
     assert sum(s["visits_b"] for s in stats) > 0
     assert sum(s["visits_c"] for s in stats) > 0
+
+
+def test_block_pool_overflow_fails_loudly_emulation():
+    """A pool that is too small is a sticky, reported error (never a silent wrong map)."""
+    import gie as _gie
+    from emu_py import EmuMapper
+    from parity import Scenario
+    sc = Scenario("tiny_pool", (40, 40, 16), sensor="depth", frames=2)
+    cfg = _gie.make_config(sc.voxel, sc.size, cutoff_dist=1.0, max_blocks=5)
+    m = EmuMapper(cfg)
+    with pytest.raises(RuntimeError) as e:
+        for pos, q, kind, data, kw in sc.frames_iter():
+            m.update(pos, q, kind, data, **kw)
+            m.sync()
+    assert "block pool" in str(e.value)
+    m.close()
