@@ -45,7 +45,7 @@ struct op_classify_scan2d { static constexpr bool rolled = false;
 struct op_raycast_finalize { static constexpr bool rolled = false;
     /* no ray went through the tile (the robot sphere of for_motion_planner is written without rays) */
     GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.for_motion_planner && !c.tray[gie_tile_index(c, x, y, z0)]; }
-    GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const { return c.ray_count[id] == 0 && !c.for_motion_planner; }
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.ray_count[id] == 0 && !c.for_motion_planner; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_raycast_finalize(c, x, y, z); } };
 /* staged ops (k_voxa<F, true>): st = per-voxel registers, load1/load2/finish as in gie_ops.h */
 struct op_fuse { static constexpr bool rolled = false;

@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int 
 }
 __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb, const int record_seeds, gie_wg_scratch &s_wg)
 {
-    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
+    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x;
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;
     if (boss) {
