@@ -22,7 +22,21 @@ struct op_classify_depth { static constexpr bool rolled = false;
         const int t = gie_classify_depth(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
 struct op_classify_multiscan { static constexpr bool rolled = false;
-    GIE_DEVM bool tile_skip(const gie_ctx &, int, int, int) const { return false; } const float *img; gie_multiscan_param p; float tan_lo, tan_hi; int fov_test;
+    const float *img; gie_multiscan_param p; float tan_lo, tan_hi; int fov_test;
+    /* the whole z-column (a straight segment in the sensor frame) lies above or below the field of
+     * view when both its end voxels do: lz - hor*tan_hi is concave along a segment for tan_hi >= 0
+     * (hor = distance from the sensor axis is convex), lz - hor*tan_lo convex for tan_lo <= 0, so
+     * the end points bound the interior.  The per-voxel test's 1e-4 widening covers the rounding. */
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const {
+        if (!fov_test || c.for_motion_planner || !(tan_hi >= 0.f && tan_lo <= 0.f)) return false;
+        const float w = c.voxel_width;
+        const int z1 = (z0 + 7 < c.Z) ? z0 + 7 : c.Z - 1;
+        float ax, ay, az, bx, by, bz;
+        gie_se3_apply(c.G2L, (float)(x + c.pvt[0]) * w, (float)(y + c.pvt[1]) * w, (float)(z0 + c.pvt[2]) * w, &ax, &ay, &az);
+        gie_se3_apply(c.G2L, (float)(x + c.pvt[0]) * w, (float)(y + c.pvt[1]) * w, (float)(z1 + c.pvt[2]) * w, &bx, &by, &bz);
+        const float ha = sqrtf(ay * ay + ax * ax), hb = sqrtf(by * by + bx * bx);
+        return (az > ha * tan_hi && bz > hb * tan_hi) || (az < ha * tan_lo && bz < hb * tan_lo);
+    }
     /* conservative field-of-view test: elevation surely outside [phi_min - inc/2, phi_max + inc/2]
      * (bounds widened by 1e-3 rad on the host, far above the 2-ulp error of gie_atan2f) */
     GIE_DEVM bool skip(const gie_ctx &c, int, int x, int y, int z) const {
