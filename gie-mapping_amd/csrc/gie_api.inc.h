@@ -371,7 +371,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_lin(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     be_prof(&m->be, GIE_K_ALLOC, 1);
     be_prof(&m->be, GIE_K_FUSE, 0);
-    be_vox_list(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, true, false);
+    be_vox_list<true>(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, false);
     be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
@@ -397,17 +397,17 @@ extern "C" int gie_merge(gie_mapper *m)
     be_time(&m->be, 6);
     const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
     be_prof(&m->be, GIE_K_MARK, 0);
-    be_vox_list(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false, false);
+    be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false);
     be_prof(&m->be, GIE_K_MARK, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_lin(&m->be, m->c, op_tile_summary(), ntile);
     /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
      * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
-    be_vox_list(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, false, true);
+    be_vox_list<false>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, true);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     be_prof(&m->be, GIE_K_COMMIT, 0);
-    be_vox_list(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, true, false);
+    be_vox_list<true>(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, false);
     be_prof(&m->be, GIE_K_COMMIT, 1);
     be_time(&m->be, 7);
     return GIE_OK;
@@ -718,7 +718,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
     be_waves(&m->be, c, 0, 0, 0);
-    be_vox_list(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, true, false);
+    be_vox_list<true>(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, false);
     if (!seeded) return GIE_OK;          /* enqueue only: a fixed number of exchange rounds needs no answer */
     rc = gie_sync(m);
     *seeded = m->h_cnt[GIE_CNT_FRONT_C];

@@ -242,14 +242,12 @@ static void be_edt_z(be_state *b, const gie_ctx &c, int full) { gie_launch_edt_d
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
 /* adaptive sweep (k_voxa): the kernel walks the list or sweeps the volume, whichever the list's
  * length calls for; staged = the functor's load1/load2/finish form; always_list = never sweep */
-template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool staged, bool always_list)
+template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool always_list)
 {
     /* workgroups per compute unit: 8 / 16 / 32 / 64 measured 0.33 / 0.27 / 0.25 / 0.25 ms for Mark on a densely known
      * volume (sweep side); the list side does not care */
     static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
-    const int grid = b->cu_total * mult;
-    if (staged) hipLaunchKernelGGL((k_voxa<F, true>), dim3(grid), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
-    else hipLaunchKernelGGL((k_voxa<F, false>), dim3(grid), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
+    hipLaunchKernelGGL((k_voxa<F, STAGED>), dim3(b->cu_total * mult), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
 }
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {

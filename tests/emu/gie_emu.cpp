@@ -63,7 +63,7 @@ static void be_vox_list_col(const gie_ctx &c, const op_fuse &f, int x, int y, in
     for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f(c, x, y, z)) known |= 1u << (z - z0); }
     f.column(c, x, y, z0, known, valid);
 }
-template <class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool, bool always_list)
+template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool always_list)
 {
     const int n = c.cnt[count_idx];
     if (!always_list && !gie_use_lists(c, n)) { be_vox(b, c, f); return; }        /* the same choice the device kernel makes */
