@@ -801,7 +801,10 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
     } else {
         const int gx = (c.X + 63) / 64, gy = (c.Y + 3) / 4, gz = (c.Z + 7) / 8;
         const int nv = gx * gy * gz;
-        for (int v = blockIdx.x; v < nv; v += gridDim.x)
+        /* a workgroup takes a contiguous run of virtual workgroups (whole x rows of one (y, z) strip):
+         * measured a little faster than striding through the volume (fuse 0.18 -> 0.155 ms, dense) */
+        const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
+        for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++)
             gie_vox_column<F, STAGED>(c, f, (v % gx) * 64 + lane, ((v / gx) % gy) * 4 + (int)(threadIdx.x >> 6), (v / (gx * gy)) * 8);
     }
 }
