@@ -827,20 +827,35 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
         const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3), z0 = tz * 8;
         if (x >= c.X || y >= c.Y) continue;
         const size_t o = (size_t)y * c.X + x;
-        uint32_t best[8], win[8];
+        /* key = (dist² << 10) | site rank: one v_min per voxel and site, ties go to the smaller rank =
+         * smaller z (dist² < 2^22 is gie_create's envelope limit); four plane reads in flight per trip */
+        uint32_t best[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { best[k] = 0xffffffffu; win[k] = GIE_BCOC_NONE; }
-        for (int j = 0; j < K; j++) {
-            const int zj = c.zlist[j];
-            const uint32_t v = c.cxy2[(size_t)zj * plane + o];
-            const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16);
-            const uint32_t a = (uint32_t)(dx * dx + dy * dy);
-            const uint32_t pk = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), zj);
+        for (int k = 0; k < 8; k++) best[k] = 0xffffffffu;
+        for (int j0 = 0; j0 < K; j0 += 4) {
+            int zj[4]; uint32_t v[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int dz = z0 + k - zj;
-                const uint32_t key = a + (uint32_t)(dz * dz);
-                if (key < best[k]) { best[k] = key; win[k] = pk; }
+            for (int u = 0; u < 4; u++) { const int j = j0 + u < K ? j0 + u : K - 1; zj[u] = c.zlist[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u < K ? j0 + u : K - 1;           /* a repeated site does not change a minimum */
+                const int dx = x - (int)(v[u] & 0xffffu), dy = y - (int)(v[u] >> 16);
+                const uint32_t a = (uint32_t)(dx * dx + dy * dy);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int dz = z0 + k - zj[u];
+                    best[k] = min(best[k], ((a + (uint32_t)(dz * dz)) << 10) | (uint32_t)j);
+                }
+            }
+        }
+        uint32_t win[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            win[k] = GIE_BCOC_NONE;
+            if (K > 0) {
+                const int zw = c.zlist[best[k] & 1023u];
+                const uint32_t vw = c.cxy2[(size_t)zw * plane + o];
+                win[k] = gie_pack_bcoc((int)(vw & 0xffffu), (int)(vw >> 16), zw);
             }
         }
 #pragma unroll
