@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c)
  * reads a quarter of the types and publishes its mask words through LDS, then every thread
  * holds the whole mask in registers and writes the answers of its own quarter — 4x the waves
  * in flight of a thread-per-column scan, same HBM traffic (1 B read + 2 B written per voxel). */
+#ifndef GIE_EDTY_COLS
 #define GIE_EDTY_COLS 64
+#endif
 template <int YW, int TPC>
 __global__ __launch_bounds__(GIE_EDTY_COLS * TPC) void k_edt_y(const gie_ctx c)
 {
