@@ -400,7 +400,7 @@ extern "C" int gie_merge(gie_mapper *m)
     be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false);
     be_prof(&m->be, GIE_K_MARK, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
-    be_lin(&m->be, m->c, op_tile_summary(), ntile);
+    be_list(&m->be, m->c, op_tile_summary(), m->c.tl_known, GIE_CNT_TL_KNOWN);   /* only tiles with a known voxel can have anything to look at */
     /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
      * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
     be_vox_list<false>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, true);

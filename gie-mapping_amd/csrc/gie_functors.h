@@ -127,10 +127,13 @@ struct op_frontier { static constexpr bool rolled = false;
 struct op_tile_summary {
     /* tile holds an unknown voxel: fuse said so, or fuse never looked at it (then it is all-unknown) */
     GIE_DEVM static int unk(const gie_ctx &c, int t) { return c.tunk[t] | (c.tact[t] ^ 1); }
+    /* called for the tiles on tl_known (t = -1: a padding lane of the last wave) */
     GIE_DEVM void operator()(const gie_ctx &c, int t) const {
+        const bool real = t >= 0;
+        if (!real) t = 0;
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
         uint8_t v = 0;
-        if (c.tknown[t]) {
+        if (real && c.tknown[t]) {
             if (tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1) v = 1;
             else {
                 const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
@@ -138,7 +141,7 @@ struct op_tile_summary {
                   | unk(c, t + sy) | c.tflag[t + sy] | unk(c, t - sz) | c.tflag[t - sz] | unk(c, t + sz) | c.tflag[t + sz]);
             }
         }
-        c.tsum[t] = v;
+        if (real) c.tsum[t] = v;
         /* the tiles with something to look at, as a list (order is irrelevant) */
 #if defined(GIE_HOST_EMU)
         if (v) c.tl_front[c.cnt[GIE_CNT_TL_FRONT]++] = t;

@@ -249,6 +249,10 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
     static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
     hipLaunchKernelGGL((k_voxa<F, STAGED>), dim3(b->cu_total * mult), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
 }
+template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
+{
+    hipLaunchKernelGGL(k_list<F>, dim3(b->cu_total), dim3(256), 0, b->stream, c, f, list, count_idx);
+}
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {
     hipLaunchKernelGGL(k_edt_z_direct, dim3(b->cu_total * 8), dim3(256), 0, b->stream, c);

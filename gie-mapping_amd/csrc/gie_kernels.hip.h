@@ -752,6 +752,18 @@ __global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int nco
     if (k) c.tl_known[base + __popcll(m & ((1ull << tz) - 1ull))] = t;
 }
 
+/* f(c, list[e]) for every entry of a device-side list (fixed grid, the length lives in device memory) */
+template <class F>
+__global__ __launch_bounds__(256) void k_list(const gie_ctx c, const F f, const int32_t *list, const int count_idx)
+{
+    const int n = c.cnt[count_idx];
+    /* whole waves run (the functor may ballot): lanes past the end get the entry -1 */
+    for (int e0 = blockIdx.x * 256; e0 < n; e0 += gridDim.x * 256) {
+        const int e = e0 + (int)threadIdx.x;
+        f(c, e < n ? list[e] : -1);
+    }
+}
+
 /* ------------------------------------------------------------------ adaptive sweeps */
 /* The per-voxel functors of fuse / Mark / obtainFrontiers / commit over either the tiles on a list
  * (one wave per 8x8x8 tile, lane = (x,y) column of the tile) or the whole volume (the geometry of

@@ -54,6 +54,8 @@ static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
         f.column(c, x, y, z0, known, valid);
     }
 }
+template <class F> static void be_list(be_state *, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
+{ const int n = c.cnt[count_idx]; for (int e = 0; e < n; e++) f(c, list[e]); }
 /* the list form: only the listed tiles, one (x,y) column of a tile at a time like a device lane */
 template <class F> static void be_vox_list_col(const gie_ctx &c, const F &f, int x, int y, int z0)
 { for (int z = z0; z < z0 + 8 && z < c.Z; z++) if (!f.skip(c, gie_lid(c, x, y, z), x, y, z)) f(c, x, y, z); }
