@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     __shared__ int s_ready[GIE_RAY_SEGS];
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
-    const bool ray = i < n;
+    const bool ray = i < n && gie_point_ok(g[3 * (i < n ? i : 0)], g[3 * (i < n ? i : 0) + 1], g[3 * (i < n ? i : 0) + 2]);
     if (seg == 0) s_stop[lane] = 0x7fffffff;
     if (threadIdx.x < GIE_RAY_SEGS) s_ready[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_bound = 0;

@@ -205,7 +205,7 @@ GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out
     float gx, gy, gz;
     gie_se3_apply(c.L2G, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &gx, &gy, &gz);
     g_out[3 * i] = gx; g_out[3 * i + 1] = gy; g_out[3 * i + 2] = gz;
-    if (gz >= c.min_h && gz <= c.max_h) {
+    if (gie_point_ok(gx, gy, gz) && gz >= c.min_h && gz <= c.max_h) {
         const int lx = gie_pos2coord(gx, c.voxel_width) - c.pvt[0];
         const int ly = gie_pos2coord(gy, c.voxel_width) - c.pvt[1];
         const int lz = gie_pos2coord(gz, c.voxel_width) - c.pvt[2];
@@ -282,6 +282,7 @@ GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
     gie_dda d;
     int s0[3];
     gie_ray_marks last_tile = { -1, -1 };
+    if (!gie_point_ok(g[3 * i], g[3 * i + 1], g[3 * i + 2])) return;
     const int walk = gie_dda_init(c, g, i, d, s0);
     {   /* clearRayLoc on the sensor's own cell */
         const int id0 = gie_in_loc(c, s0[0], s0[1], s0[2]) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;

@@ -123,7 +123,9 @@ void gie_destroy(gie_mapper *h);
 int gie_set_pose(gie_mapper *h, const float pos[3], const float quat_wxyz[4]);
 
 /* PntcldMapMaker::updateLocalOGM (pntcld_map_maker.cpp:63-73) →
- * PNTCLD_RAYCAST::localOGMKernels (pntcld_raycast.cu:105-117). xyz: n sensor-frame points. */
+ * PNTCLD_RAYCAST::localOGMKernels (pntcld_raycast.cu:105-117). xyz: n sensor-frame points.
+ * n == 0 is a valid (empty) scan.  A point whose global-frame coordinates are not finite or lie
+ * beyond +-1e6 m is ignored (gie_math.h gie_point_ok; undefined in the reference). */
 int gie_ogm_pointcloud(gie_mapper *h, const float *xyz, int n);
 int gie_ogm_pointcloud_dev(gie_mapper *h, const float *d_xyz, int n);
 /* Vlp16MapMaker::updateLocalOGM (vlp16_map_maker.cpp:51-71) → VLP_FAST::localOGMKernels

@@ -69,6 +69,16 @@ GIE_HD void gie_se3_apply(const gie_se3 s, float px, float py, float pz, float *
 /* local_batch.h:250-258 */
 GIE_HD int gie_pos2coord(float p, float w) { return (int)floorf(p / w + 0.5f); }
 
+/* A cloud point takes part in ray casting only if its global-frame coordinates are finite and
+ * within +-1e6 m: the reference converts whatever it gets to a voxel coordinate
+ * (pntcld_raycast.cu:88-94, ray_cast.h:62-66), which for NaN / Inf / huge values is an undefined
+ * float->int conversion; PointCloud2 messages with is_dense == false do carry NaN points.  Here
+ * such a point is ignored: it registers nothing and casts no ray (not even the sensor's own cell). */
+GIE_HD int gie_point_ok(float gx, float gy, float gz)
+{
+    return fabsf(gx) <= 1.0e6f && fabsf(gy) <= 1.0e6f && fabsf(gz) <= 1.0e6f;   /* false for NaN */
+}
+
 /* atan on [0, inf) by the classic three-interval reduction and a degree-4 (in z = x*x) odd
  * polynomial; |error| < 2 ulp.  The reference calls CUDA atan2f under -use_fast_math, which is
  * not reproducible anywhere else; this is the pinned stand-in on both sides. */

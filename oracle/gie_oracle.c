@@ -323,7 +323,7 @@ int go_ogm_pointcloud(gie_oracle *o, const float *xyz, int n)
     for (int i = 0; i < n; i++) {
         gie_se3_apply(o->L2G, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &g[3 * i], &g[3 * i + 1], &g[3 * i + 2]);
         const float gz = g[3 * i + 2];
-        if (gz >= o->cfg.ogm_min_h && gz <= o->cfg.ogm_max_h) {
+        if (gie_point_ok(g[3 * i], g[3 * i + 1], gz) && gz >= o->cfg.ogm_min_h && gz <= o->cfg.ogm_max_h) {
             const int lx = gie_pos2coord(g[3 * i], w) - o->pvt[0];
             const int ly = gie_pos2coord(g[3 * i + 1], w) - o->pvt[1];
             const int lz = gie_pos2coord(gz, w) - o->pvt[2];
@@ -331,7 +331,8 @@ int go_ogm_pointcloud(gie_oracle *o, const float *xyz, int n)
         }
     }
     const float max_len = 0.707f * (float)o->X * w;   /* pntcld_raycast.cu:79 */
-    for (int i = 0; i < n; i++) ray_cast(o, o->origin, &g[3 * i], max_len);
+    for (int i = 0; i < n; i++)
+        if (gie_point_ok(g[3 * i], g[3 * i + 1], g[3 * i + 2])) ray_cast(o, o->origin, &g[3 * i], max_len);   /* gie_math.h: non-finite points are ignored */
     free(g);
     /* getAllocKeys: robot sphere → count = -1; count>0 OCC, <0 FREE (the block key it also
      * writes is "this voxel was observed", which is inst_type != UNKNOWN here). */

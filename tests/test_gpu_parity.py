@@ -288,3 +288,11 @@ def test_block_pool_overflow_fails_loudly():
             m.sync()
     assert "block pool" in str(e.value)
     m.close()
+
+
+@pytest.mark.gpu
+def test_edge_inputs(oracle_lib):
+    """Empty scans, NaN / Inf / far / duplicate / zero-length points, negative far-away poses,
+    images without a valid reading (tests/edge_inputs.py): HIP equals the oracle on all of them."""
+    import edge_inputs
+    edge_inputs.run(OracleMapper, gie.Mapper)

@@ -55,3 +55,10 @@ def test_block_pool_overflow_fails_loudly_emulation():
             m.sync()
     assert "block pool" in str(e.value)
     m.close()
+
+
+def test_edge_inputs_emulation(oracle_lib):
+    """Empty scans, NaN / Inf / far / duplicate / zero-length points, negative far-away poses,
+    images without a valid reading: the emulated device logic equals the oracle on all of them."""
+    import edge_inputs
+    edge_inputs.run(OracleMapper, EmuMapper)
