@@ -190,8 +190,7 @@ static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, 
 static void be_free_rays(be_state *b, const gie_ctx &c, const float *g, int n)
 {
     if (n <= 0) return;
-    const int seg_steps = (gie_ray_max_steps(c) + GIE_RAY_SEGS - 1) / GIE_RAY_SEGS;
-    hipLaunchKernelGGL(k_free_rays, dim3((n + 63) / 64), dim3(64 * GIE_RAY_SEGS), 0, b->stream, c, g, n, seg_steps);
+    hipLaunchKernelGGL(k_free_rays, dim3((n + 63) / 64), dim3(64 * GIE_RAY_SEGS), 0, b->stream, c, g, n, gie_ray_max_steps(c));
 }
 static void be_exclusive_scan(be_state *b, const int32_t *flag, int32_t *rank, int n)
 {

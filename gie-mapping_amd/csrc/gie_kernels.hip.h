@@ -85,45 +85,37 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
 #ifndef GIE_RAY_SPIN_SLEEP
 #define GIE_RAY_SPIN_SLEEP 4
 #endif
-__global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int max_seg_steps)
+__global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int max_steps)
 {
     __shared__ int s_stop[64];
-    __shared__ int s_bound;
     __shared__ int s_cur[GIE_RAY_SEGS][3][64];
     __shared__ float s_tmax[GIE_RAY_SEGS][3][64];
-    __shared__ int s_walk[GIE_RAY_SEGS][64];
     __shared__ int s_ready[GIE_RAY_SEGS];
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     const bool ray = i < n && gie_point_ok(g[3 * (i < n ? i : 0)], g[3 * (i < n ? i : 0) + 1], g[3 * (i < n ? i : 0) + 2]);
     if (seg == 0) s_stop[lane] = 0x7fffffff;
     if (threadIdx.x < GIE_RAY_SEGS) s_ready[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_bound = 0;
     gie_dda d;
     int s0[3] = { 0, 0, 0 };
     gie_ray_marks last_tile = { -1, -1 };
-    bool walk = ray && gie_dda_init(c, g, i, d, s0);      /* constants of the ray (direction, deltas, end cell) in every wave */
-    __syncthreads();
-    /* The segment length follows the workgroup's own rays (neighbours in the scan: similar
-     * lengths), so that all waves have work whether the rays end after 40 cells or after
-     * 600.  Bound on the steps of a walk: along axis a at most L / tDelta_a + 1 cell borders lie
-     * within L = min(len, max_length), and the walk ends with the first step past L. */
-    if (seg == 0) {
-        int nb = 0;
-        if (walk) {
-            const float L = d.len < d.max_length ? d.len : d.max_length;
-            float f = 8.0f;                                /* 3 (+1 per axis) + 1 (last step) + rounding margin */
+    const bool walk = ray && gie_dda_init(c, g, i, d, s0);      /* constants of the ray (direction, deltas, end cell) in every wave */
+    if (!walk) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) if (d.step[k] != 0) f += L / d.tDelta[k];
-            nb = f < 1.0e6f ? (int)f : 1000000;
-        }
-#pragma unroll
-        for (int w = 1; w < 64; w <<= 1) { const int o = __shfl_xor(nb, w); nb = nb > o ? nb : o; }
-        if (lane == 0) s_bound = nb;
+        for (int k = 0; k < 3; k++) { d.cur[k] = 0; d.step[k] = 0; d.tMax[k] = 3.402823466e+38f; d.tDelta[k] = 0.0f; }
+        d.len = 0.0f;
     }
     __syncthreads();
-    int seg_steps = (s_bound + GIE_RAY_SEGS - 1) / GIE_RAY_SEGS;
-    seg_steps = seg_steps < 4 ? 4 : (seg_steps > max_seg_steps ? max_seg_steps : seg_steps);
+    /* Segment `seg` owns the border crossings whose time along the ray lies in [T(seg), T(seg+1)),
+     * T(k) = k/SEGS of the ray's length (capped by the maximum length); the last one is open-ended
+     * and runs into the reference's own stop test.  The walk takes crossings in the order of
+     * their times, so every crossing before T(k) precedes every crossing after it, and the state
+     * at T(k) is, per axis, the first border time >= T(k) — three independent chains of float
+     * additions (the same additions the walk performs, so the same roundings), which a wave
+     * follows for its own interval and hands to the next one: the chain that has to run ahead
+     * of the memory work costs one add per crossing instead of a whole DDA step. */
+    const float L = walk ? (d.len < d.max_length ? d.len : d.max_length) : 0.0f;
+    const float Tn = (seg + 1 < GIE_RAY_SEGS) ? L * ((float)(seg + 1) * (1.0f / (float)GIE_RAY_SEGS)) : __builtin_inff();
     if (seg == 0) {   /* clearRayLoc on the sensor's own cell */
         const int id0 = (ray && gie_in_loc(c, s0[0], s0[1], s0[2])) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
         if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
@@ -135,7 +127,6 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
         for (int k = 0; k < 3; k++) { d.cur[k] = s_cur[seg - 1][k][lane]; d.tMax[k] = s_tmax[seg - 1][k][lane]; }
-        walk = s_walk[seg - 1][lane] != 0;                /* a walk that ended earlier leaves nothing to do */
     }
 #if defined(GIE_RAY_TIMING)
 #if GIE_RAY_TIMING < 0      /* every workgroup: first and last stamp of wave 0 */
@@ -147,37 +138,40 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
 #define GIE_RTS(k) do { } while (0)
 #endif
     GIE_RTS(0);
-    const int first = seg * seg_steps;
+    const int base = seg << 20;                           /* step index = (segment, step inside it): orders the stops of all segments */
     const gie_dda at_start = d;
-    const bool walk_start = walk;
-    if (seg + 1 < GIE_RAY_SEGS) {                         /* my steps in registers only, for the next wave */
-        /* uniform loop, no per-lane masking: a walk that has ended keeps stepping (its state is never
-         * used again: the later segments of an ended walk do nothing), only the flag is kept */
-        int ended = walk ? 0 : 1;
-        for (int k0 = 0; k0 < seg_steps; k0 += 8) {
+    if (seg + 1 < GIE_RAY_SEGS) {                         /* where my interval ends, for the next wave: registers only */
+        float t0 = d.tMax[0], t1 = d.tMax[1], t2 = d.tMax[2];
+        int n0 = 0, n1 = 0, n2 = 0;
+        for (int k0 = 0; k0 < max_steps; k0 += 8) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) if (k0 + k < seg_steps) ended |= gie_dda_step(d);
-            if (__all(ended)) break;
+            for (int k = 0; k < 8; k++) {
+                const bool a0 = t0 < Tn, a1 = t1 < Tn, a2 = t2 < Tn;
+                t0 += a0 ? d.tDelta[0] : 0.0f; n0 += a0 ? 1 : 0;
+                t1 += a1 ? d.tDelta[1] : 0.0f; n1 += a1 ? 1 : 0;
+                t2 += a2 ? d.tDelta[2] : 0.0f; n2 += a2 ? 1 : 0;
+            }
+            if (!__any((t0 < Tn) | (t1 < Tn) | (t2 < Tn))) break;
         }
-        walk = !ended;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { s_cur[seg][k][lane] = d.cur[k]; s_tmax[seg][k][lane] = d.tMax[k]; }
-        s_walk[seg][lane] = walk ? 1 : 0;
+        s_cur[seg][0][lane] = d.cur[0] + d.step[0] * n0; s_tmax[seg][0][lane] = t0;
+        s_cur[seg][1][lane] = d.cur[1] + d.step[1] * n1; s_tmax[seg][1][lane] = t1;
+        s_cur[seg][2][lane] = d.cur[2] + d.step[2] * n2; s_tmax[seg][2][lane] = t2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) { volatile int *w = &s_ready[seg]; *w = 1; }
     }
     GIE_RTS(1);
-    d = at_start; walk = walk_start;
     /* phase 1 (starts as soon as this wave has its state; no workgroup barrier before it): types of the segment's cells → where does the ray stop? (exclusive step index) */
     if (walk) {
         int stop = 0x7fffffff;
-        for (int k0 = 0; k0 < seg_steps && stop == 0x7fffffff; k0 += GIE_RAY_BATCH) {
-            int ids[GIE_RAY_BATCH], end[GIE_RAY_BATCH];
+        bool more = true;
+        for (int k0 = 0; k0 < max_steps && more && stop == 0x7fffffff; k0 += GIE_RAY_BATCH) {
+            if (*(volatile int *)&s_stop[lane] < base) break;        /* an earlier segment already ends this walk */
+            int ids[GIE_RAY_BATCH], end[GIE_RAY_BATCH], went[GIE_RAY_BATCH];
 #pragma unroll
             for (int j = 0; j < GIE_RAY_BATCH; j++) {
-                end[j] = gie_dda_step(d);
+                end[j] = gie_dda_step_lim(d, Tn, went[j]);
                 const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
-                ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
+                ids[j] = (went[j] && gie_in_loc(c, lx, ly, lz)) ? gie_lid(c, lx, ly, lz) : -1;
             }
             int8_t ty[GIE_RAY_BATCH];
 #pragma unroll
@@ -188,10 +182,11 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
 #endif
 #pragma unroll
             for (int j = 0; j < GIE_RAY_BATCH; j++) {
-                if (stop != 0x7fffffff || k0 + j >= seg_steps) continue;
-                if (ty[j] == GIE_VOX_OCCUPIED) stop = first + k0 + j;          /* this cell is not cleared */
-                else if (end[j]) stop = first + k0 + j + 1;                     /* this cell is the last one cleared */
+                if (stop != 0x7fffffff || !went[j]) continue;
+                if (ty[j] == GIE_VOX_OCCUPIED) stop = base + k0 + j;           /* this cell is not cleared */
+                else if (end[j]) stop = base + k0 + j + 1;                      /* this cell is the last one cleared */
             }
+            more = went[GIE_RAY_BATCH - 1] != 0;
         }
         if (stop != 0x7fffffff) atomicMin(&s_stop[lane], stop);
     }
@@ -202,14 +197,15 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
      * wave aggregation; lanes without work pass -1) */
     const int stop = s_stop[lane];
     d = at_start;
-    for (int k = 0; k < seg_steps; k++) {
-        int id = -1;
-        if (walk && first + k < stop) {
-            gie_dda_step(d);
+    for (int k = 0; k < max_steps; k++) {
+        int id = -1, went = 0;
+        if (walk && base + k < stop) {
+            gie_dda_step_lim(d, Tn, went);
             const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
-            if (gie_in_loc(c, lx, ly, lz)) { id = gie_lid(c, lx, ly, lz); gie_ray_touch(c, lx, ly, lz, &last_tile); }
+            if (went && gie_in_loc(c, lx, ly, lz)) { id = gie_lid(c, lx, ly, lz); gie_ray_touch(c, lx, ly, lz, &last_tile); }
         }
-        if (__ballot(id >= 0) == 0ull) { if (__ballot(walk && first + k + 1 < stop) == 0ull) break; continue; }
+        if (__ballot(went) == 0ull) break;                /* a lane that did not step now never steps again */
+        if (__ballot(id >= 0) == 0ull) continue;
 #if !defined(GIE_RAY_ABLATE) || GIE_RAY_ABLATE != 1
         gie_wave_add(c, id, -1);
 #endif
