@@ -85,6 +85,27 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
 #ifndef GIE_RAY_SPIN_SLEEP
 #define GIE_RAY_SPIN_SLEEP 4
 #endif
+/* The per-step address arithmetic of the kernel: the same values as gie_in_loc / gie_lid /
+ * gie_tile_index / gie_tab_index, written without short-circuit branches and with 24-bit
+ * multiplies (sides <= 1024, checked by gie_create) — a step of the walk is a few dozen
+ * instructions, and the compute units that hold the longest rays are instruction-bound. */
+__device__ __forceinline__ int gie_ray_cell(const gie_ctx &c, const gie_dda &d, int &lx, int &ly, int &lz)
+{
+    lx = d.cur[0] - c.pvt[0]; ly = d.cur[1] - c.pvt[1]; lz = d.cur[2] - c.pvt[2];
+    const bool in = ((unsigned)lx < (unsigned)c.X) & ((unsigned)ly < (unsigned)c.Y) & ((unsigned)lz < (unsigned)c.Z);
+    return in ? __mul24(__mul24(lz, c.Y) + ly, c.X) + lx : -1;
+}
+__device__ __forceinline__ void gie_ray_touch_k(const gie_ctx &c, const gie_dda &d, const int lx, const int ly, const int lz, gie_ray_marks *last)
+{
+    const int t = __mul24(__mul24(lz >> 3, c.tfd[1]) + (ly >> 3), c.tfd[0]) + (lx >> 3);
+    const int b = __mul24(__mul24((d.cur[2] >> 3) - c.tb0[2], c.tdim[1]) + ((d.cur[1] >> 3) - c.tb0[1]), c.tdim[0]) + ((d.cur[0] >> 3) - c.tb0[0]);
+    if ((t != last->tile) | (b != last->blk)) { c.tray[t] = 1; c.blk_need[b] = 1; last->tile = t; last->blk = b; }   /* both stores are idempotent */
+}
+__device__ __forceinline__ bool gie_dda_before(const gie_dda &d, const float limit)
+{
+    return fminf(fminf(d.tMax[0], d.tMax[1]), d.tMax[2]) < limit;      /* the crossing the next step takes is the smallest tMax */
+}
+
 __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int max_steps)
 {
     __shared__ int s_stop[64];
@@ -166,12 +187,13 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
         bool more = true;
         for (int k0 = 0; k0 < max_steps && more && stop == 0x7fffffff; k0 += GIE_RAY_BATCH) {
             if (*(volatile int *)&s_stop[lane] < base) break;        /* an earlier segment already ends this walk */
-            int ids[GIE_RAY_BATCH], end[GIE_RAY_BATCH], went[GIE_RAY_BATCH];
+            int ids[GIE_RAY_BATCH], end[GIE_RAY_BATCH];
+            bool went[GIE_RAY_BATCH];
 #pragma unroll
             for (int j = 0; j < GIE_RAY_BATCH; j++) {
-                end[j] = gie_dda_step_lim(d, Tn, went[j]);
-                const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
-                ids[j] = (went[j] && gie_in_loc(c, lx, ly, lz)) ? gie_lid(c, lx, ly, lz) : -1;
+                went[j] = gie_dda_before(d, Tn);
+                end[j] = 0; ids[j] = -1;
+                if (went[j]) { int lx, ly, lz; end[j] = gie_dda_step(d); ids[j] = gie_ray_cell(c, d, lx, ly, lz); }
             }
             int8_t ty[GIE_RAY_BATCH];
 #pragma unroll
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
                 if (ty[j] == GIE_VOX_OCCUPIED) stop = base + k0 + j;           /* this cell is not cleared */
                 else if (end[j]) stop = base + k0 + j + 1;                      /* this cell is the last one cleared */
             }
-            more = went[GIE_RAY_BATCH - 1] != 0;
+            more = went[GIE_RAY_BATCH - 1];
         }
         if (stop != 0x7fffffff) atomicMin(&s_stop[lane], stop);
     }
@@ -198,11 +220,13 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     const int stop = s_stop[lane];
     d = at_start;
     for (int k = 0; k < max_steps; k++) {
-        int id = -1, went = 0;
-        if (walk && base + k < stop) {
-            gie_dda_step_lim(d, Tn, went);
-            const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
-            if (went && gie_in_loc(c, lx, ly, lz)) { id = gie_lid(c, lx, ly, lz); gie_ray_touch(c, lx, ly, lz, &last_tile); }
+        int id = -1;
+        const bool went = walk && base + k < stop && gie_dda_before(d, Tn);
+        if (went) {
+            int lx, ly, lz;
+            gie_dda_step(d);
+            id = gie_ray_cell(c, d, lx, ly, lz);
+            if (id >= 0) gie_ray_touch_k(c, d, lx, ly, lz, &last_tile);
         }
         if (__ballot(went) == 0ull) break;                /* a lane that did not step now never steps again */
         if (__ballot(id >= 0) == 0ull) continue;

@@ -272,25 +272,6 @@ GIE_DEV int gie_dda_step(gie_dda &d)
     const int at_end = (d.cur[0] == d.i1[0]) & (d.cur[1] == d.i1[1]) & (d.cur[2] == d.i1[2]);
     return at_end | (int)(dist > d.max_length) | (int)(dist > d.len);
 }
-/* The same step, taken only if the border it crosses lies before `limit` along the ray (the
- * crossing time is the smallest tMax, which is what the step selects): the segmented kernel cuts
- * a walk into intervals of crossing time.  went = 0: nothing changed. */
-GIE_DEV int gie_dda_step_lim(gie_dda &d, const float limit, int &went)
-{
-    const bool c01 = d.tMax[0] < d.tMax[1], c02 = d.tMax[0] < d.tMax[2], c12 = d.tMax[1] < d.tMax[2];
-    bool is0 = c01 & c02, is1 = (!c01) & c12, is2 = !(is0 | is1);
-    const float v = is0 ? d.tMax[0] : (is1 ? d.tMax[1] : d.tMax[2]);
-    const bool go = v < limit;
-    is0 &= go; is1 &= go; is2 &= go;
-    d.cur[0] = is0 ? d.cur[0] + d.step[0] : d.cur[0]; d.tMax[0] = is0 ? d.tMax[0] + d.tDelta[0] : d.tMax[0];
-    d.cur[1] = is1 ? d.cur[1] + d.step[1] : d.cur[1]; d.tMax[1] = is1 ? d.tMax[1] + d.tDelta[1] : d.tMax[1];
-    d.cur[2] = is2 ? d.cur[2] + d.step[2] : d.cur[2]; d.tMax[2] = is2 ? d.tMax[2] + d.tDelta[2] : d.tMax[2];
-    const float m01 = d.tMax[0] < d.tMax[1] ? d.tMax[0] : d.tMax[1];
-    const float dist = m01 < d.tMax[2] ? m01 : d.tMax[2];
-    const int at_end = (d.cur[0] == d.i1[0]) & (d.cur[1] == d.i1[1]) & (d.cur[2] == d.i1[2]);
-    went = go ? 1 : 0;
-    return go ? (at_end | (int)(dist > d.max_length) | (int)(dist > d.len)) : 0;
-}
 /* upper bound of the cells one ray can visit: max_length / w voxels along the ray, at most
  * |dx|+|dy|+|dz| <= sqrt(3) cell changes per voxel of length */
 GIE_HD int gie_ray_max_steps(const gie_ctx &c) { return (int)(0.707f * (float)c.X * 1.7321f) + 8; }

@@ -20,7 +20,7 @@ for pos, q, pts, _ in frames[:3]:
 pos, q, pts, _ = frames[3]
 m.set_pose(pos, q); m.ogm_pointcloud(pts); m.sync()
 e = m.read_local(vtype=False, dist_sq=False, coc=False)["edt"].ravel()[:16 * 8].reshape(16, 8)
-t0 = e[:, 0].min()
+t0 = e[:8, 0].min()
 print("seg  start  state+publish  phase1  barrier  phase2   (us since the first stamp)")
-for s in range(16):
+for s in range(8):
     print("%3d %6.1f %10.1f %10.1f %8.1f %8.1f" % ((s,) + tuple(((e[s, k] - t0) % 16777216) / 100.0 for k in range(5))))

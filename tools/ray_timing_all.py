@@ -19,3 +19,6 @@ t0 = e[:, 0].min()
 st = ((e[:, 0] - t0) % 16777216) / 100.0; en = ((e[:, 1] - t0) % 16777216) / 100.0
 print("blocks", nb, "start min/median/max %.1f %.1f %.1f us" % (st.min(), np.median(st), st.max()), "end max %.1f us" % en.max(), "duration median %.1f max %.1f" % (np.median(en - st), (en - st).max()))
 print("starts histogram (10 us bins):", np.histogram(st, bins=np.arange(0, 110, 10))[0].tolist())
+print("durations histogram (5 us bins):", np.histogram(en - st, bins=np.arange(0, 80, 5))[0].tolist())
+o = np.argsort(en - st)[::-1][:8]
+print("slowest blocks:", [(int(b), round(float(st[b]), 1), round(float(en[b] - st[b]), 1)) for b in o])
