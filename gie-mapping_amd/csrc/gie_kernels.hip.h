@@ -1108,6 +1108,19 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, 0, &s_fail };
+    {   /* nothing seeded anywhere (the usual case of a sparse scan over a settled map): nothing can be
+         * produced either, so the launch ends here — same counters for every workgroup, no barrier */
+        const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);
+        if ((with_ab ? (na | nb | nc) : nc) == 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                if (with_ab) { c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0; c.cnt[GIE_CNT_SEED_C] = 0;
+                               gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+                c.cnt[GIE_CNT_FRONT_C] = 0;
+                if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = 0; c.cnt[GIE_CNT_SEED_A] = na; c.cnt[GIE_CNT_SEED_B] = nb; }
+            }
+            return;
+        }
+    }
     __syncthreads();
     if (with_ab) {
         gie_wave_a_run(c, gb);
