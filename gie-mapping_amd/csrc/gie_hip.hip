@@ -40,6 +40,12 @@ static void gie_set_err(const std::string &s);
 
 #define GIE_HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { gie_set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
 
+#include <mutex>
+static std::mutex g_waves_mutex;
+static hipEvent_t g_waves_event[64];
+static bool g_waves_event_set[64];
+static int g_live_mappers[64];          /* mappers alive per device: waves launches are chained only when there is more than one */
+
 static int be_init(be_state *b, int device)
 {
     int n = 0;
@@ -57,10 +63,15 @@ static int be_init(be_state *b, int device)
     for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
     b->prof_on = 0; b->last_end = -1; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
     for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; b->open_start[i] = -1; }
+    {   /* a second mapper on this device: whatever the first one has in flight was launched unchained — let it finish once */
+        std::lock_guard<std::mutex> lock(g_waves_mutex);
+        if (++g_live_mappers[device & 63] == 2) (void)hipDeviceSynchronize();
+    }
     return 0;
 }
 static void be_fini(be_state *b)
 {
+    { std::lock_guard<std::mutex> lock(g_waves_mutex); g_live_mappers[b->device & 63]--; }
     if (b->scan_tmp) (void)hipFree(b->scan_tmp);
     for (hipEvent_t e : *b->pool) (void)hipEventDestroy(e);
     delete b->pool; delete b->pending;
@@ -289,23 +300,22 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
  * different mappers on the same device at the same time need not be.  Waves launches of one
  * device are therefore chained through an event: a launch waits for the previous one, whichever
  * mapper (stream) it came from. */
-#include <mutex>
-static std::mutex g_waves_mutex;
-static hipEvent_t g_waves_event[64];
-static bool g_waves_event_set[64];
 static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
     std::lock_guard<std::mutex> lock(g_waves_mutex);
     const int dv = b->device & 63;
     (void)hipSetDevice(b->device);
-    if (g_waves_event_set[dv]) GIE_HIP_OK(hipStreamWaitEvent(b->stream, g_waves_event[dv], 0));
-    else { GIE_HIP_OK(hipEventCreateWithFlags(&g_waves_event[dv], hipEventDisableTiming)); g_waves_event_set[dv] = true; }
+    const bool chain = g_live_mappers[dv] > 1;       /* a lone mapper's launches follow each other on its stream anyway (an event is a marker packet the next kernel waits for) */
+    if (chain) {
+        if (g_waves_event_set[dv]) GIE_HIP_OK(hipStreamWaitEvent(b->stream, g_waves_event[dv], 0));
+        else { GIE_HIP_OK(hipEventCreateWithFlags(&g_waves_event[dv], hipEventDisableTiming)); g_waves_event_set[dv] = true; }
+    }
     if (clear_first) {
         GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
         GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     }
     hipLaunchKernelGGL(k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, with_ab, record_seeds);
-    GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
+    if (chain) GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
 }
 
 #include "gie_api.inc.h"
