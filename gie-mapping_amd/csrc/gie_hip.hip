@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
 #include "gie_kernels.hip.h"
 
@@ -29,8 +30,7 @@ struct be_state {
     std::vector<hipEvent_t> *pool;      /* event pool */
     std::vector<int> *pending;          /* triples (kernel id, start event idx, stop event idx) */
     int pool_used;
-    int open_start[32];
-    int last_end;                       /* event that closed the previous bracket of this stage (-1: none): the next bracket starts there */
+    int cur_id;                         /* bracket the launches currently belong to (-1: none) */
     double acc_ms[32]; int acc_n[32];
 };
 #include <vector>
@@ -61,8 +61,8 @@ static int be_init(be_state *b, int device)
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
     for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
-    b->prof_on = 0; b->last_end = -1; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
-    for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; b->open_start[i] = -1; }
+    b->prof_on = 0; b->cur_id = -1; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
+    for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; }
     {   /* a second mapper on this device: whatever the first one has in flight was launched unchained — let it finish once */
         std::lock_guard<std::mutex> lock(g_waves_mutex);
         if (++g_live_mappers[device & 63] == 2) (void)hipDeviceSynchronize();
@@ -123,7 +123,6 @@ static void be_time(be_state *b, int i)
 {
     if (!b->prof_on) { b->ev_set[i] = 0; return; }
     GIE_HIP_OK(hipEventRecord(b->ev[i], b->stream)); b->ev_set[i] = 1;
-    if ((i & 1) == 0) b->last_end = -1;               /* a stage starts: the host may have left the stream idle before it */
 }
 static void be_times(be_state *b, float *ogm, float *fuse, float *edt, float *merge)
 {
@@ -135,41 +134,43 @@ static void be_times(be_state *b, float *ogm, float *fuse, float *edt, float *me
     }
 }
 
+/* Per-kernel timing: the start / stop events ride on the kernel's own dispatch packet
+ * (hipExtLaunchKernelGGL), so a profiled map update has no marker packets between its kernels
+ * (event records between the launches cost the map update +18 %) and a kernel's time is its
+ * execution, as rocprofv3 reports it, without the dispatch gap. */
 static int be_prof_event(be_state *b)
 {
     if (b->pool_used == (int)b->pool->size()) { hipEvent_t e; GIE_HIP_OK(hipEventCreate(&e)); b->pool->push_back(e); }
-    const int i = b->pool_used++;
-    GIE_HIP_OK(hipEventRecord((*b->pool)[i], b->stream));
-    return i;
+    return b->pool_used++;
 }
+#define GIE_LAUNCH(b, kern, grid, block, lds, ...) do { \
+        if ((b)->prof_on && (b)->cur_id >= 0) { \
+            const int e0_ = be_prof_event(b), e1_ = be_prof_event(b); \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, (b)->stream, (*(b)->pool)[e0_], (*(b)->pool)[e1_], 0, __VA_ARGS__); \
+            (b)->pending->push_back((b)->cur_id); (b)->pending->push_back(e0_); (b)->pending->push_back(e1_); \
+        } else hipLaunchKernelGGL(kern, grid, block, lds, (b)->stream, __VA_ARGS__); \
+    } while (0)
 static void be_prof_resolve(be_state *b)
 {
-    if (b->pending->empty()) { b->pool_used = 0; b->last_end = -1; return; }
+    if (b->pending->empty()) { b->pool_used = 0; return; }
     GIE_HIP_OK(hipStreamSynchronize(b->stream));
     for (size_t i = 0; i + 2 < b->pending->size(); i += 3) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, (*b->pool)[(*b->pending)[i + 1]], (*b->pool)[(*b->pending)[i + 2]]) == hipSuccess) {
-            b->acc_ms[(*b->pending)[i]] += ms; b->acc_n[(*b->pending)[i]] += 1;
+            b->acc_ms[(*b->pending)[i]] += ms;
         }
     }
-    b->pending->clear(); b->pool_used = 0; b->last_end = -1;
+    b->pending->clear(); b->pool_used = 0;
 }
 static void be_prof(be_state *b, int id, int end)
 {
     if (!b->prof_on) return;
-    /* brackets inside a stage follow each other on the stream: the event that closed one opens
-     * the next (half the marker packets; a kernel's time then includes its dispatch gap) */
     if (!end) {
-        if (b->pool_used > 4000) { be_prof_resolve(b); b->last_end = -1; }
-        b->open_start[id] = b->last_end >= 0 ? b->last_end : be_prof_event(b);
-    } else if (b->open_start[id] >= 0) {
-        const int e1 = be_prof_event(b);
-        b->pending->push_back(id); b->pending->push_back(b->open_start[id]); b->pending->push_back(e1);
-        b->open_start[id] = -1;
-        b->last_end = e1;
-    }
+        if (b->pool_used > 4000) be_prof_resolve(b);
+        b->cur_id = id;
+    } else { b->cur_id = -1; b->acc_n[id] += 1; }       /* acc_n counts brackets, acc_ms sums the kernels launched inside them */
 }
-static void be_prof_enable(be_state *b, int on) { be_prof_resolve(b); b->prof_on = on; b->last_end = -1; }
+static void be_prof_enable(be_state *b, int on) { be_prof_resolve(b); b->prof_on = on; b->cur_id = -1; }
 static void be_prof_collect(be_state *b, float *ms, int *n, int num)
 {
     be_prof_resolve(b);
@@ -180,28 +181,28 @@ template <class F> static void be_vox(be_state *b, const gie_ctx &c, const F &f)
 {
     dim3 blk(GIE_VOX_BX, GIE_VOX_BY, 1);
     dim3 grd((c.X + GIE_VOX_BX - 1) / GIE_VOX_BX, (c.Y + GIE_VOX_BY - 1) / GIE_VOX_BY, (c.Z + GIE_VOX_ZPER - 1) / GIE_VOX_ZPER);
-    hipLaunchKernelGGL(k_voxz<F>, grd, blk, 0, b->stream, c, f);
+    GIE_LAUNCH(b, k_voxz<F>, grd, blk, 0, c, f);
 }
 template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f, int n)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, b->stream, c, f, n);
+    GIE_LAUNCH(b, k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, c, f, n);
 }
 static void be_clear(be_state *b, const gie_clear_list &l)
 {
-    if (l.n > 0) hipLaunchKernelGGL(k_clear, dim3(32, l.n), dim3(256), 0, b->stream, l);
+    if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(32, l.n), dim3(256), 0, l);
 }
 /* allocHashTB + block table (see k_cell_alloc) */
 static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, int clear_list)
 {
     if (clear_list) GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_NEWLIST], 0, sizeof(int32_t), b->stream));
-    hipLaunchKernelGGL(k_cell_alloc, dim3((ncell + 255) / 256), dim3(256), 0, b->stream, c, ncell);
-    hipLaunchKernelGGL(k_block_init_list, dim3(b->cu_total * 4), dim3(256), 0, b->stream, c);
+    GIE_LAUNCH(b, k_cell_alloc, dim3((ncell + 255) / 256), dim3(256), 0, c, ncell);
+    GIE_LAUNCH(b, k_block_init_list, dim3(b->cu_total * 4), dim3(256), 0, c);
 }
 static void be_free_rays(be_state *b, const gie_ctx &c, const float *g, int n)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_free_rays, dim3((n + 63) / 64), dim3(64 * GIE_RAY_SEGS), 0, b->stream, c, g, n, gie_ray_max_steps(c));
+    GIE_LAUNCH(b, k_free_rays, dim3((n + 63) / 64), dim3(64 * GIE_RAY_SEGS), 0, c, g, n, gie_ray_max_steps(c));
 }
 static void be_exclusive_scan(be_state *b, const int32_t *flag, int32_t *rank, int n)
 {
@@ -228,13 +229,13 @@ template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, c
     int wgs = (int)((160 * 1024) / (lds + 256));            /* workgroups that fit one CU's LDS */
     if (wgs < 1) wgs = 1; if (wgs > 4) wgs = 4;
     int grid = wgs * b->cu_total; if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((k_edt_z<CP, TX, WAVES>), dim3(grid), dim3(64 * WAVES), lds, b->stream, c, ntx, ntiles, full);
+    GIE_LAUNCH(b, (k_edt_z<CP, TX, WAVES>), dim3(grid), dim3(64 * WAVES), lds, c, ntx, ntiles, full);
 }
 template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass, int full)
 {
     if (!zpass) {
         const int rows = c.Y * c.Z;
-        hipLaunchKernelGGL(k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, b->stream, c);
+        GIE_LAUNCH(b, k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, c);
     } else {
         gie_launch_edt_z<CP, 16, 8>(b, c, full);      /* 2 workgroups per CU overlap load / envelope / store phases */
     }
@@ -257,20 +258,20 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
     /* workgroups per compute unit: 8 / 16 / 32 / 64 measured 0.33 / 0.27 / 0.25 / 0.25 ms for Mark on a densely known
      * volume (sweep side); the list side does not care */
     static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
-    hipLaunchKernelGGL((k_voxa<F, STAGED>), dim3(b->cu_total * mult), dim3(256), 0, b->stream, c, f, list, count_idx, always_list ? 1 : 0);
+    GIE_LAUNCH(b, (k_voxa<F, STAGED>), dim3(b->cu_total * mult), dim3(256), 0, c, f, list, count_idx, always_list ? 1 : 0);
 }
 template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
 {
-    hipLaunchKernelGGL(k_list<F>, dim3(b->cu_total), dim3(256), 0, b->stream, c, f, list, count_idx);
+    GIE_LAUNCH(b, k_list<F>, dim3(b->cu_total), dim3(256), 0, c, f, list, count_idx);
 }
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {
-    hipLaunchKernelGGL(k_edt_z_direct, dim3(b->cu_total * 8), dim3(256), 0, b->stream, c);
+    GIE_LAUNCH(b, k_edt_z_direct, dim3(b->cu_total * 8), dim3(256), 0, c);
 }
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {
     const int ncol = c.tfd[0] * c.tfd[1];
-    hipLaunchKernelGGL(k_edt_prep, dim3((ncol + 3) / 4), dim3(256), 0, b->stream, c, ncol);
+    GIE_LAUNCH(b, k_edt_prep, dim3((ncol + 3) / 4), dim3(256), 0, c, ncol);
 }
 /* full = 1: whole volume (column kernel); 0: only where Mark reads — the direct kernel over tl_known
  * and the column kernel are both launched and the one the known-tile count does not call for
@@ -281,9 +282,9 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 6, 0);   /* GIE_K_EDT_Y */
     /* one 32-voxel mask word per thread: with only the planes that hold obstacles at work, the
      * pass is bound by how many loads are in flight, not by bytes */
-    if (c.Y <= 256) hipLaunchKernelGGL((k_edt_y<8, 8>), gy, dim3(GIE_EDTY_COLS, 8), 0, b->stream, c);
-    else if (c.Y <= 512) hipLaunchKernelGGL((k_edt_y<16, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, b->stream, c);
-    else hipLaunchKernelGGL((k_edt_y<32, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, b->stream, c);
+    if (c.Y <= 256) GIE_LAUNCH(b, (k_edt_y<8, 8>), gy, dim3(GIE_EDTY_COLS, 8), 0, c);
+    else if (c.Y <= 512) GIE_LAUNCH(b, (k_edt_y<16, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, c);
+    else GIE_LAUNCH(b, (k_edt_y<32, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, c);
     be_prof(b, 6, 1);
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0);                                                              /* GIE_K_EDT_Z */
@@ -314,7 +315,7 @@ static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seed
         GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
         GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     }
-    hipLaunchKernelGGL(k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, b->stream, c, with_ab, record_seeds);
+    GIE_LAUNCH(b, k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, with_ab, record_seeds);
     if (chain) GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
 }
 
