@@ -909,7 +909,17 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
 #define GIE_WAVE_THREADS 1024
 #define GIE_BAR_SPIN_LIMIT (1 << 22)
 
-#define GIE_WAVE_SOLO 4096   /* frontiers this small are finished by workgroup 0 alone (block barriers only) */
+/* Frontiers this small are finished by workgroup 0 alone (block barriers only).  A solo level costs
+ * one chain of round trips per 1024 entries, a level of all workgroups one chain + the grid barrier:
+ * measured on the dense-observation run, wave C at 0 / 128 / 512 / 1024 / 2048 / 4096 / 8192:
+ * 1.05 / 1.06 / 1.07 / 1.09 / 1.13 / 1.29 / 1.82 ms per map update, and on a 256^3 volume (small
+ * waves only) 0.104 / 0.084 / 0.082 / 0.087 / 0.085 / 0.084 / 0.083 ms. */
+#ifndef GIE_WAVE_SOLO
+#define GIE_WAVE_SOLO 512
+#endif
+#ifndef GIE_WAVE_SOLO_AB
+#define GIE_WAVE_SOLO_AB 4096 /* waves A / B decide once, from their seed count (512 / 2048 / 4096 measure the same) */
+#endif
 
 struct gie_gridbar { int32_t *word; int epoch; int failed; int solo; int *s_fail; };
 
@@ -951,7 +961,7 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab), cur = 0, level = 0;
     if (boss) { c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-    if (n <= GIE_WAVE_SOLO) {                            /* small wave: workgroup 0 runs it alone, block barriers only */
+    if (n <= GIE_WAVE_SOLO_AB) {                         /* small wave: workgroup 0 runs it alone, block barriers only */
         if (blockIdx.x != 0) return;
         gb.solo = 1;
     }
@@ -974,7 +984,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     const bool boss = (gtid == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
     if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-    if (n <= GIE_WAVE_SOLO) {                            /* small wave: workgroup 0 runs it alone, block barriers only */
+    if (n <= GIE_WAVE_SOLO_AB) {                         /* small wave: workgroup 0 runs it alone, block barriers only */
         if (blockIdx.x != 0) return;
         gb.solo = 1;
     }
