@@ -1007,13 +1007,16 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
  * workgroup runs the same trips), so queue space is reserved ONCE PER WORKGROUP AND TRIP: ballot
  * prefix inside the wave, LDS prefix across the 16 waves, one global atomicAdd — instead of up
  * to six same-address atomics per thread. */
-struct gie_wg_scratch { int32_t tot[GIE_WAVE_THREADS / 64]; int32_t vis[GIE_WAVE_THREADS / 64]; int32_t base; };
+struct gie_wg_scratch { int32_t tot[GIE_WAVE_THREADS / 64]; int32_t vis[GIE_WAVE_THREADS / 64]; int32_t base; int32_t n_local; };
 
 /* entries [first, last) belong to this workgroup (the frontier is split EVENLY over the
  * workgroups: every entry costs a dozen scattered 8-byte transactions, and a compute unit's path
  * to the fabric, not the fabric, is what a level waits for) */
-__device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int level, int first, int last, gie_wg_scratch *sc)
+/* solo = this workgroup runs the level alone: the next queue is filled from a count in LDS (no
+ * global reservation, no read-back of the level's size: two fabric round trips per level less) */
+__device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int level, int first, int last, gie_wg_scratch *sc, const bool solo)
 {
+    if (solo && threadIdx.x == 0) sc->n_local = 0;      /* read again only behind the barriers of the trips below */
     int32_t *next_cnt = &c.lvl_next[level];
     int32_t *next = c.qc[cur ^ 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1044,7 +1047,8 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int 
         if (threadIdx.x == 0) {
             int t = 0, v = 0;
             for (int w = 0; w < GIE_WAVE_THREADS / 64; w++) { t += sc->tot[w]; v += sc->vis[w]; }
-            sc->base = t ? gie_aadd32(next_cnt, t) : 0;
+            if (solo) { sc->base = sc->n_local; sc->n_local += t; }
+            else sc->base = t ? gie_aadd32(next_cnt, t) : 0;
             if (v) gie_aadd32(&c.lvl_vis[level], v);
         }
         __syncthreads();
@@ -1081,9 +1085,9 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
              * small, the others wait at ONE grid barrier and then pick up the published state */
             if (blockIdx.x == 0) {
                 do {
-                    gie_wave_c_level(c, cur, level, 0, n, &s_wg);
-                    __syncthreads();
-                    n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c); cur ^= 1; level++;
+                    gie_wave_c_level(c, cur, level, 0, n, &s_wg, true);
+                    n = gie_clampi(s_wg.n_local, c.qcap_c); cur ^= 1; level++;
+                    __syncthreads();                   /* everybody has the size before the next level resets it */
                 } while (n > 0 && n <= GIE_WAVE_SOLO && level < GIE_MAX_LEVELS - 1);
                 if (boss) { gie_st(&c.cnt[GIE_CNT_STATE], n); gie_st(&c.cnt[GIE_CNT_STATE + 1], cur); gie_st(&c.cnt[GIE_CNT_STATE + 2], level); }
             }
@@ -1093,7 +1097,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
         } else {
             const int share = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;      /* whole waves */
             const int first = (int)blockIdx.x * share;
-            gie_wave_c_level(c, cur, level, first < n ? first : n, first + share < n ? first + share : n, &s_wg);
+            gie_wave_c_level(c, cur, level, first < n ? first : n, first + share < n ? first + share : n, &s_wg, false);
             gie_grid_sync(gb, c);
             GIE_TS(5);
             n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c);
