@@ -22,6 +22,9 @@ SCENARIOS = [
                     cutoff_dist=0.5),
     parity.Scenario("odd_dims", (37, 29, 11), sensor="mixed", frames=9, delta_vox=3, yaw_deg=33.0),
     parity.Scenario("flat_2d", (40, 40, 1), sensor="scan2d", frames=5, delta_vox=3, yaw_deg=10.0),
+    # ray casting in thin volumes: rays cut by the maximum length 0.707*X*w (X = 16), and rays that leave the volume long before they end
+    parity.Scenario("thin_x", (16, 200, 8), sensor="lidar_points", frames=6, delta_vox=5, yaw_deg=40.0, lidar_az=720),
+    parity.Scenario("thin_y", (200, 16, 8), sensor="lidar_points", frames=6, delta_vox=5, yaw_deg=40.0, lidar_az=720),
     # BASELINE C3's wave parameters (ugv yaml: cutoff 100 m => no cutoff at all, full waves A+B), small volume
     parity.Scenario("c3_no_cutoff", (56, 56, 20), voxel=0.1, sensor="multiscan", frames=10, delta_vox=6, yaw_deg=12.0,
                     cutoff_dist=100.0, extent=(5.0, 5.0, 1.5)),
