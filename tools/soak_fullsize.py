@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--pattern", default="rrp")
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--delta", type=int, default=8)
+    ap.add_argument("--ray-sensor", default="vlp16", help="bench.SENSORS preset used for the ray-casting updates (vlp16 | lidar64)")
     args = ap.parse_args()
     import bench
     import gie
@@ -29,7 +30,7 @@ def main():
 
     size = tuple(args.size)
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
-    fr = {"r": bench.make_frames(scenes, 0.05, args.frames, 5, "vlp16", delta_vox=args.delta),
+    fr = {"r": bench.make_frames(scenes, 0.05, args.frames, 5, args.ray_sensor, delta_vox=args.delta),
           "p": bench.make_frames(scenes, 0.05, args.frames, 5, "vlp16_projective", delta_vox=args.delta)}
     rings, az, phi_min, phi_inc, bins = bench.SENSORS["vlp16_projective"]
     kw = dict(theta_inc=2.0 * np.pi / bins, theta_min=-np.pi, phi_inc=np.radians(phi_inc), phi_min=np.radians(phi_min))
