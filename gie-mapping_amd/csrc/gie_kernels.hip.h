@@ -106,6 +106,26 @@ __device__ __forceinline__ bool gie_dda_before(const gie_dda &d, const float lim
     return fminf(fminf(d.tMax[0], d.tMax[1]), d.tMax[2]) < limit;      /* the crossing the next step takes is the smallest tMax */
 }
 
+/* advance the walk's state past every border crossed before `limit`, without looking at the cells:
+ * per axis the very additions the walk performs (same roundings), three independent chains */
+__device__ __forceinline__ void gie_dda_skip_to(gie_dda &d, const float limit, const int max_steps)
+{
+    float t0 = d.tMax[0], t1 = d.tMax[1], t2 = d.tMax[2];
+    int n0 = 0, n1 = 0, n2 = 0;
+    for (int k0 = 0; k0 < max_steps && __any((t0 < limit) | (t1 < limit) | (t2 < limit)); k0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool a0 = t0 < limit, a1 = t1 < limit, a2 = t2 < limit;
+            t0 += a0 ? d.tDelta[0] : 0.0f; n0 += a0 ? 1 : 0;
+            t1 += a1 ? d.tDelta[1] : 0.0f; n1 += a1 ? 1 : 0;
+            t2 += a2 ? d.tDelta[2] : 0.0f; n2 += a2 ? 1 : 0;
+        }
+    }
+    d.cur[0] += d.step[0] * n0; d.tMax[0] = t0;
+    d.cur[1] += d.step[1] * n1; d.tMax[1] = t1;
+    d.cur[2] += d.step[2] * n2; d.tMax[2] = t2;
+}
+
 __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c, const float *g, const int n, const int max_steps)
 {
     __shared__ int s_stop[64];
@@ -136,11 +156,41 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
      * follows for its own interval and hands to the next one: the chain that has to run ahead
      * of the memory work costs one add per crossing instead of a whole DDA step. */
     const float L = walk ? (d.len < d.max_length ? d.len : d.max_length) : 0.0f;
-    const float Tn = (seg + 1 < GIE_RAY_SEGS) ? L * ((float)(seg + 1) * (1.0f / (float)GIE_RAY_SEGS)) : __builtin_inff();
+    /* Only the part of the ray inside the local volume has cells to look at (a straight ray never
+     * comes back into a box it has left; the rays of a scan that ends outside a thin volume or —
+     * for a tile of a larger volume — never touch this tile are most of the walk): the segments
+     * share [Ts, Te] = the ray's stay in the volume grown by one cell, clipped to [0, L].  A
+     * volume the walk is still inside at L keeps the open end. */
+    float Ts = 0.0f, Te = L;
+    bool open_end = true;
+    if (walk) {
+        const float w = c.voxel_width;
+        const int dim[3] = { c.X, c.Y, c.Z };
+        float tin = 0.0f, tout = 3.402823466e+38f;
+        bool hit = true;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float lo = ((float)c.pvt[a] - 1.5f) * w, hi = ((float)(c.pvt[a] + dim[a]) + 0.5f) * w;
+            if (d.step[a] != 0) {
+                const float inv = (float)d.step[a] * d.tDelta[a] / w;       /* 1 / direction component */
+                const float ta = (lo - c.origin[a]) * inv, tb = (hi - c.origin[a]) * inv;
+                tin = fmaxf(tin, fminf(ta, tb)); tout = fminf(tout, fmaxf(ta, tb));
+            } else if (c.origin[a] < lo || c.origin[a] > hi) hit = false;
+        }
+        const float slack = 2.0f * w;
+        float te_box = tout + slack;
+        Ts = fmaxf(0.0f, tin - slack);
+        if (!hit || !(Ts < te_box)) { Ts = 0.0f; te_box = 0.0f; }             /* never inside */
+        if (te_box < L) { Te = te_box; open_end = false; }
+        if (Ts > Te) Ts = Te;
+    }
+    const float Tn = (seg + 1 < GIE_RAY_SEGS) ? Ts + (Te - Ts) * ((float)(seg + 1) * (1.0f / (float)GIE_RAY_SEGS))
+                                              : (open_end ? __builtin_inff() : Te);
     if (seg == 0) {   /* clearRayLoc on the sensor's own cell */
         const int id0 = (ray && gie_in_loc(c, s0[0], s0[1], s0[2])) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
         if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
         gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
+        gie_dda_skip_to(d, Ts, max_steps);                /* sensor outside the volume: up to where the ray enters it */
     } else {
         /* state at the end of segment seg-1 = at the start of mine */
         volatile int *rdy = &s_ready[seg - 1];
@@ -162,21 +212,10 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
     const int base = seg << 20;                           /* step index = (segment, step inside it): orders the stops of all segments */
     const gie_dda at_start = d;
     if (seg + 1 < GIE_RAY_SEGS) {                         /* where my interval ends, for the next wave: registers only */
-        float t0 = d.tMax[0], t1 = d.tMax[1], t2 = d.tMax[2];
-        int n0 = 0, n1 = 0, n2 = 0;
-        for (int k0 = 0; k0 < max_steps; k0 += 8) {
+        gie_dda nx = d;
+        gie_dda_skip_to(nx, Tn, max_steps);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool a0 = t0 < Tn, a1 = t1 < Tn, a2 = t2 < Tn;
-                t0 += a0 ? d.tDelta[0] : 0.0f; n0 += a0 ? 1 : 0;
-                t1 += a1 ? d.tDelta[1] : 0.0f; n1 += a1 ? 1 : 0;
-                t2 += a2 ? d.tDelta[2] : 0.0f; n2 += a2 ? 1 : 0;
-            }
-            if (!__any((t0 < Tn) | (t1 < Tn) | (t2 < Tn))) break;
-        }
-        s_cur[seg][0][lane] = d.cur[0] + d.step[0] * n0; s_tmax[seg][0][lane] = t0;
-        s_cur[seg][1][lane] = d.cur[1] + d.step[1] * n1; s_tmax[seg][1][lane] = t1;
-        s_cur[seg][2][lane] = d.cur[2] + d.step[2] * n2; s_tmax[seg][2][lane] = t2;
+        for (int k = 0; k < 3; k++) { s_cur[seg][k][lane] = nx.cur[k]; s_tmax[seg][k][lane] = nx.tMax[k]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) { volatile int *w = &s_ready[seg]; *w = 1; }
     }
