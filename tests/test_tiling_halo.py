@@ -191,3 +191,119 @@ def test_eight_mappers_share_one_device(oracle_lib):
     for t in range(8):
         for key in ("type", "dist_sq", "coc"):
             assert np.array_equal(want[t][key], got[t][key]), (t, key)
+
+
+class _InProcessTransport:
+    """Stands in for torch.distributed in test_rank_exchange_code_path: the P2P calls that
+    tiling.exchange_rounds_device makes (P2POp / isend / irecv / batch_isend_irecv, work.wait())
+    between two tiles that live in two THREADS of this process on one GPU.  A receive is a
+    device-to-device copy on the receiver's current stream, ordered after an event on the sender's
+    stream; a send's wait() orders the sender's stream after that copy (as RCCL would: the send
+    buffer is free again)."""
+
+    def __init__(self):
+        import threading
+        self.cv = threading.Condition()
+        self.posted = {}      # (src, dst, seq) -> (tensor, event on the sender's stream)
+        self.copied = {}      # (src, dst, seq) -> event on the receiver's stream
+
+    def view(self, rank):
+        return _RankView(self, rank)
+
+
+class _Work:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def wait(self):
+        self.fn()
+
+
+class _RankView:
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, shared, rank):
+        self.s, self.rank, self.seq = shared, rank, {}
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def batch_isend_irecv(self, ops):
+        import torch
+        s, works = self.s, []
+        cur = torch.cuda.current_stream()
+        for o in ops:
+            key = (self.rank, o.peer, o.op)
+            n = self.seq[key] = self.seq.get(key, 0) + 1
+            if o.op == self.isend:
+                ev = torch.cuda.Event(); ev.record(cur)
+                with s.cv:
+                    s.posted[(self.rank, o.peer, n)] = (o.tensor, ev); s.cv.notify_all()
+
+                def wait_send(k=(self.rank, o.peer, n), cur=cur):
+                    with s.cv:
+                        assert s.cv.wait_for(lambda: k in s.copied, timeout=60)
+                    cur.wait_event(s.copied[k])
+                works.append(_Work(wait_send))
+            else:
+                k = (o.peer, self.rank, n)
+                with s.cv:
+                    assert s.cv.wait_for(lambda: k in s.posted, timeout=60)
+                src, ev = s.posted[k]
+                cur.wait_event(ev)
+                o.tensor.copy_(src, non_blocking=True)
+                done = torch.cuda.Event(); done.record(cur)
+                with s.cv:
+                    s.copied[k] = done; s.cv.notify_all()
+                works.append(_Work(lambda: None))
+        return works
+
+
+@pytest.mark.gpu
+def test_rank_exchange_code_path(oracle_lib):
+    """tiling.exchange_rounds_device — the function bench.py calls once per map update on every
+    rank of a multi-GPU run — with an in-process transport instead of RCCL: two tiles, two
+    threads, one GPU.  Same export / transfer / import / refine sequence on the mappers' own
+    streams (torch.cuda.ExternalStream, cached P2P op list and pointer tables); the result must
+    equal the in-process stream-ordered rounds, i.e. the oracle's (test above)."""
+    import threading
+    import torch
+    device = torch.device("cuda", 0)
+    want = _run_tiled(gie.Mapper, device=device, fixed_rounds=4)
+    cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
+    frames = _sensor_frames(FR)
+    shared = _InProcessTransport()
+    step_barrier = threading.Barrier(2)
+    hist, errors = [[], []], []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            m = gie.Mapper(cfg)
+            m.set_tile(tiling.tile_offset_voxels(rank, 2, TILE), WHOLE)
+            dist, bufs = shared.view(rank), {}
+            try:
+                for pos, q, img in frames:
+                    m.update(pos, q, "multiscan", img, **KW)
+                    tiling.exchange_rounds_device(m, dist, rank, 2, device, bufs, rounds=4)
+                    hist[rank].append((m.read_local(), m.pivot()))
+                    step_barrier.wait(timeout=120)
+            finally:
+                m.close()
+        except Exception as e:                       # noqa: BLE001 — reported by the main thread
+            errors.append((rank, repr(e)))
+            step_barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert len(hist[0]) == FR and len(hist[1]) == FR
+    for k, (ra, _, pa) in enumerate(want):
+        for t in range(2):
+            assert pa[t] == hist[t][k][1]
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[t][key], hist[t][k][0][key]), (k, t, key)
