@@ -206,6 +206,8 @@ class _InProcessTransport:
         self.cv = threading.Condition()
         self.posted = {}      # (src, dst, seq) -> (tensor, event on the sender's stream)
         self.copied = {}      # (src, dst, seq) -> event on the receiver's stream
+        self.reduce_in = {}   # all-reduce round -> {rank: value}
+        self.meet = threading.Barrier(2)
 
     def view(self, rank):
         return _RankView(self, rank)
@@ -221,6 +223,17 @@ class _Work:
 
 class _RankView:
     isend, irecv = "isend", "irecv"
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def all_reduce(self, t, op=None):
+        """sum of a one-element tensor over the two ranks (host-synchronous, like the caller's use)"""
+        n = self.seq[("ar",)] = self.seq.get(("ar",), 0) + 1
+        with self.s.cv:
+            self.s.reduce_in.setdefault(n, {})[self.rank] = int(t.item())
+        self.s.meet.wait(timeout=60)
+        t.fill_(sum(self.s.reduce_in[n].values()))
 
     def __init__(self, shared, rank):
         self.s, self.rank, self.seq = shared, rank, {}
@@ -261,16 +274,18 @@ class _RankView:
 
 
 @pytest.mark.gpu
-def test_rank_exchange_code_path(oracle_lib):
+@pytest.mark.parametrize("form", ["stream_ordered", "until_stable"])
+def test_rank_exchange_code_path(oracle_lib, form):
     """tiling.exchange_rounds_device — the function bench.py calls once per map update on every
     rank of a multi-GPU run — with an in-process transport instead of RCCL: two tiles, two
     threads, one GPU.  Same export / transfer / import / refine sequence on the mappers' own
     streams (torch.cuda.ExternalStream, cached P2P op list and pointer tables); the result must
-    equal the in-process stream-ordered rounds, i.e. the oracle's (test above)."""
+    equal the in-process stream-ordered rounds, i.e. the oracle's (test above).  "until_stable" =
+    tiling.exchange_until_stable_device, the host-synchronised form bench.py falls back to."""
     import threading
     import torch
     device = torch.device("cuda", 0)
-    want = _run_tiled(gie.Mapper, device=device, fixed_rounds=4)
+    want = _run_tiled(gie.Mapper, device=device, fixed_rounds=4 if form == "stream_ordered" else 0)
     cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
     frames = _sensor_frames(FR)
     shared = _InProcessTransport()
@@ -286,7 +301,10 @@ def test_rank_exchange_code_path(oracle_lib):
             try:
                 for pos, q, img in frames:
                     m.update(pos, q, "multiscan", img, **KW)
-                    tiling.exchange_rounds_device(m, dist, rank, 2, device, bufs, rounds=4)
+                    if form == "stream_ordered":
+                        tiling.exchange_rounds_device(m, dist, rank, 2, device, bufs, rounds=4)
+                    else:                            # bench.py's fall-back: host-synchronised rounds until no tile changes
+                        tiling.exchange_until_stable_device(m, dist, rank, 2, device, bufs)
                     hist[rank].append((m.read_local(), m.pivot()))
                     step_barrier.wait(timeout=120)
             finally:
