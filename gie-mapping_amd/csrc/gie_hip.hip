@@ -282,7 +282,15 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 6, 0);   /* GIE_K_EDT_Y */
     /* one 32-voxel mask word per thread: with only the planes that hold obstacles at work, the
      * pass is bound by how many loads are in flight, not by bytes */
-    if (c.Y <= 256) GIE_LAUNCH(b, (k_edt_y<8, 8>), gy, dim3(GIE_EDTY_COLS, 8), 0, c);
+    /* X % 4 == 0: four columns per lane, dword loads / 8-byte stores (k_edt_y4) */
+    static const int y4 = getenv("GIE_EDTY4") ? atoi(getenv("GIE_EDTY4")) : 1;
+    if (y4 && (c.X & 3) == 0) {
+        const int yb = (y4 == 2 || c.Y > 512) ? 32 : 16;
+        dim3 g4((c.X / 4 + GIE_EDTY4_LANES - 1) / GIE_EDTY4_LANES, c.Z), b4(GIE_EDTY4_LANES, (c.Y + yb - 1) / yb);
+        if (yb == 16) GIE_LAUNCH(b, k_edt_y4<16>, g4, b4, 0, c);
+        else GIE_LAUNCH(b, k_edt_y4<32>, g4, b4, 0, c);
+    }
+    else if (c.Y <= 256) GIE_LAUNCH(b, (k_edt_y<8, 8>), gy, dim3(GIE_EDTY_COLS, 8), 0, c);
     else if (c.Y <= 512) GIE_LAUNCH(b, (k_edt_y<16, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, c);
     else GIE_LAUNCH(b, (k_edt_y<32, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, c);
     be_prof(b, 6, 1);

@@ -413,6 +413,76 @@ __global__ __launch_bounds__(GIE_EDTY_COLS * TPC) void k_edt_y(const gie_ctx c)
     }
 }
 
+/* The same pass for X % 4 == 0 with FOUR adjacent columns per lane: a lane reads the four type
+ * bytes of (x..x+3, y, z) as one dword and stores its four answers as one 8-byte vector, so a
+ * wave moves 128-byte row segments per instruction instead of 64 single bytes (the byte form is
+ * bound by the number of memory instructions, not by bytes).  Thread (l, q) owns the YB
+ * positions y = q·YB .. of its four columns; what lies below / above its own mask word comes
+ * from the other threads' words in LDS (one 16-byte read per word covers the four columns). */
+#define GIE_EDTY4_LANES 32
+template <int YB>
+__global__ __launch_bounds__(1024) void k_edt_y4(const gie_ctx c)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_m[32][GIE_EDTY4_LANES * 4];
+    const int l = threadIdx.x, q = threadIdx.y, nq = blockDim.y;
+    const int x = (blockIdx.x * GIE_EDTY4_LANES + l) * 4;
+    const int z = blockIdx.y;
+    if (!c.zocc[z]) return;                              /* plane without obstacle: passes X/Z never read its cy1 */
+    const int X = c.X, Y = c.Y;
+    const bool in = x < X;
+    const size_t base = (size_t)z * X * Y + (in ? x : 0);
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
+    if (in) {
+        const int8_t *t = c.glb_type + base;
+        uint32_t v[YB];
+#pragma unroll
+        for (int k = 0; k < YB; k++) {
+            const int y = q * YB + k;
+            v[k] = (y < Y) ? *reinterpret_cast<const uint32_t *>(t + (size_t)y * X) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < YB; k++) {
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) m[cc] |= (uint32_t)(((v[k] >> (8 * cc)) & 0xffu) == (uint32_t)GIE_VOX_OCCUPIED) << k;
+        }
+    }
+    *reinterpret_cast<uint4 *>(&s_m[q][4 * l]) = make_uint4(m[0], m[1], m[2], m[3]);
+    __syncthreads();
+    if (!in) return;
+    int pl[4] = {-1, -1, -1, -1}, nf[4] = {-1, -1, -1, -1};
+    for (int w = 0; w < q; w++) {                         /* last obstacle below this thread's positions */
+        const uint4 o = *reinterpret_cast<const uint4 *>(&s_m[w][4 * l]);
+        const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) if (ow[cc]) pl[cc] = w * YB + 31 - __clz(ow[cc]);
+    }
+    for (int w = nq - 1; w > q; w--) {                    /* first obstacle above them */
+        const uint4 o = *reinterpret_cast<const uint4 *>(&s_m[w][4 * l]);
+        const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) if (ow[cc]) nf[cc] = w * YB + __ffs(ow[cc]) - 1;
+    }
+    uint16_t *out = c.cy1 + base;
+#pragma unroll
+    for (int k = 0; k < YB; k++) {
+        const int y = q * YB + k;
+        if (y >= Y) break;
+        uint32_t r4[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const uint32_t bw = m[cc];
+            const uint32_t lo = bw & (0xffffffffu >> (31 - k));
+            const int below = lo ? q * YB + 31 - __clz(lo) : pl[cc];
+            const uint32_t hi = bw >> k;
+            const int above = hi ? y + __ffs(hi) - 1 : nf[cc];
+            int r;
+            if (above >= 0 && (below < 0 || above - y <= y - below)) r = above; else r = below;
+            r4[cc] = r < 0 ? 0xffffu : (uint32_t)r;
+        }
+        *reinterpret_cast<uint2 *>(out + (size_t)y * X) = make_uint2(r4[0] | (r4[1] << 16), r4[2] | (r4[3] << 16));
+    }
+}
+
 /* ------------------------------------------------------------------ lower-envelope argmin */
 /* One wave computes, for every position u of a row of L sites (L <= 64*CP), the site
  *     argmin_i (u-i)² + a_i     with ties going to the smaller i
