@@ -266,7 +266,7 @@ template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f
 }
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {
-    GIE_LAUNCH(b, k_edt_z_direct, dim3(b->cu_total * 8), dim3(256), 0, c);
+    GIE_LAUNCH(b, k_edt_z_direct, dim3(b->cu_total * 16), dim3(256), 0, c);
 }
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {
@@ -285,10 +285,14 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     /* X % 4 == 0: four columns per lane, dword loads / 8-byte stores (k_edt_y4) */
     static const int y4 = getenv("GIE_EDTY4") ? atoi(getenv("GIE_EDTY4")) : 1;
     if (y4 && (c.X & 3) == 0) {
-        const int yb = (y4 == 2 || c.Y > 512) ? 32 : 16;
-        dim3 g4((c.X / 4 + GIE_EDTY4_LANES - 1) / GIE_EDTY4_LANES, c.Z), b4(GIE_EDTY4_LANES, (c.Y + yb - 1) / yb);
-        if (yb == 16) GIE_LAUNCH(b, k_edt_y4<16>, g4, b4, 0, c);
-        else GIE_LAUNCH(b, k_edt_y4<32>, g4, b4, 0, c);
+        /* y4: 1 = 16 lanes x 4 columns per workgroup (more, smaller workgroups), 3 = 32 lanes */
+        const int yb = c.Y > 512 ? 32 : 16, nq = (c.Y + yb - 1) / yb;
+        const int lanes = (y4 == 3) ? 32 : 16;
+        dim3 g4((c.X / 4 + lanes - 1) / lanes, c.Z), b4(lanes, nq);
+        if (yb == 16 && lanes == 16) GIE_LAUNCH(b, (k_edt_y4<16, 16>), g4, b4, 0, c);
+        else if (yb == 16) GIE_LAUNCH(b, (k_edt_y4<16, 32>), g4, b4, 0, c);
+        else if (lanes == 16) GIE_LAUNCH(b, (k_edt_y4<32, 16>), g4, b4, 0, c);
+        else GIE_LAUNCH(b, (k_edt_y4<32, 32>), g4, b4, 0, c);
     }
     else if (c.Y <= 256) GIE_LAUNCH(b, (k_edt_y<8, 8>), gy, dim3(GIE_EDTY_COLS, 8), 0, c);
     else if (c.Y <= 512) GIE_LAUNCH(b, (k_edt_y<16, 16>), gy, dim3(GIE_EDTY_COLS, 16), 0, c);

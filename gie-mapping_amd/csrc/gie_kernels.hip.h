@@ -419,13 +419,12 @@ __global__ __launch_bounds__(GIE_EDTY_COLS * TPC) void k_edt_y(const gie_ctx c)
  * bound by the number of memory instructions, not by bytes).  Thread (l, q) owns the YB
  * positions y = q·YB .. of its four columns; what lies below / above its own mask word comes
  * from the other threads' words in LDS (one 16-byte read per word covers the four columns). */
-#define GIE_EDTY4_LANES 32
-template <int YB>
-__global__ __launch_bounds__(1024) void k_edt_y4(const gie_ctx c)
+template <int YB, int LANES>
+__global__ __launch_bounds__(32 * LANES) void k_edt_y4(const gie_ctx c)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_m[32][GIE_EDTY4_LANES * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_m[32][LANES * 4];
     const int l = threadIdx.x, q = threadIdx.y, nq = blockDim.y;
-    const int x = (blockIdx.x * GIE_EDTY4_LANES + l) * 4;
+    const int x = (blockIdx.x * LANES + l) * 4;
     const int z = blockIdx.y;
     if (!c.zocc[z]) return;                              /* plane without obstacle: passes X/Z never read its cy1 */
     const int X = c.X, Y = c.Y;
@@ -437,14 +436,17 @@ __global__ __launch_bounds__(1024) void k_edt_y4(const gie_ctx c)
         uint32_t v[YB];
 #pragma unroll
         for (int k = 0; k < YB; k++) {
-            const int y = q * YB + k;
-            v[k] = (y < Y) ? *reinterpret_cast<const uint32_t *>(t + (size_t)y * X) : 0u;
+            const int y = q * YB + k;                     /* rows past the end re-read the last one and are masked out */
+            v[k] = *reinterpret_cast<const uint32_t *>(t + (size_t)min(y, Y - 1) * X);
         }
+        const uint32_t ymask = (q * YB + YB <= Y) ? 0xffffffffu : ((q * YB < Y) ? (0xffffffffu >> (32 - (Y - q * YB))) : 0u);
 #pragma unroll
         for (int k = 0; k < YB; k++) {
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) m[cc] |= (uint32_t)(((v[k] >> (8 * cc)) & 0xffu) == (uint32_t)GIE_VOX_OCCUPIED) << k;
         }
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) m[cc] &= ymask;
     }
     *reinterpret_cast<uint4 *>(&s_m[q][4 * l]) = make_uint4(m[0], m[1], m[2], m[3]);
     __syncthreads();
@@ -960,28 +962,33 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
     if (!gie_use_lists(c, n)) return;                     /* many known tiles: the column kernel (launched next to this one) does the pass */
+    /* workgroup = known tile; its four waves split the planes with obstacles between them (the
+     * pass is a chain of dependent plane reads per tile: a quarter of the chain each), merge their
+     * minima through LDS, and each wave finishes two of the tile's eight z */
+    __shared__ uint32_t s_best[4][8][64];
     const int K = *c.zcount;
-    const int lane = threadIdx.x & 63;
-    const int waves = gridDim.x * 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t plane = (size_t)c.X * c.Y;
-    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+    const int kq = (((K + 3) >> 2) + 3) & ~3;              /* planes per wave, a multiple of the four reads in flight */
+    const int jlo = w * kq, jhi = min(K, jlo + kq);
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const int t = c.tl_known[e];
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
         const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3), z0 = tz * 8;
-        if (x >= c.X || y >= c.Y) continue;
-        const size_t o = (size_t)y * c.X + x;
+        const bool ok = x < c.X && y < c.Y;
+        const size_t o = ok ? (size_t)y * c.X + x : 0;
         /* key = (dist² << 10) | site rank: one v_min per voxel and site, ties go to the smaller rank =
          * smaller z (dist² < 2^22 is gie_create's envelope limit); four plane reads in flight per trip */
         uint32_t best[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) best[k] = 0xffffffffu;
-        for (int j0 = 0; j0 < K; j0 += 4) {
+        for (int j0 = jlo; j0 < jhi; j0 += 4) {
             int zj[4]; uint32_t v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int j = j0 + u < K ? j0 + u : K - 1; zj[u] = c.zlist[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; }
+            for (int u = 0; u < 4; u++) { const int j = j0 + u < jhi ? j0 + u : jhi - 1; zj[u] = c.zlist[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int j = j0 + u < K ? j0 + u : K - 1;           /* a repeated site does not change a minimum */
+                const int j = j0 + u < jhi ? j0 + u : jhi - 1;       /* a repeated site does not change a minimum */
                 const int dx = x - (int)(v[u] & 0xffffu), dy = y - (int)(v[u] >> 16);
                 const uint32_t a = (uint32_t)(dx * dx + dy * dy);
 #pragma unroll
@@ -991,18 +998,22 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
                 }
             }
         }
-        uint32_t win[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            win[k] = GIE_BCOC_NONE;
+        for (int k = 0; k < 8; k++) s_best[w][k][lane] = best[k];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int k = 2 * w + kk;
+            const uint32_t bk = min(min(s_best[0][k][lane], s_best[1][k][lane]), min(s_best[2][k][lane], s_best[3][k][lane]));
+            uint32_t win = GIE_BCOC_NONE;
             if (K > 0) {
-                const int zw = c.zlist[best[k] & 1023u];
+                const int zw = c.zlist[bk & 1023u];
                 const uint32_t vw = c.cxy2[(size_t)zw * plane + o];
-                win[k] = gie_pack_bcoc((int)(vw & 0xffffu), (int)(vw >> 16), zw);
+                win = gie_pack_bcoc((int)(vw & 0xffffu), (int)(vw >> 16), zw);
             }
+            if (ok && z0 + k < c.Z) c.bcoc[(size_t)(z0 + k) * plane + o] = win;
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (z0 + k < c.Z) c.bcoc[(size_t)(z0 + k) * plane + o] = win[k];
+        __syncthreads();                                   /* s_best is rewritten by the next tile */
     }
 }
 
