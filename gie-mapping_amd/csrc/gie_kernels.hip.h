@@ -662,11 +662,15 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
     const uint16_t *in = c.cy1 + (size_t)row * X;
     uint2 *ce = s_ce[wave];
     int K = 0;
-    for (int i0 = 0; i0 < X; i0 += 64) {
-        const int i = i0 + lane;
-        const uint16_t cy = (i < X) ? in[i] : (uint16_t)0xffff;
+    uint16_t cyv[CP];                                           /* the whole row in flight at once: one memory round trip per row, not CP */
+#pragma unroll
+    for (int m = 0; m < CP; m++) { const int i = 64 * m + lane; cyv[m] = in[min(i, X - 1)]; }
+#pragma unroll
+    for (int m = 0; m < CP; m++) {
+        const int i = 64 * m + lane;
+        const uint16_t cy = (i < X) ? cyv[m] : (uint16_t)0xffff;
         const int d = y - (int)cy;
-        K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane);
+        if (64 * m < X) K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane);
     }
     uint32_t *out = c.cxy2 + (size_t)row * X;
     const int u0 = lane * CP;
@@ -966,7 +970,10 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
      * pass is a chain of dependent plane reads per tile: a quarter of the chain each), merge their
      * minima through LDS, and each wave finishes two of the tile's eight z */
     __shared__ uint32_t s_best[4][8][64];
+    __shared__ uint16_t s_zl[1024];                        /* the planes with obstacles (sides are <= 1024): read from LDS, not through a dependent load per trip */
     const int K = *c.zcount;
+    for (int j = threadIdx.x; j < K; j += 256) s_zl[j] = c.zlist[j];
+    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t plane = (size_t)c.X * c.Y;
     const int kq = (((K + 3) >> 2) + 3) & ~3;              /* planes per wave, a multiple of the four reads in flight */
@@ -985,7 +992,7 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
         for (int j0 = jlo; j0 < jhi; j0 += 4) {
             int zj[4]; uint32_t v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int j = j0 + u < jhi ? j0 + u : jhi - 1; zj[u] = c.zlist[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; }
+            for (int u = 0; u < 4; u++) { const int j = j0 + u < jhi ? j0 + u : jhi - 1; zj[u] = s_zl[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + u < jhi ? j0 + u : jhi - 1;       /* a repeated site does not change a minimum */
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
             const uint32_t bk = min(min(s_best[0][k][lane], s_best[1][k][lane]), min(s_best[2][k][lane], s_best[3][k][lane]));
             uint32_t win = GIE_BCOC_NONE;
             if (K > 0) {
-                const int zw = c.zlist[bk & 1023u];
+                const int zw = s_zl[bk & 1023u];
                 const uint32_t vw = c.cxy2[(size_t)zw * plane + o];
                 win = gie_pack_bcoc((int)(vw & 0xffffu), (int)(vw >> 16), zw);
             }
