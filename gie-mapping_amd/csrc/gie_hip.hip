@@ -235,7 +235,7 @@ template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, b
 {
     if (!zpass) {
         const int rows = c.Y * c.Z;
-        GIE_LAUNCH(b, k_edt_x<CP>, dim3((rows + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES), dim3(64 * GIE_EDTX_WAVES), 0, c);
+        GIE_LAUNCH(b, k_edt_x<CP>, dim3((c.Y + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES, c.Z), dim3(64 * GIE_EDTX_WAVES), 0, c);
     } else {
         gie_launch_edt_z<CP, 16, 8>(b, c, full);      /* 2 workgroups per CU overlap load / envelope / store phases */
     }

@@ -631,14 +631,96 @@ __device__ __forceinline__ void gie_row_argmin_banded(const uint2 *ce, const int
     }
 }
 
+/* The banded argmin with LINEAR keys.  For one position u the order of the candidates does not
+ * change when u² << 10 is taken off every key:
+ *     ((u-i)² + a) << 10 | j   -   (u² << 10)   =   u · M_j + B_j ,     M_j = -(2 i) << 10 ,   B_j = (i² + a) << 10 | j
+ * so a candidate costs one 24-bit multiply-add and one SIGNED minimum; the low ten bits are still
+ * the rank.  Needs (u-i)² + a < 2^21 and i² + a < 2^21 (pass X: always, sides are <= 1024).
+ * mb[j] = { M_j, B_j }, j < K, followed by neutral entries { 0, INT_MAX } (gie_row_mb_pad);
+ * the array is 16-byte aligned and GIE_BAND_MAXK + GIE_BAND_PAD entries long. */
+#ifndef GIE_BAND_TRIP
+#define GIE_BAND_TRIP 8                                   /* sites per trip of a band loop (4, 8 or 16), = the alignment of its start: the loops are bound by the LDS round trip of a trip, not by the candidates */
+#endif
+#define GIE_BAND_PAD 16                                   /* neutral entries behind the K sites (>= GIE_BAND_TRIP - 1) */
+__device__ __forceinline__ void gie_row_mb_pad(int2 *mb, const int K, const int lane)
+{
+    if (lane < GIE_BAND_PAD - 1) mb[K + lane] = make_int2(0, 0x7fffffff);
+}
+template <int CP>
+__device__ __forceinline__ void gie_row_argmin_banded_lin(const int2 *mb, const int K, const int L, const int lane, int (&sj)[CP])
+{
+    constexpr int G = 64 / CP;                            /* lanes per band start */
+    const int b = lane / G, r = lane % G;
+    int b0 = 0x7fffffff, b1 = 0x7fffffff, b2 = 0x7fffffff, b3 = 0x7fffffff;
+    {
+        const int u = 64 * b, kl = K - 1;
+        for (int j = r; j < K; j += 4 * G) {
+            const int2 v0 = mb[j], v1 = mb[min(j + G, kl)], v2 = mb[min(j + 2 * G, kl)], v3 = mb[min(j + 3 * G, kl)];
+            b0 = min(b0, __mul24(u, v0.x) + v0.y);
+            b1 = min(b1, __mul24(u, v1.x) + v1.y);
+            b2 = min(b2, __mul24(u, v2.x) + v2.y);
+            b3 = min(b3, __mul24(u, v3.x) + v3.y);
+        }
+    }
+    int bg = min(min(b0, b1), min(b2, b3));
+#pragma unroll
+    for (int w = 1; w < G; w <<= 1) bg = min(bg, __shfl_xor(bg, w));
+    const int sg = (64 * b < L) ? (bg & 1023) : K - 1;
+    int sa[CP + 1];
+#pragma unroll
+    for (int m = 0; m < CP; m++) sa[m] = __builtin_amdgcn_readlane(sg, m * G);
+    sa[CP] = K - 1;
+#pragma unroll
+    for (int m = 0; m < CP; m++) {
+        /* the winner over ALL sites lies in sa[m] .. sa[m+1] and keys are distinct (they carry the
+         * rank), so a candidate outside that range can never win: the trips are aligned groups of four
+         * sites read as two 16-byte vectors, with no clamping (mb[K .. K+2] hold neutral entries) */
+        const int lo = sa[m] & ~(GIE_BAND_TRIP - 1), hi = sa[m + 1];   /* wave-uniform */
+        const int u = 64 * m + lane;
+        int c0 = 0x7fffffff, c1 = 0x7fffffff, c2 = 0x7fffffff, c3 = 0x7fffffff;
+        for (int j = lo; j <= hi; j += GIE_BAND_TRIP) {
+            const int4 p0 = *reinterpret_cast<const int4 *>(mb + j), p1 = *reinterpret_cast<const int4 *>(mb + j + 2);
+#if GIE_BAND_TRIP >= 8
+            const int4 p2 = *reinterpret_cast<const int4 *>(mb + j + 4), p3 = *reinterpret_cast<const int4 *>(mb + j + 6);
+#endif
+#if GIE_BAND_TRIP == 16
+            const int4 p4 = *reinterpret_cast<const int4 *>(mb + j + 8), p5 = *reinterpret_cast<const int4 *>(mb + j + 10);
+            const int4 p6 = *reinterpret_cast<const int4 *>(mb + j + 12), p7 = *reinterpret_cast<const int4 *>(mb + j + 14);
+#endif
+            c0 = min(c0, __mul24(u, p0.x) + p0.y);
+            c1 = min(c1, __mul24(u, p0.z) + p0.w);
+            c2 = min(c2, __mul24(u, p1.x) + p1.y);
+            c3 = min(c3, __mul24(u, p1.z) + p1.w);
+#if GIE_BAND_TRIP >= 8
+            c0 = min(c0, __mul24(u, p2.x) + p2.y);
+            c1 = min(c1, __mul24(u, p2.z) + p2.w);
+            c2 = min(c2, __mul24(u, p3.x) + p3.y);
+            c3 = min(c3, __mul24(u, p3.z) + p3.w);
+#endif
+#if GIE_BAND_TRIP == 16
+            c0 = min(c0, __mul24(u, p4.x) + p4.y);
+            c1 = min(c1, __mul24(u, p4.z) + p4.w);
+            c2 = min(c2, __mul24(u, p5.x) + p5.y);
+            c3 = min(c3, __mul24(u, p5.z) + p5.w);
+            c0 = min(c0, __mul24(u, p6.x) + p6.y);
+            c1 = min(c1, __mul24(u, p6.z) + p6.w);
+            c2 = min(c2, __mul24(u, p7.x) + p7.y);
+            c3 = min(c3, __mul24(u, p7.z) + p7.w);
+#endif
+        }
+        sj[m] = min(min(c0, c1), min(c2, c3)) & 1023;
+    }
+}
+
 /* wave64 stream compaction of the row's real sites; returns K.  `a` = value or ~0u (none),
  * `hi16` is carried in the upper half of ce[].y (pass X keeps the site's closest y there). */
-__device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const bool valid, const uint32_t a, const int i, const uint32_t hi16, const int lane)
+__device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const bool valid, const uint32_t a, const int i, const uint32_t hi16, const int lane, int2 *mb = nullptr)
 {
     const unsigned long long m = __ballot(valid);
     if (valid) {
         const int j = base + __popcll(m & ((1ull << lane) - 1ull));
         ce[j] = make_uint2((a << 10) | (uint32_t)j, ((uint32_t)i << 5) | (hi16 << 16));
+        if (mb && j < GIE_BAND_MAXK) mb[j] = make_int2(-(i << 11), (int)((((uint32_t)(i * i) + a) << 10) | (uint32_t)j));   /* linear keys of the banded form */
     }
     return base + __popcll(m);
 }
@@ -647,20 +729,31 @@ __device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const b
 /* one wave per (y,z) row; rows are contiguous in memory so loads/stores are coalesced; every
  * lane ends up with the CP consecutive results of its chunk in registers and stores them as
  * 16-byte vectors (the wave covers one contiguous run) */
+#ifndef GIE_EDTX_WAVES
 #define GIE_EDTX_WAVES 4
+#endif
 template <int CP>
 __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
 {
     constexpr int LP = 64 * CP;
     __shared__ __attribute__((aligned(16))) uint2 s_ce[GIE_EDTX_WAVES][LP];
+    /* the linear site records of the banded form (K <= GIE_BAND_MAXK) live in the upper half of the
+     * wave's site list when that is long enough — a longer row overwrites them with its own sites
+     * and does not use them — so that eight workgroups fit a compute unit's LDS */
+    constexpr bool OVL = LP >= 2 * (GIE_BAND_MAXK + GIE_BAND_PAD) && LP / 2 >= GIE_BAND_MAXK;
+    __shared__ __attribute__((aligned(16))) int2 s_mb[OVL ? 1 : GIE_EDTX_WAVES][OVL ? 1 : GIE_BAND_MAXK + GIE_BAND_PAD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * GIE_EDTX_WAVES + wave;        /* row = z*Y + y */
-    if (row >= c.Y * c.Z) return;
-    if (!c.zocc[row / c.Y]) return;                             /* empty plane: pass Z does not read its cxy2 */
+    /* grid = (rows of a plane / waves, planes): no division by a run-time size — most waves
+     * belong to a plane without obstacle and leave after one flag read, and an integer division
+     * was a quarter of all the instructions of the launch */
+    const int z = blockIdx.y, y = blockIdx.x * GIE_EDTX_WAVES + wave;
+    if (!c.zocc[z]) return;                                     /* empty plane: pass Z does not read its cxy2 */
+    if (y >= c.Y) return;
     const int X = c.X;
-    const int y = row % c.Y;
-    const uint16_t *in = c.cy1 + (size_t)row * X;
+    const size_t row = (size_t)z * c.Y + y;                     /* row = z*Y + y */
+    const uint16_t *in = c.cy1 + row * X;
     uint2 *ce = s_ce[wave];
+    int2 *mb = OVL ? reinterpret_cast<int2 *>(ce + LP / 2) : s_mb[OVL ? 0 : wave];
     int K = 0;
     uint16_t cyv[CP];                                           /* the whole row in flight at once: one memory round trip per row, not CP */
 #pragma unroll
@@ -670,9 +763,9 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
         const int i = 64 * m + lane;
         const uint16_t cy = (i < X) ? cyv[m] : (uint16_t)0xffff;
         const int d = y - (int)cy;
-        if (64 * m < X) K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane);
+        if (64 * m < X) K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane, mb);
     }
-    uint32_t *out = c.cxy2 + (size_t)row * X;
+    uint32_t *out = c.cxy2 + row * X;
     const int u0 = lane * CP;
     uint32_t o[CP];
     if (K == 0) {                                               /* slice without obstacle */
@@ -681,9 +774,10 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
     } else if (K <= GIE_BAND_MAXK) {
         /* few sites (the usual case: a handful of obstacle columns per row): banded form, results
          * for positions lane, 64 + lane, ... — stored as 4-byte coalesced rows */
+        gie_row_mb_pad(mb, K, lane);
         gie_wave_sync();
         int sj[CP];
-        gie_row_argmin_banded<CP>(ce, K, X, lane, sj);
+        gie_row_argmin_banded_lin<CP>(mb, K, X, lane, sj);
 #pragma unroll
         for (int m = 0; m < CP; m++) {
             const uint32_t e = ce[sj[m]].y;
