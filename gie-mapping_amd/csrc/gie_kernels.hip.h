@@ -956,10 +956,15 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
 __global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int ncol)
 {
     if (blockIdx.x == 0 && threadIdx.x < 64) {
+        /* all flag loads first (sides are <= 1024: 16 per lane), then the ballots: one memory round trip, not Z/64 */
+        uint8_t f[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int z = 64 * i + (int)threadIdx.x; f[i] = c.zocc[min(z, c.Z - 1)]; }
         int k = 0;
-        for (int z0 = 0; z0 < c.Z; z0 += 64) {
-            const int z = z0 + (int)threadIdx.x;
-            const bool v = z < c.Z && c.zocc[z];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int z = 64 * i + (int)threadIdx.x;
+            const bool v = z < c.Z && f[i];
             const unsigned long long m = __ballot(v);
             if (v) c.zlist[k + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = (uint16_t)z;
             k += __popcll(m);
