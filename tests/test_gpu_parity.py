@@ -54,6 +54,9 @@ def test_hip_matches_oracle(oracle_lib, sc):
     ((1024, 16, 12), 0.002, 11), ((16, 1024, 12), 0.002, 12), ((12, 16, 1024), 0.002, 13),
     # pass Z picks its argmin form by the number of planes with obstacles: banded (<= 160) or divide & conquer
     ((8, 8, 1000), 0.001, 14), ((24, 24, 400), 0.02, 15), ((20, 20, 200), 0.05, 16), ((16, 16, 130), 0.003, 17),
+    # pass X the same way by the number of obstacle columns of a plane: divide & conquer with more sites than half the
+    # wave's site list (they overwrite the banded form's linear records, which live there), with fewer, and banded rows
+    ((512, 24, 8), 0.05, 18), ((320, 16, 8), 0.08, 19), ((512, 12, 6), 0.01, 20), ((1024, 12, 4), 0.06, 21),
 ])
 def test_batch_edt_random_grids(oracle_lib, shape, dens, seed):
     """EDT passes alone on random obstacle fields, through the full C-ABI: types are injected
