@@ -1,19 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — map-update throughput of the MI355X incremental-EDT path.
 
-One step = one full map update of the 512^3 local volume at 0.05 m voxels (set_pose →
-OGM of a synthetic lidar point cloud → block alloc + fuse → batch EDT → Mark /
-frontiers / waves A,B,C / commit), i.e. VOLMAPNODE::publishMap's GPU work
-(src/volumetric_mapper.cpp:138-224).  Sensor frames are generated on the host beforehand and are
-resident in HBM when the timed region starts.
+One step = one full map update of a 512^3 local volume at 0.05 m voxels (set_pose → OGM → block
+allocation + fuse → batch EDT → Mark / obtainFrontiers / waves A,B,C / commit), i.e. the GPU work
+of VOLMAPNODE::publishMap (src/volumetric_mapper.cpp:138-224).  Inputs are resident in HBM when
+a timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|vlp16_projective|vlp16|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Workloads (all synthetic):
+  c5 (default)       BASELINE config 5's sensor-less world: voxel occupied iff hash(x,y,z) < 1 %, FULL
+                     observation, a quarter of the obstacles toggles every frame, the robot moves 8 voxels
+                     per frame.  Every voxel of the volume goes through every stage, so the algorithmic
+                     bytes of a map update are 132 B x N exactly, and the toggling obstacles next to the
+                     faces of the moving volume seed waves A, B and C in every timed step.
+  vlp16_projective   16-ring lidar cloud binned into the 16x440 range image of the reference's laser3D
+                     path (projective OGM): a quarter of the volume becomes known, flood waves.
+  vlp16 / lidar64*   the cloud through parallel ray casting (ugv_dataset / uav_raycast path): < 1 % of the
+                     volume known per frame.
 With N > 1 every rank owns one 512^3 tile of a larger volume around the same robot (2x2x2 tiles =
-1024^3 on 8 GPUs): same sensor stream, one-voxel halo exchange + refinement rounds over RCCL
-point-to-point after every update (gie/tiling.py).  Per-GPU work is fixed: scaling is "weak".
-Rank 0 prints ONE JSON line.
+1024^3 on 8 GPUs = BASELINE config 5 itself): one-voxel halo exchange + refinement over RCCL after
+every update (gie/tiling.py).  Per-GPU work is fixed: scaling is "weak".  Rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
+synchronize on both sides (MAX over ranks); regions repeat until >= 0.5 s has been timed and
+`value` / `ms_per_step` come from the median region.  Per-step latencies (median, p95) come from a
+further pass with one event pair per step on the mapper's stream, kernel durations from a replay of
+the first region on a fresh mapper with HIP events on every kernel's dispatch.
 """
 import argparse
 import json
@@ -27,132 +41,445 @@ sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured with a float4 copy)
 
 # algorithmic bytes per voxel per launch (reference field widths)
 ALG_BYTES = {
-    "ogm_classify": 1, "ray_finalize": 5, "fuse": 15, "edt_pass_y": 9, "edt_pass_x": 16, "edt_pass_z": 16,
+    "ogm_classify": 1, "fuse": 7, "edt_pass_y": 9, "edt_pass_x": 16, "edt_pass_z": 16,
     "mark": 33, "frontiers": 13, "commit": 37,
 }
-EDT_UPDATE_BYTES = 124  # V3..V8
+WAVE_VISIT_BYTES = 64      # own record + six 8-byte read-modify-writes
+RAY_CELL_BYTES = 13        # row R: 1 B label read + 4 B atomic + 4 B return + ray state amortised
+WAVEFRONT_SWEEP = ("mark", "frontiers", "waves", "commit")   # GlbHashMap::mergeNewObsv, glb_hash_map.cu:146-207
 
-
-# sensor models: name -> (rings, azimuth steps of the synthetic cloud, phi_min_deg, phi_inc_deg, range-image bins or None)
-SENSORS = {
-    # DEFAULT — BASELINE config "UGV VLP-16 3D LiDAR (ugv_dataset), 512^3 local volume, full wavefront A+B":
-    # launch/ugv_dataset.launch sets data_case=ugv_corridor, i.e. the point cloud goes through
-    # PntcldMapMaker → PNTCLD_RAYCAST (parallel ray casting).  Synthetic 16-ring x 1800 cloud.
+# lidar models: name -> (rings, azimuth steps, phi_min_deg, phi_inc_deg, range-image bins or None = ray casting)
+LIDARS = {
     "vlp16": (16, 1800, -15.0, 2.0, None),
-    # the same cloud through the projective path of launch/ugv_laser3d.launch (data_case=laser3D):
-    # convertPyntCld binning → MulScanParam(440,16,10,2pi/440,-pi,2deg,-15deg) (volumetric_mapper.cpp:327)
-    # → VLP_FAST.  Classifies every voxel of the +-15 deg wedge: dense maps, heavy wavefronts.
     "vlp16_projective": (16, 1800, -15.0, 2.0, 440),
-    # a denser 64-ring unit through both paths
     "lidar64": (64, 1800, -30.0, 60.0 / 64, None),
     "lidar64_projective": (64, 1800, -30.0, 60.0 / 64, 1800),
 }
+WORKLOADS = ["c5"] + sorted(LIDARS)
+C5 = {"seed": 5, "p_occ": 0.01, "toggle_frac": 0.25, "delta_vox": 8, "yaw_deg": 2.0}
 
 
-def make_frames(scenes, voxel, nframes, seed, sensor, delta_vox=8, yaw_deg=2.0, offset=(0.0, 0.0, 0.0)):
-    rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
-    world = scenes.BoxWorld(seed, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5,
-                            min_size=0.4, max_size=3.0)
-    out = []
-    for k in range(nframes):
-        pos, q = scenes.pose(k, voxel, delta_vox=delta_vox, yaw_deg=yaw_deg)
-        pos = tuple(np.float32(pos[i] + offset[i]) for i in range(3))
-        pts, _ = scenes.lidar_frame(world, k, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc,
-                                    max_range=30.0)
-        npts = pts.shape[0]
-        if bins is not None:   # Vlp16MapMaker::convertPyntCld binning of the cloud (vlp16_map_maker.cpp:73-147)
-            pts = scenes.range_image(pts, scan_num=bins, ring_num=rings, phi_min_deg=phi_min, phi_inc_deg=phi_inc)
-        out.append((pos, q, pts, npts))
+class HashWorldFeed:
+    """BASELINE config 5: label planes of the hash world, built on the device between timed regions."""
+
+    kind = "labels"
+
+    def __init__(self, torch, scenes, dev, voxel, size, tile_off):
+        self.torch, self.scenes, self.dev, self.voxel, self.size, self.tile_off = torch, scenes, dev, voxel, size, tile_off
+        self.first, self.planes = 0, []
+
+    def pose(self, i):
+        return self.scenes.pose(i, self.voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+
+    def prepare(self, first, count):
+        torch = self.torch
+        while len(self.planes) < count:
+            self.planes.append(torch.empty(self.size[2], self.size[1], self.size[0], dtype=torch.int8, device=self.dev))
+        for j in range(count):
+            pos, _ = self.pose(first + j)
+            pvt = self.scenes.local_pivot(pos, self.voxel, self.size, self.tile_off)
+            lab = self.scenes.hash_world_labels(
+                pvt, self.size, first + j, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"],
+                arange=lambda n: torch.arange(n, dtype=torch.int64, device=self.dev),
+                where=lambda c, a, b: torch.where(c, torch.tensor(a, dtype=torch.int8, device=self.dev), torch.tensor(b, dtype=torch.int8, device=self.dev)))
+            self.planes[j].copy_(lab)
+            del lab
+        self.first = first
+        torch.cuda.synchronize()
+
+    def step_input(self, m, i):
+        pos, q = self.pose(i)
+        m.set_pose(pos, q)
+        m.ogm_labels_dev(self.planes[i - self.first].data_ptr())
+
+    def describe(self):
+        return ("sensor-less hash world (BASELINE config 5): occupied iff hash(x,y,z) < %.0f %%, full observation, %.0f %% of the "
+                "obstacles toggle per frame, robot +%d voxels/frame" % (100 * C5["p_occ"], 100 * C5["toggle_frac"], C5["delta_vox"]))
+
+
+class LidarFeed:
+    """A 16- or 64-ring lidar in a box world: point clouds (ray casting) or range images (projective OGM)."""
+
+    def __init__(self, torch, scenes, dev, voxel, sensor, nframes):
+        self.torch, self.scenes, self.dev, self.voxel, self.sensor = torch, scenes, dev, voxel, sensor
+        self.rings, self.az, self.phi_min, self.phi_inc, self.bins = LIDARS[sensor]
+        self.kind = "pointcloud" if self.bins is None else "multiscan"
+        self.world = scenes.BoxWorld(5, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5, min_size=0.4, max_size=3.0)
+        self.frames = {}
+        self.npts = []
+
+    def _frame(self, i):
+        if i not in self.frames:
+            pos, q = self.scenes.pose(i, self.voxel, delta_vox=8, yaw_deg=2.0)
+            pts, _ = self.scenes.lidar_frame(self.world, i, pos, q, rings=self.rings, az=self.az, phi_min_deg=self.phi_min,
+                                             phi_inc_deg=self.phi_inc, max_range=30.0)
+            self.npts.append(pts.shape[0])
+            if self.bins is not None:   # Vlp16MapMaker::convertPyntCld binning (vlp16_map_maker.cpp:73-147)
+                pts = self.scenes.range_image(pts, scan_num=self.bins, ring_num=self.rings, phi_min_deg=self.phi_min, phi_inc_deg=self.phi_inc)
+            self.frames[i] = (pos, q, pts, self.torch.from_numpy(pts).to(self.dev))
+        return self.frames[i]
+
+    def prepare(self, first, count):
+        for i in range(first, first + count):
+            self._frame(i)
+        self.torch.cuda.synchronize()
+
+    def step_input(self, m, i):
+        pos, q, _, d = self._frame(i)
+        m.set_pose(pos, q)
+        if self.bins is None:
+            m.ogm_pointcloud_dev(d.data_ptr(), d.shape[0])
+        else:
+            m.ogm_multiscan_dev(d.data_ptr(), self.bins, self.rings, 2.0 * math.pi / self.bins, -math.pi,
+                                math.radians(self.phi_inc), math.radians(self.phi_min))
+
+    def oracle_update(self, om, i):
+        pos, q, pts, _ = self._frame(i)
+        if self.bins is None:
+            om.update(pos, q, "pointcloud", pts)
+        else:
+            om.update(pos, q, "multiscan", pts, theta_inc=2.0 * math.pi / self.bins, theta_min=-math.pi,
+                      phi_inc=math.radians(self.phi_inc), phi_min=math.radians(self.phi_min))
+
+    def describe(self):
+        return ("synthetic %d-ring x %d lidar cloud (%d pts/frame) in a box world with 25 %% toggling boxes via %s"
+                % (self.rings, self.az, int(np.mean(self.npts)) if self.npts else 0,
+                   "parallel ray casting" if self.bins is None else "%dx%d range image (projective OGM)" % (self.rings, self.bins)))
+
+
+def make_feed(workload, torch, scenes, dev, voxel, size, tile_off, nframes):
+    if workload == "c5":
+        return HashWorldFeed(torch, scenes, dev, voxel, size, tile_off)
+    return LidarFeed(torch, scenes, dev, voxel, workload, nframes)
+
+
+def percentile(xs, p):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * p
+    lo, hi = int(math.floor(k)), int(math.ceil(k))
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+class Runner:
+    """One mapper + its feed + (N > 1) the halo exchange after every update."""
+
+    def __init__(self, torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, exchange=True):
+        self.torch, self.dist, self.feed, self.rank, self.world, self.dev, self.backend = torch, dist, feed, rank, world, dev, backend
+        self.tiling = tiling
+        self.m = gie.Mapper(cfg)
+        self.exchange = exchange and world > 1
+        if world > 1:
+            tgrid = tiling.tile_grid(world)
+            self.m.set_tile(tiling.tile_offset_voxels(rank, world, size), tuple(tgrid[i] * size[i] for i in range(3)))
+        self.halo_bufs = {}
+        hr = os.environ.get("GIE_HALO_ROUNDS", "1")
+        self.halo_mode = "stable" if hr == "stable" else "stream"
+        self.halo_rounds = 1 if hr == "stable" else max(1, int(hr))
+        self.rounds_total = 0
+        self.updates = 0
+        self.checked_pivot = False
+
+    def step(self, i):
+        m = self.m
+        self.feed.step_input(m, i)
+        if not self.checked_pivot and self.feed.kind == "labels":       # the label planes were built for this pivot
+            pos, _ = self.feed.pose(i)
+            assert m.pivot() == self.feed.scenes.local_pivot(pos, self.feed.voxel, self.feed.size, self.feed.tile_off), "pivot mismatch"
+            self.checked_pivot = True
+        m.step()
+        self.updates += 1
+        if self.exchange:
+            t, d = self.tiling, self.dist
+            if self.backend != "nccl":
+                self.rounds_total += t.exchange_until_stable(m, d, self.rank, self.world)
+            elif self.halo_mode == "stream":
+                # one exchange round per map update, enqueued on the mapper's own stream (RCCL included): the host never waits
+                try:
+                    self.rounds_total += t.exchange_rounds_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, rounds=self.halo_rounds)
+                except Exception as e:                                  # e.g. no external-stream support: host-synchronised rounds
+                    sys.stderr.write("bench: stream-ordered exchange failed (%s); falling back to synchronised rounds\n" % e)
+                    self.halo_mode = "stable"
+                    self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs)
+            else:
+                self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, v):
+        if self.dist is None:
+            return v
+        t = self.torch.tensor([v], device=self.dev if self.backend == "nccl" else "cpu", dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def warmup(self, W):
+        self.feed.prepare(0, W)
+        for i in range(W):
+            self.step(i)
+        self.m.sync()
+        return W
+
+    def region(self, first, K):
+        """EXACTLY K timed steps between barrier + synchronize on both sides; MAX over ranks."""
+        self.feed.prepare(first, K)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(first, first + K):
+            self.step(i)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        self.m.sync()                                   # surfaces device-side capacity errors
+        return self.max_over_ranks(dt)
+
+    def latency_pass(self, first, K):
+        """Per-step device time: one event pair per step on the mapper's own stream."""
+        torch = self.torch
+        self.feed.prepare(first, K)
+        s = torch.cuda.ExternalStream(self.m.stream_handle(), device=self.dev)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        self.barrier()
+        for j in range(K):
+            evs[j][0].record(s)
+            self.step(first + j)
+            evs[j][1].record(s)
+        self.barrier()
+        self.m.sync()
+        return [a.elapsed_time(b) for a, b in evs]
+
+    def close(self):
+        self.m.close()
+
+
+def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff_dist, W, K, rank, world, dev, local_rank, backend,
+                 min_timed_s=0.5, max_regions=12, with_latency=True):
+    """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
+    n_vox = size[0] * size[1] * size[2]
+    tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
+    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank)
+    feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
+    r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend)
+    first = r.warmup(W)
+    st0 = r.m.stats()
+    regions = []
+    while True:
+        regions.append(r.region(first, K))
+        first += K
+        if sum(regions) >= min_timed_s or len(regions) >= max_regions:
+            break
+    st1 = r.m.stats()
+    timed_updates = K * len(regions)
+    lat = r.latency_pass(first, K) if with_latency else []
+    first += K if with_latency else 0
+    res = None
+    if rank == 0:
+        ty = r.m.read_local(edt=False, dist_sq=False, coc=False)["type"]
+        kn = ty != 0
+        n_known = int(kn.sum())
+        planes = int((ty == 2).any(axis=(1, 2)).sum())
+        Zs, Ys, Xs = ty.shape
+        pad = [(0, (-Zs) % 8), (0, (-Ys) % 8), (0, (-Xs) % 8)]
+        kt = np.pad(kn, pad).reshape((Zs + pad[0][1]) // 8, 8, (Ys + pad[1][1]) // 8, 8, (Xs + pad[2][1]) // 8, 8).any(axis=(1, 3, 5))
+        # the units one launch works on (SURVEY §8d: per-unit bytes x units per launch): observed voxels for the sweeps,
+        # the planes that hold obstacles for EDT passes Y / X, the tiles Mark reads for pass Z; all = N under full observation
+        units = {"fuse": n_known, "mark": n_known, "frontiers": n_known, "commit": n_known,
+                 "edt_pass_y": planes * Ys * Xs, "edt_pass_x": planes * Ys * Xs, "edt_pass_z": int(kt.sum()) * 512,
+                 "ogm_classify": n_vox}
+        known = n_known / float(n_vox)
+        ray_cells = None
+        del ty, kn, kt
+        res = {"known": known, "units": units}
+    blocks = st1["blocks_total"]
+    rounds_per_step = r.rounds_total / float(max(1, r.updates))
+    halo_mode = r.halo_mode
+    r.close()
+    if rank != 0:
+        return None
+    # kernel durations: the first region replayed on a fresh mapper with start / stop events on every kernel's dispatch
+    # (rank 0's tile, no halo exchange: the exchange kernels are not roofline candidates)
+    feed2 = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
+    r2 = Runner(torch, gie, tiling, None, feed2, cfg, rank, world, size, dev, backend, exchange=False)
+    r2.warmup(W)
+    if feed2.kind == "pointcloud":          # cells one scan's ray casting counts in (hits + cleared cells = the ray kernels' unit)
+        feed2.prepare(W, 1)
+        feed2.step_input(r2.m, W)
+        ray_cells = int(np.abs(r2.m.read_ogm()["ray_count"].astype(np.int64)).sum())
+        r2.m.step()
+        w0 = W + 1
+    else:
+        w0 = W
+    r2.m.profile_enable(True)
+    sv0 = r2.m.stats()
+    dt_instr = r2.region(w0, K)
+    prof = {k: v for k, v in r2.m.profile_read().items() if v[1] > 0}
+    sv1 = r2.m.stats()
+    r2.close()
+
+    med = percentile(regions, 0.5)
+    ms_per_step = 1e3 * med / K
+    hz = K / med
+    value = world * n_vox * hz / 1e6
+    visits = {k: (st1["total_visits_" + k] - st0["total_visits_" + k]) / float(timed_updates) for k in "abc"}
+    visits_instr = sum(sv1["total_visits_" + k] - sv0["total_visits_" + k] for k in "abc") / float(K)
+    units = res["units"]
+    alg = dict(ALG_BYTES)
+    if feed2.kind == "pointcloud":
+        alg["fuse"] = 15                     # ray-cast fuse also reads / zeroes _ray_count
+
+    def kernel_roof(name):
+        tot_ms, n = prof[name]
+        avg_ms = tot_ms / n
+        if name in alg:
+            b = alg[name] * units.get(name, n_vox)
+            what = {"alg_bytes_per_voxel": alg[name], "voxels_per_launch": units.get(name, n_vox)}
+        elif name == "waves":
+            b = WAVE_VISIT_BYTES * visits_instr
+            what = {"alg_bytes_per_visit": WAVE_VISIT_BYTES, "visits_per_launch": round(visits_instr, 1)}
+        elif name in ("ray_free", "ray_register") and ray_cells:
+            b = RAY_CELL_BYTES * ray_cells
+            what = {"alg_bytes_per_cell": RAY_CELL_BYTES, "cells_per_launch": ray_cells}
+        else:
+            return None
+        ach = b / (avg_ms * 1e-3) / 1e9
+        o = {"kernel": name, "avg_launch_ms": round(avg_ms, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": int(b)}
+        o.update(what)
+        return o
+
+    sweeps = {k: kernel_roof(k) for k in prof}
+    sweeps = {k: v for k, v in sweeps.items() if v}
+    dom = max(prof, key=lambda k: prof[k][0])
+    traffic = load_traffic(workload, size, world)
+    dom_roof = sweeps.get(dom)
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_roof["achieved"] if dom_roof else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom_roof["frac"] if dom_roof else None,
+                "traffic": (traffic or {}).get("kernels", {}).get(dom), "traffic_source": (traffic or {}).get("source"),
+                "avg_launch_ms": round(prof[dom][0] / prof[dom][1], 4)}
+    if dom_roof:
+        roofline.update({k: v for k, v in dom_roof.items() if k not in ("kernel", "achieved", "frac", "avg_launch_ms")})
+    roofline["note"] = ("achieved = SURVEY 8(d)'s bytes per unit x the units one launch works on / the kernel's average duration from HIP events on its "
+                        "own dispatch (the mapper's stream); traffic = rocprofv3 PMC bytes per launch from the committed profile named in "
+                        "traffic_source (null when no profile of this exact workload is committed) — it is not measured in this run")
+    # the wavefront sweep the north-star target names: Mark + obtainFrontiers + waves A/B/C + commit
+    ws = [sweeps[k] for k in WAVEFRONT_SWEEP if k in sweeps]
+    ws_ms = sum(prof[k][0] / prof[k][1] for k in WAVEFRONT_SWEEP if k in prof)
+    ws_bytes = sum(s["alg_bytes_per_launch"] for s in ws)
+    wavefront = {"kernels": [k for k in WAVEFRONT_SWEEP if k in prof], "ms_per_step": round(ws_ms, 4), "alg_bytes_per_step": int(ws_bytes),
+                 "achieved": round(ws_bytes / (ws_ms * 1e-3) / 1e9, 1) if ws_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ws_bytes / (ws_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ws_ms > 0 else None,
+                 "per_kernel_frac": {k: sweeps[k]["frac"] for k in WAVEFRONT_SWEEP if k in sweeps}}
+    all_bytes = sum(s["alg_bytes_per_launch"] for s in sweeps.values())
+    update = {"alg_bytes_per_step": int(all_bytes), "ms_per_step": round(ms_per_step, 4),
+              "achieved": round(all_bytes / (ms_per_step * 1e-3) / 1e9, 1), "frac": round(all_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "note": "every stage of the map update: algorithmic bytes of all kernels of a step / the uninstrumented step time"}
+    tgrid = tiling.tile_grid(world)
+    out = {
+        "value": round(value, 2), "ms_per_step": round(ms_per_step, 4), "hz": round(hz, 3),
+        "timed_regions": len(regions), "region_ms": [round(1e3 * x, 3) for x in regions], "timed_s": round(sum(regions), 3),
+        "step_ms": ({"median": round(percentile(lat, 0.5), 4), "p95": round(percentile(lat, 0.95), 4), "min": round(min(lat), 4),
+                     "max": round(max(lat), 4), "n": len(lat), "how": "one event pair per step on the mapper's stream, separate pass"} if lat else None),
+        "config": {"workload": "%dx%dx%d local grid @ %.2f m, %s, OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m, fast_mode off"
+                               % (size[0], size[1], size[2], voxel, feed2.describe(), cutoff_dist),
+                   "preset": workload,
+                   "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement (%.1f rounds/step, %s)"
+                             % (tgrid + tuple(size) + (rounds_per_step, "stream-ordered, fixed" if (halo_mode == "stream" and backend == "nccl")
+                                                       else "until no tile changes"))) if world > 1 else "single volume",
+                   "known_voxel_fraction": round(res["known"], 4),
+                   "wave_visits_per_step": [round(visits[k], 1) for k in "abc"],
+                   "wave_levels_last_step": [st1["levels_a"], st1["levels_b"], st1["levels_c"]],
+                   "blocks": blocks},
+        "kernels_ms_per_step": {k: round(v[0] / K, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "ms_per_step_instrumented": round(1e3 * dt_instr / K, 4),
+        "roofline": roofline, "roofline_wavefront_sweep": wavefront, "roofline_update": update,
+        "roofline_sweeps": {k: {kk: vv for kk, vv in v.items() if kk != "kernel"} for k, v in sweeps.items()},
+    }
     return out
 
 
-def cpu_baseline(scenes, voxel, cutoff_dist, sensor):
-    """The CPU oracle (a scalar port of the reference's algorithm) on a bounded sample of the
-    same workload: same scene generator / sensor, 256^3 local grid, 24 map updates (≈ 12 s)."""
+def load_traffic(workload, size, world):
+    """PMC bytes per launch from the committed profile of this exact workload (profiles/traffic_r02.json), or None."""
+    tp = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    if world != 1 or not os.path.exists(tp):
+        return None
+    try:
+        tj = json.load(open(tp))
+    except Exception:
+        return None
+    return tj.get("%s_%dx%dx%d" % (workload, size[0], size[1], size[2]))
+
+
+def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
+    """(i) the timed full-size CPU baseline of BASELINE.md §2 row B1: exact separable EDT with closest-obstacle tracking on
+    the SAME local grid, multi-threaded over all host cores (oracle/edt_mt.c, validated against brute force in tests/);
+    (ii) the scalar CPU restatement of the whole map update (the oracle) on one core, on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_py import OracleMapper
+    import oracle_py
     import gie
-    size = (256, 256, 256)
-    frames = make_frames(scenes, voxel, 24, 5, sensor)
-    rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
-    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False)
-    m = OracleMapper(cfg)
+    cores = os.cpu_count() or 1
+    # the occupancy the EDT works on: frame W of the workload (for the hash world the fused types are the labels: a first
+    # observation of an obstacle gives 250 * 0.8 = 200 > 180)
+    if workload == "c5":
+        pos, _ = scenes.pose(W, voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+        pvt = scenes.local_pivot(pos, voxel, size)
+        lab = scenes.hash_world_labels(pvt, size, W, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"],
+                                       arange=lambda n: torch.arange(n, dtype=torch.int64, device=dev),
+                                       where=lambda c, a, b: torch.where(c, torch.tensor(a, dtype=torch.int8, device=dev), torch.tensor(b, dtype=torch.int8, device=dev)))
+        types = lab.cpu().numpy()
+        del lab
+    else:
+        feed = LidarFeed(torch, scenes, dev, voxel, workload, W + 1)
+        cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=dev.index or 0)
+        m = gie.Mapper(cfg)
+        feed.prepare(0, W + 1)
+        for i in range(W + 1):
+            feed.step_input(m, i)
+            m.step()
+        types = m.read_local(edt=False, dist_sq=False, coc=False)["type"]
+        m.close()
+    n = size[0] * size[1] * size[2]
     t0 = time.perf_counter()
-    for pos, q, pts, _ in frames:
-        if bins is None:
-            m.update(pos, q, "pointcloud", pts)
+    oracle_py.edt_mt(types, nthreads=cores)
+    t1 = time.perf_counter() - t0
+    reps = max(1, min(8, int(12.0 / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle_py.edt_mt(types, nthreads=cores)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"value": round(n / dt / 1e6, 2), "unit": "Mvoxels/s", "cores": cores, "host_cores": cores, "kind": "port",
+           "stage": "batch EDT only (exact separable 3-pass EDT + closest obstacle), %d threads" % cores,
+           "ms_per_update": round(1e3 * dt, 2),
+           "sample": "%dx%dx%d grid of frame %d of the same workload (%d obstacles), %d + 1 repetitions, %.1f s of wall time"
+                     % (size[0], size[1], size[2], W, int((types == 2).sum()), reps, t1 + dt * reps)}
+    del types
+    # the whole map update, scalar port on one core, bounded sample (128^3 under full observation, 256^3 for the sparse lidar scans)
+    s2 = (128, 128, 128) if workload in ("c5", "vlp16_projective", "lidar64_projective") else (256, 256, 256)
+    cfg = gie.make_config(voxel, s2, cutoff_dist=cutoff_dist, fast_mode=False)
+    om = oracle_py.OracleMapper(cfg)
+    lf = None if workload == "c5" else LidarFeed(torch, scenes, torch.device("cpu"), voxel, workload, 32)
+    t0 = time.perf_counter()
+    k = 0
+    while k < 32 and (k < 3 or time.perf_counter() - t0 < 10.0):
+        if workload == "c5":
+            pos, q = scenes.pose(k, voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+            lab = scenes.hash_world_labels(scenes.local_pivot(pos, voxel, s2), s2, k, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"])
+            om.update(pos, q, "labels", lab.astype(np.int8))
         else:
-            m.update(pos, q, "multiscan", pts, theta_inc=2.0 * math.pi / bins, theta_min=-math.pi,
-                     phi_inc=math.radians(phi_inc), phi_min=math.radians(phi_min))
-    dt = time.perf_counter() - t0
-    m.close()
-    n = size[0] * size[1] * size[2] * len(frames)
-    return {"value": round(n / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": "256^3 local grid, same scene/%s generator, %d map updates (%.1f s)" % (sensor, len(frames), dt)}
-
-
-def timed_updates(torch, dist, m, step, warmup, steps, instrumented):
-    """W untimed map updates, then exactly K timed ones between barrier + synchronize on both sides.
-    instrumented = per-kernel HIP events on the mapper's stream: every timed kernel then carries a
-    completion signal the next dispatch waits for (≈ +0.1 ms per map update), so the throughput is
-    taken from an uninstrumented pass and the kernel durations from an instrumented pass over the
-    same map updates on a fresh mapper."""
-    for i in range(warmup):
-        step(m, i)
-    m.sync()
-    st0 = m.stats()
-    m.profile_enable(bool(instrumented))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        step(m, i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    m.sync()  # surfaces device-side capacity errors
-    return dt, st0
-
-
-def secondary_run(gie, scenes, torch, dev, sensor, size, voxel, cutoff_dist, warmup, steps):
-    """The same map update on the dense-observation preset (range-image OGM: most of the volume
-    becomes known and waves A/B/C flood), reported beside the headline so that the wavefront
-    kernels are seen under load.  Same timing rules as the main run."""
-    rings, az, phi_min, phi_inc, bins = SENSORS[sensor]
-    frames = make_frames(scenes, voxel, warmup + steps, 5, sensor)
-    d_pts = [torch.from_numpy(f[2]).to(dev) for f in frames]
-    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=dev.index or 0)
-
-    def step(m, i):
-        m.set_pose(frames[i][0], frames[i][1])
-        m.ogm_multiscan_dev(d_pts[i].data_ptr(), bins, rings, 2.0 * math.pi / bins, -math.pi, math.radians(phi_inc), math.radians(phi_min))
-        m.step()
-
-    m = gie.Mapper(cfg)
-    dt, st0 = timed_updates(torch, None, m, step, warmup, steps, False)
-    st = m.stats()
-    known = float((m.read_local(edt=False, dist_sq=False, coc=False)["type"] != 0).mean())
-    m.close()
-    m = gie.Mapper(cfg)                                   # the same map updates again, with per-kernel events
-    timed_updates(torch, None, m, step, warmup, steps, True)
-    prof = {k: v for k, v in m.profile_read().items() if v[1] > 0}
-    m.close()
-    n_vox = size[0] * size[1] * size[2]
-    visits = {k: (st["total_visits_" + k] - st0["total_visits_" + k]) / float(steps) for k in "abc"}
-    wave_ms = sum(prof[k][0] for k in ("waves",) if k in prof) / steps
-    return {"sensor": sensor, "ms_per_step": round(1e3 * dt / steps, 4), "hz": round(steps / dt, 3),
-            "value": round(n_vox * steps / dt / 1e6, 2), "unit": "Mvoxels/s", "known_voxel_fraction": round(known, 4),
-            "wave_visits_per_step": [round(visits[k], 1) for k in "abc"],
-            "wave_ms_per_step": round(wave_ms, 4),
-            "wave_visit_rate_Mvisits_per_s": round(sum(visits.values()) / (wave_ms * 1e-3) / 1e6, 1) if wave_ms > 0 else None,
-            "edt_update_frac_of_hbm_peak": round(EDT_UPDATE_BYTES * n_vox * (steps / dt) / (HBM_PEAK_GBS * 1e9), 4),
-            "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+            pos, q, pts, _ = lf._frame(k)
+            lf.oracle_update(om, k)
+        k += 1
+    dt2 = time.perf_counter() - t0
+    om.close()
+    out["full_update_1core"] = {"value": round(s2[0] * s2[1] * s2[2] * k / dt2 / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+                                "sample": "%dx%dx%d grid, same generator, %d map updates through the scalar oracle (%.1f s, input generation included)"
+                                          % (s2[0], s2[1], s2[2], k, dt2)}
+    return out
 
 
 def main():
@@ -162,14 +489,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--voxel", type=float, default=0.05)
+    ap.add_argument("--workload", "--sensor", dest="workload", choices=WORKLOADS, default="c5")
+    ap.add_argument("--min-timed-s", type=float, default=0.5, help="repeat the K-step region until this much has been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the dense-observation run reported beside the headline")
-    ap.add_argument("--sensor", choices=sorted(SENSORS), default="vlp16")
+    ap.add_argument("--no-extras", "--no-secondary", dest="no_extras", action="store_true",
+                    help="skip the projective-lidar and ray-casting runs reported beside the headline")
     args = ap.parse_args()
 
     import torch
     import gie
-    from gie import scenes
+    from gie import scenes, tiling
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -192,210 +521,31 @@ def main():
             dist.init_process_group(backend)
 
     size = tuple(args.size)
-    n_vox = size[0] * size[1] * size[2]
     cutoff_dist = 2.0
-    rings, az, phi_min, phi_inc, bins = SENSORS[args.sensor]
-    ALG_BYTES["fuse"] = 15 if bins is None else 7      # ray-cast fuse also reads/zeroes _ray_count
-    nframes = args.warmup + args.steps
-    # rank r maps tile r of a block-aligned arrangement of 512^3 tiles (2x2x2 = 1024^3 on 8 GPUs):
-    # ONE robot / sensor stream shared by all ranks, each rank's local volume offset to its tile,
-    # one-voxel halo exchange + refinement rounds over RCCL after every map update
-    from gie import tiling
-    frames = make_frames(scenes, args.voxel, nframes, 5, args.sensor)
-    tgrid = tiling.tile_grid(world)
-    whole = tuple(tgrid[i] * size[i] for i in range(3))
     dev = torch.device("cuda", local_rank)
-    d_pts = [torch.from_numpy(f[2]).to(dev) for f in frames]
-    torch.cuda.synchronize()
-
-    cfg = gie.make_config(args.voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank)
-    m = gie.Mapper(cfg)
-    halo_bufs = {}
-    if world > 1:
-        m.set_tile(tiling.tile_offset_voxels(rank, world, size), whole)
-    rounds_total = [0]
-    hr = os.environ.get("GIE_HALO_ROUNDS", "1")
-    halo_mode = ["stable" if hr == "stable" else "stream"]
-    halo_rounds = 1 if hr == "stable" else max(1, int(hr))
-    ray_cells = [None]
-
-    exchange = [world > 1]
-
-    def step(m, i):
-        pos, q = frames[i][0], frames[i][1]
-        m.set_pose(pos, q)
-        if bins is None:
-            m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0])
-        else:
-            m.ogm_multiscan_dev(d_pts[i].data_ptr(), bins, rings, 2.0 * math.pi / bins, -math.pi,
-                                math.radians(phi_inc), math.radians(phi_min))
-        if ray_cells[0] is None and bins is None and rank == 0:
-            # once, in the warm-up: how many cells does a scan's ray casting count in?  (|_ray_count| summed over
-            # the volume: every hit and every cleared cell is one visit = the algorithmic unit of the ray kernels)
-            ray_cells[0] = int(np.abs(m.read_ogm()["ray_count"].astype(np.int64)).sum())
-        m.step()
-        if exchange[0]:
-            if backend != "nccl":
-                rounds_total[0] += tiling.exchange_until_stable(m, dist, rank, world)
-            elif halo_mode[0] == "stream":
-                # one exchange round per map update, enqueued on the mapper's own stream (RCCL included): the host never waits.
-                # Information crosses one tile boundary per map update.  GIE_HALO_ROUNDS=stable: rounds until no tile changes.
-                try:
-                    rounds_total[0] += tiling.exchange_rounds_device(m, dist, rank, world, dev, halo_bufs, rounds=halo_rounds)
-                except Exception as e:                                  # e.g. no external-stream support: host-synchronised rounds
-                    sys.stderr.write("bench: stream-ordered exchange failed (%s); falling back to synchronised rounds\n" % e)
-                    halo_mode[0] = "stable"
-                    rounds_total[0] += tiling.exchange_until_stable_device(m, dist, rank, world, dev, halo_bufs)
-            else:
-                rounds_total[0] += tiling.exchange_until_stable_device(m, dist, rank, world, dev, halo_bufs)
-
-    dt, st0 = timed_updates(torch, dist, m, step, args.warmup, args.steps, False)
-    st = m.stats()
-    known = None
-    units = {}
+    W, K = args.warmup, args.steps
+    main_res = run_workload(torch, gie, scenes, tiling, dist, args.workload, size, args.voxel, cutoff_dist, W, K, rank, world, dev,
+                            local_rank, backend, min_timed_s=args.min_timed_s)
     if rank == 0:
-        ty = m.read_local(edt=False, dist_sq=False, coc=False)["type"]
-        kn = ty != 0
-        known = float(kn.mean())
-        # the units a launch processes (per-unit bytes x units of one launch): the sweeps only work on
-        # observed voxels, the EDT passes Y / X on the planes that hold obstacles, pass Z on the tiles Mark reads
-        n_known = int(kn.sum())
-        planes = int((ty == 2).any(axis=(1, 2)).sum())
-        Zs, Ys, Xs = ty.shape
-        pad = [(0, (-Zs) % 8), (0, (-Ys) % 8), (0, (-Xs) % 8)]
-        kt = np.pad(kn, pad).reshape((Zs + pad[0][1]) // 8, 8, (Ys + pad[1][1]) // 8, 8, (Xs + pad[2][1]) // 8, 8).any(axis=(1, 3, 5))
-        units = {"fuse": n_known, "mark": n_known, "frontiers": n_known, "commit": n_known,
-                 "edt_pass_y": planes * Ys * Xs, "edt_pass_x": planes * Ys * Xs, "edt_pass_z": int(kt.sum()) * 512,
-                 "ogm_classify": n_vox}
-        del ty, kn, kt
-    m.close()
-    prof, dt_instr = {}, None
-    if rank == 0:
-        # the same map updates once more on a fresh mapper, with per-kernel HIP events on its stream (rank 0's
-        # tile; no halo exchange: the exchange kernels are not roofline candidates)
-        exchange[0] = False
-        m2 = gie.Mapper(cfg)
-        if world > 1:
-            m2.set_tile(tiling.tile_offset_voxels(rank, world, size), whole)
-        dt_instr, _ = timed_updates(torch, None, m2, step, args.warmup, args.steps, True)
-        prof = m2.profile_read()
-        m2.close()
-
-    t_max = dt
-    if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-
-    if rank == 0:
-        ms_per_step = 1e3 * t_max / args.steps
-        hz = args.steps / t_max
-        value = world * n_vox * args.steps / t_max / 1e6
-        # dominant kernel of the timed map updates (HIP events on the mapper's own stream, instrumented pass)
-        sweeps = {k: v for k, v in prof.items() if v[1] > 0}
-        total_kernel_ms = sum(v[0] for v in sweeps.values())
-        dom = max(sweeps, key=lambda k: sweeps[k][0])
-        dom_ms = sweeps[dom][0] / sweeps[dom][1]
-        roof = None
-        if dom in ALG_BYTES:
-            achieved = ALG_BYTES[dom] * units.get(dom, n_vox) / (dom_ms * 1e-3) / 1e9
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tp):
-                try:
-                    traffic = sum(v for k3, v in json.load(open(tp)).items() if k3 == dom or k3.startswith(dom + ".")) or None
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(dom_ms, 4), "alg_bytes_per_voxel": ALG_BYTES[dom], "voxels_per_launch": units.get(dom, n_vox),
-                    "note": "achieved = the reference's per-voxel bytes x the voxels one launch works on (observed voxels for the "
-                            "sweeps, the planes that hold obstacles for EDT passes Y/X, the tiles Mark reads for pass Z; state of "
-                            "the last timed map update) / average launch time; traffic = rocprofv3 PMC bytes per launch"}
-        elif dom == "waves":
-            # BFS waves A+B+C (one launch): algorithmic bytes = 64 B per visited voxel (own record + six 8-byte RMWs)
-            visits = sum(st["total_visits_" + k] - st0["total_visits_" + k] for k in "abc") / float(sweeps[dom][1])
-            achieved = 64.0 * visits / (dom_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(dom_ms, 4),
-                    "alg_bytes_per_visit": 64, "visits_per_launch": round(visits, 1),
-                    "note": "level-synchronous BFS over %.0f voxels per launch on average: bound by the dependent "
-                            "cross-XCD round trips of each level (grid barrier), not by HBM bandwidth" % visits}
-        elif dom in ("ray_free", "ray_register") and ray_cells[0]:
-            # ray casting: algorithmic bytes = 13 B per visited cell (1 B scan label read + one 4-byte atomic
-            # read-modify-write + its 4-byte return path + 4 B of the ray's own state amortised), SURVEY §8d row R
-            achieved = 13.0 * ray_cells[0] / (dom_ms * 1e-3) / 1e9
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tp):
-                try:
-                    traffic = sum(v for k3, v in json.load(open(tp)).items() if k3 == dom or k3.startswith(dom + ".")) or None
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(dom_ms, 4),
-                    "alg_bytes_per_cell": 13, "cells_per_launch": ray_cells[0],
-                    "note": "per-ray 3-D DDA: a chain of dependent cell visits with one atomic each; bound by that latency chain "
-                            "(8 segments of a ray run side by side, 64 adjacent rays share atomics), not by HBM bandwidth"}
-        else:
-            roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                    "traffic": None, "avg_launch_ms": round(dom_ms, 4),
-                    "note": "dominant kernel is not volume-proportional"}
-        # every volume sweep against the same roofline (algorithmic bytes of SURVEY §8d)
-        sweeps_roof = {}
-        for k2, v2 in sweeps.items():
-            if k2 in ALG_BYTES:
-                ms2 = v2[0] / v2[1]
-                u2 = units.get(k2, n_vox)
-                sweeps_roof[k2] = {"avg_launch_ms": round(ms2, 4), "voxels_per_launch": u2,
-                                   "achieved_GBps": round(ALG_BYTES[k2] * u2 / (ms2 * 1e-3) / 1e9, 1),
-                                   "frac": round(ALG_BYTES[k2] * u2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        # HBM bytes one map update really moves: rocprofv3 PMC (FETCH_SIZE corrected + WRITE_SIZE) per launch of the
-        # committed profile of this workload, summed over the kernels of a step (None without the profile)
-        measured_bytes = None
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if args.sensor == "vlp16" and tuple(args.size) == (512, 512, 512) and os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                measured_bytes = tj.get("_per_step_total_bytes")
-            except Exception:
-                measured_bytes = None
-        line = {
-            "metric": "edt_map_update_throughput", "value": round(value, 2), "unit": "Mvoxels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "hz": round(hz, 3),
-            "config": {"workload": "%dx%dx%d local grid @ %.2f m, synthetic %d-ring x %d lidar point cloud (%d pts/frame) via %s, "
-                                   "OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m"
-                                   % (size[0], size[1], size[2], args.voxel, rings, az, int(np.mean([f[3] for f in frames])),
-                                      "parallel ray casting" if bins is None else "%dx%d range image (projective OGM)" % (rings, bins),
-                                      cutoff_dist),
-                       "sensor": args.sensor,
-                       "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement (%.1f rounds/step, %s)"
-                                 % (tgrid + size + (rounds_total[0] / float(nframes),
-                                                    "stream-ordered, fixed" if (halo_mode[0] == "stream" and backend == "nccl") else "until no tile changes"))) if world > 1 else "single volume",
-                       "known_voxel_fraction": known,
-                       "wave_visits_per_step": [round((st["total_visits_" + k] - st0["total_visits_" + k]) / args.steps, 1) for k in "abc"],
-                       "wave_levels_last_step": [st["levels_a"], st["levels_b"], st["levels_c"]],
-                       "blocks": st["blocks_total"]},
-            "edt_update_frac_of_hbm_peak": round(EDT_UPDATE_BYTES * n_vox * hz / (HBM_PEAK_GBS * 1e9), 4),
-            "edt_update_frac_note": "BASELINE.md's convention: the reference's 124 B per voxel of the WHOLE volume x Hz / 8 TB/s; above 1 "
-                                    "because the kernels only touch observed space (see measured_hbm_bytes_per_step)",
-            "measured_hbm_bytes_per_step": measured_bytes,
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(sweeps.items(), key=lambda kv: -kv[1][0])},
-            "kernel_time_fraction_of_step": round(total_kernel_ms / (1e3 * dt), 3),
-            "ms_per_step_instrumented": round(1e3 * dt_instr / args.steps, 4),
-            "instrumentation_note": "value / ms_per_step: the K timed map updates without per-kernel events; kernels_ms_per_step, roofline: "
-                                    "the same K map updates replayed on a fresh mapper with start/stop events on every kernel's dispatch "
-                                    "(hipExtLaunchKernelGGL, the mapper's stream), which costs ms_per_step_instrumented - ms_per_step",
-            "roofline": roof,
-            "roofline_sweeps": sweeps_roof,
-        }
-        if world == 1 and args.sensor == "vlp16" and not args.no_secondary:
-            line["dense_observation_run"] = secondary_run(gie, scenes, torch, dev, "vlp16_projective", size, args.voxel, cutoff_dist,
-                                                          args.warmup, args.steps)
+        line = {"metric": "edt_map_update_throughput", "value": main_res["value"], "unit": "Mvoxels/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+                "data": "synthetic"}
+        line.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+        line["timing_note"] = ("value / ms_per_step: median of the timed regions, each EXACTLY K steps between barrier + synchronize, MAX over ranks; "
+                               "kernels_ms_per_step and the roofline objects: the first region replayed on a fresh mapper with start / stop events "
+                               "on every kernel's dispatch (costs ms_per_step_instrumented - ms_per_step)")
+        if world == 1 and not args.no_extras:
+            extras = {}
+            for wl in ("vlp16_projective", "vlp16"):
+                if wl == args.workload:
+                    continue
+                e = run_workload(torch, gie, scenes, tiling, None, wl, size, args.voxel, cutoff_dist, W, K, 0, 1, dev, local_rank, backend,
+                                 min_timed_s=0.1, max_regions=4)
+                extras[wl] = {k: e[k] for k in ("value", "ms_per_step", "hz", "timed_regions", "step_ms", "config", "kernels_ms_per_step", "roofline",
+                                                "roofline_wavefront_sweep", "roofline_sweeps")}
+            line["extra_runs"] = extras
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scenes, args.voxel, cutoff_dist, args.sensor)
+            line["cpu_baseline"] = cpu_baseline(scenes, torch, dev, args.voxel, size, cutoff_dist, args.workload, W)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()                                    # rank 0's instrumented pass is over

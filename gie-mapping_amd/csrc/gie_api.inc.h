@@ -284,6 +284,31 @@ extern "C" int gie_ogm_scan2d(gie_mapper *m, const float *ranges, const gie_scan
     m->has_ogm = 1;
     return GIE_OK;
 }
+extern "C" int gie_ogm_labels_dev(gie_mapper *m, const int8_t *d_labels)
+{
+    int rc = gie_need_pose(m, "gie_ogm_labels"); if (rc) return rc;
+    if (!d_labels) { gie_set_err("gie_ogm_labels: bad arguments"); return GIE_ERR_INVALID; }
+    m->c.pntcld_mode = 0;
+    be_time(&m->be, 0);
+    be_prof(&m->be, GIE_K_CLASSIFY, 0); be_labels(&m->be, m->c, d_labels); be_prof(&m->be, GIE_K_CLASSIFY, 1);
+    be_time(&m->be, 1);
+    m->has_ogm = 1;
+    return GIE_OK;
+}
+extern "C" int gie_ogm_labels(gie_mapper *m, const int8_t *labels)
+{
+    int rc = gie_need_pose(m, "gie_ogm_labels"); if (rc) return rc;
+    if (!labels) { gie_set_err("gie_ogm_labels: bad arguments"); return GIE_ERR_INVALID; }
+    const size_t nfl = ((size_t)m->c.N + 3) / 4;                    /* the staging buffer is counted in floats */
+    if (nfl > m->sensor_cap) {
+        if (m->d_sensor) { be_sync(&m->be); be_free(&m->be, m->d_sensor); }
+        m->d_sensor = (float *)be_alloc(&m->be, nfl * sizeof(float), false);
+        m->sensor_cap = m->d_sensor ? nfl : 0;
+        if (!m->d_sensor) { gie_set_err("sensor buffer allocation failed"); return GIE_ERR_DEVICE; }
+    }
+    be_h2d(&m->be, m->d_sensor, labels, (size_t)m->c.N);
+    return gie_ogm_labels_dev(m, (const int8_t *)m->d_sensor);
+}
 extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
 {
     int rc = gie_need_pose(m, "gie_ogm_pointcloud"); if (rc) return rc;

@@ -56,6 +56,13 @@ struct op_classify_scan2d { static constexpr bool rolled = false;
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
         const int t = gie_classify_scan2d(c, img, p, x, y, z);
         if (t != GIE_VOX_UNKNOWN) { c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t; gie_mark_block_needed(c, x, y, z); } } };
+struct op_classify_labels { static constexpr bool rolled = false;
+    GIE_DEVM bool tile_skip(const gie_ctx &, int, int, int) const { return false; } const int8_t *labels;
+    GIE_DEVM bool skip(const gie_ctx &, int, int, int, int) const { return false; }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const {
+        const int t = gie_classify_label(c, labels, x, y, z);
+        c.inst_type[gie_lid(c, x, y, z)] = (int8_t)t;              /* the scan IS the label plane: unknown is written too */
+        if (t != GIE_VOX_UNKNOWN) gie_mark_block_needed(c, x, y, z); } };
 struct op_raycast_finalize { static constexpr bool rolled = false;
     /* no ray went through the tile (the robot sphere of for_motion_planner is written without rays) */
     GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.for_motion_planner && !c.tray[gie_tile_index(c, x, y, z0)]; }

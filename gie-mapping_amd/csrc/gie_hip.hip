@@ -188,6 +188,13 @@ template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f,
     if (n <= 0) return;
     GIE_LAUNCH(b, k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, c, f, n);
 }
+static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels)
+{
+    if ((c.X & 15) == 0 && !c.for_motion_planner && ((uintptr_t)labels & 15) == 0) {
+        const int nvec = c.N >> 4;
+        GIE_LAUNCH(b, k_labels16, dim3((nvec + 255) / 256), dim3(256), 0, c, labels, nvec);
+    } else { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
+}
 static void be_clear(be_state *b, const gie_clear_list &l)
 {
     if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(32, l.n), dim3(256), 0, l);

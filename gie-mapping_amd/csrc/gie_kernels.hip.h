@@ -67,6 +67,39 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
     if (i < n) f(c, i);
 }
 
+/* gie_ogm_labels for X % 16 == 0 without a robot sphere: a thread moves 16 voxels of a row (one
+ * 16-byte load, one 16-byte store) and flags the (at most three) blocks its observed voxels lie in */
+__global__ __launch_bounds__(256) void k_labels16(const gie_ctx c, const int8_t *labels, const int nvec)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const int xv = c.X >> 4;
+    const int x0 = (v % xv) << 4, row = v / xv, y = row % c.Y, z = row / c.Y;
+    const uint4 q = reinterpret_cast<const uint4 *>(labels)[v];
+    uint32_t w[4] = { q.x, q.y, q.z, q.w };
+    unsigned known = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t l = (w[j] >> (8 * b)) & 0xffu;
+            const bool ok = (l == (uint32_t)GIE_VOX_FREE) | (l == (uint32_t)GIE_VOX_OCCUPIED);
+            if (!ok) w[j] &= ~(0xffu << (8 * b));
+            known |= (ok ? 1u : 0u) << (4 * j + b);
+        }
+    }
+    reinterpret_cast<uint4 *>(c.inst_type)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (!known) return;
+    const int gx0 = x0 + c.pvt[0], gy = y + c.pvt[1], gz = z + c.pvt[2];
+    const int cell0 = (((gz >> 3) - c.tb0[2]) * c.tdim[1] + ((gy >> 3) - c.tb0[1])) * c.tdim[0] - c.tb0[0];
+    const int b0 = gx0 >> 3, b1 = (gx0 + 15) >> 3;
+    for (int bx = b0; bx <= b1; bx++) {
+        const int lo = max(bx * 8 - gx0, 0), hi = min(bx * 8 + 7 - gx0, 15);     /* voxels of this thread inside block bx */
+        const unsigned m = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+        if (known & m) c.blk_need[cell0 + bx] = 1;                              /* all writers store 1 */
+    }
+}
+
 /* ------------------------------------------------------------------ ray casting, segmented */
 /* freeLocObs with the walk of every ray cut into GIE_RAY_SEGS segments: lane = ray (64 rays
  * adjacent in the cloud per workgroup, so that the wave aggregation of the _ray_count atomics

@@ -198,6 +198,14 @@ GIE_DEV void gie_mark_block_needed(const gie_ctx &c, int x, int y, int z)
     c.blk_need[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])] = 1;
 }
 
+/* a pre-classified scan (gie_ogm_labels): the label a projective kernel would have left */
+GIE_DEV int gie_classify_label(const gie_ctx &c, const int8_t *labels, int x, int y, int z)
+{
+    if (gie_robot_sphere(c, x, y, z)) return GIE_VOX_FREE;
+    const int8_t l = labels[gie_lid(c, x, y, z)];
+    return (l == GIE_VOX_FREE || l == GIE_VOX_OCCUPIED) ? l : GIE_VOX_UNKNOWN;
+}
+
 /* ================================================================== OGM: ray casting */
 /* registerLocObs, pntcld_raycast.cu:83-102.  g_out receives the global-frame point. */
 GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out, int i)

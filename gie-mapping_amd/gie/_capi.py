@@ -82,6 +82,7 @@ SIGNATURES = {
     "ogm_multiscan": (C.c_int, [_H, C.c_void_p, C.POINTER(MultiScanParam)]),
     "ogm_depth": (C.c_int, [_H, C.c_void_p, C.POINTER(CamParam)]),
     "ogm_scan2d": (C.c_int, [_H, C.c_void_p, C.POINTER(ScanParam)]),
+    "ogm_labels": (C.c_int, [_H, C.c_void_p]),
     "set_ext_boxes": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "fuse": (C.c_int, [_H]),
     "batch_edt": (C.c_int, [_H]),
@@ -120,6 +121,7 @@ DEVICE_ONLY = {
     "halo_import_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "ogm_multiscan_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(MultiScanParam)]),
     "ogm_depth_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(CamParam)]),
+    "ogm_labels_dev": (C.c_int, [_H, C.c_void_p]),
 }
 
 

@@ -110,6 +110,12 @@ class MapperBase:
         p = ScanParam(ranges.shape[0], max_r, theta_inc, theta_min)
         self._chk(self._f["ogm_scan2d"](self._h, _ptr(ranges), C.byref(p)))
 
+    def ogm_labels(self, labels):
+        """A pre-classified scan: int8 [Z][Y][X], 0 unknown / 1 free / 2 occupied."""
+        labels = np.ascontiguousarray(labels, dtype=np.int8)
+        assert labels.size == self.n
+        self._chk(self._f["ogm_labels"](self._h, _ptr(labels)))
+
     def set_ext_boxes(self, ll, ur, active):
         ll = np.ascontiguousarray(ll, dtype=np.float32).reshape(-1, 3)
         ur = np.ascontiguousarray(ur, dtype=np.float32).reshape(-1, 3)
@@ -237,6 +243,8 @@ class MapperBase:
             self.ogm_multiscan(sensor_data, **kw)
         elif sensor_kind == "pointcloud":
             self.ogm_pointcloud(sensor_data)
+        elif sensor_kind == "labels":
+            self.ogm_labels(sensor_data)
         else:
             raise ValueError(sensor_kind)
         self.fuse()
@@ -318,6 +326,9 @@ class Mapper(MapperBase):
     def ogm_depth_dev(self, dptr, rows, cols, cx, cy, fx, fy, valid_nan=False):
         p = CamParam(rows, cols, cx, cy, fx, fy, int(valid_nan))
         self._chk(self._f["ogm_depth_dev"](self._h, C.c_void_p(dptr), C.byref(p)))
+
+    def ogm_labels_dev(self, dptr):
+        self._chk(self._f["ogm_labels_dev"](self._h, C.c_void_p(dptr)))
 
     def ogm_pointcloud_dev(self, dptr, n):
         self._chk(self._f["ogm_pointcloud_dev"](self._h, C.c_void_p(dptr), n))

@@ -135,3 +135,45 @@ def range_image(points, scan_num=440, ring_num=16, phi_min_deg=-15.0, phi_inc_de
     ok = (b >= 0) & (b < scan_num) & (ring >= 0) & (ring < ring_num)
     img[ring[ok], b[ok]] = hor[ok]
     return img
+
+
+# ---- the sensor-less synthetic world of BASELINE config 5 -----------------------
+# "voxel (x,y,z) occupied iff hash32(x,y,z,seed,frame_epoch) < p * 2^32, full observation; 25 % of the
+# obstacles toggle per frame".  Written with operators only, so the same code runs on numpy int64
+# arrays (tests) and torch int64 tensors (bench.py generates the label planes on the GPU).
+def _mix32(h):
+    h = h & 0xffffffff
+    h = h ^ (h >> 16)
+    h = (h * 0x7feb352d) & 0xffffffff
+    h = h ^ (h >> 15)
+    h = (h * 0x846ca68b) & 0xffffffff        # the int64 product may wrap: its low 32 bits do not care
+    h = h ^ (h >> 16)
+    return h
+
+
+def pos2coord(p, voxel_width):
+    """LocMap::pos2coord (local_batch.h:250-258): floorf(p / w + 0.5f) in fp32."""
+    return int(np.floor(np.float32(p) / np.float32(voxel_width) + np.float32(0.5)))
+
+
+def local_pivot(pos, voxel_width, size, tile_off=(0, 0, 0)):
+    """calculate_pivot_origin (local_batch.h:128-142) + the tile offset of gie_set_tile."""
+    return tuple(pos2coord(pos[i], voxel_width) - size[i] // 2 + int(tile_off[i]) for i in range(3))
+
+
+def hash_world_labels(pvt, size, frame, seed=5, p_occ=0.01, toggle_frac=0.25, arange=None, where=None):
+    """Label plane [Z][Y][X] (int8: 1 free, 2 occupied) of the local volume with pivot `pvt` at `frame`.
+    arange(n) / where(c, a, b) default to numpy; pass torch twins to build it on a device."""
+    if arange is None:
+        arange = lambda n: np.arange(n, dtype=np.int64)                     # noqa: E731
+        where = np.where
+    X, Y, Z = size
+    gx = (arange(X) + int(pvt[0])).reshape(1, 1, X)
+    gy = (arange(Y) + int(pvt[1])).reshape(1, Y, 1)
+    gz = (arange(Z) + int(pvt[2])).reshape(Z, 1, 1)
+    h = _mix32((gx * 73856093) ^ (gy * 19349669) ^ (gz * 83492791) ^ (int(seed) * 0x9e3779b1))
+    base = h < int(p_occ * 4294967296.0)
+    h2 = _mix32(h ^ 0x5bd1e995)
+    toggler = (h2 >> 8) < int(toggle_frac * 16777216.0)
+    present = base & (~toggler | (((h2 & 1) + int(frame)) % 2 == 0))
+    return where(present, 2, 1)

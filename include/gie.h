@@ -138,6 +138,16 @@ int gie_ogm_depth(gie_mapper *h, const float *depth, const gie_cam_param *p);
 int gie_ogm_depth_dev(gie_mapper *h, const float *d_depth, const gie_cam_param *p);
 /* HokuyoMapMaker::updateLocalOGM (hokuyo_map_maker.cpp:44-50) → HOKUYO_FAST::localOGMKernels. */
 int gie_ogm_scan2d(gie_mapper *h, const float *ranges, const gie_scan_param *p);
+/* A scan that arrives already classified: labels[idx] for every voxel of the local volume
+ * (x fastest), GIE_VOX_UNKNOWN = not observed, GIE_VOX_FREE, GIE_VOX_OCCUPIED (anything else is
+ * ignored).  This is the state the reference's projective kernels leave behind — `_inst_type` plus
+ * the block key of every observed voxel (setLocalOccupancy: vlp16_fast.cu:76-86,
+ * realsense_fast.cu:80-93, hokuyo_fast.cu:68-80) — without a sensor model in front of it; fused
+ * like any projective scan (updateHashOGMWithSensor).  It is how the sensor-less synthetic world
+ * of BASELINE config 5 (occupancy from a hash of the voxel, full observation) is
+ * fed.  The robot sphere of for_motion_planner is forced FREE as in every OGM kernel. */
+int gie_ogm_labels(gie_mapper *h, const int8_t *labels);
+int gie_ogm_labels_dev(gie_mapper *h, const int8_t *d_labels);
 
 /* Ext_Obs_Wrapper boxes as consumed by the fuse kernels (pre_map.cu:80-101,
  * unify_helper.cuh:68-86). ll/ur: n x 3 floats (metres); active: n flags. Box 0 is the inverted

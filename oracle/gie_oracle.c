@@ -394,6 +394,21 @@ int go_ogm_multiscan(gie_oracle *o, const float *ranges, const gie_multiscan_par
     return 0;
 }
 
+/* A scan that arrives classified (include/gie.h gie_ogm_labels): what the projective kernels'
+ * store phase leaves behind (vlp16_fast.cu:76-86) for a given label plane.  The plane replaces
+ * the scan labels; the robot sphere is FREE as in every setLocalOccupancy. */
+int go_ogm_labels(gie_oracle *o, const int8_t *labels)
+{
+    o->pntcld_mode = 0;
+    for (int z = 0; z < o->Z; z++) for (int y = 0; y < o->Y; y++) for (int x = 0; x < o->X; x++) {
+        const int id = lid(o, x, y, z);
+        if (robot_sphere(o, x, y, z)) { o->inst_type[id] = GIE_VOX_FREE; continue; }
+        const int8_t l = labels[id];
+        o->inst_type[id] = (l == GIE_VOX_FREE || l == GIE_VOX_OCCUPIED) ? l : GIE_VOX_UNKNOWN;
+    }
+    return 0;
+}
+
 /* REALSENSE_FAST::setLocalOccupancy (realsense_fast.cu:9-94) with CAM_HELPER::G2L
  * (camera_helper.h:11-23). */
 int go_ogm_depth(gie_oracle *o, const float *depth, const gie_cam_param *p)

@@ -11,7 +11,7 @@ class Scenario:
     def __init__(self, name, size, voxel=0.1, sensor="depth", frames=6, delta_vox=5, yaw_deg=40.0, seed=2,
                  cutoff_dist=2.0, fast_mode=False, n_boxes=30, extent=(4.0, 4.0, 1.5), for_motion_planner=False,
                  img=(120, 160, 130.0), toggle=0.25, lidar_az=360, ext_boxes=False, min_h=-1000.0, max_h=1000.0,
-                 max_depth=6.0):
+                 max_depth=6.0, p_occ=0.01):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -43,6 +43,11 @@ class Scenario:
                 img = scenes.range_image(pts)
                 yield pos, q, "multiscan", img, dict(theta_inc=2.0 * np.pi / 440, theta_min=-np.pi,
                                                      phi_inc=np.radians(2.0), phi_min=np.radians(-15.0))
+            elif kind == "labels":
+                # BASELINE config 5's sensor-less world: occupancy from a hash of the global voxel, full observation
+                pvt = scenes.local_pivot(pos, self.voxel, self.size, getattr(self, "tile_off", (0, 0, 0)))
+                yield pos, q, "labels", scenes.hash_world_labels(pvt, self.size, k, seed=self.seed, p_occ=self.p_occ,
+                                                                 toggle_frac=self.toggle).astype(np.int8), {}
             elif kind == "scan2d":
                 pts, rng = scenes.lidar_frame(world, k, pos, q, rings=1, az=360, phi_min_deg=0.0, max_range=30.0)
                 r = np.where(np.isfinite(rng[0]), rng[0], np.nan).astype(np.float32)
@@ -60,6 +65,8 @@ def _feed(m, kind, data, kw):
         m.ogm_multiscan(data, **kw)
     elif kind == "scan2d":
         m.ogm_scan2d(data, **kw)
+    elif kind == "labels":
+        m.ogm_labels(data)
 
 
 def probe_coords(pvt, size, rng, n=4000):

@@ -36,6 +36,15 @@ SCENARIOS = [
                     extent=(3.0, 3.0, 1.2), img=(240, 320, 260.0)),
     parity.Scenario("c4_slab", (320, 320, 40), voxel=0.05, sensor="lidar_points", frames=5, delta_vox=4, yaw_deg=2.0,
                     extent=(8.0, 8.0, 1.0), n_boxes=60, cutoff_dist=5.0, lidar_az=900),
+    # BASELINE C5's sensor-less world through gie_ogm_labels (vector kernel: X % 16 == 0; functor path: odd sizes / robot sphere)
+    parity.Scenario("c5_hash_world", (48, 48, 32), voxel=0.05, sensor="labels", frames=8, delta_vox=8, yaw_deg=2.0, seed=5,
+                    cutoff_dist=2.0, p_occ=0.01),
+    parity.Scenario("c5_dense_odd", (40, 36, 20), voxel=0.05, sensor="labels", frames=8, delta_vox=3, yaw_deg=2.0, seed=6,
+                    cutoff_dist=0.5, p_occ=0.05, toggle=0.5),
+    parity.Scenario("c5_planner", (64, 48, 24), voxel=0.05, sensor="labels", frames=5, delta_vox=5, yaw_deg=2.0, seed=7,
+                    cutoff_dist=1.0, p_occ=0.02, for_motion_planner=True),
+    parity.Scenario("c5_128cube", (128, 128, 128), voxel=0.05, sensor="labels", frames=5, delta_vox=8, yaw_deg=2.0, seed=5,
+                    cutoff_dist=2.0, p_occ=0.01),
     parity.Scenario("c2_256cube", (256, 256, 256), voxel=0.05, sensor="mixed", frames=4, delta_vox=4, yaw_deg=2.0,
                     extent=(6.0, 6.0, 3.0), n_boxes=60, img=(480, 640, 525.0)),
 ]

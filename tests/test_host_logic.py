@@ -26,6 +26,12 @@ SCENARIOS = [
     # BASELINE C3's wave parameters (ugv yaml: cutoff 100 m => no cutoff at all, full waves A+B), small volume
     parity.Scenario("c3_no_cutoff", (56, 56, 20), voxel=0.1, sensor="multiscan", frames=10, delta_vox=6, yaw_deg=12.0,
                     cutoff_dist=100.0, extent=(5.0, 5.0, 1.5)),
+    # BASELINE C5's sensor-less world (hash occupancy, full observation, 25 % toggling, block-aligned motion) and a
+    # denser / misaligned variant; the pre-classified scan goes through gie_ogm_labels
+    parity.Scenario("c5_hash_world", (48, 48, 32), voxel=0.05, sensor="labels", frames=8, delta_vox=8, yaw_deg=2.0, seed=5,
+                    cutoff_dist=2.0, p_occ=0.01),
+    parity.Scenario("c5_dense_odd", (40, 36, 20), voxel=0.05, sensor="labels", frames=8, delta_vox=3, yaw_deg=2.0, seed=6,
+                    cutoff_dist=0.5, p_occ=0.05, toggle=0.5),
 ]
 
 
@@ -65,3 +71,21 @@ def test_edge_inputs_emulation(oracle_lib):
     images without a valid reading: the emulated device logic equals the oracle on all of them."""
     import edge_inputs
     edge_inputs.run(OracleMapper, EmuMapper)
+
+
+def test_hash_world_numpy_equals_torch():
+    """The C5 label generator is written once and run on numpy (tests) or torch (bench.py, on the GPU)."""
+    import numpy as np
+    import torch
+    from gie import scenes
+    for pvt, frame in (((-37, 12, -5), 0), ((100000, -70001, 33), 7)):
+        a = scenes.hash_world_labels(pvt, (24, 20, 12), frame, seed=5)
+        b = scenes.hash_world_labels(pvt, (24, 20, 12), frame, seed=5,
+                                     arange=lambda n: torch.arange(n, dtype=torch.int64), where=lambda c, x, y: torch.where(c, x, y))
+        assert np.array_equal(np.asarray(a), b.numpy())
+    lab = scenes.hash_world_labels((0, 0, 0), (128, 128, 64), 0, seed=5, p_occ=0.01)
+    frac = float((lab == 2).mean())
+    assert 0.006 < frac < 0.011                   # p_occ minus the toggled-off share
+    nxt = scenes.hash_world_labels((0, 0, 0), (128, 128, 64), 1, seed=5, p_occ=0.01)
+    changed = float(((lab == 2) != (nxt == 2)).sum()) / float(((lab == 2) | (nxt == 2)).sum())
+    assert 0.15 < changed < 0.35                  # about a quarter of the obstacles toggle per frame

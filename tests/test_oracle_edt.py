@@ -164,3 +164,27 @@ def test_incremental_field_against_the_definition(oracle_lib, toggle, sensor):
         assert (d[inside] == true_sq[inside]).mean() > 0.995                     # measured: 1.0 / 1.0 / 1.0 / 0.9997
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("shape,dens,seed,threads", [
+    ((32, 32, 32), 0.01, 1, 1), ((64, 48, 40), 0.002, 2, 3), ((33, 70, 17), 0.05, 3, 8), ((1, 40, 1), 0.1, 4, 2),
+    ((50, 1, 30), 0.03, 5, 4), ((24, 24, 24), 1.0, 6, 5), ((40, 40, 40), 0.00002, 7, 8),
+])
+def test_edt_mt_equals_brute_force(oracle_lib, shape, dens, seed, threads):
+    """The full-size CPU baseline (multi-threaded separable EDT, oracle/edt_mt.c) is exact: its
+    squared distances equal the O(N*M) brute force, and its closest obstacle is an occupied voxel at
+    exactly that distance."""
+    from oracle_py import EDT_MT_NONE, brute_force_edt, edt_mt
+    X, Y, Z = shape
+    rng = np.random.default_rng(seed)
+    occ = rng.random((Z, Y, X)) < dens
+    occ[Z // 2, Y // 2, X // 2] = True
+    ty = np.where(occ, 2, 1).astype(np.int8)
+    d, c = edt_mt(ty, nthreads=threads)
+    assert np.array_equal(d, brute_force_edt(occ.astype(np.int8)))
+    cx, cy, cz = c & 1023, (c >> 10) & 1023, c >> 20
+    zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    assert occ[cz, cy, cx].all()
+    assert np.array_equal((xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2, d)
+    d0, c0 = edt_mt(np.ones((6, 5, 4), np.int8), nthreads=2)
+    assert (d0 == EDT_MT_NONE).all() and (c0 == -1).all()

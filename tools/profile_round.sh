@@ -6,7 +6,7 @@
 # Summaries land in gpurun_out/prof_<tag>/ ; copy what is to be judged into profiles/.
 set -u
 TAG=${1:-r01}
-ARGS=${2:-"--steps 10 --warmup 3 --no-cpu-baseline --no-secondary"}
+ARGS=${2:-"--steps 10 --warmup 3 --no-cpu-baseline --no-extras --min-timed-s 0"}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
