@@ -63,6 +63,30 @@ WORKLOADS = ["c5"] + sorted(LIDARS)
 C5 = {"seed": 5, "p_occ": 0.01, "toggle_frac": 0.25, "delta_vox": 8, "yaw_deg": 2.0}
 
 
+SENSORS = LIDARS
+
+
+def lidar_world(scenes):
+    return scenes.BoxWorld(5, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5, min_size=0.4, max_size=3.0)
+
+
+def lidar_host_frame(scenes, world, voxel, sensor, i):
+    """(pos, quat, cloud or range image, points in the cloud) of frame i of a lidar workload."""
+    rings, az, phi_min, phi_inc, bins = LIDARS[sensor]
+    pos, q = scenes.pose(i, voxel, delta_vox=8, yaw_deg=2.0)
+    pts, _ = scenes.lidar_frame(world, i, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc, max_range=30.0)
+    npts = pts.shape[0]
+    if bins is not None:   # Vlp16MapMaker::convertPyntCld binning (vlp16_map_maker.cpp:73-147)
+        pts = scenes.range_image(pts, scan_num=bins, ring_num=rings, phi_min_deg=phi_min, phi_inc_deg=phi_inc)
+    return pos, q, pts, npts
+
+
+def make_frames(scenes, voxel, nframes, seed, sensor):
+    """Host-side frames of a lidar workload (tests replay the bench's scenes through the oracle)."""
+    world = lidar_world(scenes)
+    return [lidar_host_frame(scenes, world, voxel, sensor, i) for i in range(nframes)]
+
+
 class HashWorldFeed:
     """BASELINE config 5: label planes of the hash world, built on the device between timed regions."""
 
@@ -108,18 +132,14 @@ class LidarFeed:
         self.torch, self.scenes, self.dev, self.voxel, self.sensor = torch, scenes, dev, voxel, sensor
         self.rings, self.az, self.phi_min, self.phi_inc, self.bins = LIDARS[sensor]
         self.kind = "pointcloud" if self.bins is None else "multiscan"
-        self.world = scenes.BoxWorld(5, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5, min_size=0.4, max_size=3.0)
+        self.world = lidar_world(scenes)
         self.frames = {}
         self.npts = []
 
     def _frame(self, i):
         if i not in self.frames:
-            pos, q = self.scenes.pose(i, self.voxel, delta_vox=8, yaw_deg=2.0)
-            pts, _ = self.scenes.lidar_frame(self.world, i, pos, q, rings=self.rings, az=self.az, phi_min_deg=self.phi_min,
-                                             phi_inc_deg=self.phi_inc, max_range=30.0)
-            self.npts.append(pts.shape[0])
-            if self.bins is not None:   # Vlp16MapMaker::convertPyntCld binning (vlp16_map_maker.cpp:73-147)
-                pts = self.scenes.range_image(pts, scan_num=self.bins, ring_num=self.rings, phi_min_deg=self.phi_min, phi_inc_deg=self.phi_inc)
+            pos, q, pts, npts = lidar_host_frame(self.scenes, self.world, self.voxel, self.sensor, i)
+            self.npts.append(npts)
             self.frames[i] = (pos, q, pts, self.torch.from_numpy(pts).to(self.dev))
         return self.frames[i]
 

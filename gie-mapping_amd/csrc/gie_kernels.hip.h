@@ -745,6 +745,52 @@ __device__ __forceinline__ void gie_row_argmin_banded_lin(const int2 *mb, const 
     }
 }
 
+/* DENSE rows (most sites real — e.g. pass X behind a pass Y in a volume with obstacles in every
+ * column): the argmin of position u cannot lie farther from u than the square root of ANY value
+ * already seen for u, because (u-i)² alone would exceed it.  So every position scans a window
+ * around itself that grows until its radius passes sqrt(best value) for every position of the
+ * wave: with obstacles a few voxels apart that is a dozen candidates on either side instead of a
+ * divide & conquer over hundreds of sites (2200 → 600 VALU instructions per 512-long row).
+ *   sk[i] = (a_i << 10) | i  for real sites, GIE_WIN_NONE otherwise, valid for i in [-GIE_WIN_MAX, 64 CP + GIE_WIN_MAX);
+ *   lane owns positions lane, 64 + lane, …; best[m] = min key of position 64 m + lane: its low ten
+ *   bits are the winning site, ties going to the smaller site like the envelope forms.
+ * All reads are consecutive words across the wave (no bank conflicts), the loop is wave-uniform.
+ * Returns false when some position still has no bound inside GIE_WIN_MAX (a sparse stretch of the
+ * row): the caller falls back to the envelope forms. */
+#define GIE_WIN_MAX 48
+#define GIE_WIN_NONE 0x7fffffffu                          /* (2^21 - 1) << 10 | 1023: adding (48² << 10) cannot wrap */
+template <int CP>
+__device__ __forceinline__ bool gie_row_window(const uint32_t *sk, const int L, const int lane, uint32_t (&best)[CP], const unsigned bandneed = ~0u)
+{
+#pragma unroll
+    for (int m = 0; m < CP; m++) best[m] = sk[64 * m + lane];
+    int W = 0;
+#pragma unroll 1
+    for (;;) {                                            /* one trip = four more candidates on either side (kept rolled: registers) */
+        uint32_t mx = 0;                                  /* the largest bound among this lane's positions that somebody reads */
+#pragma unroll
+        for (int m = 0; m < CP; m++) if (64 * m + lane < L && ((bandneed >> m) & 1u)) mx = max(mx, best[m] >> 10);
+        if (!__any((uint32_t)((W + 1) * (W + 1)) <= mx)) return true;     /* every candidate that could still win or tie has been seen */
+        if (W >= GIE_WIN_MAX) return false;
+        const uint32_t *lo = sk + (lane - W - 4), *hi = sk + (lane + W + 1);   /* u - (W+4) .. u - (W+1)  and  u + (W+1) .. u + (W+4) */
+        const uint32_t a1 = (uint32_t)((W + 1) * (W + 1)) << 10, a2 = (uint32_t)((W + 2) * (W + 2)) << 10;
+        const uint32_t a3 = (uint32_t)((W + 3) * (W + 3)) << 10, a4 = (uint32_t)((W + 4) * (W + 4)) << 10;
+#pragma unroll
+        for (int m = 0; m < CP; m++) {
+            if (!((bandneed >> m) & 1u)) continue;        /* wave-uniform */
+            const uint32_t l4 = lo[64 * m], l3 = lo[64 * m + 1], l2 = lo[64 * m + 2], l1 = lo[64 * m + 3];
+            const uint32_t h1 = hi[64 * m], h2 = hi[64 * m + 1], h3 = hi[64 * m + 2], h4 = hi[64 * m + 3];
+            uint32_t b = best[m];
+            b = min(b, min(l1 + a1, h1 + a1));
+            b = min(b, min(l2 + a2, h2 + a2));
+            b = min(b, min(l3 + a3, h3 + a3));
+            b = min(b, min(l4 + a4, h4 + a4));
+            best[m] = b;
+        }
+        W += 4;
+    }
+}
+
 /* wave64 stream compaction of the row's real sites; returns K.  `a` = value or ~0u (none),
  * `hi16` is carried in the upper half of ce[].y (pass X keeps the site's closest y there). */
 __device__ __forceinline__ int gie_row_compact_push(uint2 *ce, int base, const bool valid, const uint32_t a, const int i, const uint32_t hi16, const int lane, int2 *mb = nullptr)
@@ -791,6 +837,39 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
     uint16_t cyv[CP];                                           /* the whole row in flight at once: one memory round trip per row, not CP */
 #pragma unroll
     for (int m = 0; m < CP; m++) { const int i = 64 * m + lane; cyv[m] = in[min(i, X - 1)]; }
+    uint32_t *out = c.cxy2 + row * X;
+    if (CP >= 4) {
+        /* most sites real (a volume with obstacles in almost every column): windowed scan over the
+         * direct-indexed row, kept in this wave's site-list memory */
+        int kall = 0;
+#pragma unroll
+        for (int m = 0; m < CP; m++) if (64 * m < X) kall += __popcll(__ballot(64 * m + lane < X && cyv[m] != 0xffff));
+        if (kall > GIE_BAND_MAXK) {
+            static_assert(CP < 4 || (LP + 2 * GIE_WIN_MAX) * 4 + LP * 2 <= LP * 8, "the windowed row must fit the wave's site list");
+            uint32_t *sk = reinterpret_cast<uint32_t *>(ce) + GIE_WIN_MAX;
+            uint16_t *scy = reinterpret_cast<uint16_t *>(ce) + 2 * (LP + 2 * GIE_WIN_MAX);
+#pragma unroll
+            for (int m = 0; m < CP; m++) {
+                const int i = 64 * m + lane;
+                const uint16_t cy = (i < X) ? cyv[m] : (uint16_t)0xffff;
+                const int d = y - (int)cy;
+                sk[i] = (cy != 0xffff) ? (((uint32_t)(d * d) << 10) | (uint32_t)i) : GIE_WIN_NONE;
+                scy[i] = cy;
+            }
+            if (lane < GIE_WIN_MAX) { sk[-1 - lane] = GIE_WIN_NONE; sk[LP + lane] = GIE_WIN_NONE; }
+            gie_wave_sync();
+            uint32_t best[CP];
+            if (gie_row_window<CP>(sk, X, lane, best)) {
+#pragma unroll
+                for (int m = 0; m < CP; m++) {
+                    const int sx = (int)(best[m] & 1023u);
+                    if (64 * m + lane < X) out[64 * m + lane] = (uint32_t)sx | ((uint32_t)scy[sx] << 16);
+                }
+                return;
+            }
+            gie_wave_sync();                                    /* a sparse stretch: the envelope forms take the row (they rebuild the site list) */
+        }
+    }
 #pragma unroll
     for (int m = 0; m < CP; m++) {
         const int i = 64 * m + lane;
@@ -798,7 +877,6 @@ __global__ __launch_bounds__(64 * GIE_EDTX_WAVES) void k_edt_x(const gie_ctx c)
         const int d = y - (int)cy;
         if (64 * m < X) K = gie_row_compact_push(ce, K, cy != 0xffff, (uint32_t)(d * d), i, (uint32_t)cy, lane, mb);
     }
-    uint32_t *out = c.cxy2 + row * X;
     const int u0 = lane * CP;
     uint32_t o[CP];
     if (K == 0) {                                               /* slice without obstacle */
@@ -876,6 +954,9 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
      * every voxel of the plane a closest obstacle): one list for the whole launch (k_edt_prep) */
     const int K = *c.zcount;
     for (int j = threadIdx.x; j < K; j += NT) s_zl[j] = c.zlist[j];
+    unsigned zvalid = 0;                                  /* bit m: plane 64 m + lane holds obstacles (windowed form) */
+#pragma unroll
+    for (int m = 0; m < CP; m++) { const int z = 64 * m + lane; if (z < Z && c.zocc[z]) zvalid |= 1u << m; }
     __syncthreads();
 
     int t = blockIdx.x;
@@ -926,6 +1007,47 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 3
             continue;                                           /* measurement only: no column work at all */
 #endif
+            if (CP >= 4 && K > GIE_BAND_MAXK) {
+                /* obstacles in most planes: windowed scan along z over the direct-indexed column (the
+                 * wave's site-list memory holds it); planes without obstacles carry no value */
+                unsigned bn = 0;
+#pragma unroll
+                for (int m = 0; m < CP && m < 8; m++) if ((nc >> (8 * m)) & 0xffull) bn |= 1u << m;
+                if (full) bn = ~0u;
+                uint32_t *sk = reinterpret_cast<uint32_t *>(ce) + GIE_WIN_MAX;
+#pragma unroll
+                for (int m = 0; m < CP; m++) {
+                    const int i = 64 * m + lane;
+                    uint32_t key = GIE_WIN_NONE;
+                    if ((zvalid >> m) & 1u) {                    /* rows of planes without obstacles are never staged */
+                        const uint32_t v = tile[i * TS + col];
+                        if (v != 0xffffffffu) { const int dx = x - (int)(v & 0xffffu), dy = y - (int)(v >> 16); key = ((uint32_t)(dx * dx + dy * dy) << 10) | (uint32_t)i; }
+                    }
+                    sk[i] = key;
+                }
+                if (lane < GIE_WIN_MAX) { sk[-1 - lane] = GIE_WIN_NONE; sk[LP + lane] = GIE_WIN_NONE; }
+                gie_wave_sync();
+                uint32_t best[CP];
+                const bool okw = gie_row_window<CP>(sk, Z, lane, best, bn);
+                if (okw) {
+                    uint32_t oc[CP];
+#pragma unroll
+                    for (int m = 0; m < CP; m++) {
+                        if (64 * m + lane < Z && ((bn >> m) & 1u)) {
+                            const int s = (int)(best[m] & 1023u);
+                            const uint32_t v = tile[s * TS + col];
+                            oc[m] = gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), s);
+                        }
+                    }
+                    gie_wave_sync();
+#pragma unroll
+                    for (int m = 0; m < CP; m++)
+                        if (64 * m + lane < Z && ((bn >> m) & 1u)) tile[(64 * m + lane) * TS + col] = oc[m];
+                    gie_wave_sync();
+                    continue;
+                }
+                gie_wave_sync();                                /* a sparse stretch of the column: envelope forms below */
+            }
             for (int j = lane; j < K; j += 64) {                /* site j = plane s_zl[j]: value = in-plane distance² */
                 const int i = s_zl[j];
                 const uint32_t v = tile[i * TS + col];

@@ -102,6 +102,51 @@ def test_batch_edt_random_grids(oracle_lib, shape, dens, seed):
         b.close()
 
 
+def _edt_pair(shape, occ):
+    """Batch EDT of an occupancy grid through oracle and HIP (types injected by one point per obstacle voxel)."""
+    X, Y, Z = shape
+    w = 0.1
+    cfg = gie.make_config(w, shape, cutoff_dist=1.0)
+    zz, yy, xx = np.nonzero(occ)
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        for m in (a, b):
+            m.set_pose((0.0, 0.0, 0.0))
+        pv = np.array(a.pivot())
+        pts = ((np.stack([xx, yy, zz], -1) + pv) * np.float32(w)).astype(np.float32)
+        for m in (a, b):
+            m.ogm_pointcloud(pts)
+            m.fuse()
+            m.batch_edt()
+        return a.read_batch_edt(), b.read_batch_edt()
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("shape,dens,gap,seed", [
+    # dense rows / columns take the windowed form of passes X and Z (most sites real); a wide empty stretch inside a
+    # dense row makes the window give up and the envelope forms take over — both sides of that switch, every template
+    ((256, 200, 8), 0.01, None, 31), ((512, 64, 4), 0.3, None, 32), ((16, 16, 512), 0.01, None, 33), ((24, 20, 300), 0.2, None, 34),
+    ((512, 40, 6), 0.05, ("x", 120, 400), 35), ((12, 12, 512), 0.05, ("z", 100, 330), 36), ((320, 48, 8), 0.04, ("x", 10, 150), 37),
+    ((1024, 24, 4), 0.1, ("x", 300, 340), 38), ((8, 24, 1024), 0.1, ("z", 500, 600), 39), ((512, 512, 2), 0.01, None, 40),
+])
+def test_batch_edt_dense_rows(oracle_lib, shape, dens, gap, seed):
+    X, Y, Z = shape
+    rng = np.random.default_rng(seed)
+    occ = rng.random((Z, Y, X)) < dens
+    if gap is not None:
+        ax, lo, hi = gap
+        if ax == "x":
+            occ[:, :, lo:hi] = False
+        else:
+            occ[lo:hi, :, :] = False
+    occ[0, 0, 0] = True
+    ea, eb = _edt_pair(shape, occ)
+    assert np.array_equal(ea["dist_sq"], eb["dist_sq"])
+    assert np.array_equal(ea["coc"], eb["coc"])
+
+
 def test_empty_volume(oracle_lib):
     cfg = gie.make_config(0.1, (24, 20, 12))
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
@@ -178,6 +223,49 @@ def test_full_size_512_cube(oracle_lib):
         assert np.array_equal(rc["dist_sq"][known], rb["dist_sq"][known])
     finally:
         a.close(); b.close()
+
+
+def test_full_size_512_cube_hash_world(oracle_lib):
+    """The bench's headline workload at full size (BASELINE config 5 on one 512^3 tile: hash world, full
+    observation).  The scalar oracle is too slow for 134 M fully observed voxels, so the batch EDT is
+    pinned by the INDEPENDENT multi-threaded CPU EDT (oracle/edt_mt.c, itself pinned by brute force):
+    squared distances bit for bit, the closest obstacle as a witness.  After the merge: every voxel
+    is known, its distance is witnessed by its closest obstacle, and never below the true distance."""
+    from gie import scenes
+    from oracle_py import edt_mt
+    size = (512, 512, 512)
+    cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
+    b = gie.Mapper(cfg)
+    try:
+        for k in range(2):
+            pos, q = scenes.pose(k, 0.05, delta_vox=8, yaw_deg=2.0)
+            lab = scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, size), size, k, seed=5).astype(np.int8)
+            b.set_pose(pos, q)
+            b.ogm_labels(lab)
+            b.fuse(); b.batch_edt()
+            eb = b.read_batch_edt()
+            ty = b.read_local(edt=False, dist_sq=False, coc=False)["type"]
+            assert (ty != 0).all()
+            d_cpu, _ = edt_mt(ty, want_coc=False)
+            assert np.array_equal(eb["dist_sq"], d_cpu), "batch EDT differs in %d voxels" % int((eb["dist_sq"] != d_cpu).sum())
+            c = eb["coc"]
+            assert (ty[c[..., 2], c[..., 1], c[..., 0]] == 2).all()
+            zz, yy, xx = np.meshgrid(np.arange(512, dtype=np.int32), np.arange(512, dtype=np.int32), np.arange(512, dtype=np.int32), indexing="ij")
+            assert np.array_equal((xx - c[..., 0]) ** 2 + (yy - c[..., 1]) ** 2 + (zz - c[..., 2]) ** 2, d_cpu)
+            del eb, c, xx, yy, zz
+            b.merge()
+            rb = b.read_local(edt=False)
+            st = b.stats()
+            pv = np.array(b.pivot(), dtype=np.int64)
+            assert (rb["dist_sq"] >= d_cpu).all()          # propagation never undershoots the true distance
+            assert float((rb["dist_sq"] == d_cpu).mean()) > 0.999
+            g = np.stack(np.meshgrid(np.arange(512), np.arange(512), np.arange(512), indexing="ij")[::-1], -1) + pv
+            assert np.array_equal(((rb["coc"].astype(np.int64) - g) ** 2).sum(-1), rb["dist_sq"])
+            if k == 1:
+                assert st["visits_a"] + st["visits_b"] + st["visits_c"] > 0
+            del rb, g, d_cpu, ty
+    finally:
+        b.close()
 
 
 @pytest.mark.gpu
