@@ -180,21 +180,26 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
 {
     if (!m || !pos || !q) { gie_set_err("gie_set_pose: null"); return GIE_ERR_INVALID; }
     gie_ctx &c = m->c;
+    /* validate before anything changes: a rejected pose leaves the mapper exactly as it was */
+    int crd[3];
+    for (int i = 0; i < 3; i++) {
+        if (!(fabsf(pos[i]) <= 1.0e6f)) { gie_set_err("gie_set_pose: position is not finite"); return GIE_ERR_INVALID; }
+        crd[i] = gie_pos2coord(pos[i], c.voxel_width);
+        if (crd[i] > 900000 || crd[i] < -900000) { gie_set_err("gie_set_pose: position outside the representable map"); return GIE_ERR_INVALID; }
+    }
     c.map_ct += 1;                                        /* _time++, volumetric_mapper.cpp:144 */
     c.L2G = gie_se3_from_quat(q[0], q[1], q[2], q[3], pos[0], pos[1], pos[2]);
     c.G2L = gie_se3_inv(c.L2G);
     const int sz[3] = { c.X, c.Y, c.Z };
     for (int i = 0; i < 3; i++) {
         c.origin[i] = pos[i];
-        const int crd = gie_pos2coord(pos[i], c.voxel_width);
-        c.pvt[i] = crd - sz[i] / 2 + m->next_off[i];      /* calculate_pivot_origin, local_batch.h:128-142 (+ tile offset) */
+        c.pvt[i] = crd[i] - sz[i] / 2 + m->next_off[i];   /* calculate_pivot_origin, local_batch.h:128-142 (+ tile offset) */
         c.tile_off[i] = m->next_off[i];
         c.whole_lo[i] = -(m->next_whole[i] / 2) + sz[i] / 2 - m->next_off[i];
         c.whole_hi[i] = c.whole_lo[i] + m->next_whole[i];
         m->msg_origin[i] = (float)c.pvt[i] * c.voxel_width;
-        c.upvt[i] = crd - c.wr[i] / 2;                    /* calculate_update_pivot, :159-166 */
+        c.upvt[i] = crd[i] - c.wr[i] / 2;                 /* calculate_update_pivot, :159-166 */
         c.tb0[i] = (c.pvt[i] - 1) >> 3;
-        if (crd > 900000 || crd < -900000) { gie_set_err("gie_set_pose: position outside the representable map"); return GIE_ERR_INVALID; }
     }
     const uint32_t f = (uint32_t)c.map_ct & 0x3ffffu;
     if (f == 0) {                                         /* stamp wrap: clear the stamp planes once */
@@ -367,6 +372,8 @@ extern "C" int gie_set_ext_boxes(gie_mapper *m, const float *ll, const float *ur
 extern "C" int gie_fuse(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_fuse"); if (rc) return rc;
+    if (!m->has_ogm) { gie_set_err("gie_fuse: no scan has been fed since the last fuse (call gie_ogm_* first)"); return GIE_ERR_INVALID; }
+    m->has_ogm = 0;
     m->ogm_unlabelled = 0;                /* fuse consumes the scan */
     be_time(&m->be, 2);
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive

@@ -257,13 +257,25 @@ def test_full_size_512_cube_hash_world(oracle_lib):
             rb = b.read_local(edt=False)
             st = b.stats()
             pv = np.array(b.pivot(), dtype=np.int64)
-            assert (rb["dist_sq"] >= d_cpu).all()          # propagation never undershoots the true distance
-            assert float((rb["dist_sq"] == d_cpu).mean()) > 0.999
+            # d_cpu only knows the obstacles INSIDE the volume.  A closest obstacle inside the volume can never be
+            # closer than that; one outside it (an obstacle the volume has left behind: limited observation, waves)
+            # may be, and then it has to be a voxel the global map believes occupied
+            cl = rb["coc"].astype(np.int64) - pv
+            inside = ((cl >= 0) & (cl < 512)).all(-1)
+            assert (rb["dist_sq"][inside] >= d_cpu[inside]).all()
+            assert (rb["dist_sq"][~inside] <= d_cpu[~inside]).all()
+            if k == 0:
+                assert inside.all() and np.array_equal(rb["dist_sq"], d_cpu)     # nothing is known outside yet
+            else:
+                assert 0 < int((~inside).sum()) < 0.05 * inside.size
+                far = np.ascontiguousarray(rb["coc"][~inside][::97][:4096], dtype=np.int32)
+                assert (b.query_global(far)["vox_type"] == 2).all()
+            assert float((rb["dist_sq"][inside] == d_cpu[inside]).mean()) > 0.999
             g = np.stack(np.meshgrid(np.arange(512), np.arange(512), np.arange(512), indexing="ij")[::-1], -1) + pv
             assert np.array_equal(((rb["coc"].astype(np.int64) - g) ** 2).sum(-1), rb["dist_sq"])
             if k == 1:
                 assert st["visits_a"] + st["visits_b"] + st["visits_c"] > 0
-            del rb, g, d_cpu, ty
+            del rb, g, d_cpu, ty, cl, inside
     finally:
         b.close()
 

@@ -89,3 +89,28 @@ def test_hash_world_numpy_equals_torch():
     nxt = scenes.hash_world_labels((0, 0, 0), (128, 128, 64), 1, seed=5, p_occ=0.01)
     changed = float(((lab == 2) != (nxt == 2)).sum()) / float(((lab == 2) | (nxt == 2)).sum())
     assert 0.15 < changed < 0.35                  # about a quarter of the obstacles toggle per frame
+
+
+def test_rejected_pose_leaves_the_mapper_untouched_and_fuse_needs_a_scan():
+    """gie_set_pose validates before it changes anything (a rejected pose does not bump the frame counter or the
+    pivots); gie_fuse without a scan since the last fuse is an error, not a re-fuse of stale labels."""
+    import numpy as np
+    import gie as _gie
+    cfg = _gie.make_config(0.1, (24, 24, 8), cutoff_dist=1.0)
+    m = EmuMapper(cfg)
+    try:
+        m.set_pose((1.0, 2.0, 0.5))
+        pvt, frame = m.pivot(), m.stats()["frame"]
+        for bad in ((1.0e9, 0.0, 0.0), (0.0, float("nan"), 0.0), (0.0, 0.0, -95000.0)):
+            with pytest.raises(RuntimeError):
+                m.set_pose(bad)
+            assert m.pivot() == pvt and m.stats()["frame"] == frame
+        with pytest.raises(RuntimeError) as e:
+            m.fuse()
+        assert "no scan" in str(e.value)
+        m.ogm_labels(np.ones((8, 24, 24), np.int8))
+        m.fuse()
+        with pytest.raises(RuntimeError):
+            m.fuse()                                  # the scan was consumed
+    finally:
+        m.close()
