@@ -47,10 +47,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured w
 ALG_BYTES = {
     "ogm_classify": 1, "fuse": 7, "edt_pass_y": 9, "edt_pass_x": 16, "edt_pass_z": 16,
     "mark": 33, "frontiers": 13, "commit": 37,
+    "mark_commit": 33 + 37,    # Mark and commit as one sweep (rows V6 + V8)
 }
 WAVE_VISIT_BYTES = 64      # own record + six 8-byte read-modify-writes
 RAY_CELL_BYTES = 13        # row R: 1 B label read + 4 B atomic + 4 B return + ray state amortised
-WAVEFRONT_SWEEP = ("mark", "frontiers", "waves", "commit")   # GlbHashMap::mergeNewObsv, glb_hash_map.cu:146-207
+WAVEFRONT_SWEEP = ("mark", "mark_commit", "frontiers", "waves", "commit")   # GlbHashMap::mergeNewObsv, glb_hash_map.cu:146-207
 
 # lidar models: name -> (rings, azimuth steps, phi_min_deg, phi_inc_deg, range-image bins or None = ray casting)
 LIDARS = {
@@ -310,7 +311,7 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         kt = np.pad(kn, pad).reshape((Zs + pad[0][1]) // 8, 8, (Ys + pad[1][1]) // 8, 8, (Xs + pad[2][1]) // 8, 8).any(axis=(1, 3, 5))
         # the units one launch works on (per-unit bytes x units per launch): observed voxels for the sweeps,
         # the planes that hold obstacles for EDT passes Y / X, the tiles Mark reads for pass Z; all = N under full observation
-        units = {"fuse": n_known, "mark": n_known, "frontiers": n_known, "commit": n_known,
+        units = {"fuse": n_known, "mark": n_known, "mark_commit": n_known, "frontiers": n_known, "commit": n_known,
                  "edt_pass_y": planes * Ys * Xs, "edt_pass_x": planes * Ys * Xs, "edt_pass_z": int(kt.sum()) * 512,
                  "ogm_classify": n_vox}
         known = n_known / float(n_vox)

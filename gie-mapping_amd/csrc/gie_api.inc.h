@@ -12,9 +12,9 @@
 #include <vector>
 
 enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, GIE_K_ALLOC, GIE_K_FUSE, GIE_K_EDT_Y, GIE_K_EDT_X,
-       GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_EDT_ZFACES, GIE_K_NUM };
+       GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_EDT_ZFACES, GIE_K_MARKC, GIE_K_NUM };
 static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
-       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "waves", "commit", "edt_prep" };
+       "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "waves", "commit", "edt_prep", "mark_commit" };
 
 static thread_local std::string g_gie_err;
 static void gie_set_err(const std::string &s) { g_gie_err = s; }
@@ -141,6 +141,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     for (int i = 0; i < 2; i++) {
         c.qa[i] = gie_dalloc<uint64_t>(m, (size_t)qab, false);
         c.qb[i] = gie_dalloc<uint64_t>(m, (size_t)qab, false);
+        c.qa_a[i] = gie_dalloc<int32_t>(m, (size_t)qab, false);
+        c.qb_a[i] = gie_dalloc<int32_t>(m, (size_t)qab, false);
         c.qc[i] = gie_dalloc<int32_t>(m, (size_t)qc, false);
     }
     const size_t rec = (size_t)(qab > qc ? qab : qc);
@@ -403,7 +405,8 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_lin(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     be_prof(&m->be, GIE_K_ALLOC, 1);
     be_prof(&m->be, GIE_K_FUSE, 0);
-    be_vox_list<true>(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, false);
+    be_vox_list<true>(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, be_rows_mode());
+    be_fuse_rows(&m->be, m->c);
     be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;
@@ -423,24 +426,40 @@ extern "C" int gie_batch_edt(gie_mapper *m)
     return GIE_OK;
 }
 
+/* Mark and commit as one sweep (gie_ops.h "Mark + commit") unless the changed-block flags are on;
+ * GIE_FUSED=0 keeps the reference's order Mark -> obtainFrontiers -> waves -> commit (tests run both) */
+static int gie_fused_mode(const gie_mapper *m)
+{
+    static const int env = getenv("GIE_FUSED") ? atoi(getenv("GIE_FUSED")) : 1;
+    return (env && !m->c.track) ? 1 : 0;
+}
+
 extern "C" int gie_merge(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
-    const int ntile = m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2];
-    be_prof(&m->be, GIE_K_MARK, 0);
-    be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, false);
-    be_prof(&m->be, GIE_K_MARK, 1);
+    m->c.fused = gie_fused_mode(m);
+    const int kmark = m->c.fused ? GIE_K_MARKC : GIE_K_MARK;
+    be_prof(&m->be, kmark, 0);
+    if (m->c.fused) be_vox_list<true>(&m->be, m->c, op_markc(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0, be_sweep_lx("GIE_MARKC_LX", 32));
+    else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
+    be_prof(&m->be, kmark, 1);
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_list(&m->be, m->c, op_tile_summary(), m->c.tl_known, GIE_CNT_TL_KNOWN);   /* only tiles with a known voxel can have anything to look at */
     /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
      * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
-    be_vox_list<false>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, true);
+    {
+        static const int staged = getenv("GIE_FRONT_STAGED") ? atoi(getenv("GIE_FRONT_STAGED")) : 1;
+        if (staged) be_vox_list<true>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, 1);
+        else be_vox_list<false>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, 1);
+    }
     be_prof(&m->be, GIE_K_FRONTIER, 1);
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
-    be_prof(&m->be, GIE_K_COMMIT, 0);
-    be_vox_list<true>(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, false);
-    be_prof(&m->be, GIE_K_COMMIT, 1);
+    if (!m->c.fused) {
+        be_prof(&m->be, GIE_K_COMMIT, 0);
+        be_vox_list<true>(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
+        be_prof(&m->be, GIE_K_COMMIT, 1);
+    }
     be_time(&m->be, 7);
     return GIE_OK;
 }
@@ -749,8 +768,9 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     }
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
+    c.fused = gie_fused_mode(m);
     be_waves(&m->be, c, 0, 0, 0);
-    be_vox_list<true>(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, false);
+    if (!c.fused) be_vox_list<true>(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, 0);   /* fused: wave C has committed what it merged */
     if (!seeded) return GIE_OK;          /* enqueue only: a fixed number of exchange rounds needs no answer */
     rc = gie_sync(m);
     *seeded = m->h_cnt[GIE_CNT_FRONT_C];

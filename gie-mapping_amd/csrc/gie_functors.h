@@ -87,6 +87,14 @@ struct op_mark { static constexpr bool rolled = false;
     GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_mark_load2(c, s); }
     GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_mark_finish(c, id, x, y, z, s); return 0; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_mark_voxel(c, x, y, z); } };
+struct op_markc { static constexpr bool rolled = false;
+    typedef gie_markc_st st;
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.tknown[gie_tile_index(c, x, y, z0)]; }
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_markc_load1(c, id, x, y, z, s); }
+    GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_markc_load2(c, s); }
+    GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_markc_finish(c, id, x, y, z, s); return 0; }
+    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_markc_voxel(c, x, y, z); } };
 struct op_commit { static constexpr bool rolled = false;
     typedef gie_commit_st st;
     GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.tknown[gie_tile_index(c, x, y, z0)]; }

@@ -235,7 +235,7 @@ template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, c
     const int ntx = (c.X + TX - 1) / TX, ntiles = ntx * c.Y;
     int wgs = (int)((160 * 1024) / (lds + 256));            /* workgroups that fit one CU's LDS */
     if (wgs < 1) wgs = 1; if (wgs > 4) wgs = 4;
-    int grid = wgs * b->cu_total; if (grid > ntiles) grid = ntiles;
+    int grid = wgs * b->cu_total; if (grid > (ntiles + 1) / 2) grid = (ntiles + 1) / 2;     /* tiles are taken in pairs */
     GIE_LAUNCH(b, (k_edt_z<CP, TX, WAVES>), dim3(grid), dim3(64 * WAVES), lds, c, ntx, ntiles, full);
 }
 template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass, int full)
@@ -260,12 +260,27 @@ static void be_edt_z(be_state *b, const gie_ctx &c, int full) { gie_launch_edt_d
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
 /* adaptive sweep (k_voxa): the kernel walks the list or sweeps the volume, whichever the list's
  * length calls for; staged = the functor's load1/load2/finish form; always_list = never sweep */
-template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool always_list)
+/* mode: 0 = the kernel walks its list or sweeps the volume (decided on the device), 1 = always the list,
+ * 2 = the list or nothing (the dense form is a block-row kernel launched next to this one) */
+template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, int always_list, int lx = 64)
 {
     /* workgroups per compute unit: 8 / 16 / 32 / 64 measured 0.33 / 0.27 / 0.25 / 0.25 ms for Mark on a densely known
      * volume (sweep side); the list side does not care */
     static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
-    GIE_LAUNCH(b, (k_voxa<F, STAGED>), dim3(b->cu_total * mult), dim3(256), 0, c, f, list, count_idx, always_list ? 1 : 0);
+    const dim3 g(b->cu_total * mult), t(256);
+    if (lx == 32) GIE_LAUNCH(b, (k_voxa<F, STAGED, 32>), g, t, 0, c, f, list, count_idx, always_list);
+    else if (lx == 16) GIE_LAUNCH(b, (k_voxa<F, STAGED, 16>), g, t, 0, c, f, list, count_idx, always_list);
+    else if (lx == 8) GIE_LAUNCH(b, (k_voxa<F, STAGED, 8>), g, t, 0, c, f, list, count_idx, always_list);
+    else GIE_LAUNCH(b, (k_voxa<F, STAGED, 64>), g, t, 0, c, f, list, count_idx, always_list);
+}
+/* lanes of a wave along x in the sweep form of the kernels that touch the global block planes */
+static int be_sweep_lx(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return (v == 8 || v == 16 || v == 32) ? v : 64; }
+/* dense (block-row) form of fuse; GIE_ROWS=0 keeps the thread-per-z-column sweep */
+static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(getenv("GIE_ROWS")) : 1; return v ? 2 : 0; }
+static void be_fuse_rows(be_state *b, const gie_ctx &c)
+{
+    static const int mult = getenv("GIE_ROWS_MULT") ? atoi(getenv("GIE_ROWS_MULT")) : 16;
+    if (be_rows_mode()) GIE_LAUNCH(b, k_fuse_rows, dim3(b->cu_total * mult), dim3(256), 0, c);
 }
 template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
 {

@@ -959,7 +959,11 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     for (int m = 0; m < CP; m++) { const int z = 64 * m + lane; if (z < Z && c.zocc[z]) zvalid |= 1u << m; }
     __syncthreads();
 
-    int t = blockIdx.x;
+    /* a workgroup takes x-adjacent tiles in PAIRS, one after the other: a 16-column row segment is half
+     * a 128-byte line, and the other half is then still in this XCD's L2 */
+    int it = 0;
+#define GIE_ZTILE(i) ((((i) >> 1) * (int)gridDim.x + (int)blockIdx.x) * 2 + ((i) & 1))
+    int t = GIE_ZTILE(0);
     const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
     /* reader masks of the two 8-wide tile columns a workgroup tile spans (workgroup-uniform) */
     uint64_t nd0, nd1, ndn0 = 0, ndn1 = 0;               /* bit tz: tile (tx, ty, tz) has a reader */
@@ -977,7 +981,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && x < X) ? *src : 0xffffffffu; src += zstride; }
         }
     }
-    for (; t < ntiles; t += gridDim.x) {
+    for (; t < ntiles; t = GIE_ZTILE(it)) {
+        it++;
         const int x0 = (t % ntiles_x) * TX, y = t / ntiles_x;
         nd0 = ndn0; nd1 = ndn1;
         const bool work = (nd0 | nd1) != 0ull;            /* workgroup-uniform */
@@ -986,7 +991,7 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             for (int j = 0; j < NLD; j++) { if ((zmask >> j) & 1u) tile[(tz + j * ZSTEP) * TS + tx] = pre[j]; }   /* only site rows are ever read */
         }
         __syncthreads();
-        const int tn = t + gridDim.x;
+        const int tn = GIE_ZTILE(it);
         if (tn < ntiles) {                                /* prefetch: in flight during the column work */
             GIE_LOAD_NEED(tn, ndn0, ndn1);
             if ((ndn0 | ndn1) != 0ull) {
@@ -1189,11 +1194,17 @@ __device__ __forceinline__ void gie_vox_column(const gie_ctx &c, const F &f, con
         for (int k = 0; k < 8; k++) if (!sk[k]) f(c, x, y, z0 + k);
     }
 }
-template <class F, bool STAGED>
+/* LX = lanes of a wave along x in the sweep form (64 / LX rows of y per wave): 64 gives the local
+ * x-fastest planes whole 64-voxel rows per instruction but the global block planes 8-voxel pieces of
+ * eight blocks; smaller LX trades row length for longer runs inside a block (a block plane holds
+ * x | y<<3 | z<<6): LX = 16 reads 4 rows of 16 voxels and touches 2 blocks with 32 consecutive
+ * voxels each. */
+template <class F, bool STAGED, int LX>
 __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const int32_t *list, const int count_idx, const int always_list)
 {
     const int n = c.cnt[count_idx];
     const int lane = threadIdx.x & 63;
+    if (always_list == 2 && !gie_use_lists(c, n)) return;        /* the dense form is another kernel's (k_fuse_rows) */
     if (always_list || gie_use_lists(c, n)) {
         const int waves = gridDim.x * 4;
         for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
@@ -1202,13 +1213,202 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
             gie_vox_column<F, STAGED>(c, f, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8);
         }
     } else {
-        const int gx = (c.X + 63) / 64, gy = (c.Y + 3) / 4, gz = (c.Z + 7) / 8;
+        constexpr int LY = 64 / LX, WY = 4 * LY;               /* rows per wave / per workgroup */
+        const int gx = (c.X + LX - 1) / LX, gy = (c.Y + WY - 1) / WY, gz = (c.Z + 7) / 8;
         const int nv = gx * gy * gz;
         /* a workgroup takes a contiguous run of virtual workgroups (whole x rows of one (y, z) strip):
          * measured a little faster than striding through the volume (fuse 0.18 -> 0.155 ms, dense) */
         const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
         for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++)
-            gie_vox_column<F, STAGED>(c, f, (v % gx) * 64 + lane, ((v / gx) % gy) * 4 + (int)(threadIdx.x >> 6), (v / (gx * gy)) * 8);
+            gie_vox_column<F, STAGED>(c, f, (v % gx) * LX + lx, ((v / gx) % gy) * WY + ly, (v / (gx * gy)) * 8);
+    }
+}
+
+/* ------------------------------------------------------------------ block-row sweeps */
+/* The sweeps that touch the global map (fuse, Mark + commit) in their dense form.  A thread owns one
+ * ROW OF A GLOBAL BLOCK — the 8 voxels (8 bx .. 8 bx + 7, gy, gz) — for the eight z layers of the block,
+ * a wave owns eight blocks along x times the eight rows of one block row along y:
+ *     lane = (bx & 7) + 8 (gy & 7)
+ * so that per wave instruction
+ *   - a global block plane (in-block index x | y<<3 | z<<6) is read as 8 blocks x 64 CONSECUTIVE voxels
+ *     (one z layer of each block: 512 B of an 8-byte field per block, whole lines), and
+ *   - a local x-fastest plane is read as 8 rows x 64 consecutive voxels,
+ * each lane moving its 8 voxels of a field as 16-byte vectors (one 8-byte word for the byte planes).
+ * The volume's pivot need not be block aligned: the local side of a row starts at any x (the hardware
+ * takes unaligned vectors), rows cut by a face of the volume fall back to per-voxel accesses.  The
+ * thread-per-z-column sweeps (k_voxa) this replaces moved 8-voxel pieces of eight blocks per
+ * instruction with one 1/4/8-byte access per voxel. */
+typedef uint64_t __attribute__((aligned(1))) gie_u64u;
+typedef uint32_t gie_v4 __attribute__((ext_vector_type(4)));
+typedef gie_v4 __attribute__((aligned(4))) gie_v4u;                 /* 16 bytes at any 4-byte boundary */
+__device__ __forceinline__ uint4 gie_ld16u(const void *p) { const gie_v4 v = *reinterpret_cast<const gie_v4u *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void gie_st16u(void *p, const uint4 v) { gie_v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *reinterpret_cast<gie_v4u *>(p) = t; }
+
+struct gie_rows { int b0[3], nb[3], ngx, nvw; };
+__device__ __forceinline__ gie_rows gie_rows_of(const gie_ctx &c)
+{
+    gie_rows r;
+    const int sz[3] = { c.X, c.Y, c.Z };
+#pragma unroll
+    for (int a = 0; a < 3; a++) { r.b0[a] = c.pvt[a] >> 3; r.nb[a] = ((c.pvt[a] + sz[a] - 1) >> 3) - r.b0[a] + 1; }
+    r.ngx = (r.nb[0] + 7) >> 3;
+    r.nvw = r.ngx * r.nb[1] * r.nb[2];
+    return r;
+}
+/* what one thread of a block-row sweep owns */
+struct gie_row {
+    int slot;            /* block slot or -1 */
+    int x0, ly, lz0;     /* local coordinates of the row's first voxel / first layer (any of them may lie outside the volume) */
+    int xlo, xhi;        /* valid voxels of the row: xlo <= i < xhi (empty when the row misses the volume) */
+    int arow;            /* in-block offset of the row in layer 0: (gy & 7) << 3 */
+    bool full;           /* all eight voxels inside the volume */
+};
+__device__ __forceinline__ gie_row gie_row_of(const gie_ctx &c, const gie_rows &r, const int v, const int lane)
+{
+    gie_row w;
+    const int gxb = v % r.ngx, by = (v / r.ngx) % r.nb[1], bz = v / (r.ngx * r.nb[1]);
+    const int bx = gxb * 8 + (lane & 7);
+    const int gy = (r.b0[1] + by) * 8 + (lane >> 3);
+    w.ly = gy - c.pvt[1];
+    w.x0 = (r.b0[0] + bx) * 8 - c.pvt[0];
+    w.lz0 = (r.b0[2] + bz) * 8 - c.pvt[2];
+    w.xlo = max(0, -w.x0); w.xhi = min(8, c.X - w.x0);
+    if (bx >= r.nb[0] || (unsigned)w.ly >= (unsigned)c.Y) w.xhi = w.xlo = 0;
+    w.full = (w.xlo == 0 && w.xhi == 8);
+    w.arow = (gy & 7) << 3;
+    w.slot = -1;
+    if (w.xhi > w.xlo) {
+        const int ti = __mul24(__mul24(r.b0[2] + bz - c.tb0[2], c.tdim[1]) + (r.b0[1] + by - c.tb0[1]), c.tdim[0]) + (r.b0[0] + bx - c.tb0[0]);
+        w.slot = c.blk_tab[ti];
+    }
+    return w;
+}
+/* the (at most four) local 8x8x8 tiles a thread's 8 x 8 (x, z) voxels lie in: voxel (i, k) belongs to
+ * quadrant (i >= ix) + 2 (k >= kz); tile index -1 = that quadrant holds no voxel of the volume */
+struct gie_row_tiles { int ix, kz; int t[4]; };
+__device__ __forceinline__ gie_row_tiles gie_row_tiles_of(const gie_ctx &c, const gie_row &w)
+{
+    gie_row_tiles q;
+    q.ix = 8 - (w.x0 & 7); q.kz = 8 - (w.lz0 & 7);        /* 8 when aligned: everything in quadrant 0 */
+    const int tx0 = w.x0 >> 3, tz0 = w.lz0 >> 3, ty = w.ly >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int tx = tx0 + (j & 1), tz = tz0 + (j >> 1);
+        const bool used = ((j & 1) ? q.ix < 8 : true) && ((j >> 1) ? q.kz < 8 : true);
+        const bool in = used && (unsigned)tx < (unsigned)c.tfd[0] && (unsigned)tz < (unsigned)c.tfd[2] && w.xhi > w.xlo;
+        q.t[j] = in ? __mul24(__mul24(tz, c.tfd[1]) + ty, c.tfd[0]) + tx : -1;
+    }
+    return q;
+}
+/* 8 bytes of a local byte plane starting at element `id` (any alignment); a row cut by the volume reads its valid bytes one by one */
+__device__ __forceinline__ uint64_t gie_row_ld8(const int8_t *p, const long long id, const gie_row &w)
+{
+    if (w.full) return *reinterpret_cast<const gie_u64u *>(p + id);
+    uint64_t v = 0;
+    for (int i = w.xlo; i < w.xhi; i++) v |= (uint64_t)(uint8_t)p[id + i] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ void gie_row_st8(int8_t *p, const long long id, const gie_row &w, const uint64_t v)
+{
+    if (w.full) { *reinterpret_cast<gie_u64u *>(p + id) = v; return; }
+    for (int i = w.xlo; i < w.xhi; i++) p[id + i] = (int8_t)(v >> (8 * i));
+}
+/* 8 dwords of a local 4-byte plane */
+__device__ __forceinline__ void gie_row_ld32(const uint32_t *p, const long long id, const gie_row &w, uint32_t (&v)[8])
+{
+    if (w.full) {
+        const uint4 a = gie_ld16u(p + id), b = gie_ld16u(p + id + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (i >= w.xlo && i < w.xhi) ? p[id + i] : 0u;
+}
+
+/* updateHashOGMWithPntCld / updateHashOGMWithSensor (unify_helper.cuh:35-197), dense form: the per-voxel
+ * decisions are gie_fuse_finish's (shared gie_fuse_logic), the per-tile known / unknown summaries and
+ * the plane flags come out the same */
+__global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c)
+{
+    if (gie_use_lists(c, c.cnt[GIE_CNT_TL_FUSE])) return;        /* few tiles to look at: the list form (k_voxa<op_fuse>) does the stage */
+    const gie_rows r = gie_rows_of(c);
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int per = (r.nvw + nw - 1) / nw;                         /* a contiguous run of virtual waves per wave */
+    for (int v = wid * per; v < r.nvw && v < (wid + 1) * per; v++) {
+        const gie_row w = gie_row_of(c, r, v, lane);
+        const gie_row_tiles q = gie_row_tiles_of(c, w);
+        const bool any = w.xhi > w.xlo;
+        /* nothing stored for these voxels and nothing left from earlier frames: all unknown */
+        bool stale = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (q.t[j] >= 0 && c.tknown_prev[q.t[j]]) stale = true;
+        const bool idle = !any || (w.slot < 0 && !stale);
+        if (any && idle) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (q.t[j] >= 0) c.tunk[q.t[j]] = 1;
+        }
+        unsigned kn = 0u, un = 0u;                                /* bit = quadrant */
+        const long long plane = (long long)c.X * c.Y;
+        const long long id0 = ((long long)w.lz0 * c.Y + w.ly) * c.X + w.x0;
+#pragma unroll 2
+        for (int k = 0; k < 8; k++) {
+            const int lz = w.lz0 + k;
+            const bool live = !idle && (unsigned)lz < (unsigned)c.Z;
+            bool occ_here = false;
+            if (live) {
+                const long long id = id0 + (long long)k * plane;
+                const uint64_t it8 = gie_row_ld8(c.inst_type, id, w);
+                const uint64_t gt8 = gie_row_ld8(c.glb_type, id, w);
+                uint32_t rc[8];
+                if (c.pntcld_mode) gie_row_ld32(reinterpret_cast<const uint32_t *>(c.ray_count), id, w, rc);
+                const int a = w.slot * GIE_VBSZ + (k << 6) + w.arow;
+                uint64_t go8 = 0, gy8 = 0;
+                if (w.slot >= 0) { go8 = *reinterpret_cast<const uint64_t *>(c.g_occ + a); gy8 = *reinterpret_cast<const uint64_t *>(c.g_type + a); }
+                uint64_t no8 = go8, ny8 = gy8, ng8 = gt8;
+                bool rc_any = false;
+                const int qz = (k >= q.kz) ? 2 : 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i < w.xlo || i >= w.xhi) continue;
+                    const int count = c.pntcld_mode ? (int)rc[i] : 0;
+                    rc_any |= count != 0;
+                    const int8_t nt = (int8_t)(it8 >> (8 * i));
+                    int8_t ty = GIE_VOX_UNKNOWN;
+                    if (w.slot >= 0) {
+                        uint8_t occ = (uint8_t)(go8 >> (8 * i));
+                        ty = (int8_t)(gy8 >> (8 * i));
+                        const int occ_flag = c.nbox > 0 ? gie_fuse_occ_flag(c, w.x0 + i + c.pvt[0], w.ly + c.pvt[1], lz + c.pvt[2]) : 0;
+                        gie_fuse_logic(c, count, nt, occ_flag, &occ, &ty);
+                        no8 = (no8 & ~(0xffull << (8 * i))) | ((uint64_t)occ << (8 * i));
+                        ny8 = (ny8 & ~(0xffull << (8 * i))) | ((uint64_t)(uint8_t)ty << (8 * i));
+                    }
+                    ng8 = (ng8 & ~(0xffull << (8 * i))) | ((uint64_t)(uint8_t)ty << (8 * i));
+                    occ_here |= ty == GIE_VOX_OCCUPIED;
+                    const int qd = qz + ((i >= q.ix) ? 1 : 0);
+                    if (ty != GIE_VOX_UNKNOWN) kn |= 1u << qd; else un |= 1u << qd;
+                }
+                /* write only what changes */
+                if (rc_any) {
+                    if (w.full) { gie_st16u(c.ray_count + id, make_uint4(0, 0, 0, 0)); gie_st16u(c.ray_count + id + 4, make_uint4(0, 0, 0, 0)); }
+                    else for (int i = w.xlo; i < w.xhi; i++) c.ray_count[id + i] = 0;
+                }
+                if (it8 != 0ull) gie_row_st8(c.inst_type, id, w, 0ull);
+                if (ng8 != gt8) gie_row_st8(c.glb_type, id, w, ng8);
+                if (w.slot >= 0) {
+                    if (no8 != go8) *reinterpret_cast<uint64_t *>(c.g_occ + a) = no8;      /* bytes of voxels outside the volume keep their value */
+                    if (ny8 != gy8) { *reinterpret_cast<uint64_t *>(c.g_type + a) = ny8; if (c.track) c.g_dirty[w.slot] = 1; }
+                }
+            }
+            if (__ballot(occ_here) != 0ull && lane == __ffsll((long long)__ballot(occ_here)) - 1) c.zocc[lz] = 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (q.t[j] < 0) continue;
+            if ((kn >> j) & 1u) c.tknown[q.t[j]] = 1;
+            if ((un >> j) & 1u) c.tunk[q.t[j]] = 1;
+        }
     }
 }
 
@@ -1350,10 +1550,10 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
-        for (int e = gid; e < n; e += gstep) gie_wave_a_phase1(c, c.qa[cur], e);
+        for (int e = gid; e < n; e += gstep) gie_wave_a_phase1(c, cur, e);
         gie_grid_sync(gb, c);
         if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
-        for (int e = gid; e < n; e += gstep) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], next_cnt, e);
+        for (int e = gid; e < n; e += gstep) gie_wave_a_phase2(c, cur, next_cnt, e);
         gie_grid_sync(gb, c);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
     }
@@ -1373,12 +1573,12 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
-        for (int e = gid; e < n; e += gstep) gie_wave_b_phase1(c, c.qb[cur], e);
+        for (int e = gid; e < n; e += gstep) gie_wave_b_phase1(c, cur, e);
         gie_grid_sync(gb, c);
         if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
-        for (int e = gid; e < n; e += gstep) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], next_cnt, level, e);
+        for (int e = gid; e < n; e += gstep) gie_wave_b_phase2(c, cur, next_cnt, level, e);
         gie_grid_sync(gb, c);
-        for (int e = gid; e < n; e += gstep) gie_wave_b_phase3(c, c.qb[cur], e);
+        for (int e = gid; e < n; e += gstep) gie_wave_b_phase3(c, cur, e);
         gie_grid_sync(gb, c);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
     }

@@ -52,6 +52,13 @@ GIE_DEV void gie_push64(const gie_ctx &c, uint64_t *q, int32_t *counter, int cap
     const int i = gie_aadd32(counter, 1);
     if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
 }
+/* frontiers A / B carry the voxel's address (slot * 512 + in-block index) next to its coordinate: whoever
+ * appends an entry has just touched that voxel, and the phases that expand it need no hash probe for it */
+GIE_DEV void gie_push64a(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, int cap, uint64_t v, int a)
+{
+    const int i = gie_aadd32(counter, 1);
+    if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], (int32_t)a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+}
 GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap, int32_t v)
 {
     const int i = gie_aadd32(counter, 1);
@@ -427,6 +434,29 @@ GIE_DEV void gie_fuse_load2(const gie_ctx &c, gie_fuse_st &s)
     s.occ = c.g_occ[s.a];
     s.ty = c.g_type[s.a];
 }
+/* external obstacle boxes (unify_helper.cuh:60-78, voxmap_utils.cuh:203-207): box 0 is a fence ("outside => occupied"),
+ * boxes >= 1 are obstacles ("inside => occupied"), each only while activated */
+GIE_DEV int gie_fuse_occ_flag(const gie_ctx &c, int gx, int gy, int gz)
+{
+    if (c.nbox <= 0) return 0;
+    const float w = c.voxel_width;
+    const float px = (float)gx * w, py = (float)gy * w, pz = (float)gz * w;
+    if (c.box_act[0] && !gie_inside_aabb(px, py, pz, c.box_ll, c.box_ur)) return 1;
+    for (int i = 1; i < c.nbox; i++)
+        if (c.box_act[i] && gie_inside_aabb(px, py, pz, c.box_ll + 3 * i, c.box_ur + 3 * i)) return 1;
+    return 0;
+}
+/* the occupancy filter of one voxel on values in registers: scan (count / label) + stored (occ, ty) -> new (occ, ty) */
+GIE_DEV void gie_fuse_logic(const gie_ctx &c, int count, int8_t nt, int occ_flag, uint8_t *occ, int8_t *ty)
+{
+    if (c.pntcld_mode) {
+        if (count > 0 || occ_flag) gie_set_occ(occ, ty, 250.f, 1.f, c.occ_thresh);
+        else if (count < 0) { float pb = (float)(-count) / 10.f; if (pb > 1.f) pb = 1.f; gie_set_occ(occ, ty, 0.f, pb, c.occ_thresh); }
+    } else {
+        if (nt == GIE_VOX_OCCUPIED || occ_flag) gie_set_occ(occ, ty, 250.f, 0.8f, c.occ_thresh);
+        else if (nt == GIE_VOX_FREE) gie_set_occ(occ, ty, 0.f, 0.5f, c.occ_thresh);
+    }
+}
 /* returns 1 when the voxel ends up known (feeds the per-tile known/unknown summaries) */
 GIE_DEV int gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_fuse_st &s)
 {
@@ -437,26 +467,12 @@ GIE_DEV int gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const
     const int8_t gt0 = s.gt0;
     const int a = s.a;
     if (a < 0) { if (gt0 != GIE_VOX_UNKNOWN) c.glb_type[id] = GIE_VOX_UNKNOWN; return 0; }
-    const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz = z + c.pvt[2];
-    int occ_flag = 0;
-    if (c.nbox > 0) {
-        const float w = c.voxel_width;
-        const float px = (float)gx * w, py = (float)gy * w, pz = (float)gz * w;
-        if (c.box_act[0] && !gie_inside_aabb(px, py, pz, c.box_ll, c.box_ur)) occ_flag = 1;
-        else for (int i = 1; i < c.nbox; i++)
-            if (c.box_act[i] && gie_inside_aabb(px, py, pz, c.box_ll + 3 * i, c.box_ur + 3 * i)) { occ_flag = 1; break; }
-    }
+    const int occ_flag = gie_fuse_occ_flag(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     uint8_t occ = s.occ;
     int8_t ty = s.ty;
     const int8_t ty0 = ty;
     const uint8_t occ0 = occ;
-    if (c.pntcld_mode) {
-        if (count > 0 || occ_flag) gie_set_occ(&occ, &ty, 250.f, 1.f, c.occ_thresh);
-        else if (count < 0) { float pb = (float)(-count) / 10.f; if (pb > 1.f) pb = 1.f; gie_set_occ(&occ, &ty, 0.f, pb, c.occ_thresh); }
-    } else {
-        if (nt == GIE_VOX_OCCUPIED || occ_flag) gie_set_occ(&occ, &ty, 250.f, 0.8f, c.occ_thresh);
-        else if (nt == GIE_VOX_FREE) gie_set_occ(&occ, &ty, 0.f, 0.5f, c.occ_thresh);
-    }
+    gie_fuse_logic(c, count, nt, occ_flag, &occ, &ty);
     if (occ != occ0) c.g_occ[a] = occ;
     if (ty != ty0) { c.g_type[a] = ty; gie_touch(c, a); }
     if (gt0 != ty) c.glb_type[id] = ty;
@@ -591,7 +607,7 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
     if (c2n < nd) {                                       /* lower out → frontier B */
         c.g_wl[a] = 1;
         c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
-        gie_push64(c, c.qb[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+        gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]), a);
     } else if (c2n > nd && n_local) {                     /* raise out → frontier A */
         /* the reference reads the live _glb_type here; FNT never aliases OCCUPIED */
         if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
@@ -600,7 +616,7 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
             gie_touch(c, a);
             c.g_wl[a] = -c.map_ct;
             c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
-            gie_push64(c, c.qa[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+            gie_push64a(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]), a);
         }
     }
     return cur_in_q;
@@ -667,7 +683,13 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
         }
     }
     if (cur_in_q) { c.wl[id] = GIE_WL_SEED(c); c.cand[1][id] = seed; }   /* the pair the seed enters wave C with */
-    if (ty == GIE_VOX_FREE && has_unknown) c.glb_type[id] = GIE_VOX_FNT;
+    if (ty == GIE_VOX_FREE && has_unknown) {
+        c.glb_type[id] = GIE_VOX_FNT;
+        if (c.fused && cd != c.empty_value) {       /* UpdateHashBatch's FNT store (unify_helper.cuh:448-523); a pair wave C lowers from EMPTY brings its own */
+            const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+            if (a >= 0) c.g_type[a] = GIE_VOX_FNT;
+        }
+    }
     return cur_in_q;
 }
 GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
@@ -679,50 +701,134 @@ GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
     return gie_frontier_finish(c, id, x, y, z, s);
 }
 
+/* ================================================================== waves A / B: shared pieces */
+/* Addresses of the face neighbours k (bit k of `want`) of global voxel g, which is stored at address a.
+ * A neighbour inside g's own block shares its slot; the others are looked up TOGETHER: the first
+ * probes of all of them go out as one batch of loads, then the slots as another — a BFS phase is a
+ * chain of dependent memory round trips, and six lookups one after the other were most of it.
+ * Read-only (HashTableBase::get_alloc_blk_id, vhashing.h:125-134): nothing is inserted while the waves run. */
+GIE_DEV void gie_nbr_addr6(const gie_ctx &c, const int g[3], int a, unsigned want, int na[6])
+{
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    uint64_t key[6];
+    uint32_t h[6];
+    int hit[6], inb[6];
+    unsigned pend = 0;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        na[k] = -1; hit[k] = -1; key[k] = 0; h[k] = 0;
+        const int nx = g[0] + dx[k], ny = g[1] + dy[k], nz = g[2] + dz[k];
+        inb[k] = gie_vox_in_blk(nx, ny, nz);
+        if (!((want >> k) & 1u)) continue;
+        if ((nx >> 3) == (g[0] >> 3) && (ny >> 3) == (g[1] >> 3) && (nz >> 3) == (g[2] >> 3)) { na[k] = (a & ~(GIE_VBSZ - 1)) + inb[k]; continue; }
+        key[k] = gie_pack_crd(nx >> 3, ny >> 3, nz >> 3);
+        h[k] = gie_hash_key(nx >> 3, ny >> 3, nz >> 3) & c.hmask;
+        pend |= 1u << k;
+    }
+    while (pend) {
+        uint64_t kk[6];
+        GIE_UNROLL6
+        for (int k = 0; k < 6; k++) kk[k] = ((pend >> k) & 1u) ? c.hkeys[h[k]] : 0ull;
+        GIE_UNROLL6
+        for (int k = 0; k < 6; k++) {
+            if (!((pend >> k) & 1u)) continue;
+            if (kk[k] == key[k]) { hit[k] = (int)h[k]; pend &= ~(1u << k); }
+            else if (kk[k] == GIE_KEY_EMPTY) pend &= ~(1u << k);
+            else h[k] = (h[k] + 1) & c.hmask;
+        }
+    }
+    int sl[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) sl[k] = hit[k] >= 0 ? c.hvals[hit[k]] : -1;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) if (hit[k] >= 0 && sl[k] >= 0) na[k] = sl[k] * GIE_VBSZ + inb[k];
+}
+/* append the neighbours k in `pm` (their addresses in na[]) of g to a frontier: ONE returning atomic per entry */
+GIE_DEV void gie_push_nbrs(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, const int g[3], unsigned pm, const int na[6])
+{
+    if (!pm) return;
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    int n = 0;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) n += (int)((pm >> k) & 1u);
+    int slot = gie_aadd32(counter, n);
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        if (!((pm >> k) & 1u)) continue;
+        if (slot < c.qcap_ab) { gie_st(&q[slot], gie_pack_crd(g[0] + dx[k], g[1] + dy[k], g[2] + dz[k])); gie_st(&qaddr[slot], (int32_t)na[k]); }
+        else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+        slot++;
+    }
+}
+
 /* ================================================================== wave A (raise_outside) */
-/* wave_core.cuh:103-224, two phases per BFS level.  rec0 = lowered (dist<<… see below),
- * rec layout per entry e: rec0[e] = packed new coc (or GIE_KEY_EMPTY = not lowered),
- * rec1[e] = pair to store (or GIE_NOPROP), rec3[e] = new dist | raise-direction mask << 24. */
-GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, const uint64_t *cur, int e)
+/* wave_core.cuh:103-224, two phases per BFS level.  Per entry e: rec0[e] = packed new coc (or
+ * GIE_KEY_EMPTY = not lowered), rec1[e] = pair to store (or GIE_NOPROP), rec2[e] = the entry's closest
+ * obstacle as a parent id, rec3[e] = new dist | raise-direction mask << 24.  Every phase issues the
+ * reads that do not depend on each other as one batch (own record + neighbour lookups, then the
+ * neighbours' records, then the local types those point at). */
+GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
 {
     int g[3];
-    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    gie_unpack_crd(gie_ld(&c.qa[cur][e]), &g[0], &g[1], &g[2]);
+    const int a = gie_ld(&c.qa_a[cur][e]);
     c.rec0[e] = GIE_KEY_EMPTY; c.rec1[e] = GIE_NOPROP; c.rec3[e] = 0;
-    const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
     if (a < 0) return;
     int cd = gie_ld(&c.g_dist[a]);
-    if (cd > c.cutoff_sq) return;
-    int lc[3];
-    gie_unpack_crd(gie_ld(&c.g_coc[a]), &lc[0], &lc[1], &lc[2]);
-    const uint64_t lpar = gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]);
+    const uint64_t lcoc = gie_ld(&c.g_coc[a]);
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    unsigned want = 0;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++)
+        if (!gie_in_loc(c, g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2])) want |= 1u << k;
+    int na[6];
+    gie_nbr_addr6(c, g, a, want, na);
+    if (cd > c.cutoff_sq) return;
+    int8_t nty[6];
+    uint64_t ncc[6];
+    int nd[6], nwl[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        nty[k] = GIE_VOX_UNKNOWN; ncc[k] = 0; nd[k] = 0; nwl[k] = 0;
+        if (na[k] < 0) continue;
+        nty[k] = gie_ld(&c.g_type[na[k]]); ncc[k] = gie_ld(&c.g_coc[na[k]]); nd[k] = gie_ld(&c.g_dist[na[k]]); nwl[k] = gie_ld(&c.g_wl[na[k]]);
+    }
+    int lc[3];
+    gie_unpack_crd(lcoc, &lc[0], &lc[1], &lc[2]);
+    const uint64_t lpar = gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]);
+    unsigned ok = 0, vanished = 0;
+    int nc[6][3];
+    int8_t lt[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        lt[k] = GIE_VOX_OCCUPIED; nc[k][0] = nc[k][1] = nc[k][2] = 0;
+        if (na[k] < 0 || nty[k] == GIE_VOX_UNKNOWN) continue;
+        gie_unpack_crd(ncc[k], &nc[k][0], &nc[k][1], &nc[k][2]);
+        if (gie_invalid_coc(nc[k][0], nc[k][1], nc[k][2]) || gie_invalid_dist(c, nd[k])) continue;
+        if (nwl[k] == -c.map_ct) continue;
+        if (nc[k][0] == lc[0] && nc[k][1] == lc[1] && nc[k][2] == lc[2]) continue;
+        ok |= 1u << k;
+        /* `_aux[coc] != 0` (wave_core.cuh:177-178): the batch distance of a voxel is 0 iff it is
+         * OCCUPIED, and Mark never turns a non-zero value into 0 */
+        const int nl[3] = { nc[k][0] - c.pvt[0], nc[k][1] - c.pvt[1], nc[k][2] - c.pvt[2] };
+        if (gie_in_loc(c, nl[0], nl[1], nl[2])) { lt[k] = c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])]; vanished |= 1u << k; }
+    }
     int mask = 0, lowered = 0;
     uint64_t newcoc = GIE_KEY_EMPTY, newpair = GIE_NOPROP;
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
+        if (!((ok >> k) & 1u)) continue;
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
-        if (gie_in_loc(c, ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2])) continue;
-        const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
-        if (na < 0) continue;
-        if (gie_ld(&c.g_type[na]) == GIE_VOX_UNKNOWN) continue;
-        int nc[3];
-        gie_unpack_crd(gie_ld(&c.g_coc[na]), &nc[0], &nc[1], &nc[2]);
-        if (gie_invalid_coc(nc[0], nc[1], nc[2]) || gie_invalid_dist(c, gie_ld(&c.g_dist[na]))) continue;
-        if (gie_ld(&c.g_wl[na]) == -c.map_ct) continue;
-        if (nc[0] == lc[0] && nc[1] == lc[1] && nc[2] == lc[2]) continue;
-        const int nl[3] = { nc[0] - c.pvt[0], nc[1] - c.pvt[1], nc[2] - c.pvt[2] };
-        /* `_aux[coc] != 0` (wave_core.cuh:177-178): the batch distance of a voxel is 0 iff it is
-         * OCCUPIED, and Mark never turns a non-zero value into 0 */
-        if (gie_in_loc(c, nl[0], nl[1], nl[2]) && c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
+        if (((vanished >> k) & 1u) && lt[k] != GIE_VOX_OCCUPIED) {
             const int d = gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
-            gie_amin64(&c.g_prop[na], gie_pair_make(d, lpar));
+            gie_amin64(&c.g_prop[na[k]], gie_pair_make(d, lpar));
             mask |= 1 << k;
         } else {
-            const int d = gie_d2(nc[0], nc[1], nc[2], g[0], g[1], g[2]);
+            const int d = gie_d2(nc[k][0], nc[k][1], nc[k][2], g[0], g[1], g[2]);
             if (cd > d) {
                 cd = d; lowered = 1;
-                newcoc = gie_pack_crd(nc[0], nc[1], nc[2]);
-                const int nw[3] = { nc[0] - c.upvt[0], nc[1] - c.upvt[1], nc[2] - c.upvt[2] };
+                newcoc = gie_pack_crd(nc[k][0], nc[k][1], nc[k][2]);
+                const int nw[3] = { nc[k][0] - c.upvt[0], nc[k][1] - c.upvt[1], nc[k][2] - c.upvt[2] };
                 if (gie_in_wr(c, nw[0], nw[1], nw[2])) newpair = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
             }
         }
@@ -733,20 +839,21 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, const uint64_t *cur, int e)
     c.rec3[e] = (lowered ? cd : 0) | (mask << 24);
 }
 
-GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int32_t *next_cnt, int e)
+GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int e)
 {
+    const uint64_t gk = gie_ld(&c.qa[cur][e]);
     int g[3];
-    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
-    const int mask = (c.rec3[e] >> 24) & 63;
+    gie_unpack_crd(gk, &g[0], &g[1], &g[2]);
+    const int a = gie_ld(&c.qa_a[cur][e]);
+    const unsigned mask = (unsigned)(c.rec3[e] >> 24) & 63u;
     if (c.rec0[e] != GIE_KEY_EMPTY) {
-        const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
         gie_st(&c.g_dist[a], (int32_t)(c.rec3[e] & 0xffffff));
         gie_st(&c.g_coc[a], c.rec0[e]);
         gie_touch(c, a);
         gie_st(&c.g_wl[a], (int32_t)1);
         if (c.rec1[e] != GIE_NOPROP) {
             gie_st(&c.g_pair[a], c.rec1[e]);
-            gie_push64(c, c.qb[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_ld(&cur[e]));
+            gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gk, a);
         }
     }
     if (!mask) return;
@@ -755,21 +862,30 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *
     gie_unpack_wr(lpar, &lw[0], &lw[1], &lw[2]);
     const int lc[3] = { lw[0] + c.upvt[0], lw[1] + c.upvt[1], lw[2] + c.upvt[2] };
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    int na[6];
+    gie_nbr_addr6(c, g, a, mask, na);
+    uint64_t key[6], old[6];
+    int d[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {                          /* all compare-and-swaps of the entry in flight together */
+        key[k] = 0; old[k] = GIE_NOPROP; d[k] = 0;
+        if (!((mask >> k) & 1u)) continue;
+        d[k] = gie_d2(lc[0], lc[1], lc[2], g[0] + dx[k], g[1] + dy[k], g[2] + dz[k]);
+        key[k] = gie_pair_make(d[k], lpar);
+        old[k] = gie_acas64(&c.g_prop[na[k]], key[k], GIE_NOPROP);
+    }
+    unsigned win = 0;
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
-        if (!(mask & (1 << k))) continue;
-        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
-        const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
-        const int d = gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
-        const uint64_t key = gie_pair_make(d, lpar);
-        if (gie_acas64(&c.g_prop[na], key, GIE_NOPROP) != key) continue;   /* not the (unique) winner */
-        gie_st(&c.g_dist[na], (int32_t)d);
-        gie_st(&c.g_coc[na], gie_pack_crd(lc[0], lc[1], lc[2]));
-        gie_touch(c, na);
-        gie_st(&c.g_wl[na], (int32_t)-c.map_ct);
-        gie_st(&c.g_pair[na], key);
-        gie_push64(c, next, next_cnt, c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
+        if (!((mask >> k) & 1u) || old[k] != key[k]) continue;       /* not the (unique) winner */
+        win |= 1u << k;
+        gie_st(&c.g_dist[na[k]], (int32_t)d[k]);
+        gie_st(&c.g_coc[na[k]], gie_pack_crd(lc[0], lc[1], lc[2]));
+        gie_touch(c, na[k]);
+        gie_st(&c.g_wl[na[k]], (int32_t)-c.map_ct);
+        gie_st(&c.g_pair[na[k]], key[k]);
     }
+    gie_push_nbrs(c, c.qa[cur ^ 1], c.qa_a[cur ^ 1], next_cnt, g, win, na);
 }
 
 /* batch EDT distance of ONE voxel straight from the pass-X planes: min over the planes with
@@ -796,12 +912,10 @@ GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
 /* ================================================================== wave B (lower_outside) */
 /* wave_core.cuh:229-350, three phases per level. rec0[e] = snapshot parent (GIE_NOPROP =
  * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask. */
-GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, const uint64_t *cur, int e)
+GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int e)
 {
-    int g[3];
-    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    const int a = gie_ld(&c.qb_a[cur][e]);
     c.rec0[e] = GIE_NOPROP; c.rec3[e] = 0;
-    const int a = gie_gvox_hash(c, g[0], g[1], g[2]);
     if (a < 0) return;
     const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
     if (gie_ld(&c.g_dist[a]) > c.cutoff_sq) return;
@@ -815,77 +929,151 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, const uint64_t *cur, int e)
     c.rec1[e] = coc;
 }
 
-GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, const uint64_t *cur, uint64_t *next, int32_t *next_cnt, int level, int e)
+GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int level, int e)
 {
     if (c.rec0[e] == GIE_NOPROP) return;
     int g[3], cc[3];
-    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
+    const int a = gie_ld(&c.qb_a[cur][e]);
     gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
     const uint64_t par = c.rec0[e];
     const int32_t stamp = (int32_t)(c.stamp_base + 8u + (uint32_t)(level % 4000));
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    int mask = 0;
+    unsigned outm = 0, inm = 0;
+    int cand[6], nid[6];
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
         const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
-        const int cand = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
-        if (!gie_in_loc(c, nb[0], nb[1], nb[2])) {
-            const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
-            if (na < 0) continue;
-            if (gie_ld(&c.g_type[na]) == GIE_VOX_UNKNOWN) continue;
-            int nc[3];
-            gie_unpack_crd(gie_ld(&c.g_coc[na]), &nc[0], &nc[1], &nc[2]);
-            if (gie_invalid_coc(nc[0], nc[1], nc[2])) continue;
-            if (cand >= c.empty_value) continue;
-            const uint64_t key = gie_pair_make(cand, par) | GIE_PAIR_NEW;
-            if (gie_ld(&c.g_pair[na]) <= key) continue;      /* values only decrease: the atomic could not win */
-            const uint64_t old = gie_amin64(&c.g_pair[na], key);
-            if (gie_pair_dist(old) > cand) {
-                if (gie_axchg32(&c.g_wl[na], stamp) != stamp)
-                    gie_push64(c, next, next_cnt, c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]));
-            }
-        } else {
-            const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
-            /* `_aux[n]` (wave_core.cuh:334): for an observed voxel Mark left it equal to the pair's
-             * distance (nothing writes `pair` between Mark and wave B); for an unknown voxel it is
-             * still the batch distance */
-            const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? gie_pair_dist(gie_ld(&c.pair[nid]))
-                                                                  : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
-            if (ref > cand) {
-                gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand, par));
-                mask |= 1 << k;
-            }
+        cand[k] = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
+        nid[k] = 0;
+        if (gie_in_loc(c, nb[0], nb[1], nb[2])) { inm |= 1u << k; nid[k] = gie_lid(c, nb[0], nb[1], nb[2]); }
+        else outm |= 1u << k;
+    }
+    int na[6];
+    gie_nbr_addr6(c, g, a, outm, na);
+    /* one batch: the records of the outside neighbours, type + pair of the inside ones */
+    int8_t nty[6];
+    uint64_t ncc[6], npr[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        nty[k] = GIE_VOX_UNKNOWN; ncc[k] = 0; npr[k] = 0;
+        if (((outm >> k) & 1u) && na[k] >= 0) { nty[k] = gie_ld(&c.g_type[na[k]]); ncc[k] = gie_ld(&c.g_coc[na[k]]); npr[k] = gie_ld(&c.g_pair[na[k]]); }
+        else if ((inm >> k) & 1u) { nty[k] = c.glb_type[nid[k]]; npr[k] = gie_ld(&c.pair[nid[k]]); }
+    }
+    unsigned tryo = 0;
+    uint64_t key[6], old[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        key[k] = 0; old[k] = 0;
+        if (!((outm >> k) & 1u) || na[k] < 0 || nty[k] == GIE_VOX_UNKNOWN) continue;
+        int nc[3];
+        gie_unpack_crd(ncc[k], &nc[0], &nc[1], &nc[2]);
+        if (gie_invalid_coc(nc[0], nc[1], nc[2])) continue;
+        if (cand[k] >= c.empty_value) continue;
+        key[k] = gie_pair_make(cand[k], par) | GIE_PAIR_NEW;
+        if (npr[k] <= key[k]) continue;                   /* values only decrease: the atomic could not win */
+        tryo |= 1u << k;
+    }
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) if ((tryo >> k) & 1u) old[k] = gie_amin64(&c.g_pair[na[k]], key[k]);
+    unsigned imp = 0, pm = 0;
+    int32_t ow[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) { ow[k] = stamp; if (((tryo >> k) & 1u) && gie_pair_dist(old[k]) > cand[k]) imp |= 1u << k; }
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) if ((imp >> k) & 1u) ow[k] = gie_axchg32(&c.g_wl[na[k]], stamp);
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) if (((imp >> k) & 1u) && ow[k] != stamp) pm |= 1u << k;
+    gie_push_nbrs(c, c.qb[cur ^ 1], c.qb_a[cur ^ 1], next_cnt, g, pm, na);
+    int mask = 0;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        if (!((inm >> k) & 1u)) continue;
+        const int nb[3] = { g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2] };
+        /* `_aux[n]` (wave_core.cuh:334): for an observed voxel Mark left it equal to the pair's
+         * distance (nothing writes `pair` between Mark and wave B); for an unknown voxel it is
+         * still the batch distance */
+        const int ref = (nty[k] != GIE_VOX_UNKNOWN) ? gie_pair_dist(npr[k]) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
+        if (ref > cand[k]) {
+            gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand[k], par));
+            mask |= 1 << k;
         }
     }
     c.rec3[e] = mask;
 }
 
-GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, const uint64_t *cur, int e)
+GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int e)
 {
     if (c.rec0[e] == GIE_NOPROP) return;
-    const int mask = c.rec3[e];
+    const unsigned mask = (unsigned)c.rec3[e];
     if (!mask) return;
     int g[3], cc[3];
-    gie_unpack_crd(gie_ld(&cur[e]), &g[0], &g[1], &g[2]);
+    gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
     gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
     const uint64_t par = c.rec0[e];
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    uint64_t key[6], old[6];
+    int nid[6];
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
-        if (!(mask & (1 << k))) continue;
+        key[k] = 0; old[k] = GIE_NOPROP; nid[k] = 0;
+        if (!((mask >> k) & 1u)) continue;
         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
         const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
-        const int cand = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
-        const uint64_t key = gie_pair_make(cand, par);
-        if (gie_acas64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], key, GIE_NOPROP) != key) continue;
-        const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
-        gie_st(&c.cand[1][nid], key);                      /* the reference's plain store (wave_core.cuh:338-341), applied when wave C starts */
-        const uint32_t w = gie_ld(&c.wl[nid]);
-        if (w == GIE_WL_SEED(c) || w == GIE_WL_PUSHED(c)) continue;
-        gie_st(&c.wl[nid], GIE_WL_PUSHED(c));              /* this thread is the only writer of nid in this phase */
-        gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, nid);
+        key[k] = gie_pair_make(gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]), par);
+        nid[k] = gie_lid(c, nb[0], nb[1], nb[2]);
+        old[k] = gie_acas64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], key[k], GIE_NOPROP);
     }
+    unsigned win = 0;
+    uint32_t w[6];
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        w[k] = 0;
+        if (!((mask >> k) & 1u) || old[k] != key[k]) continue;
+        win |= 1u << k;
+        gie_st(&c.cand[1][nid[k]], key[k]);                /* the reference's plain store (wave_core.cuh:338-341), applied when wave C starts */
+        w[k] = gie_ld(&c.wl[nid[k]]);
+    }
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        if (!((win >> k) & 1u)) continue;
+        if (w[k] == GIE_WL_SEED(c) || w[k] == GIE_WL_PUSHED(c)) continue;
+        gie_st(&c.wl[nid[k]], GIE_WL_PUSHED(c));           /* this thread is the only writer of nid in this phase */
+        gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, nid[k]);
+    }
+}
+
+/* UpdateHashBatch for one voxel whose final pair is `pr` (type FNT is handled by the callers).
+ * AGENT: the stores go through agent-scope (write-through) accesses — wave C may commit the same
+ * voxel again one BFS level later from a workgroup on another XCD, and the per-XCD L2s are not
+ * coherent: two plain stores would reach memory in either order. */
+template <bool AGENT>
+GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
+{
+    const int d = gie_pair_dist(pr);
+    if (d == c.empty_value) {
+        if (gie_pair_par(pr) == GIE_PAR_NONE) { if (AGENT) gie_st(&c.edt[id], (float)c.max_loc_dist_sq); else c.edt[id] = (float)c.max_loc_dist_sq; }
+        return;
+    }
+    if (a < 0) return;
+    int cw[3];
+    gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+    const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
+    if (AGENT) {
+        gie_st(&c.g_coc[a], ncoc); gie_st(&c.g_dist[a], (int32_t)d); gie_st(&c.edt[id], sqrtf((float)d)); gie_st(&c.g_pair[a], pr);
+    } else {
+        c.g_coc[a] = ncoc; c.g_dist[a] = d; c.edt[id] = sqrtf((float)d); c.g_pair[a] = pr;
+    }
+}
+/* wave C merged `pr` into pair[id] (fused mode): commit it on the spot */
+GIE_DEV void gie_commit_merged(const gie_ctx &c, int id, int x, int y, int z, uint64_t pr)
+{
+    const int8_t ty = c.glb_type[id];
+    if (ty == GIE_VOX_UNKNOWN) return;       /* lower_inside has no type test (wave_core.cuh:353-393), UpdateHashBatch has (unify_helper.cuh:459) */
+    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    gie_commit_pair<true>(c, id, a, pr);
+    if (a >= 0 && gie_pair_dist(pr) != c.empty_value && ty == GIE_VOX_FNT) gie_st(&c.g_type[a], (int8_t)GIE_VOX_FNT);
 }
 
 /* ================================================================== wave C (lower_inside) */
@@ -924,6 +1112,7 @@ GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, in
     if (level > 0 && !(gie_pair_dist(cd) < gie_pair_dist(own))) return 0;
     const uint64_t pr = cd;
     gie_st(&c.pair[id], pr);
+    if (c.fused) gie_commit_merged(c, id, x, y, z, pr);
     const uint64_t par = gie_pair_par(pr);
     int cw[3];
     gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
@@ -997,6 +1186,80 @@ GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
     gie_commit_finish(c, id, s);
 }
 
+/* ================================================================== Mark + commit in one sweep */
+/* MarkLimitedObserve (unify_helper.cuh:201-273) and UpdateHashBatch (:448-523) for the same voxel in
+ * one pass.  Between the two the reference runs obtainFrontiers and the waves, which change the pair
+ * of a few voxels only: wave C (the only writer of `pair` after Mark) commits every pair it merges on
+ * the spot (gie_commit_merged), obtainFrontiers stores its own FNT flips in the global map, and what
+ * this sweep commits is the Mark-time pair — the value UpdateHashBatch finds for every voxel the waves
+ * never visit.  Waves A / B only touch global voxels OUTSIDE the volume, this sweep only the ones
+ * inside, so the order of the two does not matter.  Saves one read + one write of `pair` and one
+ * block-table lookup per voxel, and the previous frame's pair is read only in the one branch that
+ * needs it.  Not used while the changed-block flags are on (gie_stream_enable): a pair that is
+ * committed twice could flag a block the reference's single commit would not. */
+struct gie_markc_st { uint32_t bc; int a; int dold; uint64_t ococ; };
+
+GIE_DEV void gie_markc_load1(const gie_ctx &c, int id, int x, int y, int z, gie_markc_st &s)
+{
+    s.bc = c.bcoc[id];
+    s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+}
+GIE_DEV void gie_markc_load2(const gie_ctx &c, gie_markc_st &s)
+{
+    if (s.a < 0) return;
+    s.dold = c.g_dist[s.a];
+    s.ococ = c.g_coc[s.a];
+}
+/* MarkLimitedObserve for one voxel on values in registers: batch closest obstacle `bc`, the stored global
+ * (dold, ococ); last frame's pair is read through `old_pair` only in the one branch that needs it.
+ * Returns the new pair; *flag_tile = the voxel's closest obstacle lies (or may lie) outside the volume.
+ * (The same decisions as gie_mark_finish, in 32-bit arithmetic: every coordinate is within +-2^21.) */
+GIE_DEV uint64_t gie_mark_logic(const gie_ctx &c, int x, int y, int z, uint32_t bc, int dold, uint64_t ococ, const uint64_t *old_pair, int *flag_tile)
+{
+    int cn0, cn1, cn2;
+    const int batch_invalid = (bc == GIE_BCOC_NONE);
+    int auxv;
+    if (batch_invalid) { auxv = c.empty_value; cn0 = cn2 = 0; cn1 = 16383; }
+    else {
+        cn0 = (int)(bc & 1023u); cn1 = (int)((bc >> 10) & 1023u); cn2 = (int)(bc >> 20);
+        const int dx = x - cn0, dy = y - cn1, dz = z - cn2;
+        auxv = dx * dx + dy * dy + dz * dz;
+    }
+    const int dn = batch_invalid ? c.max_width * c.max_width : auxv;
+    if (dn > dold) {                        /* limited observation: the old closest obstacle is out of sight */
+        int ox, oy, oz;
+        gie_unpack_crd(ococ, &ox, &oy, &oz);
+        const int o0 = ox - c.pvt[0], o1 = oy - c.pvt[1], o2 = oz - c.pvt[2];
+        if (!gie_in_whole(c, o0, o1, o2)) { cn0 = o0; cn1 = o1; cn2 = o2; auxv = dold; }
+    }
+    const int wx = cn0 + c.pvt[0] - c.upvt[0], wy = cn1 + c.pvt[1] - c.upvt[1], wz = cn2 + c.pvt[2] - c.upvt[2];
+    if (!gie_in_wr(c, wx, wy, wz)) {
+        /* outside the wave range: distance EMPTY, "parent id left as is" — the only reader of last frame's pair */
+        const uint64_t oldpar = batch_invalid ? GIE_PAR_NONE : gie_pair_par(*old_pair);
+        *flag_tile = (oldpar != GIE_PAR_NONE);
+        return gie_pair_make(c.empty_value, oldpar);
+    }
+    *flag_tile = !gie_in_loc(c, cn0, cn1, cn2);
+    return gie_pair_make(auxv, gie_pack_wr(wx, wy, wz));
+}
+GIE_DEV void gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_markc_st &s)
+{
+    if (s.a < 0) { gie_commit_pair<false>(c, id, -1, c.pair[id]); return; }   /* (a known voxel always has its block) */
+    int flag_tile;
+    const uint64_t pr = gie_mark_logic(c, x, y, z, s.bc, s.dold, s.ococ, &c.pair[id], &flag_tile);
+    if (flag_tile) c.tflag[gie_tile_index(c, x, y, z)] = 1;
+    c.pair[id] = pr;
+    gie_commit_pair<false>(c, id, s.a, pr);
+}
+GIE_DEV void gie_markc_voxel(const gie_ctx &c, int x, int y, int z)
+{
+    const int id = gie_lid(c, x, y, z);
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;
+    gie_markc_st s;
+    gie_markc_load1(c, id, x, y, z, s);
+    gie_markc_load2(c, s);
+    gie_markc_finish(c, id, x, y, z, s);
+}
 /* ================================================================== halo exchange between tiles */
 /* face f: axis f/2, side f%2.  Layer index i ↔ the two remaining axes (a fastest). */
 GIE_DEV void gie_face_coord(const gie_ctx &c, int face, int i, int depth_off, int *x, int *y, int *z)

@@ -131,6 +131,7 @@ typedef struct gie_ctx {
     uint64_t *g_prop;
     int32_t *g_wl;          /* wave_layer (-map_ct raise stamp / level stamps) */
     int track;              /* changed-block flags on (gie_stream_enable) */
+    int fused;              /* Mark and commit run as one sweep, wave C commits what it merges (gie_ops.h "Mark + commit") */
     int32_t *g_dirty;       /* per slot: a voxel's type / distance / closest obstacle changed since the last stream */
     /* ---- ext boxes */
     int nbox;
@@ -138,6 +139,7 @@ typedef struct gie_ctx {
     const uint8_t *box_act;
     /* ---- frontier queues + counters */
     uint64_t *qa[2], *qb[2];
+    int32_t *qa_a[2], *qb_a[2]; /* address (slot * 512 + in-block index) of every entry of qa / qb */
     int32_t *qc[2];
     int qcap_ab, qcap_c;
     int32_t *cnt;           /* device counters, see GIE_CNT_* */

@@ -65,10 +65,14 @@ static void be_vox_list_col(const gie_ctx &c, const op_fuse &f, int x, int y, in
     for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f(c, x, y, z)) known |= 1u << (z - z0); }
     f.column(c, x, y, z0, known, valid);
 }
-template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, bool always_list)
+static int be_sweep_lx(const char *, int dflt) { return dflt; }
+static int be_rows_mode() { return 0; }
+                       /* the block-row kernels are device-only forms of the same functors */
+static void be_fuse_rows(be_state *, const gie_ctx &) {}
+template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, int always_list, int = 64)
 {
     const int n = c.cnt[count_idx];
-    if (!always_list && !gie_use_lists(c, n)) { be_vox(b, c, f); return; }        /* the same choice the device kernel makes */
+    if (always_list != 1 && !gie_use_lists(c, n)) { be_vox(b, c, f); return; }        /* the same choice the device kernel makes */
     for (int e = 0; e < n; e++) {
         const int t = list[e];
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
@@ -148,8 +152,8 @@ static void be_wave_a(be_state *, const gie_ctx &c)
     c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B];
     while (n > 0) {
         c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n;
-        for (int e = 0; e < n; e++) gie_wave_a_phase1(c, c.qa[cur], e);
-        for (int e = 0; e < n; e++) gie_wave_a_phase2(c, c.qa[cur], c.qa[cur ^ 1], &c.cnt[GIE_CNT_NEXT], e);
+        for (int e = 0; e < n; e++) gie_wave_a_phase1(c, cur, e);
+        for (int e = 0; e < n; e++) gie_wave_a_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1;
     }
 }
@@ -159,9 +163,9 @@ static void be_wave_b(be_state *, const gie_ctx &c)
     c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
     while (n > 0) {
         c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n;
-        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, c.qb[cur], e);
-        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, c.qb[cur], c.qb[cur ^ 1], &c.cnt[GIE_CNT_NEXT], level, e);
-        for (int e = 0; e < n; e++) gie_wave_b_phase3(c, c.qb[cur], e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], level, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase3(c, cur, e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
     }
 }
