@@ -37,6 +37,7 @@ struct gie_mapper {
     int32_t *d_srank, *d_slist;
     void *d_stage[2], *h_stage[2];
     std::vector<void *> allocs;
+    void *scratch[2]; size_t scratch_cap[2];   /* export buffers of the readers (grow-only, reused from call to call) */
     int32_t h_cnt[GIE_CNT_NUM];
     int32_t next_off[3], next_whole[3];
     float us[4];
@@ -47,6 +48,18 @@ template <class T> static T *gie_dalloc(gie_mapper *m, size_t n, bool zero = tru
     void *p = be_alloc(&m->be, n * sizeof(T), zero);
     if (p) m->allocs.push_back(p);
     return (T *)p;
+}
+
+/* export buffer `i` of at least `bytes` (nullptr + error text when the device is out of memory) */
+static void *gie_scratch(gie_mapper *m, int i, size_t bytes, const char *who)
+{
+    if (bytes > m->scratch_cap[i]) {
+        if (m->scratch[i]) be_free(&m->be, m->scratch[i]);
+        m->scratch[i] = be_alloc(&m->be, bytes, false);
+        m->scratch_cap[i] = m->scratch[i] ? bytes : 0;
+    }
+    if (!m->scratch[i]) gie_set_err(std::string(who) + ": device allocation of the export buffer failed");
+    return m->scratch[i];
 }
 
 static int gie_pow2_ge(long long v) { int p = 1; while ((long long)p < v) p <<= 1; return p; }
@@ -70,6 +83,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
     m->d_srank = m->d_slist = nullptr; m->d_stage[0] = m->d_stage[1] = m->h_stage[0] = m->h_stage[1] = nullptr;
     memset(m->h_cnt, 0, sizeof(m->h_cnt)); memset(m->us, 0, sizeof(m->us));
+    m->scratch[0] = m->scratch[1] = nullptr; m->scratch_cap[0] = m->scratch_cap[1] = 0;
     if (be_init(&m->be, cfg->device_id) != 0) { delete m; return nullptr; }
     gie_ctx &c = m->c;
     memset(&c, 0, sizeof(c));
@@ -173,6 +187,7 @@ extern "C" void gie_destroy(gie_mapper *m)
     if (m->d_pts_g) be_free(&m->be, m->d_pts_g);
     if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
     if (m->d_srank) { be_free(&m->be, m->d_srank); be_free(&m->be, m->d_slist); }
+    for (int i = 0; i < 2; i++) if (m->scratch[i]) be_free(&m->be, m->scratch[i]);
     for (int i = 0; i < 2; i++) { if (m->d_stage[i]) be_free(&m->be, m->d_stage[i]); if (m->h_stage[i]) be_host_free(&m->be, m->h_stage[i]); }
     be_fini(&m->be);
     delete m;
@@ -360,6 +375,13 @@ extern "C" int gie_set_ext_boxes(gie_mapper *m, const float *ll, const float *ur
         m->d_box_ur = (float *)be_alloc(&m->be, (size_t)n * 3 * sizeof(float), false);
         m->d_box_act = (uint8_t *)be_alloc(&m->be, (size_t)n, false);
         m->box_cap = n;
+        if (!m->d_box_ll || !m->d_box_ur || !m->d_box_act) {
+            if (m->d_box_ll) be_free(&m->be, m->d_box_ll);
+            if (m->d_box_ur) be_free(&m->be, m->d_box_ur);
+            if (m->d_box_act) be_free(&m->be, m->d_box_act);
+            m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0; m->c.nbox = 0;
+            gie_set_err("gie_set_ext_boxes: device allocation failed"); return GIE_ERR_DEVICE;
+        }
     }
     if (n > 0) {
         be_h2d(&m->be, m->d_box_ll, ll, (size_t)n * 3 * sizeof(float));
@@ -449,7 +471,7 @@ extern "C" int gie_merge(gie_mapper *m)
     /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
      * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
     {
-        static const int staged = getenv("GIE_FRONT_STAGED") ? atoi(getenv("GIE_FRONT_STAGED")) : 1;
+        static const int staged = getenv("GIE_FRONT_STAGED") ? atoi(getenv("GIE_FRONT_STAGED")) : 0;   /* staged: 0.64 ms, voxel by voxel: 0.37 ms (C5) */
         if (staged) be_vox_list<true>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, 1);
         else be_vox_list<false>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, 1);
     }
@@ -475,14 +497,21 @@ static int gie_fetch_counters(gie_mapper *m)
 {
     be_d2h(&m->be, m->h_cnt, m->c.cnt, sizeof(m->h_cnt));
     const int e = m->h_cnt[GIE_CNT_ERR];
-    if (e) {
+    if (e & ~GIE_ERRF_BARRIER) {
         std::string s = "device capacity exceeded:";
         if (e & GIE_ERRF_POOL) s += " block pool (raise gie_config.max_blocks)";
         if (e & GIE_ERRF_QUEUE) s += " frontier queue";
         if (e & GIE_ERRF_HASH) s += " hash table";
-        if (e & GIE_ERRF_BARRIER) s += " (grid barrier timed out: wave kernel was not fully resident)";
         gie_set_err(s);
         return GIE_ERR_CAPACITY;
+    }
+    if (e & GIE_ERRF_BARRIER) {
+        /* not sticky: reported once, then cleared (the per-frame clear leaves the error word alone) */
+        be_memset(&m->be, &m->c.cnt[GIE_CNT_ERR], 0, sizeof(int32_t));
+        be_sync(&m->be);
+        gie_set_err("grid barrier of the wavefront kernel timed out (its workgroups were not all resident: another process is holding the "
+                    "device); this map update is incomplete, the next one runs normally");
+        return GIE_ERR_TIMEOUT;
     }
     return GIE_OK;
 }
@@ -502,12 +531,13 @@ extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *
     if (edt) be_d2h(&m->be, edt, m->c.edt, N * sizeof(float));
     if (type) be_d2h(&m->be, type, m->c.glb_type, N);
     if (dist_sq || coc_xyz) {
-        int32_t *dd = dist_sq ? (int32_t *)be_alloc(&m->be, N * 4, false) : nullptr;
-        int32_t *dc = coc_xyz ? (int32_t *)be_alloc(&m->be, N * 12, false) : nullptr;
+        int32_t *dd = dist_sq ? (int32_t *)gie_scratch(m, 0, N * 4, "gie_read_local") : nullptr;
+        int32_t *dc = coc_xyz ? (int32_t *)gie_scratch(m, 1, N * 12, "gie_read_local") : nullptr;
+        if ((dist_sq && !dd) || (coc_xyz && !dc)) return GIE_ERR_DEVICE;
         op_export_pair op; op.d = dd; op.coc = dc;
         be_lin(&m->be, m->c, op, m->c.N);
-        if (dd) { be_d2h(&m->be, dist_sq, dd, N * 4); be_free(&m->be, dd); }
-        if (dc) { be_d2h(&m->be, coc_xyz, dc, N * 12); be_free(&m->be, dc); }
+        if (dd) be_d2h(&m->be, dist_sq, dd, N * 4);
+        if (dc) be_d2h(&m->be, coc_xyz, dc, N * 12);
     }
     return gie_sync(m);
 }
@@ -528,12 +558,13 @@ extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
         m->edt_partial = 0;
     }
     if (dist_sq || coc) {
-        int32_t *dd = dist_sq ? (int32_t *)be_alloc(&m->be, N * 4, false) : nullptr;
-        int32_t *dc = coc ? (int32_t *)be_alloc(&m->be, N * 12, false) : nullptr;
+        int32_t *dd = dist_sq ? (int32_t *)gie_scratch(m, 0, N * 4, "gie_read_batch_edt") : nullptr;
+        int32_t *dc = coc ? (int32_t *)gie_scratch(m, 1, N * 12, "gie_read_batch_edt") : nullptr;
+        if ((dist_sq && !dd) || (coc && !dc)) return GIE_ERR_DEVICE;
         op_export_bcoc op; op.d = dd; op.coc = dc;
         be_lin(&m->be, m->c, op, m->c.N);
-        if (dd) { be_d2h(&m->be, dist_sq, dd, N * 4); be_free(&m->be, dd); }
-        if (dc) { be_d2h(&m->be, coc, dc, N * 12); be_free(&m->be, dc); }
+        if (dd) be_d2h(&m->be, dist_sq, dd, N * 4);
+        if (dc) be_d2h(&m->be, coc, dc, N * 12);
     }
     return gie_sync(m);
 }
@@ -542,10 +573,11 @@ extern "C" int gie_read_costmap(gie_mapper *m, gie_seendist *payload, gie_costma
     if (!m) { gie_set_err("gie_read_costmap: null handle"); return GIE_ERR_INVALID; }
     if (payload) {
         const size_t N = (size_t)m->c.N;
-        gie_seendist *d = (gie_seendist *)be_alloc(&m->be, N * sizeof(gie_seendist), false);
+        gie_seendist *d = (gie_seendist *)gie_scratch(m, 1, N * sizeof(gie_seendist), "gie_read_costmap");
+        if (!d) return GIE_ERR_DEVICE;
         op_costmap op; op.out = d;
         be_lin(&m->be, m->c, op, m->c.N);
-        be_d2h(&m->be, payload, d, N * sizeof(gie_seendist)); be_free(&m->be, d);
+        be_d2h(&m->be, payload, d, N * sizeof(gie_seendist));
     }
     if (hdr) {
         hdr->x_size = m->c.X; hdr->y_size = m->c.Y; hdr->z_size = m->c.Z;
@@ -558,13 +590,13 @@ extern "C" int gie_query_global(gie_mapper *m, const int32_t *xyz, int n, gie_vo
 {
     if (!m || n < 0 || (n > 0 && (!xyz || !out))) { gie_set_err("gie_query_global: bad arguments"); return GIE_ERR_INVALID; }
     if (n == 0) return GIE_OK;
-    int32_t *dx = (int32_t *)be_alloc(&m->be, (size_t)n * 12, false);
-    gie_voxel *dv = (gie_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_voxel), false);
+    int32_t *dx = (int32_t *)gie_scratch(m, 0, (size_t)n * 12, "gie_query_global");
+    gie_voxel *dv = (gie_voxel *)gie_scratch(m, 1, (size_t)n * sizeof(gie_voxel), "gie_query_global");
+    if (!dx || !dv) return GIE_ERR_DEVICE;
     be_h2d(&m->be, dx, xyz, (size_t)n * 12);
     op_query op; op.xyz = dx; op.out = dv;
     be_lin(&m->be, m->c, op, n);
     be_d2h(&m->be, out, dv, (size_t)n * sizeof(gie_voxel));
-    be_free(&m->be, dx); be_free(&m->be, dv);
     return gie_sync(m);
 }
 extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
@@ -690,10 +722,10 @@ extern "C" int gie_halo_export(gie_mapper *m, int face, gie_halo_voxel *out)
     int rc = gie_need_pose(m, "gie_halo_export"); if (rc) return rc;
     if (face < 0 || face > 5 || !out) { gie_set_err("gie_halo_export: bad arguments"); return GIE_ERR_INVALID; }
     const int n = gie_face_count(m->c, face);
-    gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
+    gie_halo_voxel *d = (gie_halo_voxel *)gie_scratch(m, 1, (size_t)n * sizeof(gie_halo_voxel), "gie_halo_export");
+    if (!d) return GIE_ERR_DEVICE;
     rc = gie_halo_export_dev(m, face, d);
     be_d2h(&m->be, out, d, (size_t)n * sizeof(gie_halo_voxel));
-    be_free(&m->be, d);
     return rc;
 }
 extern "C" int gie_halo_import_dev(gie_mapper *m, int face, const gie_halo_voxel *d)
@@ -714,11 +746,11 @@ extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in
     int rc = gie_need_pose(m, "gie_halo_import"); if (rc) return rc;
     if (face < 0 || face > 5 || !in) { gie_set_err("gie_halo_import: bad arguments"); return GIE_ERR_INVALID; }
     const int n = gie_face_count(m->c, face);
-    gie_halo_voxel *d = (gie_halo_voxel *)be_alloc(&m->be, (size_t)n * sizeof(gie_halo_voxel), false);
+    gie_halo_voxel *d = (gie_halo_voxel *)gie_scratch(m, 1, (size_t)n * sizeof(gie_halo_voxel), "gie_halo_import");
+    if (!d) return GIE_ERR_DEVICE;
     be_h2d(&m->be, d, in, (size_t)n * sizeof(gie_halo_voxel));
     rc = gie_halo_import_dev(m, face, d);
     be_sync(&m->be);
-    be_free(&m->be, d);
     return rc;
 }
 /* several faces per call: one launch per step instead of one per face and step, and ONE block

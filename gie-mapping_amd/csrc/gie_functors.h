@@ -97,7 +97,8 @@ struct op_markc { static constexpr bool rolled = false;
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_markc_voxel(c, x, y, z); } };
 struct op_commit { static constexpr bool rolled = false;
     typedef gie_commit_st st;
-    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return !c.tknown[gie_tile_index(c, x, y, z0)]; }
+    /* a map update whose waves were cut short by a barrier timeout commits nothing (GIE_ERR_TIMEOUT, include/gie.h) */
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return (c.cnt[GIE_CNT_ERR] & GIE_ERRF_BARRIER) || !c.tknown[gie_tile_index(c, x, y, z0)]; }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_commit_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
@@ -110,7 +111,12 @@ struct op_frontier { static constexpr bool rolled = false;
     /* the ballot inside finish() works on whatever lanes are active, so skipping is safe.
      * tsum == 0: nothing in or around this 8x8x8 tile can make obtainFrontiers act. */
     GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return c.tsum[gie_tile_index(c, x, y, z0)] == 0; }
-    GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
+    /* tsum == 2: a tile on a face of the volume with nothing else to look at — only its voxels ON the face can act */
+    GIE_DEVM bool skip(const gie_ctx &c, int id, int x, int y, int z) const {
+        if (c.glb_type[id] == GIE_VOX_UNKNOWN) return true;
+        const bool on_face = x == 0 || y == 0 || z == 0 || x == c.X - 1 || y == c.Y - 1 || z == c.Z - 1;
+        return !on_face && c.tsum[gie_tile_index(c, x, y, z)] == 2;
+    }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_frontier_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}
     GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { push_seed(c, gie_frontier_finish(c, id, x, y, z, s), id); return 0; }
@@ -149,12 +155,18 @@ struct op_tile_summary {
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
         uint8_t v = 0;
         if (real && c.tknown[t]) {
-            if (tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1) v = 1;
-            else {
-                const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
-                v = (uint8_t)(unk(c, t) | c.tflag[t] | unk(c, t - sx) | c.tflag[t - sx] | unk(c, t + sx) | c.tflag[t + sx] | unk(c, t - sy) | c.tflag[t - sy]
-                  | unk(c, t + sy) | c.tflag[t + sy] | unk(c, t - sz) | c.tflag[t - sz] | unk(c, t + sz) | c.tflag[t + sz]);
-            }
+            const bool face = tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1;
+            const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
+            int w = unk(c, t) | c.tflag[t];
+            if (tx > 0) w |= unk(c, t - sx) | c.tflag[t - sx];
+            if (tx < c.tfd[0] - 1) w |= unk(c, t + sx) | c.tflag[t + sx];
+            if (ty > 0) w |= unk(c, t - sy) | c.tflag[t - sy];
+            if (ty < c.tfd[1] - 1) w |= unk(c, t + sy) | c.tflag[t + sy];
+            if (tz > 0) w |= unk(c, t - sz) | c.tflag[t - sz];
+            if (tz < c.tfd[2] - 1) w |= unk(c, t + sz) | c.tflag[t + sz];
+            /* 1: every voxel of the tile is looked at; 2: a tile on a face of the volume whose surroundings hold neither an
+             * unknown voxel nor a closest obstacle outside the volume — only the voxels on the face itself can act */
+            v = w ? 1 : (face ? 2 : 0);
         }
         if (real) c.tsum[t] = v;
         /* the tiles with something to look at, as a list (order is irrelevant) */

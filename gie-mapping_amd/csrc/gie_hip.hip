@@ -57,6 +57,16 @@ static int be_init(be_state *b, int device)
     b->cu_total = b->num_cu;
     b->num_cu = b->num_cu >= 64 ? b->num_cu / 2 : b->num_cu;   /* wave grids: 128 workgroups measured best (64: 20.6, 128: 17.7, 256: 20.0 us per BFS level — a compute unit's request queue vs barrier fan-in) */
     { const char *e = getenv("GIE_WAVE_WGS"); if (e && atoi(e) > 0 && atoi(e) <= 256) b->num_cu = atoi(e); }
+    {   /* the waves kernel meets at a hand-rolled grid barrier: its grid must fit the device at once.  Checked here, once,
+         * against the runtime's own occupancy answer (what hipLaunchCooperativeKernel would check at every launch, at
+         * +15-19 us of host time each); what it cannot guard against — another PROCESS holding compute units — ends in a
+         * bounded spin and GIE_ERR_TIMEOUT (include/gie.h). */
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_waves), GIE_WAVE_THREADS, 0) != hipSuccess || per_cu < 1) {
+            gie_set_err("the wavefront kernel (1024 threads per workgroup) cannot be resident on this device"); return 1;
+        }
+        if (b->num_cu > per_cu * b->cu_total) b->num_cu = per_cu * b->cu_total;
+    }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
@@ -214,6 +224,7 @@ static void be_free_rays(be_state *b, const gie_ctx &c, const float *g, int n)
 static void be_exclusive_scan(be_state *b, const int32_t *flag, int32_t *rank, int n)
 {
     size_t bytes = 0;
+    (void)hipSetDevice(b->device);
     GIE_HIP_OK(rocprim::exclusive_scan(nullptr, bytes, flag, rank, 0, (size_t)n, rocprim::plus<int32_t>(), b->stream));
     if (bytes > b->scan_bytes) {
         if (b->scan_tmp) { (void)hipStreamSynchronize(b->stream); (void)hipFree(b->scan_tmp); }

@@ -98,24 +98,34 @@ def exchange_until_stable_local(mappers, grid, max_rounds=64):
     return rounds
 
 
-def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64):
+def _local_face_buffers(mappers, world, device, bufs):
+    """One tensor per (exporting tile, face), allocated once and kept in `bufs`: only the mappers' own streams touch
+    them, so their lifetime must not hang on torch's allocator (a tensor dropped after round k could be handed out
+    again while a neighbour's import of round k is still reading it)."""
+    import torch
+    if "layers" not in bufs:
+        bufs["layers"] = {(r, face): torch.empty(m.halo_count(face) * 20, dtype=torch.uint8, device=device)
+                          for r, m in enumerate(mappers) for face in neighbours(r, world)}
+    return bufs["layers"]
+
+
+def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64, bufs=None):
     """In-process variant of the device-resident exchange (all tiles on one GPU): the export
     kernel of one mapper writes the tensor the import kernel of its neighbour reads."""
-    import torch
     world = grid[0] * grid[1] * grid[2]
+    bufs = {} if bufs is None else bufs
+    lay = _local_face_buffers(mappers, world, device, bufs)
     rounds = 0
     for _ in range(max_rounds):
-        layers = {}
         for r, m in enumerate(mappers):
-            for face, nb in neighbours(r, world).items():
-                t = torch.empty(m.halo_count(face) * 20, dtype=torch.uint8, device=device)
-                m.halo_export_dev(face, t.data_ptr())
-                layers[(nb, face ^ 1)] = t
+            for face in neighbours(r, world):
+                m.halo_export_dev(face, lay[(r, face)].data_ptr())
         for m in mappers:
             m.sync()
-        for (r, face), t in layers.items():
-            mappers[r].halo_import_dev(face, t.data_ptr())
-        seeded = sum(m.refine() for m in mappers)
+        for r, m in enumerate(mappers):
+            for face, nb in neighbours(r, world).items():
+                m.halo_import_dev(face, lay[(nb, face ^ 1)].data_ptr())
+        seeded = sum(m.refine() for m in mappers)          # synchronises every mapper: the layers are free again
         rounds += 1
         if seeded == 0:
             break
@@ -189,29 +199,42 @@ def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=
     return rounds
 
 
-def exchange_rounds_local_device(mappers, grid, device, rounds=1):
+def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
     """The same stream-ordered rounds with all tiles in this process (one GPU): the neighbour's
-    stream waits for an event on the exporter's stream instead of an RCCL transfer."""
+    stream waits for an event on the exporter's stream instead of an RCCL transfer.  The face layers
+    are allocated once (`bufs`, kept by the caller across calls); an exporter rewrites its layers only
+    after every import of the round before has finished (events recorded behind the imports)."""
     import torch
     world = grid[0] * grid[1] * grid[2]
-    streams = [torch.cuda.ExternalStream(m.stream_handle(), device=device) for m in mappers]
+    own = bufs is None                                    # nobody keeps the layers alive after the call: finish before returning
+    bufs = {} if bufs is None else bufs
+    lay = _local_face_buffers(mappers, world, device, bufs)
+    if "streams" not in bufs:
+        bufs["streams"] = [torch.cuda.ExternalStream(m.stream_handle(), device=device) for m in mappers]
+        bufs["imported"] = []
+    streams = bufs["streams"]
     for _ in range(rounds):
-        layers, evs = {}, []
+        evs = []
         for r, m in enumerate(mappers):
-            out = {}
-            for face, nb in neighbours(r, world).items():
-                t = torch.empty(m.halo_count(face) * 20, dtype=torch.uint8, device=device)
-                out[face] = t.data_ptr()
-                layers[(nb, face ^ 1)] = t
-            m.halo_export_all_dev(out)
+            for ev in bufs["imported"]:                   # the layers of the round before have been read
+                streams[r].wait_event(ev)
+            m.halo_export_all_dev({face: lay[(r, face)].data_ptr() for face in neighbours(r, world)})
             ev = torch.cuda.Event()
             ev.record(streams[r])
             evs.append(ev)
+        done = []
         for r, m in enumerate(mappers):
             for ev in evs:
                 streams[r].wait_event(ev)
-            m.halo_import_all_dev({face: t.data_ptr() for (rr, face), t in layers.items() if rr == r})
+            m.halo_import_all_dev({face: lay[(nb, face ^ 1)].data_ptr() for face, nb in neighbours(r, world).items()})
+            ev = torch.cuda.Event()
+            ev.record(streams[r])
+            done.append(ev)
             m.refine_async()
+        bufs["imported"] = done
+    if own:
+        for m in mappers:
+            m.sync()
     return rounds
 
 

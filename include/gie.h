@@ -25,6 +25,11 @@ extern "C" {
 #define GIE_ERR_INVALID 1   /* bad argument / bad call order            */
 #define GIE_ERR_DEVICE 2    /* HIP runtime error                        */
 #define GIE_ERR_CAPACITY 3  /* block pool / hash / frontier queue full  */
+#define GIE_ERR_TIMEOUT 4   /* the wavefront kernel's grid barrier timed out: its workgroups were kept off the device for
+                               seconds (another process's kernels holding the compute units).  The map update that hit it is
+                               incomplete (waves cut short, distances may be over-estimates until the region is observed
+                               again); the condition is reported once and cleared — the next update runs normally.  One
+                               process per device is the supported configuration. */
 
 /* voxel types, local_batch.h:7-10 */
 #define GIE_VOX_UNKNOWN 0

@@ -76,9 +76,30 @@ def probe_coords(pvt, size, rng, n=4000):
     return rng.integers(lo, hi, size=(n, 3)).astype(np.int32)
 
 
-def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False):
+def _compare_after_merge(sc, k, a, b, rng, check_stats):
+    ra, rb = a.read_local(), b.read_local()
+    for key in ("type", "dist_sq", "coc"):
+        assert np.array_equal(ra[key], rb[key]), "%s frame %d: post-merge %s differs in %d voxels" % (
+            sc.name, k, key, int((ra[key] != rb[key]).reshape(ra["type"].shape + (-1,)).any(-1).sum()))
+    assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0.0), "%s frame %d: edt differs" % (sc.name, k)
+    xyz = probe_coords(a.pivot(), sc.size, rng)
+    ga, gb = a.query_global(xyz), b.query_global(xyz)
+    for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+        assert np.array_equal(ga[key], gb[key]), "%s frame %d: global %s differs in %d probes" % (
+            sc.name, k, key, int((ga[key] != gb[key]).reshape(len(xyz), -1).any(-1).sum()))
+    sa, sb = a.stats(), b.stats()
+    if check_stats:
+        for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_c", "blocks_total"):
+            assert sa[key] == sb[key], "%s frame %d: stat %s %d != %d" % (sc.name, k, key, sa[key], sb[key])
+
+
+def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False, production=False):
     """make_a: reference mapper factory (oracle); make_b: mapper under test. Raises on mismatch.
-    Returns a list of per-frame stats dicts of the reference mapper."""
+    Returns a list of per-frame stats dicts of the reference mapper.
+    production=True drives both mappers with set_pose / ogm / step() only — the sequence a node runs — and compares
+    what is left after the map update.  (The stage-by-stage form reads the scan and the batch EDT in between, and
+    those readers complete what the update itself leaves out: scan labels of a ray-cast scan, pass Z of tiles nobody
+    reads.)"""
     cfg = sc.config()
     a, b = make_a(cfg), make_b(cfg)
     rng = np.random.default_rng(sc.seed + 77)
@@ -96,6 +117,12 @@ def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False):
             assert a.pivot() == b.pivot()
             _feed(a, kind, data, kw)
             _feed(b, kind, data, kw)
+            if production:
+                a.step()
+                b.step()
+                _compare_after_merge(sc, k, a, b, rng, check_stats)
+                out.append(a.stats())
+                continue
             oa, ob = a.read_ogm(), b.read_ogm()
             for key in ("inst_type", "ray_count"):
                 bad = int((oa[key] != ob[key]).sum())

@@ -411,3 +411,51 @@ def test_edge_inputs(oracle_lib):
     images without a valid reading (tests/edge_inputs.py): HIP equals the oracle on all of them."""
     import edge_inputs
     edge_inputs.run(OracleMapper, gie.Mapper)
+
+
+@pytest.mark.parametrize("sc", [s for s in SCENARIOS if s.name in ("raycast", "mixed", "fast_mode", "planner_boxes", "c3_no_cutoff",
+                                                                  "c5_hash_world", "thin_x", "odd_dims")], ids=lambda s: s.name)
+def test_hip_matches_oracle_production_sequence(oracle_lib, sc):
+    """set_pose / ogm / step() only: unlabelled ray-cast scans, partial or direct pass Z, Mark + commit fused —
+    exactly what a node runs (the stage-by-stage tests call readers in between that complete those stages)."""
+    parity.run_and_compare(sc, OracleMapper, gie.Mapper, production=True)
+
+
+@pytest.mark.gpu
+def test_waves_wait_out_a_kernel_that_holds_every_compute_unit(oracle_lib):
+    """The wavefront kernel meets at a hand-rolled grid barrier, so all of its workgroups have to be resident at
+    once.  Here another stream fills EVERY wave slot of the device with spinning workgroups (tests/gpu_helpers)
+    for a quarter of a second per map update, launched right before the update: the map update — wave A, B
+    and C seeded, several barrier rounds each — has to sit the intruder out and still equal the oracle bit for
+    bit, without a barrier timeout."""
+    import ctypes as C
+    import os
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_helpers", "libspin.so")
+    if not os.path.exists(so):
+        pytest.skip("tests/gpu_helpers/libspin.so not built (__graft_entry__.build())")
+    spin = C.CDLL(so)
+    spin.spin_start.argtypes = [C.c_int, C.c_double]
+    sc = parity.Scenario("vlp16", (48, 48, 16), sensor="multiscan", frames=10, delta_vox=5, yaw_deg=10.0)
+    cfg = sc.config()
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        visits = 0
+        for k, (pos, q, kind, data, kw) in enumerate(sc.frames_iter()):
+            for m in (a, b):
+                m.set_pose(pos, q)
+                parity._feed(m, kind, data, kw)
+            a.step()
+            assert spin.spin_start(2 if k % 2 else 1, 250.0) == 0      # 2 x 1024 threads per CU = every wave slot; 1 = half of them
+            b.step()                                                    # enqueued while the intruder is resident
+            b.sync()                                                    # raises on GIE_ERR_TIMEOUT
+            assert spin.spin_wait() == 0
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), (k, key)
+            sa, sb = a.stats(), b.stats()
+            for key in ("visits_a", "visits_c", "levels_a", "levels_b", "levels_c"):
+                assert sa[key] == sb[key], (k, key)
+            visits += sa["visits_a"] + sa["visits_b"] + sa["visits_c"]
+        assert visits > 0
+    finally:
+        a.close(); b.close()

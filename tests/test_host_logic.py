@@ -41,6 +41,12 @@ def test_emulated_device_logic_matches_oracle(oracle_lib, sc):
     assert len(stats) == sc.frames
 
 
+@pytest.mark.parametrize("sc", [s for s in SCENARIOS if s.name in ("raycast", "mixed", "c5_hash_world")], ids=lambda s: s.name)
+def test_production_sequence_emulation(oracle_lib, sc):
+    """set_pose / ogm / step() only (no readers between the stages)."""
+    parity.run_and_compare(sc, OracleMapper, EmuMapper, production=True)
+
+
 def test_waves_are_exercised(oracle_lib):
     """The scenarios above are only meaningful if all three wavefronts actually run."""
     sc = parity.Scenario("vlp16", (48, 48, 16), sensor="multiscan", frames=12, delta_vox=5, yaw_deg=10.0)

@@ -39,6 +39,7 @@ def _run_tiled(make, exchange=True, device=None, fixed_rounds=0):
     for r, m in enumerate(ms):
         m.set_tile(tiling.tile_offset_voxels(r, 2, TILE), WHOLE)
     hist = []
+    bufs = {}                                              # the face layers live as long as the mappers that read them
     try:
         for pos, q, img in _sensor_frames(FR):
             for m in ms:
@@ -46,10 +47,10 @@ def _run_tiled(make, exchange=True, device=None, fixed_rounds=0):
             if not exchange:
                 rounds = 0
             elif device is not None and fixed_rounds:
-                tiling.exchange_rounds_local_device(ms, (2, 1, 1), device, rounds=fixed_rounds)
+                tiling.exchange_rounds_local_device(ms, (2, 1, 1), device, rounds=fixed_rounds, bufs=bufs)
                 rounds = -1
             elif device is not None:
-                rounds = tiling.exchange_until_stable_local_device(ms, (2, 1, 1), device)
+                rounds = tiling.exchange_until_stable_local_device(ms, (2, 1, 1), device, bufs=bufs)
             else:
                 rounds = tiling.exchange_until_stable_local(ms, (2, 1, 1))
             hist.append(([m.read_local() for m in ms], rounds, [m.pivot() for m in ms]))
@@ -171,6 +172,7 @@ def test_eight_mappers_share_one_device(oracle_lib):
         for r in range(8):
             m = make(cfg); m.set_tile(tiling.tile_offset_voxels(r, 8, size), whole); ms.append(m)
         out = None
+        bufs = {}
         try:
             for k in range(4):
                 pos, q = scenes.pose(k, 0.1, delta_vox=1, yaw_deg=10.0)
@@ -180,7 +182,7 @@ def test_eight_mappers_share_one_device(oracle_lib):
                 if device is None:
                     tiling.exchange_until_stable_local(ms, grid)
                 else:
-                    tiling.exchange_rounds_local_device(ms, grid, device, rounds=6)
+                    tiling.exchange_rounds_local_device(ms, grid, device, rounds=6, bufs=bufs)
             out = [m.read_local() for m in ms]
         finally:
             for m in ms:
