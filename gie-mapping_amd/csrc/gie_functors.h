@@ -200,7 +200,6 @@ struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
         if (id >= 0 && gie_refine_voxel(c, id)) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, id);
     } };
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
-struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
 /* the fuse tile list (thread per tile; device: one atomic per wave) */
 struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
@@ -218,7 +217,6 @@ struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
         }
 #endif
     } };
-struct op_zneed { GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_zneed_column(c, i); } };
 struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };
 struct op_stream_gather { const int32_t *list; int first; int32_t *keys; gie_voxel *out;
     GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_gather(c, list, first, keys, out, i); } };
@@ -228,20 +226,6 @@ struct op_export_bcoc { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const
 struct op_costmap { gie_seendist *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const {
         gie_seendist s; s.d = c.edt[i]; s.s = 0; s.o = (uint8_t)c.glb_type[i]; s.pad[0] = s.pad[1] = 0; out[i] = s; } };
 
-/* block allocation (allocHashTB, glb_hash_map.cu:58-113) */
-struct op_cell_flag { GIE_DEVM void operator()(const gie_ctx &c, int i) const { c.blk_new[i] = gie_cell_needs_new(c, i); } };
-struct op_cell_insert { const int32_t *flag; const int32_t *rank;
-    GIE_DEVM void operator()(const gie_ctx &c, int i) const {
-        if (!flag[i]) return;
-        const int slot = *c.pool_count + rank[i];
-        if (slot >= c.max_blocks) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_POOL); return; }
-        gie_cell_insert(c, i, slot);
-    } };
-struct op_cell_table { GIE_DEVM void operator()(const gie_ctx &c, int i) const {
-        const int bx = i % c.tdim[0], by = (i / c.tdim[0]) % c.tdim[1], bz = i / (c.tdim[0] * c.tdim[1]);
-        c.blk_tab[i] = gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]);
-        c.blk_need[i] = 0;
-    } };
 
 
 #endif /* GIE_FUNCTORS_H */

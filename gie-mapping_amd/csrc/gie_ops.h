@@ -234,15 +234,6 @@ GIE_DEV void gie_register_point(const gie_ctx &c, const float *xyz, float *g_out
     }
 }
 
-/* clearRayLoc, pntcld_raycast.cu:9-18 */
-GIE_DEV int gie_clear_ray(const gie_ctx &c, int lx, int ly, int lz)
-{
-    if (!gie_in_loc(c, lx, ly, lz)) return 1;
-    const int id = gie_lid(c, lx, ly, lz);
-    if (c.inst_type[id] != GIE_VOX_OCCUPIED) { gie_ray_marks lt = { -1, -1 }; gie_ray_touch(c, lx, ly, lz, &lt); gie_aadd32(&c.ray_count[id], -1); return 1; }
-    return 0;
-}
-
 /* freeLocObs (pntcld_raycast.cu:67-80) → RAY::rayCastLoc (ray_cast.h:57-144).
  * The 3-D DDA itself, shared by the sequential walk below and by the segmented kernel
  * (k_free_rays): same float operations in the same order, so a replayed walk visits the same cells. */
@@ -291,48 +282,7 @@ GIE_DEV int gie_dda_step(gie_dda &d)
  * |dx|+|dy|+|dz| <= sqrt(3) cell changes per voxel of length */
 GIE_HD int gie_ray_max_steps(const gie_ctx &c) { return (int)(0.707f * (float)c.X * 1.7321f) + 8; }
 
-/* sequential walk of one ray (one thread per ray) */
-GIE_DEV void gie_free_ray(const gie_ctx &c, const float *g, int i)
-{
-    gie_dda d;
-    int s0[3];
-    gie_ray_marks last_tile = { -1, -1 };
-    if (!gie_point_ok(g[3 * i], g[3 * i + 1], g[3 * i + 2])) return;
-    const int walk = gie_dda_init(c, g, i, d, s0);
-    {   /* clearRayLoc on the sensor's own cell */
-        const int id0 = gie_in_loc(c, s0[0], s0[1], s0[2]) ? gie_lid(c, s0[0], s0[1], s0[2]) : -1;
-        if (id0 >= 0) gie_ray_touch(c, s0[0], s0[1], s0[2], &last_tile);
-        gie_wave_add(c, (id0 >= 0 && c.inst_type[id0] != GIE_VOX_OCCUPIED) ? id0 : -1, -1);
-    }
-    if (!walk) return;
-    /* The traversal itself (ray_cast.h:102-142) is a dependent chain "step → read the cell's
-     * type → stop or decrement"; the cells do not depend on what is read, so GIE_RAY_BATCH steps
-     * are generated ahead, their types are fetched together, and the effects are then applied in
-     * the reference's order (a speculative cell beyond the stopping point is simply dropped). */
-#define GIE_RAY_BATCH 8
-    for (;;) {
-        int ids[GIE_RAY_BATCH];            /* local voxel id, -1 = outside the volume */
-        int stop_after[GIE_RAY_BATCH];
-        int loc[GIE_RAY_BATCH][3];
-        GIE_UNROLL_BATCH
-        for (int j = 0; j < GIE_RAY_BATCH; j++) {
-            stop_after[j] = gie_dda_step(d);
-            const int lx = d.cur[0] - c.pvt[0], ly = d.cur[1] - c.pvt[1], lz = d.cur[2] - c.pvt[2];
-            ids[j] = gie_in_loc(c, lx, ly, lz) ? gie_lid(c, lx, ly, lz) : -1;
-            loc[j][0] = lx; loc[j][1] = ly; loc[j][2] = lz;
-        }
-        int8_t ty[GIE_RAY_BATCH];
-        GIE_UNROLL_BATCH
-        for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = ids[j] >= 0 ? c.inst_type[ids[j]] : (int8_t)GIE_VOX_UNKNOWN;
-        GIE_UNROLL_BATCH
-        for (int j = 0; j < GIE_RAY_BATCH; j++) {
-            if (ty[j] == GIE_VOX_OCCUPIED) return;                 /* clearRayLoc returned false */
-            if (ids[j] >= 0) gie_ray_touch(c, loc[j][0], loc[j][1], loc[j][2], &last_tile);   /* only cells that are really cleared */
-            gie_wave_add(c, ids[j], -1);
-            if (stop_after[j]) return;
-        }
-    }
-}
+#define GIE_RAY_BATCH 8     /* cells whose types a ray walk fetches together (k_free_rays) */
 
 /* getAllocKeys, pntcld_raycast.cu:21-63 */
 GIE_DEV void gie_raycast_finalize(const gie_ctx &c, int x, int y, int z)
@@ -346,14 +296,6 @@ GIE_DEV void gie_raycast_finalize(const gie_ctx &c, int x, int y, int z)
 }
 
 /* ================================================================== block allocation */
-/* RequiresAllocation (alloc_helper.cuh:13-21): table cell needs a block that does not exist */
-GIE_DEV int gie_cell_needs_new(const gie_ctx &c, int cell)
-{
-    if (!c.blk_need[cell]) return 0;
-    const int bx = cell % c.tdim[0], by = (cell / c.tdim[0]) % c.tdim[1], bz = cell / (c.tdim[0] * c.tdim[1]);
-    return gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]) < 0;
-}
-
 /* TryAllocateKernel / insert_to_id (alloc_helper.cuh:30-50, vhashing.h:387-455) without locks:
  * the slot comes from an exclusive scan (deterministic), the key is claimed by CAS. */
 GIE_DEV void gie_cell_insert(const gie_ctx &c, int cell, int slot)
@@ -1136,16 +1078,6 @@ GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, in
     return mask;
 }
 
-/* sequential form (test-only emulation) */
-GIE_DEV int gie_wave_c_step(const gie_ctx &c, const int32_t *cur, int32_t *next, int32_t *next_cnt, int level, int e)
-{
-    int nid[6];
-    const int m = gie_wave_c_relax(c, cur, level, e, nid);
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) if (m & (1 << k)) gie_push32(c, next, next_cnt, c.qcap_c, nid[k]);
-    return m >> 6;
-}
-
 /* ================================================================== commit */
 /* UpdateHashBatch, unify_helper.cuh:448-523 */
 struct gie_commit_st { int8_t ty; uint64_t pr; int a; };
@@ -1384,20 +1316,6 @@ GIE_DEV void gie_export_bcoc(const gie_ctx &c, int id, int32_t *dist_sq, int32_t
     if (bc == GIE_BCOC_NONE) { coc_xyz[3 * id] = coc_xyz[3 * id + 1] = coc_xyz[3 * id + 2] = -1; }
     else { coc_xyz[3 * id] = (int)(bc & 1023u); coc_xyz[3 * id + 1] = (int)((bc >> 10) & 1023u); coc_xyz[3 * id + 2] = (int)(bc >> 20); }
 }
-/* Who reads the batch EDT (`_aux` / `_coc_idx_aux`)?  Mark reads it at known voxels; wave B needs the
- * batch DISTANCE of the occasional unknown voxel on a face of the volume (wave_core.cuh:334) and
- * computes it on demand (gie_batch_dist_direct); nobody else: pass Z only has to produce the
- * tiles that hold a known voxel.  One 64-bit z mask per (x,y) tile column; volumes taller than
- * 64 tiles (Z > 512) run pass Z in full. */
-GIE_DEV void gie_zneed_column(const gie_ctx &c, int col)
-{
-    const int tx = col % c.tfd[0], ty = col / c.tfd[0];
-    uint64_t m = 0;
-    for (int tz = 0; tz < c.tfd[2] && tz < 64; tz++)
-        if (c.tknown[(tz * c.tfd[1] + ty) * c.tfd[0] + tx]) m |= 1ull << tz;
-    c.zneed[col] = m;
-}
-
 /* ---- changed-block streaming (streamPipeline / getUpdatedAddr / streamD2H, glb_hash_map.cu:209-247) */
 /* slot list of the flagged blocks in slot order */
 GIE_DEV void gie_stream_list(const gie_ctx &c, const int32_t *rank, int32_t *list, int slot)

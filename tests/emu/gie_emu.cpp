@@ -13,7 +13,7 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
-#include "../../gie-mapping_amd/csrc/gie_functors.h"
+#include "gie_emu_ops.h"
 
 struct be_state { int dummy; };
 static void gie_set_err(const std::string &s);

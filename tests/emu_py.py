@@ -16,7 +16,7 @@ _fns = None
 def load():
     global _fns
     if _fns is None:
-        srcs = [os.path.join(EMU_DIR, "gie_emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        srcs = [os.path.join(EMU_DIR, "gie_emu.cpp"), os.path.join(EMU_DIR, "gie_emu_ops.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
         newest = max(os.path.getmtime(s) for s in srcs)
         if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < newest:
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", EMU_SO,
