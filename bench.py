@@ -213,7 +213,10 @@ class Runner:
             pos, _ = self.feed.pose(i)
             assert m.pivot() == self.feed.scenes.local_pivot(pos, self.feed.voxel, self.feed.size, self.feed.tile_off), "pivot mismatch"
             self.checked_pivot = True
-        m.step()
+        if self.exchange:
+            m.step_begin_tiled()                        # fuse + batch EDT + first half of the merge; round 0 of the exchange finishes it
+        else:
+            m.step()
         self.updates += 1
         if self.exchange:
             t, d = self.tiling, self.dist
@@ -281,7 +284,7 @@ class Runner:
 
 
 def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff_dist, W, K, rank, world, dev, local_rank, backend,
-                 min_timed_s=0.5, max_regions=12, with_latency=True):
+                 min_timed_s=0.5, max_regions=12, with_latency=True, rms=False):
     """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
@@ -301,6 +304,9 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     lat = r.latency_pass(first, K) if with_latency else []
     first += K if with_latency else 0
     res = None
+    accuracy = None
+    if rank == 0 and rms:
+        accuracy = accuracy_check(r.m, voxel)
     if rank == 0:
         ty = r.m.read_local(edt=False, dist_sq=False, coc=False)["type"]
         kn = ty != 0
@@ -421,7 +427,29 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         "roofline": roofline, "roofline_wavefront_sweep": wavefront, "roofline_update": update,
         "roofline_sweeps": {k: {kk: vv for kk, vv in v.items() if kk != "kernel"} for k, v in sweeps.items()},
     }
+    if accuracy is not None:
+        out["accuracy"] = accuracy
     return out
+
+
+def accuracy_check(m, voxel):
+    """Gnd_truth_checker::cmp_dist (gt_checker.h:30-80) on the local volume: for every known voxel the error between the distance
+    to the nearest OCCUPIED voxel of the volume and the published EDT, in metres: RMSE, maximum, and how many voxels are more than
+    a millimetre below / above.  The nearest occupied voxel comes from the exact multi-threaded CPU EDT (oracle/edt_mt.c — a checker,
+    outside every timed region) instead of the reference's PCL KD-tree; same quantity.  Like the reference's check it only knows the
+    obstacles INSIDE the volume: a voxel whose closest obstacle the volume has left behind shows up as "EDT is less"."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py
+    loc = m.read_local(dist_sq=False, coc=False)
+    ty, edt = loc["type"], loc["edt"]
+    d2, _ = oracle_py.edt_mt(ty, want_coc=False)
+    known = ty != 0
+    if not (ty == 2).any() or not known.any():
+        return {"rms_m": None, "note": "no occupied or no known voxel in the volume"}
+    err = (np.sqrt(d2[known].astype(np.float64)) - edt[known].astype(np.float64)) * voxel
+    return {"rms_m": round(float(np.sqrt((err ** 2).mean())), 6), "max_err_m": round(float(np.abs(err).max()), 6),
+            "edt_less": int((err > 0.001).sum()), "edt_more": int((err < -0.001).sum()), "voxels": int(known.sum()),
+            "how": "Gnd_truth_checker::cmp_dist (gt_checker.h:30-80) against the exact CPU EDT of the volume's own obstacles, after the last timed update"}
 
 
 def load_traffic(workload, size, world):
@@ -513,6 +541,9 @@ def main():
     ap.add_argument("--workload", "--sensor", dest="workload", choices=WORKLOADS, default="c5")
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="repeat the K-step region until this much has been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rms", action="store_true",
+                    help="accuracy profiler (the reference's Gnd_truth_checker, gt_checker.h:30-80): RMSE of the local EDT after the last "
+                         "timed update against the exact distance to the nearest occupied voxel of the volume")
     ap.add_argument("--no-extras", "--no-secondary", dest="no_extras", action="store_true",
                     help="skip the projective-lidar and ray-casting runs reported beside the headline")
     args = ap.parse_args()
@@ -546,7 +577,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     W, K = args.warmup, args.steps
     main_res = run_workload(torch, gie, scenes, tiling, dist, args.workload, size, args.voxel, cutoff_dist, W, K, rank, world, dev,
-                            local_rank, backend, min_timed_s=args.min_timed_s)
+                            local_rank, backend, min_timed_s=args.min_timed_s, rms=args.rms)
     if rank == 0:
         line = {"metric": "edt_map_update_throughput", "value": main_res["value"], "unit": "Mvoxels/s", "n_gpus": world, "steps": K, "warmup": W,
                 "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",

@@ -25,7 +25,7 @@ struct gie_mapper {
     gie_ctx c;
     be_state be;
     int ncell;
-    int has_pose, has_ogm;
+    int has_pose, has_ogm, merge_open;
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
     int ogm_unlabelled;                   /* ray-cast scan whose _inst_type labels have not been written (gie_read_ogm does it) */
     float msg_origin[3];
@@ -77,7 +77,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->edt_partial = 0; m->ogm_unlabelled = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -456,7 +456,9 @@ static int gie_fused_mode(const gie_mapper *m)
     return (env && !m->c.track) ? 1 : 0;
 }
 
-extern "C" int gie_merge(gie_mapper *m)
+/* first half of the merge: MarkLimitedObserve — and the commit of the Mark-time pairs, so that what a tiled run exports
+ * between the two halves (gie_halo_export*) is this map update's state, not the previous one's */
+extern "C" int gie_merge_begin(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
     be_time(&m->be, 6);
@@ -466,6 +468,15 @@ extern "C" int gie_merge(gie_mapper *m)
     if (m->c.fused) be_vox_list<true>(&m->be, m->c, op_markc(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0, be_sweep_lx("GIE_MARKC_LX", 32));
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
+    m->merge_open = 1;
+    return GIE_OK;
+}
+/* second half: obtainFrontiers, waves A / B / C, commit */
+extern "C" int gie_merge_end(gie_mapper *m)
+{
+    int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
+    if (!m->merge_open) { gie_set_err("gie_merge_end: gie_merge_begin has not been called"); return GIE_ERR_INVALID; }
+    m->merge_open = 0;
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_list(&m->be, m->c, op_tile_summary(), m->c.tl_known, GIE_CNT_TL_KNOWN);   /* only tiles with a known voxel can have anything to look at */
     /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
@@ -484,6 +495,20 @@ extern "C" int gie_merge(gie_mapper *m)
     }
     be_time(&m->be, 7);
     return GIE_OK;
+}
+/* the tiled sequence's first half in the reference's order of kernels: Mark, then (only when Mark and commit are not one
+ * sweep) a commit of the Mark-time pairs for the export */
+extern "C" int gie_merge_begin_tiled(gie_mapper *m)
+{
+    int rc = gie_merge_begin(m); if (rc) return rc;
+    if (!m->c.fused) be_vox_list<true>(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
+    return GIE_OK;
+}
+
+extern "C" int gie_merge(gie_mapper *m)
+{
+    int rc = gie_merge_begin(m); if (rc) return rc;
+    return gie_merge_end(m);
 }
 
 extern "C" int gie_step(gie_mapper *m)

@@ -59,10 +59,48 @@ GIE_DEV void gie_push64a(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t 
     const int i = gie_aadd32(counter, 1);
     if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], (int32_t)a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
 }
+/* the same append for every lane of the wave that has `push` set, with ONE atomic on the counter per wave (tens of
+ * thousands of per-lane atomics on one word were most of obtainFrontiers' time when a whole face of the volume seeds waves
+ * A / B).  Only executing lanes are looked at, so it is safe in divergent code. */
+GIE_DEV void gie_push64a_wave(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, int cap, bool push, uint64_t v, int a)
+{
+#if defined(GIE_HOST_EMU)
+    if (push) gie_push64a(c, q, qaddr, counter, cap, v, a);
+#else
+    const unsigned long long m = __ballot(push);
+    if (!m) return;
+    const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = gie_aadd32(counter, __popcll(m));
+    base = __shfl(base, leader);
+    if (push) {
+        const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], (int32_t)a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    }
+#endif
+}
 GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap, int32_t v)
 {
     const int i = gie_aadd32(counter, 1);
     if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+}
+
+GIE_DEV void gie_push32_wave(const gie_ctx &c, int32_t *q, int32_t *counter, int cap, bool push, int32_t v)
+{
+#if defined(GIE_HOST_EMU)
+    if (push) gie_push32(c, q, counter, cap, v);
+#else
+    const unsigned long long m = __ballot(push);
+    if (!m) return;
+    const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = gie_aadd32(counter, __popcll(m));
+    base = __shfl(base, leader);
+    if (push) {
+        const int i = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    }
+#endif
 }
 
 /* ray_count[id] += val for every lane with id >= 0, with equal targets of NEIGHBOURING lanes merged
@@ -520,9 +558,11 @@ GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
  * that the kernel can compact the C-queue append with a wave ballot: bit0 = push to C. */
 /* obtainFrontiers' branch for a 6-neighbour outside the local volume (unify_helper.cuh:346-438).
  * Returns bit0 = the voxel became a C seed (*seed set), bit1 = the neighbour is unknown. */
+/* *push = 1: the neighbour joins frontier B, 2: frontier A (appended by the caller, wave-aggregated), *pa = its address */
 GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int nx, int ny, int nz,
-                                      const int cl[3], const int cw[3], int cd, uint64_t *seed)
+                                      const int cl[3], const int cw[3], int cd, uint64_t *seed, int *push, int *pa)
 {
+    *push = 0; *pa = -1;
     int cur_in_q = 0;
     const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
     const int a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
@@ -544,12 +584,15 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
             cur_in_q = 1;
         }
     }
-    if (c.fast_mode) return cur_in_q;
+    /* tiling: a neighbour inside the WHOLE volume is another tile's voxel, known here only as a ghost layer that the owner
+     * refreshes every map update — it can seed wave C (above) but is never raised or lowered from here, and waves A / B do
+     * not walk into other tiles' territory (this tile's copies of it are stale).  Without tiling whole = local: no effect. */
+    if (c.fast_mode || gie_in_whole(c, nx, ny, nz)) return cur_in_q;
     const int c2n = gie_d2(nx, ny, nz, cl[0], cl[1], cl[2]);
     if (c2n < nd) {                                       /* lower out → frontier B */
         c.g_wl[a] = 1;
         c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
-        gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]), a);
+        *push = 1; *pa = a;
     } else if (c2n > nd && n_local) {                     /* raise out → frontier A */
         /* the reference reads the live _glb_type here; FNT never aliases OCCUPIED */
         if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
@@ -558,7 +601,7 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
             gie_touch(c, a);
             c.g_wl[a] = -c.map_ct;
             c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
-            gie_push64a(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, gie_pack_crd(ng[0], ng[1], ng[2]), a);
+            *push = 2; *pa = a;
         }
     }
     return cur_in_q;
@@ -594,6 +637,7 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
     if (!gie_in_loc(c, cl[0], cl[1], cl[2])) return 0;
     int cur_in_q = 0, has_unknown = 0;
     uint64_t seed = 0;
+    int opush[6] = { 0, 0, 0, 0, 0, 0 }, oaddr[6] = { -1, -1, -1, -1, -1, -1 };
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     const int8_t *ntys = s.ntys;
     const uint8_t *ntf = s.ntf;
@@ -620,8 +664,16 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
         } else {
             /* a neighbour outside the volume (only voxels on the six faces get here): kept out of
              * line so that the hot interior path stays small */
-            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed);
+            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed, &opush[k], &oaddr[k]);
             cur_in_q |= r & 1; has_unknown |= (r >> 1) & 1;
+        }
+    }
+    if (!c.fast_mode && (x == 0 || y == 0 || z == 0 || x == c.X - 1 || y == c.Y - 1 || z == c.Z - 1)) {
+        GIE_UNROLL6
+        for (int k = 0; k < 6; k++) {                     /* neighbours outside the volume that seed wave B / wave A */
+            const uint64_t crd = gie_pack_crd(x + dx[k] + c.pvt[0], y + dy[k] + c.pvt[1], z + dz[k] + c.pvt[2]);
+            gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, opush[k] == 1, crd, oaddr[k]);
+            gie_push64a_wave(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, opush[k] == 2, crd, oaddr[k]);
         }
     }
     if (cur_in_q) { c.wl[id] = GIE_WL_SEED(c); c.cand[1][id] = seed; }   /* the pair the seed enters wave C with */
@@ -685,22 +737,43 @@ GIE_DEV void gie_nbr_addr6(const gie_ctx &c, const int g[3], int a, unsigned wan
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) if (hit[k] >= 0 && sl[k] >= 0) na[k] = sl[k] * GIE_VBSZ + inb[k];
 }
-/* append the neighbours k in `pm` (their addresses in na[]) of g to a frontier: ONE returning atomic per entry */
+/* append the neighbours k in `pm` (their addresses in na[]) of g to a frontier: ONE returning atomic per WAVE (the
+ * lanes' counts are ranked with one ballot per direction) */
 GIE_DEV void gie_push_nbrs(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, const int g[3], unsigned pm, const int na[6])
 {
-    if (!pm) return;
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+#if defined(GIE_HOST_EMU)
     int n = 0;
-    GIE_UNROLL6
     for (int k = 0; k < 6; k++) n += (int)((pm >> k) & 1u);
+    if (!n) return;
     int slot = gie_aadd32(counter, n);
-    GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         if (!((pm >> k) & 1u)) continue;
         if (slot < c.qcap_ab) { gie_st(&q[slot], gie_pack_crd(g[0] + dx[k], g[1] + dy[k], g[2] + dz[k])); gie_st(&qaddr[slot], (int32_t)na[k]); }
         else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
         slot++;
     }
+#else
+    unsigned long long mk[6];
+    int tot = 0;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) { mk[k] = __ballot((pm >> k) & 1u); tot += __popcll(mk[k]); }
+    if (!tot) return;
+    const int lane = __lane_id(), leader = __ffsll((long long)__ballot(1)) - 1;
+    int base = 0;
+    if (lane == leader) base = gie_aadd32(counter, tot);
+    base = __shfl(base, leader);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) {
+        if ((pm >> k) & 1u) {
+            const int slot = base + __popcll(mk[k] & lt);
+            if (slot < c.qcap_ab) { gie_st(&q[slot], gie_pack_crd(g[0] + dx[k], g[1] + dy[k], g[2] + dz[k])); gie_st(&qaddr[slot], (int32_t)na[k]); }
+            else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+        }
+        base += __popcll(mk[k]);
+    }
+#endif
 }
 
 /* ================================================================== wave A (raise_outside) */
@@ -721,8 +794,9 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     unsigned want = 0;
     GIE_UNROLL6
-    for (int k = 0; k < 6; k++)
-        if (!gie_in_loc(c, g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2])) want |= 1u << k;
+    for (int k = 0; k < 6; k++)       /* neighbours outside the volume — with tiling: outside the whole volume (see gie_frontier_outside) */
+        if (!gie_in_whole(c, g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2])
+            && !gie_in_loc(c, g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2])) want |= 1u << k;
     int na[6];
     gie_nbr_addr6(c, g, a, want, na);
     if (cd > c.cutoff_sq) return;
@@ -793,10 +867,8 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
         gie_st(&c.g_coc[a], c.rec0[e]);
         gie_touch(c, a);
         gie_st(&c.g_wl[a], (int32_t)1);
-        if (c.rec1[e] != GIE_NOPROP) {
-            gie_st(&c.g_pair[a], c.rec1[e]);
-            gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gk, a);
-        }
+        if (c.rec1[e] != GIE_NOPROP) gie_st(&c.g_pair[a], c.rec1[e]);
+        gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, c.rec1[e] != GIE_NOPROP, gk, a);
     }
     if (!mask) return;
     const uint64_t lpar = c.rec2[e];
@@ -890,7 +962,7 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
         cand[k] = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
         nid[k] = 0;
         if (gie_in_loc(c, nb[0], nb[1], nb[2])) { inm |= 1u << k; nid[k] = gie_lid(c, nb[0], nb[1], nb[2]); }
-        else outm |= 1u << k;
+        else if (!gie_in_whole(c, nb[0], nb[1], nb[2])) outm |= 1u << k;      /* (tiling: not into another tile's territory) */
     }
     int na[6];
     gie_nbr_addr6(c, g, a, outm, na);
@@ -979,10 +1051,9 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int e)
     }
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
-        if (!((win >> k) & 1u)) continue;
-        if (w[k] == GIE_WL_SEED(c) || w[k] == GIE_WL_PUSHED(c)) continue;
-        gie_st(&c.wl[nid[k]], GIE_WL_PUSHED(c));           /* this thread is the only writer of nid in this phase */
-        gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, nid[k]);
+        const bool push = ((win >> k) & 1u) && !(w[k] == GIE_WL_SEED(c) || w[k] == GIE_WL_PUSHED(c));
+        if (push) gie_st(&c.wl[nid[k]], GIE_WL_PUSHED(c)); /* this thread is the only writer of nid in this phase */
+        gie_push32_wave(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, push, nid[k]);
     }
 }
 

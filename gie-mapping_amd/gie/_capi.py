@@ -87,6 +87,8 @@ SIGNATURES = {
     "fuse": (C.c_int, [_H]),
     "batch_edt": (C.c_int, [_H]),
     "merge": (C.c_int, [_H]),
+    "merge_begin_tiled": (C.c_int, [_H]),
+    "merge_end": (C.c_int, [_H]),
     "step": (C.c_int, [_H]),
     "read_local": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "read_ogm": (C.c_int, [_H, C.c_void_p, C.c_void_p]),

@@ -132,8 +132,18 @@ class MapperBase:
     def merge(self):
         self._chk(self._f["merge"](self._h))
 
+    def merge_begin_tiled(self):
+        self._chk(self._f["merge_begin_tiled"](self._h))
+
+    def merge_end(self):
+        self._chk(self._f["merge_end"](self._h))
+
     def step(self):
         self._chk(self._f["step"](self._h))
+
+    def step_begin_tiled(self):
+        """fuse + batch EDT + the first half of the merge of a tiled run (the face layers are exported next)"""
+        self.fuse(); self.batch_edt(); self.merge_begin_tiled()
 
     def sync(self):
         f = self._f.get("sync")
@@ -233,7 +243,9 @@ class MapperBase:
         return keys, blocks, total
 
     # --- VOLMAPNODE::publishMap call order (volumetric_mapper.cpp:138-224) -------------
-    def update(self, pos, quat_wxyz, sensor_kind, sensor_data, **kw):
+    def update(self, pos, quat_wxyz, sensor_kind, sensor_data, tiled=False, **kw):
+        """One map update.  tiled=True stops after the first half of the merge (gie_merge_begin_tiled): the exchange
+        functions of gie.tiling export / import the face layers and finish the merge (gie_merge_end)."""
         self.set_pose(pos, quat_wxyz)
         if sensor_kind == "depth":
             self.ogm_depth(sensor_data, **kw)
@@ -249,7 +261,10 @@ class MapperBase:
             raise ValueError(sensor_kind)
         self.fuse()
         self.batch_edt()
-        self.merge()
+        if tiled:
+            self.merge_begin_tiled()
+        else:
+            self.merge()
 
 
 _lib = None

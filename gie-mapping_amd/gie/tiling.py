@@ -78,19 +78,29 @@ def neighbours(rank, world_size):
     return out
 
 
+# Every exchange function below expects its mappers in the middle of a TILED map update — Mapper.update(..., tiled=True) or
+# Mapper.step_begin_tiled(): fuse, batch EDT and the first half of the merge are done, the face layers hold this update's
+# Mark-time state.  Round 0 exports / imports them and finishes the merge (gie_merge_end: obtainFrontiers + waves with fresh
+# ghosts); the rounds after it are export / import / gie_refine.
+
 def exchange_until_stable_local(mappers, grid, max_rounds=64):
     """All tiles live in this process (tests, single-GPU checks): export every shared face, hand
-    it to the neighbour, refine, repeat until no tile seeded anything.  Returns the rounds run."""
+    it to the neighbour, finish the merge (round 0) or refine, repeat until no tile seeded anything.
+    Returns the refinement rounds run."""
     world = grid[0] * grid[1] * grid[2]
     assert world == len(mappers)
     rounds = 0
-    for _ in range(max_rounds):
+    for k in range(max_rounds + 1):
         layers = {}
         for r, m in enumerate(mappers):
             for face, nb in neighbours(r, world).items():
                 layers[(nb, face ^ 1)] = m.halo_export(face)
         for (r, face), layer in layers.items():
             mappers[r].halo_import(face, layer)
+        if k == 0:
+            for m in mappers:
+                m.merge_end()
+            continue
         seeded = sum(m.refine() for m in mappers)
         rounds += 1
         if seeded == 0:
@@ -116,7 +126,7 @@ def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64, buf
     bufs = {} if bufs is None else bufs
     lay = _local_face_buffers(mappers, world, device, bufs)
     rounds = 0
-    for _ in range(max_rounds):
+    for k in range(max_rounds + 1):
         for r, m in enumerate(mappers):
             for face in neighbours(r, world):
                 m.halo_export_dev(face, lay[(r, face)].data_ptr())
@@ -125,6 +135,11 @@ def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64, buf
         for r, m in enumerate(mappers):
             for face, nb in neighbours(r, world).items():
                 m.halo_import_dev(face, lay[(nb, face ^ 1)].data_ptr())
+        if k == 0:
+            for m in mappers:
+                m.merge_end()
+                m.sync()                                   # the layers are free again
+            continue
         seeded = sum(m.refine() for m in mappers)          # synchronises every mapper: the layers are free again
         rounds += 1
         if seeded == 0:
@@ -145,7 +160,7 @@ def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=No
             n = mapper.halo_count(face) * 20
             bufs[face] = (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
     rounds = 0
-    for _ in range(max_rounds):
+    for k in range(max_rounds + 1):
         ops = []
         for face, nb in sorted(nbs.items()):
             snd, rcv = bufs[face]
@@ -159,6 +174,9 @@ def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=No
             torch.cuda.synchronize(device)
         for face in sorted(nbs):
             mapper.halo_import_dev(face, bufs[face][1].data_ptr())
+        if k == 0:
+            mapper.merge_end()
+            continue
         n = torch.tensor([mapper.refine()], dtype=torch.int64, device=device)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         rounds += 1
@@ -189,13 +207,16 @@ def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=
         bufs["ops"] = ops
     ops = bufs["ops"]
     with torch.cuda.stream(bufs["stream"]):
-        for _ in range(rounds):
+        for k in range(rounds + 1):
             mapper.halo_export_all_dev(bufs["out"])
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()                              # stream-level: the current (= the mapper's) stream waits for RCCL
             mapper.halo_import_all_dev(bufs["in"])
-            mapper.refine_async()
+            if k == 0:
+                mapper.merge_end()                        # round 0 finishes the merge with this update's ghosts
+            else:
+                mapper.refine_async()
     return rounds
 
 
@@ -213,7 +234,7 @@ def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
         bufs["streams"] = [torch.cuda.ExternalStream(m.stream_handle(), device=device) for m in mappers]
         bufs["imported"] = []
     streams = bufs["streams"]
-    for _ in range(rounds):
+    for k in range(rounds + 1):
         evs = []
         for r, m in enumerate(mappers):
             for ev in bufs["imported"]:                   # the layers of the round before have been read
@@ -230,7 +251,10 @@ def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
             ev = torch.cuda.Event()
             ev.record(streams[r])
             done.append(ev)
-            m.refine_async()
+            if k == 0:
+                m.merge_end()
+            else:
+                m.refine_async()
         bufs["imported"] = done
     if own:
         for m in mappers:
@@ -241,12 +265,12 @@ def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
 def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64):
     """One tile per rank: face layers travel with torch.distributed point-to-point ops (RCCL over
     xGMI with backend "nccl", gloo on CPU); a 1-int all-reduce(sum) of the seed counts is the
-    convergence test.  Returns the rounds run."""
+    convergence test.  Returns the refinement rounds run."""
     import torch
     from .mapper import HALO_DTYPE
     nbs = neighbours(rank, world_size)
     rounds = 0
-    for _ in range(max_rounds):
+    for k in range(max_rounds + 1):
         sends, recvs, ops = {}, {}, []
         for face, nb in sorted(nbs.items()):
             lay = mapper.halo_export(face)
@@ -262,6 +286,9 @@ def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_round
                 w.wait()
         for face in sorted(nbs):
             mapper.halo_import(face, recvs[face].cpu().numpy().view(HALO_DTYPE))
+        if k == 0:
+            mapper.merge_end()
+            continue
         n = torch.tensor([mapper.refine()], dtype=torch.int64, device=device if device is not None else "cpu")
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         rounds += 1

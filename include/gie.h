@@ -165,6 +165,12 @@ int gie_fuse(gie_mapper *h);
 int gie_batch_edt(gie_mapper *h);
 /* GlbHashMap::mergeNewObsv (glb_hash_map.cu:146-207). */
 int gie_merge(gie_mapper *h);
+/* The two halves of gie_merge for a TILED run (gie_set_tile): gie_merge_begin_tiled = MarkLimitedObserve + commit of the
+ * Mark-time pairs, so that the face layers exported next are THIS map update's state; gie_merge_end = obtainFrontiers +
+ * waves + commit, run after the neighbours' layers have been imported.  gie_merge = begin + end. */
+int gie_merge_begin(gie_mapper *h);
+int gie_merge_begin_tiled(gie_mapper *h);
+int gie_merge_end(gie_mapper *h);
 /* fuse + batch_edt + merge, asynchronous on the mapper's stream. */
 int gie_step(gie_mapper *h);
 /* GPU_DEV_SYNC (cuda_macro.h:38); also surfaces device-side capacity errors. */
@@ -210,11 +216,13 @@ int gie_stream_enable(gie_mapper *h, int on);
 int gie_stream_changed(gie_mapper *h, int32_t *keys, gie_voxel *blocks, int max_blocks, int32_t *n_changed);
 
 /* ---- spatial tiling across GPUs (no counterpart in the reference, which is single-GPU; SURVEY
- * §8e).  A large volume is cut into tiles, one mapper per tile/GPU.  After gie_merge every tile
- * exports the one-voxel layer on each of its faces; the neighbour imports it as "ghost" voxels just
- * outside its own volume — exactly the role old out-of-volume voxels play in the reference — and
- * gie_refine lowers inside voxels from them (obtainFrontiers' C seeds restricted to the faces →
- * wave C → commit).  Rounds of export / exchange / import / refine repeat until no tile changes.
+ * §8e).  A large volume is cut into tiles, one mapper per tile/GPU.  Per map update every tile runs
+ * fuse, batch EDT and gie_merge_begin_tiled on its own volume, exports the one-voxel layer on each of
+ * its faces, imports its neighbours' layers as "ghost" voxels just outside its own volume — the role
+ * old out-of-volume voxels play in the reference, but refreshed every update — and finishes with
+ * gie_merge_end.  Then rounds of export / exchange / import / gie_refine (obtainFrontiers' C seeds
+ * restricted to the faces → wave C → commit) repeat until no tile changes.  Voxels of ANOTHER tile
+ * are only ever read as ghosts: waves A / B (raise / lower outside) run outside the whole volume.
  * face = 2*axis + side (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z); a layer is indexed b*A + a with (a,b) the
  * two remaining axes in x<y<z order. */
 typedef struct gie_halo_voxel {

@@ -102,6 +102,7 @@ typedef struct gie_oracle {
 /* ------------------------------------------------------------------ small helpers */
 static int fdiv8(int a) { return a >> 3; }                 /* get_VB_key, voxmap_utils.cuh:94-101 */
 static int vox_in_blk(int gx, int gy, int gz) { return ((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7); }
+static int in_whole(const gie_oracle *o, int x, int y, int z);
 static int in_loc(const gie_oracle *o, int x, int y, int z)   /* local_batch.h:113-126 */
 { return x >= 0 && x < o->X && y >= 0 && y < o->Y && z >= 0 && z < o->Z; }
 static int in_wr(const gie_oracle *o, int x, int y, int z)    /* local_batch.h:144-157 */
@@ -713,7 +714,8 @@ static void obtain_frontiers(gie_oracle *o, queue *fa, queue *fb, queue *fc)
                         if (!cur_in_q) { cur_in_q = 1; o->wave_layer[id] = 1; q_push(fc, x, y, z); }
                     }
                 }
-                if (o->cfg.fast_mode) continue;
+                /* tiling (include/gie.h): another tile's voxel is only ever read as a ghost, never raised / lowered from here */
+                if (o->cfg.fast_mode || in_whole(o, nx, ny, nz)) continue;
                 const int c2n = d2i(nx, ny, nz, cl[0], cl[1], cl[2]);
                 if (c2n < nd) {                                      /* lower out */
                     nv->wave_layer = 1; nv->update_ct = ct;
@@ -763,6 +765,7 @@ static void wave_a(gie_oracle *o, queue *front, queue *fb)
             for (int k = 0; k < 6; k++) {
                 const int ng[3] = { g[0] + DIRS[k][0], g[1] + DIRS[k][1], g[2] + DIRS[k][2] };
                 if (in_loc(o, ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2])) continue;
+                if (in_whole(o, ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2])) continue;   /* tiling: not into another tile's territory */
                 ovox *nv = vox_find(o, ng[0], ng[1], ng[2]);
                 if (!nv) continue;
                 if (nv->vox_type == GIE_VOX_UNKNOWN || invalid_coc_glb(nv->coc) || invalid_dist_glb(o, nv->dist_sq)) continue;
@@ -875,6 +878,7 @@ static void wave_b(gie_oracle *o, queue *front, queue *fc)
                 const int nb[3] = { ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2] };
                 const int cand = d2i(sn[e].coc[0], sn[e].coc[1], sn[e].coc[2], ng[0], ng[1], ng[2]);
                 if (!in_loc(o, nb[0], nb[1], nb[2])) {
+                    if (in_whole(o, nb[0], nb[1], nb[2])) continue;   /* tiling: not into another tile's territory */
                     ovox *nv = vox_find(o, ng[0], ng[1], ng[2]);
                     if (!nv) continue;
                     if (nv->vox_type == GIE_VOX_UNKNOWN) continue;
@@ -1002,11 +1006,23 @@ static void update_hash_batch(gie_oracle *o)
     }
 }
 
+/* union of all tiles in local coordinates (= the local volume without tiling) */
+static int in_whole(const gie_oracle *o, int x, int y, int z)
+{ return x >= o->whole_lo[0] && x < o->whole_hi[0] && y >= o->whole_lo[1] && y < o->whole_hi[1] && z >= o->whole_lo[2] && z < o->whole_hi[2]; }
+
+static int merge_rest(gie_oracle *o);
 /* GlbHashMap::mergeNewObsv, glb_hash_map.cu:146-207 */
 int go_merge(gie_oracle *o)
 {
-    queue fa = { 0, 0, 0 }, fb = { 0, 0, 0 }, fc = { 0, 0, 0 };
     mark_limited_observe(o);
+    return merge_rest(o);
+}
+/* the two halves of a tiled run's merge (include/gie.h): Mark + commit of the Mark-time pairs | the rest */
+int go_merge_begin_tiled(gie_oracle *o) { mark_limited_observe(o); update_hash_batch(o); return 0; }
+int go_merge_end(gie_oracle *o) { return merge_rest(o); }
+static int merge_rest(gie_oracle *o)
+{
+    queue fa = { 0, 0, 0 }, fb = { 0, 0, 0 }, fc = { 0, 0, 0 };
     obtain_frontiers(o, &fa, &fb, &fc);
     o->st.seeds_a = fa.n; o->st.seeds_b = fb.n; o->st.seeds_c = fc.n;
     if (!o->cfg.fast_mode) {

@@ -237,14 +237,26 @@ def o_pivot(sc, frame):
 
 
 def test_rms_check_and_sets(driver, tmp_path):
+    _rms_check(driver, tmp_path, (32, 32, 12))
+
+
+@pytest.mark.gpu
+def test_rms_check_and_csv_log_on_gpu(tmp_path):
+    """The accuracy profiler (gt_checker.h:30-80: RMSE of the EDT against the nearest occupied voxel) and the
+    CSV timing log (simple_logger.h:18-71) through the real binary on the MI355X, against a KD-tree in Python."""
+    import __graft_entry__ as ge
+    _rms_check(ge.build_host(), tmp_path, (64, 64, 24))
+
+
+def _rms_check(driver, tmp_path, size):
     from scipy.spatial import cKDTree
-    sc = Scenario("host_rms", (32, 32, 12), voxel=0.1, sensor="depth", frames=3, cutoff_dist=100.0)
+    sc = Scenario("host_rms", size, voxel=0.1, sensor="depth", frames=3, cutoff_dist=100.0)
     frames = list(sc.frames_iter())
     records = [("depth", pos, q, (d.shape[0], d.shape[1], 1), (kw["cx"], kw["cy"], kw["fx"], kw["fy"]), d) for pos, q, _, d, kw in frames]
     fpath, out, log = (str(tmp_path / n) for n in ("in.gief", "out", "run.csv"))
     write_frames(fpath, records)
-    args = [driver, "--frames", fpath, "--out", out, "--rms", "--log", log, "--set", "voxel_width=0.1", "--set", "local_size_x=3.2001",
-            "--set", "local_size_y=3.2001", "--set", "local_size_z=1.2001", "--set", "wave/cutoff_dist=100", "--set", "wave/fast_mode=false",
+    args = [driver, "--frames", fpath, "--out", out, "--rms", "--log", log, "--set", "voxel_width=0.1", "--set", "local_size_x=%.4f" % (size[0] * 0.1 + 1e-4),
+            "--set", "local_size_y=%.4f" % (size[1] * 0.1 + 1e-4), "--set", "local_size_z=%.4f" % (size[2] * 0.1 + 1e-4), "--set", "wave/cutoff_dist=100", "--set", "wave/fast_mode=false",
             "--set", "ogm/min_height=-1000", "--set", "ogm/max_height=1000", "--set", "profile_loc_rms=true"]
     res = subprocess.run(args, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
@@ -256,8 +268,11 @@ def test_rms_check_and_sets(driver, tmp_path):
     line = [l for l in res.stdout.split("\n") if l.startswith("rms")][0].split()
     assert abs(float(line[1]) - np.sqrt((err ** 2).mean())) < 1e-5
     assert int(line[9]) == len(known)
-    last = open(log).read().strip().split("\n")[-1].split(",")
+    rows = open(log).read().strip().split("\n")
+    assert [c.strip('"') for c in rows[0].split(",")[:3]] == ["Occupancy time", "EDT time", "RMSE"] and len(rows) == 1 + len(frames)
+    last = rows[-1].split(",")
     assert abs(float(last[2]) - float(line[1])) < 1e-4
+    assert float(last[0]) > 0 and float(last[1]) > 0        # the two timing columns of the reference's log
 
 
 def test_bad_inputs_fail_loudly(driver, tmp_path):

@@ -90,7 +90,7 @@ def _worker_halo(rank, world, port, out):
     m.set_tile(tiling.tile_offset_voxels(rank, world, T.TILE), T.WHOLE)
     res = []
     for pos, q, img in T._sensor_frames(4):
-        m.update(pos, q, "multiscan", img, **T.KW)
+        m.update(pos, q, "multiscan", img, tiled=True, **T.KW)
         rounds = tiling.exchange_until_stable(m, dist, rank, world)
         r = m.read_local()
         res.append((rounds, r["type"].copy(), r["dist_sq"].copy(), r["coc"].copy()))

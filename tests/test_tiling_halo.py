@@ -43,8 +43,10 @@ def _run_tiled(make, exchange=True, device=None, fixed_rounds=0):
     try:
         for pos, q, img in _sensor_frames(FR):
             for m in ms:
-                m.update(pos, q, "multiscan", img, **KW)
+                m.update(pos, q, "multiscan", img, tiled=True, **KW)
             if not exchange:
+                for m in ms:
+                    m.merge_end()
                 rounds = 0
             elif device is not None and fixed_rounds:
                 tiling.exchange_rounds_local_device(ms, (2, 1, 1), device, rounds=fixed_rounds, bufs=bufs)
@@ -178,7 +180,7 @@ def test_eight_mappers_share_one_device(oracle_lib):
                 pos, q = scenes.pose(k, 0.1, delta_vox=1, yaw_deg=10.0)
                 pts, _ = scenes.lidar_frame(world, k, pos, q, rings=32, az=360, phi_min_deg=-40.0, phi_inc_deg=2.5, max_range=10.0)
                 for m in ms:
-                    m.update(pos, q, "pointcloud", pts)
+                    m.update(pos, q, "pointcloud", pts, tiled=True)
                 if device is None:
                     tiling.exchange_until_stable_local(ms, grid)
                 else:
@@ -193,6 +195,114 @@ def test_eight_mappers_share_one_device(oracle_lib):
     for t in range(8):
         for key in ("type", "dist_sq", "coc"):
             assert np.array_equal(want[t][key], got[t][key]), (t, key)
+
+
+def _run_c5_tiled(make, tile, frames, device=None, fixed_rounds=0, delta_vox=8):
+    """BASELINE config 5 in small: the sensor-less hash world (full observation, a quarter of the obstacles toggles
+    per frame) on 2x2x2 tiles, every tile fed the label plane of its own part of the world."""
+    grid = tiling.tile_grid(8)
+    whole = tuple(grid[i] * tile[i] for i in range(3))
+    cfg = gie.make_config(0.05, tile, cutoff_dist=0.5)
+    ms = []
+    for r in range(8):
+        m = make(cfg); m.set_tile(tiling.tile_offset_voxels(r, 8, tile), whole); ms.append(m)
+    out, bufs = [], {}
+    try:
+        for k in range(frames):
+            pos, q = scenes.pose(k, 0.05, delta_vox=delta_vox, yaw_deg=2.0)
+            for r, m in enumerate(ms):
+                pvt = scenes.local_pivot(pos, 0.05, tile, tiling.tile_offset_voxels(r, 8, tile))
+                m.set_pose(pos, q)
+                assert tuple(m.pivot()) == tuple(pvt)
+                m.ogm_labels(scenes.hash_world_labels(pvt, tile, k, seed=5, p_occ=0.01).astype(np.int8))
+                m.step_begin_tiled()
+            if device is None:
+                rounds = tiling.exchange_until_stable_local(ms, grid)
+            elif fixed_rounds:
+                tiling.exchange_rounds_local_device(ms, grid, device, rounds=fixed_rounds, bufs=bufs)
+                rounds = -1
+            else:
+                rounds = tiling.exchange_until_stable_local_device(ms, grid, device, bufs=bufs)
+            out.append(([m.read_local() for m in ms], rounds, [tuple(m.pivot()) for m in ms]))
+    finally:
+        for m in ms:
+            m.close()
+    return out
+
+
+def _run_c5_whole(make, tile, frames, delta_vox=8):
+    whole = tuple(2 * t for t in tile)
+    m = make(gie.make_config(0.05, whole, cutoff_dist=0.5))
+    out = []
+    try:
+        for k in range(frames):
+            pos, q = scenes.pose(k, 0.05, delta_vox=delta_vox, yaw_deg=2.0)
+            m.set_pose(pos, q)
+            m.ogm_labels(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, whole), whole, k, seed=5, p_occ=0.01).astype(np.int8))
+            m.step()
+            out.append((m.read_local(), tuple(m.pivot())))
+    finally:
+        m.close()
+    return out
+
+
+def _stitch(tiles, key):
+    """tiles: rank r = tx + 2 (ty + 2 tz) -> one array [Z][Y][X] of the 2x2x2 arrangement"""
+    return np.concatenate([np.concatenate([np.concatenate([tiles[tx + 2 * (ty + 2 * tz)][key] for tx in range(2)], axis=2)
+                                           for ty in range(2)], axis=1) for tz in range(2)], axis=0)
+
+
+def _c5_tiled_vs_whole(tiled, whole):
+    """What the exchange promises: the same voxels known, and a stitched field that is the single volume's almost
+    everywhere (BFS propagation across a cut is not an exact EDT: a few voxels end half a voxel above)."""
+    diff = total = 0
+    for (rt, _, pt), (rw, pw) in zip(tiled, whole):
+        assert pt[0] == pw
+        assert np.array_equal(_stitch(rt, "type") != 0, rw["type"] != 0)
+        a, b = _stitch(rt, "dist_sq"), rw["dist_sq"]
+        known = rw["type"] != 0
+        total += int(known.sum())
+        diff += int((a[known] != b[known]).sum())
+        assert (a[known] >= b[known]).mean() > 0.999      # the tiles never know more than the single volume
+    assert diff <= 0.01 * total, (diff, total)
+    return diff, total
+
+
+def test_c5_hash_world_tiled_emulation(oracle_lib):
+    """2x2x2 tiles of 24^3 (CPU: oracle against the emulated device logic, and against the single 48^3 volume)."""
+    from emu_py import EmuMapper
+    tile, frames = (24, 24, 24), 4
+    want = _run_c5_tiled(OracleMapper, tile, frames)
+    got = _run_c5_tiled(EmuMapper, tile, frames)
+    for k, ((ra, na, pa), (rb, nb, pb)) in enumerate(zip(want, got)):
+        assert na == nb and pa == pb
+        for t in range(8):
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[t][key], rb[t][key]), (k, t, key)
+    _c5_tiled_vs_whole(want, _run_c5_whole(OracleMapper, tile, frames))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["until_stable", "stream_ordered"])
+def test_c5_hash_world_2x2x2_tiles_of_64_cubed_on_one_gpu(oracle_lib, form):
+    """BASELINE config 5's arrangement at 1/8 scale per axis: 2x2x2 tiles of 64^3 (one 128^3 volume), hash world, full
+    observation, 25 % toggling, all eight mappers on one GPU with the device-resident exchange — until no tile
+    changes, and as the fixed stream-ordered rounds the multi-GPU bench enqueues.  Against the tiled oracle bit for
+    bit, and against the single 128^3 volume."""
+    import torch
+    tile, frames = (64, 64, 64), 4
+    want = _run_c5_tiled(OracleMapper, tile, frames)
+    assert max(n for _, n, _ in want) <= 6
+    got = _run_c5_tiled(gie.Mapper, tile, frames, device=torch.device("cuda", 0), fixed_rounds=6 if form == "stream_ordered" else 0)
+    for k, ((ra, na, pa), (rb, nb, pb)) in enumerate(zip(want, got)):
+        assert pa == pb and (form == "stream_ordered" or na == nb)
+        for t in range(8):
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[t][key], rb[t][key]), (k, t, key)
+            assert np.allclose(ra[t]["edt"], rb[t]["edt"], rtol=1e-6, atol=0)
+    whole = _run_c5_whole(gie.Mapper, tile, frames)
+    diff, total = _c5_tiled_vs_whole(got, whole)
+    print("tiled vs single volume: %d of %d voxel-frames differ" % (diff, total))
 
 
 class _InProcessTransport:
@@ -302,7 +412,7 @@ def test_rank_exchange_code_path(oracle_lib, form):
             dist, bufs = shared.view(rank), {}
             try:
                 for pos, q, img in frames:
-                    m.update(pos, q, "multiscan", img, **KW)
+                    m.update(pos, q, "multiscan", img, tiled=True, **KW)
                     if form == "stream_ordered":
                         tiling.exchange_rounds_device(m, dist, rank, 2, device, bufs, rounds=4)
                     else:                            # bench.py's fall-back: host-synchronised rounds until no tile changes

@@ -21,10 +21,16 @@ import time
 for i, (pos, q, pts, _) in enumerate(frames):
     if i == 3:
         m.sync(); t0 = time.perf_counter()
-    m.set_pose(pos, q); m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0]); m.step()
+    m.set_pose(pos, q); m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0]); m.step_begin_tiled()
     if ex:
-        m.halo_export_all_dev({f: bufs[f].data_ptr() for f in nbs})
-        m.halo_import_all_dev({f: bufs[f].data_ptr() for f in nbs})
-        m.refine_async()
+        for rnd in range(2):                              # round 0 finishes the merge, round 1 refines
+            m.halo_export_all_dev({f: bufs[f].data_ptr() for f in nbs})
+            m.halo_import_all_dev({f: bufs[f].data_ptr() for f in nbs})
+            if rnd == 0:
+                m.merge_end()
+            else:
+                m.refine_async()
+    else:
+        m.merge_end()
 m.sync()
 print("exchange", ex, "ms per update %.4f" % (1e3 * (time.perf_counter() - t0) / 10))

@@ -27,7 +27,7 @@ for i, (pos, q, pts, _) in enumerate(frames):
     for m in ms: m.sync()
     t0 = time.perf_counter()
     for m in ms:
-        m.set_pose(pos, q); m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0]); m.step()
+        m.set_pose(pos, q); m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0]); m.step_begin_tiled()
     for m in ms: m.sync()
     t1 = time.perf_counter()
     rounds.append(tiling.exchange_until_stable_local_device(ms, grid, dev))
@@ -40,7 +40,7 @@ def run(rounds):
     t0 = time.perf_counter()
     for i, (pos, q, pts, _) in enumerate(frames):
         for m in ms:
-            m.set_pose(pos, q); m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0]); m.step()
+            m.set_pose(pos, q); m.ogm_pointcloud_dev(d_pts[i].data_ptr(), d_pts[i].shape[0]); m.step_begin_tiled()
         if rounds:
             tiling.exchange_rounds_local_device(ms, grid, dev, rounds=rounds)
     for m in ms: m.sync()
