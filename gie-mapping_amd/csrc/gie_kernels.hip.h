@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
 #define GIE_WAVE_SOLO_AB 4096 /* waves A / B decide once, from their seed count (512 / 2048 / 4096 measure the same) */
 #endif
 
-struct gie_gridbar { int32_t *word; int epoch; int failed; int solo; int *s_fail; };
+struct gie_gridbar { int32_t *word; int epoch; int failed; int nwg; int *s_fail; };   /* nwg = workgroups that meet at this barrier */
 
 /* Everything the wave kernels share between workgroups is read and written with agent-scope
  * (write-through, L1-bypassing) accesses — gie_ld / gie_st / atomics — so the barrier needs no
@@ -1512,10 +1512,10 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (gb.solo) return;                 /* one workgroup left: its waves share the CU's L2 path */
+    if (gb.nwg <= 1) return;             /* one workgroup: its waves share the CU's L2 path */
     gb.epoch += 1;
     if (threadIdx.x == 0 && !gb.failed) {
-        const int target = gb.epoch * (int)gridDim.x;
+        const int target = gb.epoch * gb.nwg;
         __hip_atomic_fetch_add(gb.word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(gb.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -1532,21 +1532,21 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
 
 __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : hi; }
 
-/* The three waves run inside ONE launch (k_waves), separated by grid barriers: a wave without
- * seeds costs a counter read instead of a launch.  Every workgroup executes the same number of
- * grid barriers: a small wave is run by workgroup 0 alone (block barriers only, gb.solo) while
- * the others fall through to the barrier that separates it from the next wave. */
-__device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb)
+/* The three waves run inside ONE launch (k_waves), separated by grid barriers of all workgroups: a wave
+ * without seeds costs a counter read instead of a launch.  Waves A and B expand a few thousand entries
+ * per phase — a chain of dependent round trips, then a barrier — so they run on the first `ab_wgs`
+ * workgroups only (a barrier's cost grows with the workgroups that meet at it; one workgroup alone,
+ * block barriers only, below GIE_WAVE_SOLO_AB seeds) with a barrier word of their own, while the others
+ * fall through to the barrier that separates the wave from the next one. */
+__device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
 {
-    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
-    const bool boss = (gtid == 0);
+    const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab), cur = 0, level = 0;
     if (boss) { c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-    if (n <= GIE_WAVE_SOLO_AB) {                         /* small wave: workgroup 0 runs it alone, block barriers only */
-        if (blockIdx.x != 0) return;
-        gb.solo = 1;
-    }
-    const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
+    const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
+    if ((int)blockIdx.x >= nwg) return;
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_B], 0, gb_all.failed, nwg, s_fail };
+    const int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
@@ -1557,19 +1557,18 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
         gie_grid_sync(gb, c);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
     }
+    gb_all.failed |= gb.failed;
 }
 
-__device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb)
+__device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
 {
-    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gsz = gridDim.x * GIE_WAVE_THREADS;
-    const bool boss = (gtid == 0);
+    const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
     if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-    if (n <= GIE_WAVE_SOLO_AB) {                         /* small wave: workgroup 0 runs it alone, block barriers only */
-        if (blockIdx.x != 0) return;
-        gb.solo = 1;
-    }
-    const int gid = gb.solo ? (int)threadIdx.x : gtid, gstep = gb.solo ? GIE_WAVE_THREADS : gsz;
+    const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
+    if ((int)blockIdx.x >= nwg) return;
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_AB2], 0, gb_all.failed, nwg, s_fail };
+    const int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
@@ -1582,6 +1581,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         gie_grid_sync(gb, c);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
     }
+    gb_all.failed |= gb.failed;
 }
 
 /* One BFS level of wave C.  `wg_first`/`stride` are workgroup-uniform (every thread of the
@@ -1697,12 +1697,12 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
 }
 
 /* waves A, B (unless fast_mode / refinement) and C in one launch */
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds)
+__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds, const int ab_wgs)
 {
     __shared__ gie_wg_scratch s_wg;
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, 0, &s_fail };
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail };
     {   /* nothing seeded anywhere (the usual case of a sparse scan over a settled map): nothing can be
          * produced either, so the launch ends here — same counters for every workgroup, no barrier */
         const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);
@@ -1718,11 +1718,9 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     }
     __syncthreads();
     if (with_ab) {
-        gie_wave_a_run(c, gb);
-        gb.solo = 0;
+        gie_wave_a_run(c, gb, ab_wgs, &s_fail);
         gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
-        gie_wave_b_run(c, gb);
-        gb.solo = 0;
+        gie_wave_b_run(c, gb, ab_wgs, &s_fail);
         gie_grid_sync(gb, c);
     }
     gie_wave_c_run(c, gb, record_seeds, s_wg);

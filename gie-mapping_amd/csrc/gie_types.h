@@ -163,11 +163,11 @@ enum {
     GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (n, cur, level) published after a solo episode */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
-    GIE_CNT_BAR_B = 34,                         /* (unused; first word of the second cleared range) */
+    GIE_CNT_BAR_B = 34,                         /* barrier word of wave A's workgroups (first word of the second cleared range) */
     GIE_CNT_BAR_C = 35,                         /* grid-barrier word of the waves launch */
     GIE_CNT_NEWLIST = 36,                       /* entries in the list of blocks to initialise (blk_new) */
     GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
-    GIE_CNT_SPARE1 = 39,
+    GIE_CNT_BAR_AB2 = 39,                       /* barrier word of wave B's workgroups */
     GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
     GIE_CNT_AUX_END = 41,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 48

@@ -17,7 +17,7 @@ from collections import defaultdict
 
 SHORT = [
     (r"op_classify|k_labels16", "ogm_classify"), (r"op_tile_summary", "frontiers"), (r"op_register_point", "ray_register"), (r"k_free_rays|op_free_ray", "ray_free"),
-    (r"op_raycast_finalize", "ray_finalize"), (r"op_fuse", "fuse"), (r"k_edt_y", "edt_pass_y"), (r"k_edt_x", "edt_pass_x"),
+    (r"op_raycast_finalize", "ray_finalize"), (r"op_fuse|k_fuse_rows", "fuse"), (r"k_edt_y", "edt_pass_y"), (r"k_edt_x", "edt_pass_x"),
     (r"k_edt_prep", "edt_prep"), (r"k_edt_z_direct", "edt_pass_z.direct"), (r"k_edt_z", "edt_pass_z.column"), (r"op_markc", "mark_commit"), (r"op_mark", "mark"), (r"op_frontier", "frontiers"), (r"k_waves", "waves"), (r"op_commit", "commit"),
     (r"k_cell_alloc|k_block_init|k_clear|op_cell_|k_pool_advance|rocprim", "block_alloc"), (r"op_stream", "stream_changed"),
 ]
@@ -80,6 +80,18 @@ def pmc(fetch_db, write_db):
         out.append("%-16s %8d %16.0f %18.1f %16.0f %18.1f" % (k, n, fk, 2.0 * fk * 1024 / 1e6, wk, total / 1e6))
     steps = f.get("edt_pass_y", (0, 0))[1] or w.get("edt_pass_y", (0, 0))[1]        # one launch per map update
     if steps:
+        # bytes per MAP UPDATE under the names gie_profile_read / bench.py use (a stage may be several kernels)
+        per_step = defaultdict(float)
+        for k in set(f) | set(w):
+            if k.startswith("__") or k.startswith("void "):
+                continue
+            fk, n = f.get(k, (0.0, 0)); wk, n2 = w.get(k, (0.0, 0))
+            per_step[k.split(".")[0]] += (2.0 * fk * n + wk * n2) * 1024.0 / steps
+        js["_per_step_by_stage"] = {k: round(v) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
+        js["_map_updates"] = steps
+        out.append("")
+        out.append("per MAP UPDATE and stage (the names of gie_profile_read; a stage may be several kernels), MB: "
+                   + ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])))
         tot = 0.0
         for k in set(f) | set(w):
             if k.startswith("__"):
