@@ -281,3 +281,94 @@ def test_bad_inputs_fail_loudly(driver, tmp_path):
     assert subprocess.run([driver, "--frames", bad], capture_output=True).returncode == 1
     assert subprocess.run([driver, "--frames", str(tmp_path / "missing")], capture_output=True).returncode == 1
     assert subprocess.run([driver], capture_output=True).returncode == 2
+
+
+# ------------------------------------------------------------------ the tiled C++ node (gie_tiled.hpp), ranks as processes
+
+def _free_port_block(n):
+    import socket
+    for base in range(29500, 60000, 97):
+        socks = []
+        try:
+            for k in range(n):
+                s = socket.socket(); s.bind(("127.0.0.1", base + k)); socks.append(s)
+            return base
+        except OSError:
+            continue
+        finally:
+            for s in socks:
+                s.close()
+    raise RuntimeError("no free port block")
+
+
+def _tiled_replay(exe, tmp_path, world, tile, frames_n, extra=()):
+    """Runs `world` ranks of gie_tiled_driver (socket transport) on the multiscan frames of test_tiling_halo and returns
+    the per-rank outputs; the expectation is the in-process tiled oracle on the same frames."""
+    import test_tiling_halo as T
+    from gie import tiling
+    frames = T._sensor_frames(frames_n)
+    records = [("multiscan", pos, q, (img.shape[1], img.shape[0]), (100.0, T.KW["theta_inc"], T.KW["theta_min"], T.KW["phi_inc"], T.KW["phi_min"]), img)
+               for pos, q, img in frames]
+    fpath, out = str(tmp_path / "in.gief"), str(tmp_path / "out")
+    write_frames(fpath, records)
+    port = _free_port_block(world)
+    args = ["--frames", fpath, "--world", str(world), "--port", str(port), "--out", out, "--set", "voxel_width=%g" % T.W,
+            "--set", "local_size_x=%.4f" % (tile[0] * T.W + 1e-4), "--set", "local_size_y=%.4f" % (tile[1] * T.W + 1e-4),
+            "--set", "local_size_z=%.4f" % (tile[2] * T.W + 1e-4), "--set", "wave/cutoff_dist=1.0", "--set", "wave/fast_mode=false",
+            "--set", "ogm/min_height=-1000", "--set", "ogm/max_height=1000", "--set", "display_glb_edt=false", "--set", "display_glb_ogm=false"] + list(extra)
+    procs = [subprocess.Popen([exe, "--rank", str(r)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][1])
+    got = [load_out(out + ".r%d" % r, tile) for r in range(world)]
+    # expectation: the oracle's tiles in one process, exchange until stable
+    grid = tiling.tile_grid(world)
+    whole = tuple(grid[i] * tile[i] for i in range(3))
+    cfg = gie.make_config(T.W, tile, cutoff_dist=1.0)
+    ms = []
+    for r in range(world):
+        m = OracleMapper(cfg); m.set_tile(tiling.tile_offset_voxels(r, world, tile), whole); ms.append(m)
+    rounds = 0
+    try:
+        for pos, q, img in frames:
+            for m in ms:
+                m.update(pos, q, "multiscan", img, tiled=True, **T.KW)
+            rounds += tiling.exchange_until_stable_local(ms, grid)
+        want = [m.read_local() for m in ms]
+    finally:
+        for m in ms:
+            m.close()
+    return got, want, rounds, [o[0] for o in outs]
+
+
+@pytest.fixture(scope="module")
+def tiled_driver(tmp_path_factory):
+    load_emu()
+    exe = str(tmp_path_factory.mktemp("host") / "gie_tiled_driver_emu")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(HOST, "gie_tiled_driver.cpp"), "-o", exe,
+                           "-L" + EMU_DIR, "-lgie_emu", "-Wl,-rpath," + EMU_DIR, "-lpthread"])
+    return exe
+
+
+@pytest.mark.parametrize("world,tile", [(2, (32, 32, 16)), (4, (24, 24, 16))])
+def test_tiled_cpp_node_ranks_as_processes(tiled_driver, tmp_path, oracle_lib, world, tile):
+    """gie_host::TiledMapper with the socket transport, one process per rank (the C++ node tiles WITHOUT PyTorch): every
+    rank's tile must equal the corresponding tile of the in-process tiled oracle, and the ranks must have run the same
+    number of refinement rounds (the all-reduce of the seed count is the convergence test)."""
+    got, want, rounds, stdout = _tiled_replay(tiled_driver, tmp_path, world, tile, 5)
+    for r in range(world):
+        for key in ("type", "dist_sq", "coc"):
+            assert np.array_equal(got[r][key], want[r][key]), (r, key)
+        assert np.allclose(got[r]["edt"], want[r]["edt"], rtol=1e-6, atol=0)
+        assert stdout[r].strip().split()[-1] == str(rounds), (stdout[r], rounds)
+
+
+@pytest.mark.gpu
+def test_tiled_cpp_node_on_gpu_two_ranks_share_the_device(tmp_path, oracle_lib):
+    """The same through the real binary on the MI355X: two rank processes on ONE GPU, socket transport with host staging
+    (RCCL needs one GPU per rank; its transport is compiled by build() and exercised on a multi-GPU node only)."""
+    import __graft_entry__ as ge
+    got, want, rounds, stdout = _tiled_replay(ge.build_tiled_driver(), tmp_path, 2, (32, 32, 16), 5, extra=("--device", "0"))
+    for r in range(2):
+        for key in ("type", "dist_sq", "coc"):
+            assert np.array_equal(got[r][key], want[r][key]), (r, key)
