@@ -424,7 +424,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
      * earlier frames); fuse, Mark, commit and pass Z walk their list or sweep the volume — each kernel
      * decides from the length of its list (gie_use_lists) */
-    be_lin(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
+    be_range(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     be_prof(&m->be, GIE_K_ALLOC, 1);
     be_prof(&m->be, GIE_K_FUSE, 0);
     be_vox_list<true>(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, be_rows_mode());

@@ -13,6 +13,32 @@
 #define GIE_DEVM __device__ __forceinline__
 #endif
 
+#if !defined(GIE_HOST_EMU)
+/* Append slots for the threads of a WORKGROUP that have `flag` set: ballot inside the waves, LDS prefix across them, ONE
+ * atomic on the counter per workgroup (the list builders below append from thousands of waves to one counter; per-wave
+ * atomics on one word serialise at ~10 ns each).  Every thread of the workgroup has to call it (block barriers inside). */
+__device__ __forceinline__ int gie_wg_reserve(int32_t *counter, const bool flag)
+{
+    __shared__ int s_cnt[16];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < nw; w++) tot += s_cnt[w];
+        s_base = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wave; w++) base += s_cnt[w];
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();                                       /* the scratch is reused by the next call */
+    return flag ? slot : -1;
+}
+#endif
+
 /* skip(c, id, x, y, z): cheap test (at most one small load, issued for a whole z-column up
  * front by k_voxz) that is true only when operator() would do nothing for the voxel. */
 struct op_classify_depth { static constexpr bool rolled = false;
@@ -173,14 +199,8 @@ struct op_tile_summary {
 #if defined(GIE_HOST_EMU)
         if (v) c.tl_front[c.cnt[GIE_CNT_TL_FRONT]++] = t;
 #else
-        const unsigned long long bm = __ballot(v != 0);
-        if (bm) {
-            const int lane = __lane_id(), leader = __ffsll((long long)bm) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&c.cnt[GIE_CNT_TL_FRONT], __popcll(bm));
-            base = __shfl(base, leader);
-            if (v) c.tl_front[base + __popcll(bm & ((1ull << lane) - 1ull))] = t;
-        }
+        const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FRONT], v != 0);
+        if (slot >= 0) c.tl_front[slot] = t;
 #endif
     } };
 struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
@@ -202,19 +222,14 @@ struct op_refine { GIE_DEVM void operator()(const gie_ctx &c, int j) const {
 struct op_register_point { const float *xyz; float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_register_point(c, xyz, g, i); } };
 struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_query_voxel(c, xyz, i, out); } };
 /* the fuse tile list (thread per tile; device: one atomic per wave) */
+/* (called for every thread of a workgroup: t = -1 past the end) */
 struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
-        const int v = gie_fuse_tile_listed(c, t);
+        const int v = t >= 0 ? gie_fuse_tile_listed(c, t) : 0;
 #if defined(GIE_HOST_EMU)
         if (v) c.tl_front[c.cnt[GIE_CNT_TL_FUSE]++] = t;
 #else
-        const unsigned long long bm = __ballot(v != 0);
-        if (bm) {
-            const int lane = __lane_id(), leader = __ffsll((long long)bm) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&c.cnt[GIE_CNT_TL_FUSE], __popcll(bm));
-            base = __shfl(base, leader);
-            if (v) c.tl_front[base + __popcll(bm & ((1ull << lane) - 1ull))] = t;
-        }
+        const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FUSE], v != 0);
+        if (slot >= 0) c.tl_front[slot] = t;
 #endif
     } };
 struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };

@@ -295,7 +295,14 @@ static void be_fuse_rows(be_state *b, const gie_ctx &c)
 }
 template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
 {
-    GIE_LAUNCH(b, k_list<F>, dim3(b->cu_total), dim3(256), 0, c, f, list, count_idx);
+    GIE_LAUNCH(b, k_list<F>, dim3(b->cu_total), dim3(1024), 0, c, f, list, count_idx);
+}
+/* f(c, i) for i < n with whole workgroups calling (see k_range) */
+template <class F> static void be_range(be_state *b, const gie_ctx &c, const F &f, int n)
+{
+    if (n <= 0) return;
+    const int wgs = (n + 1023) / 1024;
+    GIE_LAUNCH(b, k_range<F>, dim3(wgs < b->cu_total ? wgs : b->cu_total), dim3(1024), 0, c, f, n);
 }
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {
@@ -304,7 +311,7 @@ static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {
     const int ncol = c.tfd[0] * c.tfd[1];
-    GIE_LAUNCH(b, k_edt_prep, dim3((ncol + 3) / 4), dim3(256), 0, c, ncol);
+    GIE_LAUNCH(b, k_edt_prep, dim3((ncol + GIE_PREP_WAVES - 1) / GIE_PREP_WAVES), dim3(64 * GIE_PREP_WAVES), 0, c, ncol);
 }
 /* full = 1: whole volume (column kernel); 0: only where Mark reads — the direct kernel over tl_known
  * and the column kernel are both launched and the one the known-tile count does not call for

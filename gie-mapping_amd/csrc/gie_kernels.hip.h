@@ -1113,7 +1113,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
 
 /* Before the EDT passes: the list of planes that hold obstacles (workgroup 0, wave 0) and the
  * reader masks of pass Z (one thread per (x,y) tile column). */
-__global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int ncol)
+#define GIE_PREP_WAVES 16
+__global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx c, const int ncol)
 {
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         /* all flag loads first (sides are <= 1024: 16 per lane), then the ballots: one memory round trip, not Z/64 */
@@ -1132,27 +1133,36 @@ __global__ __launch_bounds__(256) void k_edt_prep(const gie_ctx c, const int nco
         if (threadIdx.x == 0) *c.zcount = k;
     }
     /* one wave per (x,y) tile column, lane = z tile: the ballot IS the mask */
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6), tz = threadIdx.x & 63;
-    if (col >= ncol) return;
-    const int tx = col % c.tfd[0], ty = col / c.tfd[0];
+    const int col = blockIdx.x * GIE_PREP_WAVES + (threadIdx.x >> 6), tz = threadIdx.x & 63;
+    const bool colok = col < ncol;
+    const int tx = colok ? col % c.tfd[0] : 0, ty = colok ? col / c.tfd[0] : 0;
     const int t = (tz * c.tfd[1] + ty) * c.tfd[0] + tx;
-    const bool k = tz < c.tfd[2] && c.tknown[t];
+    const bool k = colok && tz < c.tfd[2] && c.tknown[t];
     const unsigned long long m = __ballot(k);
-    if (tz == 0) c.zneed[col] = m;
-    /* the same tiles as a list (mark / commit / pass Z visit only these when they are few) */
-    int base = 0;
-    if (tz == 0 && m) base = atomicAdd(&c.cnt[GIE_CNT_TL_KNOWN], __popcll(m));
-    base = __shfl(base, 0);
-    if (k) c.tl_known[base + __popcll(m & ((1ull << tz) - 1ull))] = t;
+    if (colok && tz == 0) c.zneed[col] = m;
+    /* the same tiles as a list (mark / commit / pass Z visit only these when they are few): one atomic per workgroup */
+    const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_KNOWN], k);
+    if (slot >= 0) c.tl_known[slot] = t;
+}
+
+/* f(c, i) for i in [0, n), every thread of every workgroup calling f the same number of times (i = -1 past the end):
+ * for functors that meet at block barriers (gie_wg_reserve) */
+template <class F>
+__global__ __launch_bounds__(1024) void k_range(const gie_ctx c, const F f, const int n)
+{
+    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + (int)threadIdx.x;
+        f(c, i < n ? i : -1);
+    }
 }
 
 /* f(c, list[e]) for every entry of a device-side list (fixed grid, the length lives in device memory) */
 template <class F>
-__global__ __launch_bounds__(256) void k_list(const gie_ctx c, const F f, const int32_t *list, const int count_idx)
+__global__ __launch_bounds__(1024) void k_list(const gie_ctx c, const F f, const int32_t *list, const int count_idx)
 {
     const int n = c.cnt[count_idx];
     /* whole waves run (the functor may ballot): lanes past the end get the entry -1 */
-    for (int e0 = blockIdx.x * 256; e0 < n; e0 += gridDim.x * 256) {
+    for (int e0 = blockIdx.x * blockDim.x; e0 < n; e0 += gridDim.x * blockDim.x) {
         const int e = e0 + (int)threadIdx.x;
         f(c, e < n ? list[e] : -1);
     }

@@ -85,6 +85,7 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
 }
 static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels) { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
+template <class F> static void be_range(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell);
