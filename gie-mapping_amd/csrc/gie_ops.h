@@ -607,27 +607,32 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
     return cur_in_q;
 }
 
-struct gie_frontier_st { uint64_t p0; int8_t ty; int8_t ntys[6]; uint8_t ntf[6]; };
+struct gie_frontier_st { uint64_t p0; uint32_t tys; uint32_t tfm; };   /* tys: own type | six neighbour types << 4 (k + 1); tfm: bit k = tile flag of neighbour k */
 
 /* every read that does not depend on another one is issued together — own pair + type, six
  * neighbour types, six tile flags: one memory round trip per voxel (the sweep is latency-bound) */
 GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, gie_frontier_st &s)
 {
-    s.ty = c.glb_type[id];
+    int8_t ty[7];
+    uint8_t tf[6];
+    ty[0] = c.glb_type[id];
     s.p0 = c.pair[id];      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
         const int inl = gie_in_loc(c, nx, ny, nz);
-        s.ntys[k] = c.glb_type[inl ? gie_lid(c, nx, ny, nz) : id];
-        s.ntf[k] = c.tflag[inl ? gie_tile_index(c, nx, ny, nz) : 0];
+        ty[k + 1] = c.glb_type[inl ? gie_lid(c, nx, ny, nz) : id];
+        tf[k] = c.tflag[inl ? gie_tile_index(c, nx, ny, nz) : 0];
     }
+    s.tys = (uint32_t)(ty[0] & 15); s.tfm = 0;
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) { s.tys |= (uint32_t)(ty[k + 1] & 15) << (4 * (k + 1)); s.tfm |= (tf[k] ? 1u : 0u) << k; }
 }
 
 GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s)
 {
-    const int8_t ty = s.ty;
+    const int8_t ty = (int8_t)(s.tys & 15u);
     if (ty == GIE_VOX_UNKNOWN) return 0;
     const uint64_t p0 = s.p0;
     int cw[3];
@@ -639,18 +644,16 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
     uint64_t seed = 0;
     int opush[6] = { 0, 0, 0, 0, 0, 0 }, oaddr[6] = { -1, -1, -1, -1, -1, -1 };
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    const int8_t *ntys = s.ntys;
-    const uint8_t *ntf = s.ntf;
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
         if (gie_in_loc(c, nx, ny, nz)) {
             const int nid = gie_lid(c, nx, ny, nz);
-            const int8_t nty = ntys[k];
+            const int8_t nty = (int8_t)((s.tys >> (4 * (k + 1))) & 15u);
             if (nty == GIE_VOX_UNKNOWN) { has_unknown = 1; continue; }
             /* only a neighbour whose closest obstacle is outside the volume can seed C; Mark
              * flagged the 8x8x8 tiles that contain one */
-            if (!ntf[k]) continue;
+            if (!((s.tfm >> k) & 1u)) continue;
             int nw[3];
             gie_unpack_wr(gie_pair_par(c.pair[nid]), &nw[0], &nw[1], &nw[2]);
             const int nl[3] = { nw[0] + c.upvt[0] - c.pvt[0], nw[1] + c.upvt[1] - c.pvt[1], nw[2] + c.upvt[2] - c.pvt[2] };
