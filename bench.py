@@ -71,10 +71,15 @@ def lidar_world(scenes):
     return scenes.BoxWorld(5, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5, min_size=0.4, max_size=3.0)
 
 
+LIDAR_TURN = 24          # the robot of the lidar workloads drives 24 frames out and 24 back: it stays inside the 12 m box world
+                         # however many regions are timed (the hash world of c5 is unbounded)
+
+
 def lidar_host_frame(scenes, world, voxel, sensor, i):
     """(pos, quat, cloud or range image, points in the cloud) of frame i of a lidar workload."""
     rings, az, phi_min, phi_inc, bins = LIDARS[sensor]
-    pos, q = scenes.pose(i, voxel, delta_vox=8, yaw_deg=2.0)
+    j = i % (2 * LIDAR_TURN)
+    pos, q = scenes.pose(j if j <= LIDAR_TURN else 2 * LIDAR_TURN - j, voxel, delta_vox=8, yaw_deg=2.0)
     pts, _ = scenes.lidar_frame(world, i, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc, max_range=30.0)
     npts = pts.shape[0]
     if bins is not None:   # Vlp16MapMaker::convertPyntCld binning (vlp16_map_maker.cpp:73-147)

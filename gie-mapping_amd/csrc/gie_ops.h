@@ -1083,11 +1083,11 @@ GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
     }
 }
 /* wave C merged `pr` into pair[id] (fused mode): commit it on the spot */
-GIE_DEV void gie_commit_merged(const gie_ctx &c, int id, int x, int y, int z, uint64_t pr)
+/* (type and block slot of the voxel are read by the caller together with everything else the entry needs: one round trip) */
+GIE_DEV void gie_commit_merged(const gie_ctx &c, int id, int8_t ty, int slot, int x, int y, int z, uint64_t pr)
 {
-    const int8_t ty = c.glb_type[id];
     if (ty == GIE_VOX_UNKNOWN) return;       /* lower_inside has no type test (wave_core.cuh:353-393), UpdateHashBatch has (unify_helper.cuh:459) */
-    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    const int a = slot < 0 ? -1 : slot * GIE_VBSZ + gie_vox_in_blk(x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     gie_commit_pair<true>(c, id, a, pr);
     if (a >= 0 && gie_pair_dist(pr) != c.empty_value && ty == GIE_VOX_FNT) gie_st(&c.g_type[a], (int8_t)GIE_VOX_FNT);
 }
@@ -1115,6 +1115,9 @@ GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, in
     uint64_t *slot = &c.cand[(level - 1) & 1][id];
     const uint64_t cd = gie_ld(slot);
     const uint64_t own = gie_ld(&c.pair[id]);
+    int8_t own_ty = GIE_VOX_UNKNOWN;
+    int own_slot = -1;
+    if (c.fused) { own_ty = c.glb_type[id]; own_slot = c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])]; }   /* for the commit of the merge below */
     uint64_t seen[6];
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
@@ -1128,7 +1131,7 @@ GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, in
     if (level > 0 && !(gie_pair_dist(cd) < gie_pair_dist(own))) return 0;
     const uint64_t pr = cd;
     gie_st(&c.pair[id], pr);
-    if (c.fused) gie_commit_merged(c, id, x, y, z, pr);
+    if (c.fused) gie_commit_merged(c, id, own_ty, own_slot, x, y, z, pr);
     const uint64_t par = gie_pair_par(pr);
     int cw[3];
     gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
