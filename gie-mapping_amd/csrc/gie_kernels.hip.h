@@ -764,20 +764,30 @@ __device__ __forceinline__ bool gie_row_window(const uint32_t *sk, const int L, 
 {
 #pragma unroll
     for (int m = 0; m < CP; m++) best[m] = sk[64 * m + lane];
+    unsigned active = 0;                                  /* bands (64 positions each) that still have a position without its bound */
+#pragma unroll
+    for (int m = 0; m < CP; m++) if (64 * m < L && ((bandneed >> m) & 1u)) active |= 1u << m;
     int W = 0;
 #pragma unroll 1
     for (;;) {                                            /* one trip = four more candidates on either side (kept rolled: registers) */
-        uint32_t mx = 0;                                  /* the largest bound among this lane's positions that somebody reads */
+        /* a band is finished when every candidate that could still win or tie one of its positions has been seen:
+         * (W + 1)^2 above the position's current value.  Bands finish on their own (the sparse stretch of a row
+         * keeps only its own band going). */
+        const uint32_t w1 = (uint32_t)((W + 1) * (W + 1));
 #pragma unroll
-        for (int m = 0; m < CP; m++) if (64 * m + lane < L && ((bandneed >> m) & 1u)) mx = max(mx, best[m] >> 10);
-        if (!__any((uint32_t)((W + 1) * (W + 1)) <= mx)) return true;     /* every candidate that could still win or tie has been seen */
+        for (int m = 0; m < CP; m++) {
+            if (!((active >> m) & 1u)) continue;          /* wave-uniform */
+            const uint32_t bm = (64 * m + lane < L) ? (best[m] >> 10) : 0u;
+            if (!__any(w1 <= bm)) active &= ~(1u << m);
+        }
+        if (!active) return true;
         if (W >= GIE_WIN_MAX) return false;
         const uint32_t *lo = sk + (lane - W - 4), *hi = sk + (lane + W + 1);   /* u - (W+4) .. u - (W+1)  and  u + (W+1) .. u + (W+4) */
-        const uint32_t a1 = (uint32_t)((W + 1) * (W + 1)) << 10, a2 = (uint32_t)((W + 2) * (W + 2)) << 10;
+        const uint32_t a1 = w1 << 10, a2 = (uint32_t)((W + 2) * (W + 2)) << 10;
         const uint32_t a3 = (uint32_t)((W + 3) * (W + 3)) << 10, a4 = (uint32_t)((W + 4) * (W + 4)) << 10;
 #pragma unroll
         for (int m = 0; m < CP; m++) {
-            if (!((bandneed >> m) & 1u)) continue;        /* wave-uniform */
+            if (!((active >> m) & 1u)) continue;          /* wave-uniform */
             const uint32_t l4 = lo[64 * m], l3 = lo[64 * m + 1], l2 = lo[64 * m + 2], l1 = lo[64 * m + 3];
             const uint32_t h1 = hi[64 * m], h2 = hi[64 * m + 1], h3 = hi[64 * m + 2], h4 = hi[64 * m + 3];
             uint32_t b = best[m];
@@ -1548,6 +1558,18 @@ __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : h
  * workgroups only (a barrier's cost grows with the workgroups that meet at it; one workgroup alone,
  * block barriers only, below GIE_WAVE_SOLO_AB seeds) with a barrier word of their own, while the others
  * fall through to the barrier that separates the wave from the next one. */
+/* the tail of a wave: once a level is this small, workgroup 0 finishes the wave alone (block barriers only: a phase
+ * of a few hundred entries costs its chain of round trips, not a grid barrier on top); the others leave for the
+ * barrier behind the wave.  Same n in every workgroup (read behind the level's last barrier). */
+#ifndef GIE_WAVE_TAIL_SOLO
+#define GIE_WAVE_TAIL_SOLO 768
+#endif
+#define GIE_WAVE_GO_SOLO(n) \
+    if (gb.nwg > 1 && (n) > 0 && (n) <= GIE_WAVE_TAIL_SOLO) { \
+        if (blockIdx.x != 0) break;                     /* leaves the level loop */ \
+        gb.nwg = 1; gid = (int)threadIdx.x; gstep = GIE_WAVE_THREADS; \
+    }
+
 __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
 {
     const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -1556,7 +1578,7 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
     if ((int)blockIdx.x >= nwg) return;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_B], 0, gb_all.failed, nwg, s_fail };
-    const int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
+    int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
@@ -1566,6 +1588,7 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
         for (int e = gid; e < n; e += gstep) gie_wave_a_phase2(c, cur, next_cnt, e);
         gie_grid_sync(gb, c);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
+        GIE_WAVE_GO_SOLO(n);
     }
     gb_all.failed |= gb.failed;
 }
@@ -1578,7 +1601,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
     if ((int)blockIdx.x >= nwg) return;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_AB2], 0, gb_all.failed, nwg, s_fail };
-    const int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
+    int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
@@ -1590,6 +1613,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         for (int e = gid; e < n; e += gstep) gie_wave_b_phase3(c, cur, e);
         gie_grid_sync(gb, c);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
+        GIE_WAVE_GO_SOLO(n);
     }
     gb_all.failed |= gb.failed;
 }

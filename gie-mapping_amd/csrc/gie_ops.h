@@ -1079,7 +1079,7 @@ GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
     if (AGENT) {
         gie_st(&c.g_coc[a], ncoc); gie_st(&c.g_dist[a], (int32_t)d); gie_st(&c.edt[id], sqrtf((float)d)); gie_st(&c.g_pair[a], pr);
     } else {
-        c.g_coc[a] = ncoc; c.g_dist[a] = d; c.edt[id] = sqrtf((float)d); c.g_pair[a] = pr;
+        c.g_coc[a] = ncoc; c.g_dist[a] = d; c.edt[id] = sqrtf((float)d); c.g_pair[a] = pr;     /* (nontemporal stores: no gain measured) */
     }
 }
 /* wave C merged `pr` into pair[id] (fused mode): commit it on the spot */

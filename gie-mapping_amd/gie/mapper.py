@@ -275,7 +275,7 @@ def load_library(path=None):
     """Load the HIP C-ABI library. Raises if it has not been built (no fallback)."""
     global _lib, _fns
     if _fns is None:
-        p = path or LIB_PATH
+        p = path or os.environ.get("GIE_LIB") or LIB_PATH    # GIE_LIB: another build of the same HIP library (ablation builds of tools/)
         if not os.path.exists(p):
             raise RuntimeError("%s not found: build it with __graft_entry__.build() "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
