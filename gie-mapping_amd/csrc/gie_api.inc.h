@@ -133,7 +133,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     long long mb = cfg->max_blocks > 0 ? cfg->max_blocks : 3ll * m->ncell + 4096;
     if (mb > 4000000) mb = 4000000;            /* slot*512 must stay below 2^31 */
     c.max_blocks = (int)mb;
-    const int hcap = gie_pow2_ge(2 * mb);
+    const int hcap = gie_pow2_ge(4 * mb);              /* load factor <= 1/4: probe chains stay short (16 bytes per slot) */
     c.hmask = (uint32_t)(hcap - 1);
     c.hkeys = gie_dalloc<uint64_t>(m, (size_t)hcap, false);
     c.hvals = gie_dalloc<int32_t>(m, (size_t)hcap, false);
@@ -159,11 +159,14 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
         c.qb_a[i] = gie_dalloc<int32_t>(m, (size_t)qab, false);
         c.qc[i] = gie_dalloc<int32_t>(m, (size_t)qc, false);
     }
-    const size_t rec = (size_t)(qab > qc ? qab : qc);
+    const size_t rec = (size_t)qab;                       /* per-entry records of waves A / B */
     c.rec0 = gie_dalloc<uint64_t>(m, rec, false);
     c.rec1 = gie_dalloc<uint64_t>(m, rec, false);
     c.rec2 = gie_dalloc<uint64_t>(m, rec, false);
     c.rec3 = gie_dalloc<int32_t>(m, rec, false);
+    c.rec0b = gie_dalloc<uint64_t>(m, rec, false);
+    c.rec1b = gie_dalloc<uint64_t>(m, rec, false);
+    c.rec3b = gie_dalloc<int32_t>(m, rec, false);
     c.cnt = gie_dalloc<int32_t>(m, GIE_CNT_NUM);
     c.lvl_next = gie_dalloc<int32_t>(m, 2 * GIE_MAX_LEVELS);
     c.lvl_vis = c.lvl_next + GIE_MAX_LEVELS;

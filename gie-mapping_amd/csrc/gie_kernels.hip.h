@@ -1558,6 +1558,17 @@ __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : h
  * workgroups only (a barrier's cost grows with the workgroups that meet at it; one workgroup alone,
  * block barriers only, below GIE_WAVE_SOLO_AB seeds) with a barrier word of their own, while the others
  * fall through to the barrier that separates the wave from the next one. */
+/* measurement only (tools/wave_timing.py): the boss thread stamps the wall clock (10 ns ticks, 24 bits) and the level size at
+ * every phase boundary of waves A / B / C into the middle row of the edt plane (interior voxels: no wave writes there) */
+#if defined(GIE_WAVE_TIMING)
+#define GIE_TS2(tag, n) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_ts_i < 500) { \
+        float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * g_ts_i; \
+        p_[0] = (float)(wall_clock64() & 0xffffff); p_[1] = (float)((tag) * 1000000 + ((n) < 999999 ? (n) : 999999)); g_ts_i++; } } while (0)
+static __device__ int g_ts_i;
+#else
+#define GIE_TS2(tag, n) do { } while (0)
+#endif
+
 /* the tail of a wave: once a level is this small, workgroup 0 finishes the wave alone (block barriers only: a phase
  * of a few hundred entries costs its chain of round trips, not a grid barrier on top); the others leave for the
  * barrier behind the wave.  Same n in every workgroup (read behind the level's last barrier). */
@@ -1567,8 +1578,16 @@ __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : h
 #define GIE_WAVE_GO_SOLO(n) \
     if (gb.nwg > 1 && (n) > 0 && (n) <= GIE_WAVE_TAIL_SOLO) { \
         if (blockIdx.x != 0) break;                     /* leaves the level loop */ \
-        gb.nwg = 1; gid = (int)threadIdx.x; gstep = GIE_WAVE_THREADS; \
+        gb.nwg = 1; \
     }
+
+/* entries [first, last) of a level belong to this workgroup: the level is split EVENLY over the workgroups that run the wave
+ * (whole waves each).  Every entry issues dozens of scattered 8-byte fabric transactions, and a compute unit's own request
+ * queue — not the fabric — is what a phase waits for: with consecutive entries on consecutive threads a level of a few
+ * thousand entries sat on a handful of compute units (33 us per phase whatever its size; evenly split: see DESIGN.md). */
+#define GIE_WAVE_SHARE(n, first, last) \
+    const int share_ = (((n) + gb.nwg - 1) / gb.nwg + 63) & ~63; \
+    const int first = min((n), (int)blockIdx.x * share_), last = min((n), (int)blockIdx.x * share_ + share_)
 
 __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
 {
@@ -1578,21 +1597,27 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
     if ((int)blockIdx.x >= nwg) return;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_B], 0, gb_all.failed, nwg, s_fail };
-    int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
     while (n > 0 && !gb.failed) {
         int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
         if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
-        for (int e = gid; e < n; e += gstep) gie_wave_a_phase1(c, cur, e);
+        GIE_TS2(1, n);
+        GIE_WAVE_SHARE(n, first, last);
+        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_a_phase1(c, cur, e);
         gie_grid_sync(gb, c);
+        GIE_TS2(2, n);
         if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
-        for (int e = gid; e < n; e += gstep) gie_wave_a_phase2(c, cur, next_cnt, e);
+        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_a_phase2(c, cur, next_cnt, e);
         gie_grid_sync(gb, c);
+        GIE_TS2(3, n);
         n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
         GIE_WAVE_GO_SOLO(n);
     }
     gb_all.failed |= gb.failed;
 }
 
+/* Wave B: per level phase 2 (relax the neighbours) and, as ONE phase, phase 3 of this level (the winners among the inside
+ * voxels) together with phase 1 of the next (commit + snapshot of the entries phase 2 appended) — they touch different data
+ * apart from the per-entry records, which come in two sets.  Two barriers per level instead of three. */
 __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
 {
     const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -1601,18 +1626,34 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
     if ((int)blockIdx.x >= nwg) return;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_AB2], 0, gb_all.failed, nwg, s_fail };
-    int gid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x, gstep = nwg * GIE_WAVE_THREADS;
-    while (n > 0 && !gb.failed) {
-        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
+    if (n > 0) {
         if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
-        for (int e = gid; e < n; e += gstep) gie_wave_b_phase1(c, cur, e);
+        GIE_TS2(4, n);
+        GIE_WAVE_SHARE(n, first, last);
+        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur, 0, e);
+        gie_grid_sync(gb, c);                   /* (also orders the two counter resets above before the first append) */
+        GIE_TS2(5, n);
+    }
+    while (n > 0 && !gb.failed) {
+        const int rp = level & 1;
+        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + rp];
+        GIE_WAVE_SHARE(n, first, last);
+        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase2(c, cur, next_cnt, level, rp, e);
         gie_grid_sync(gb, c);
-        if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
-        for (int e = gid; e < n; e += gstep) gie_wave_b_phase2(c, cur, next_cnt, level, e);
+        GIE_TS2(6, n);
+        const int nn = gie_clampi(gie_ld(next_cnt), c.qcap_ab);
+        if (boss) {
+            gie_st(&c.cnt[GIE_CNT_NEXT + (rp ^ 1)], 0);             /* the next level's append counter (its last reader is long past) */
+            if (nn > 0) { c.cnt[GIE_CNT_VIS_B] += nn; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += nn; }
+        }
+        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase3(c, cur, rp, e);
+        {
+            GIE_WAVE_SHARE(nn, first, last);
+            for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur ^ 1, rp ^ 1, e);
+        }
         gie_grid_sync(gb, c);
-        for (int e = gid; e < n; e += gstep) gie_wave_b_phase3(c, cur, e);
-        gie_grid_sync(gb, c);
-        n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
+        GIE_TS2(7, nn);
+        n = nn; cur ^= 1; level++;
         GIE_WAVE_GO_SOLO(n);
     }
     gb_all.failed |= gb.failed;
@@ -1636,11 +1677,7 @@ __device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int 
     int32_t *next = c.qc[cur ^ 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-#if defined(GIE_WAVE_TIMING)
-#define GIE_TS(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && level < 4000) c.edt[level * 8 + (k)] = (float)(wall_clock64() & 0xffffff); } while (0)
-#else
-#define GIE_TS(k) do { } while (0)
-#endif
+#define GIE_TS(k) do { } while (0)      /* (round 1's per-level stamps of wave C; see GIE_TS2) */
     GIE_TS(0);
     for (int b0 = first; b0 < last; b0 += GIE_WAVE_THREADS) {
         const int e = b0 + (int)threadIdx.x;
@@ -1751,13 +1788,20 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
         }
     }
     __syncthreads();
+#if defined(GIE_WAVE_TIMING)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
+#endif
+    GIE_TS2(0, 0);
     if (with_ab) {
         gie_wave_a_run(c, gb, ab_wgs, &s_fail);
         gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
+        GIE_TS2(8, 0);
         gie_wave_b_run(c, gb, ab_wgs, &s_fail);
         gie_grid_sync(gb, c);
+        GIE_TS2(9, 0);
     }
     gie_wave_c_run(c, gb, record_seeds, s_wg);
+    GIE_TS2(10, 0);
 }
 
 #endif /* GIE_KERNELS_HIP_H */

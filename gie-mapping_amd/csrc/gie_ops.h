@@ -928,11 +928,15 @@ GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
 
 /* ================================================================== wave B (lower_outside) */
 /* wave_core.cuh:229-350, three phases per level. rec0[e] = snapshot parent (GIE_NOPROP =
- * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask. */
-GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int e)
+ * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask.  The records come in two sets (rp = level
+ * parity): phase 3 of a level and phase 1 of the next touch different data apart from them, so the kernel runs the two as
+ * one barrier-separated phase. */
+GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e)
 {
+    uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
+    int32_t *const rec3 = rp ? c.rec3b : c.rec3;
     const int a = gie_ld(&c.qb_a[cur][e]);
-    c.rec0[e] = GIE_NOPROP; c.rec3[e] = 0;
+    rec0[e] = GIE_NOPROP; rec3[e] = 0;
     if (a < 0) return;
     const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
     if (gie_ld(&c.g_dist[a]) > c.cutoff_sq) return;
@@ -942,18 +946,20 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int e)
     gie_st(&c.g_coc[a], coc);
     gie_st(&c.g_dist[a], (int32_t)gie_pair_dist(pr));
     gie_touch(c, a);
-    c.rec0[e] = gie_pair_par(pr);
-    c.rec1[e] = coc;
+    rec0[e] = gie_pair_par(pr);
+    rec1[e] = coc;
 }
 
-GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int level, int e)
+GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int level, int rp, int e)
 {
-    if (c.rec0[e] == GIE_NOPROP) return;
+    const uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
+    int32_t *const rec3 = rp ? c.rec3b : c.rec3;
+    if (rec0[e] == GIE_NOPROP) return;
     int g[3], cc[3];
     gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
     const int a = gie_ld(&c.qb_a[cur][e]);
-    gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
-    const uint64_t par = c.rec0[e];
+    gie_unpack_crd(rec1[e], &cc[0], &cc[1], &cc[2]);
+    const uint64_t par = rec0[e];
     const int32_t stamp = (int32_t)(c.stamp_base + 8u + (uint32_t)(level % 4000));
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     unsigned outm = 0, inm = 0;
@@ -1017,18 +1023,20 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
             mask |= 1 << k;
         }
     }
-    c.rec3[e] = mask;
+    rec3[e] = mask;
 }
 
-GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int e)
+GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int rp, int e)
 {
-    if (c.rec0[e] == GIE_NOPROP) return;
-    const unsigned mask = (unsigned)c.rec3[e];
+    const uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
+    const int32_t *const rec3 = rp ? c.rec3b : c.rec3;
+    if (rec0[e] == GIE_NOPROP) return;
+    const unsigned mask = (unsigned)rec3[e];
     if (!mask) return;
     int g[3], cc[3];
     gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
-    gie_unpack_crd(c.rec1[e], &cc[0], &cc[1], &cc[2]);
-    const uint64_t par = c.rec0[e];
+    gie_unpack_crd(rec1[e], &cc[0], &cc[1], &cc[2]);
+    const uint64_t par = rec0[e];
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     uint64_t key[6], old[6];
     int nid[6];

@@ -164,9 +164,9 @@ static void be_wave_b(be_state *, const gie_ctx &c)
     c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
     while (n > 0) {
         c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n;
-        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, e);
-        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], level, e);
-        for (int e = 0; e < n; e++) gie_wave_b_phase3(c, cur, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, level & 1, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], level, level & 1, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase3(c, cur, level & 1, e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
     }
 }

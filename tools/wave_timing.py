@@ -1,6 +1,6 @@
-"""Measurement aid: per-phase time stamps of wave C (build variant with -DGIE_WAVE_TIMING; the
-stamps overwrite the start of the edt plane).  tools/wave_timing.py build | run"""
-import math, os, subprocess, sys
+"""Measurement aid: time stamps at every phase boundary of the waves kernel (build variant with -DGIE_WAVE_TIMING; the boss
+thread writes them into the middle row of the edt plane).   python tools/wave_timing.py build | run [workload]"""
+import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tools", "ablate", "libgie_hip_wt.so")
 if sys.argv[1] == "build":
@@ -12,29 +12,31 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd")]
 import numpy as np, torch, bench, gie
 from gie import mapper, scenes
 mapper.load_library(LIB)
-sensor = "vlp16_projective"
-rings, az, phi_min, phi_inc, bins = bench.SENSORS[sensor]
-frames = bench.make_frames(scenes, 0.05, 8, 5, sensor)
+wl = sys.argv[2] if len(sys.argv) > 2 else "c5"
 dev = torch.device("cuda", 0)
-d_pts = [torch.from_numpy(f[2]).to(dev) for f in frames]
-m = gie.Mapper(gie.make_config(0.05, (512, 512, 512), cutoff_dist=2.0, fast_mode=False))
-for i, (pos, q, pts, _) in enumerate(frames):
-    m.set_pose(pos, q)
-    m.ogm_multiscan_dev(d_pts[i].data_ptr(), bins, rings, 2.0 * math.pi / bins, -math.pi, math.radians(phi_inc), math.radians(phi_min))
-    m.fuse(); m.batch_edt()
-    if i == 7:
-        # stop before commit overwrites the stamps: run merge's pieces through gie_merge, then read edt (commit only writes known voxels' edt)
-        pass
-    m.merge(); m.sync()
+size = (512, 512, 512)
+m = gie.Mapper(gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False))
+feed = bench.make_feed(wl, torch, scenes, dev, 0.05, size, (0, 0, 0), 8)
+feed.prepare(0, 8)
+for i in range(8):
+    feed.step_input(m, i); m.step(); m.sync()
 st = m.stats()
-e = m.read_local(vtype=False, dist_sq=False, coc=False)["edt"].ravel()[:8 * 400].reshape(-1, 8)
-lv = st["levels_c"]
-print("levels", lv, "visits", st["visits_c"])
-d = np.diff(e[:, :7], axis=1)
-d = np.where(d < 0, d + 16777216.0, d)          # 24-bit wrap
-ok = (e[:, 0] > 0) & (np.abs(d) < 1e5).all(1)
-names = ["relax", "ballot+sync", "reserve+sync", "stores+sync", "grid barrier", "read n"]
-print("rows used", int(ok.sum()))
-for k, nme in enumerate(names):
-    print("%-14s %.2f us" % (nme, d[ok, k].mean() / 100.0))
-print("sum %.2f us" % (d[ok].sum(1).mean() / 100.0))
+row = m.read_local(vtype=False, dist_sq=False, coc=False)["edt"][size[2] // 2, size[1] // 2, :]
+names = {0: "start", 1: "A level start", 2: "A phase 1 + barrier", 3: "A phase 2 + barrier", 4: "B start", 5: "B phase 1 (first) + barrier", 6: "B phase 2 + barrier",
+         7: "B phase 3 + next phase 1 + barrier", 8: "A done + grid barrier", 9: "B done + grid barrier", 10: "C done"}
+print("visits", st["visits_a"], st["visits_b"], st["visits_c"], "levels", st["levels_a"], st["levels_b"], st["levels_c"])
+prev = None
+tot = {}
+for k in range(0, 1000, 2):
+    t, tag = float(row[k]), int(row[k + 1])
+    if k > 0 and tag // 1000000 == 0 and t == 0:
+        break
+    tg, n = tag // 1000000, tag % 1000000
+    if prev is not None:
+        dt = (t - prev) % 16777216.0 / 100.0
+        print("%-38s n %7d   %8.2f us" % (names.get(tg, tg), n, dt))
+        tot[tg] = tot.get(tg, 0.0) + dt
+    prev = t
+    if tg == 10:
+        break
+print({names[k]: round(v, 1) for k, v in tot.items()})
