@@ -807,20 +807,19 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
     uint64_t ncc[6];
     int nd[6], nwl[6];
     GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        nty[k] = GIE_VOX_UNKNOWN; ncc[k] = 0; nd[k] = 0; nwl[k] = 0;
-        if (na[k] < 0) continue;
-        nty[k] = gie_ld(&c.g_type[na[k]]); ncc[k] = gie_ld(&c.g_coc[na[k]]); nd[k] = gie_ld(&c.g_dist[na[k]]); nwl[k] = gie_ld(&c.g_wl[na[k]]);
+    for (int k = 0; k < 6; k++) {      /* straight-line code: a neighbour that does not exist re-reads the entry's own record (ignored below) */
+        const int ak = na[k] >= 0 ? na[k] : a;
+        nty[k] = gie_ld(&c.g_type[ak]); ncc[k] = gie_ld(&c.g_coc[ak]); nd[k] = gie_ld(&c.g_dist[ak]); nwl[k] = gie_ld(&c.g_wl[ak]);
     }
     int lc[3];
     gie_unpack_crd(lcoc, &lc[0], &lc[1], &lc[2]);
     const uint64_t lpar = gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]);
     unsigned ok = 0, vanished = 0;
-    int nc[6][3];
+    int nc[6][3], lidk[6];
     int8_t lt[6];
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
-        lt[k] = GIE_VOX_OCCUPIED; nc[k][0] = nc[k][1] = nc[k][2] = 0;
+        nc[k][0] = nc[k][1] = nc[k][2] = 0; lidk[k] = 0;
         if (na[k] < 0 || nty[k] == GIE_VOX_UNKNOWN) continue;
         gie_unpack_crd(ncc[k], &nc[k][0], &nc[k][1], &nc[k][2]);
         if (gie_invalid_coc(nc[k][0], nc[k][1], nc[k][2]) || gie_invalid_dist(c, nd[k])) continue;
@@ -830,8 +829,10 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
         /* `_aux[coc] != 0` (wave_core.cuh:177-178): the batch distance of a voxel is 0 iff it is
          * OCCUPIED, and Mark never turns a non-zero value into 0 */
         const int nl[3] = { nc[k][0] - c.pvt[0], nc[k][1] - c.pvt[1], nc[k][2] - c.pvt[2] };
-        if (gie_in_loc(c, nl[0], nl[1], nl[2])) { lt[k] = c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])]; vanished |= 1u << k; }
+        if (gie_in_loc(c, nl[0], nl[1], nl[2])) { lidk[k] = gie_lid(c, nl[0], nl[1], nl[2]); vanished |= 1u << k; }
     }
+    GIE_UNROLL6
+    for (int k = 0; k < 6; k++) lt[k] = c.glb_type[lidk[k]];         /* one batch (voxel 0 stands in where there is nothing to look up) */
     int mask = 0, lowered = 0;
     uint64_t newcoc = GIE_KEY_EMPTY, newpair = GIE_NOPROP;
     GIE_UNROLL6
@@ -979,10 +980,17 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     int8_t nty[6];
     uint64_t ncc[6], npr[6];
     GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        nty[k] = GIE_VOX_UNKNOWN; ncc[k] = 0; npr[k] = 0;
-        if (((outm >> k) & 1u) && na[k] >= 0) { nty[k] = gie_ld(&c.g_type[na[k]]); ncc[k] = gie_ld(&c.g_coc[na[k]]); npr[k] = gie_ld(&c.g_pair[na[k]]); }
-        else if ((inm >> k) & 1u) { nty[k] = c.glb_type[nid[k]]; npr[k] = gie_ld(&c.pair[nid[k]]); }
+    for (int k = 0; k < 6; k++) {      /* straight-line code: both records of every direction, the one that does not apply read at a stand-in address */
+        const bool out = ((outm >> k) & 1u) && na[k] >= 0;
+        const int ak = out ? na[k] : a;
+        const int8_t oty = gie_ld(&c.g_type[ak]);
+        const uint64_t occ = gie_ld(&c.g_coc[ak]), opr = gie_ld(&c.g_pair[ak]);
+        const int8_t ity = c.glb_type[nid[k]];
+        const uint64_t ipr = gie_ld(&c.pair[nid[k]]);
+        const bool in = (inm >> k) & 1u;
+        nty[k] = out ? oty : (in ? ity : (int8_t)GIE_VOX_UNKNOWN);
+        ncc[k] = out ? occ : 0ull;
+        npr[k] = out ? opr : (in ? ipr : 0ull);
     }
     unsigned tryo = 0;
     uint64_t key[6], old[6];
