@@ -790,11 +790,11 @@ __device__ __forceinline__ bool gie_row_window(const uint32_t *sk, const int L, 
             if (!((active >> m) & 1u)) continue;          /* wave-uniform */
             const uint32_t l4 = lo[64 * m], l3 = lo[64 * m + 1], l2 = lo[64 * m + 2], l1 = lo[64 * m + 3];
             const uint32_t h1 = hi[64 * m], h2 = hi[64 * m + 1], h3 = hi[64 * m + 2], h4 = hi[64 * m + 3];
-            uint32_t b = best[m];
-            b = min(b, min(l1 + a1, h1 + a1));
-            b = min(b, min(l2 + a2, h2 + a2));
-            b = min(b, min(l3 + a3, h3 + a3));
-            b = min(b, min(l4 + a4, h4 + a4));
+            uint32_t b = best[m];                         /* min(l + a, h + a) = min(l, h) + a: one add per PAIR of candidates */
+            b = min(b, min(l1, h1) + a1);
+            b = min(b, min(l2, h2) + a2);
+            b = min(b, min(l3, h3) + a3);
+            b = min(b, min(l4, h4) + a4);
             best[m] = b;
         }
         W += 4;
