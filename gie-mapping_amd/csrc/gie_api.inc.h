@@ -168,6 +168,9 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.rec1b = gie_dalloc<uint64_t>(m, rec, false);
     c.rec3b = gie_dalloc<int32_t>(m, rec, false);
     c.cnt = gie_dalloc<int32_t>(m, GIE_CNT_NUM);
+    for (int i = 0; i < 2; i++) c.wc_list[i] = gie_dalloc<int32_t>(m, ntile, false);
+    c.wc_flag[0] = gie_dalloc<int32_t>(m, 2 * ntile);          /* one allocation: cleared as one region with the frame */
+    c.wc_flag[1] = c.wc_flag[0] ? c.wc_flag[0] + ntile : nullptr;
     c.lvl_next = gie_dalloc<int32_t>(m, 2 * GIE_MAX_LEVELS);
     c.lvl_vis = c.lvl_next + GIE_MAX_LEVELS;
     bool ok = c.cnt != nullptr;
@@ -421,6 +424,7 @@ extern "C" int gie_fuse(gie_mapper *m)
         add(c.cnt + GIE_CNT_ERR + 1, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
         add(c.cnt + GIE_CNT_BAR_B, (GIE_CNT_AUX_END - GIE_CNT_BAR_B) * sizeof(int32_t));
         add(c.lvl_next, 2 * GIE_MAX_LEVELS * sizeof(int32_t));
+        add(c.wc_flag[0], 2 * ntile * sizeof(int32_t));          /* (zero again after every complete wave C; a wave cut short may leave flags) */
         be_clear(&m->be, l);
     }
     be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0);

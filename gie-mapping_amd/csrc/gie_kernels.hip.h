@@ -1659,109 +1659,177 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     gb_all.failed |= gb.failed;
 }
 
-/* One BFS level of wave C.  `wg_first`/`stride` are workgroup-uniform (every thread of the
- * workgroup runs the same trips), so queue space is reserved ONCE PER WORKGROUP AND TRIP: ballot
- * prefix inside the wave, LDS prefix across the 16 waves, one global atomicAdd — instead of up
- * to six same-address atomics per thread. */
-struct gie_wg_scratch { int32_t tot[GIE_WAVE_THREADS / 64]; int32_t vis[GIE_WAVE_THREADS / 64]; int32_t base; int32_t n_local; };
+/* ------------------------------------------------------------------ wave C: tile rounds */
+/* lower_inside (wave_core.cuh:353-393) in the canonical TILE-ROUND schedule: in a round every ACTIVE 8x8x8
+ * tile — one that holds proposals from the round before (or seeds) — is taken by ONE WAVE: its pairs, its proposals and the
+ * pairs of the one-voxel halo around it go into LDS (one batch of loads), a level-synchronous BFS runs inside the tile to
+ * exhaustion out of LDS (64-bit LDS atomic minima, wave barriers, no memory traffic: the reference's BFS_in_block idea),
+ * what it proposes to voxels of a neighbouring tile is min-resolved in that voxel's slot of the other candidate plane (agent
+ * atomics) and activates the neighbour for the next round.  A flood front needs one grid barrier per TILE it crosses, not
+ * per voxel, and an entry's seven pair reads are LDS reads of a block that was fetched as whole rows.
+ *   planes: round r reads cand[(r+1) & 1] (the seeds come in cand[1]) and proposes into cand[r & 1];
+ *   tiles:  list wc_list[r & 1] with lvl_next[r] entries, membership flag wc_flag[r & 1][tile] (cleared by the wave that
+ *           takes the tile, set by whoever activates it for round r + 2);
+ *   rule:   a proposal replaces a pair on a strict distance improvement over the value at the start of the (sub-)level,
+ *           among proposals the smaller (dist, parent) wins; the seeds of round 0 are assignments. */
+#define GIE_WC_WAVES 10                                   /* waves of a workgroup that take tiles: 15 KB of LDS each */
+struct gie_wc_tile { uint64_t pair[512], ca[512], cb[512], halo[6][64]; };
 
-/* entries [first, last) belong to this workgroup (the frontier is split EVENLY over the
- * workgroups: every entry costs a dozen scattered 8-byte transactions, and a compute unit's path
- * to the fabric, not the fabric, is what a level waits for) */
-/* solo = this workgroup runs the level alone: the next queue is filled from a count in LDS (no
- * global reservation, no read-back of the level's size: two fabric round trips per level less) */
-__device__ __forceinline__ void gie_wave_c_level(const gie_ctx &c, int cur, int level, int first, int last, gie_wg_scratch *sc, const bool solo)
+__device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L, const int t, const int round, const int lane)
 {
-    if (solo && threadIdx.x == 0) sc->n_local = 0;      /* read again only behind the barriers of the trips below */
-    int32_t *next_cnt = &c.lvl_next[level];
-    int32_t *next = c.qc[cur ^ 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#define GIE_TS(k) do { } while (0)      /* (round 1's per-level stamps of wave C; see GIE_TS2) */
-    GIE_TS(0);
-    for (int b0 = first; b0 < last; b0 += GIE_WAVE_THREADS) {
-        const int e = b0 + (int)threadIdx.x;
-        int nid[6];
-        int m = 0;
-        if (e < last) m = gie_wave_c_relax(c, c.qc[cur], level, e, nid);
-        GIE_TS(1);
-        int off[6], wtot = 0;
+    const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+    const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool colin = x < c.X && y < c.Y;
+    uint64_t *const rd = c.cand[(round + 1) & 1], *const wr = c.cand[round & 1];
+    const size_t plane = (size_t)c.X * c.Y;
+    const size_t col = (size_t)y * c.X + x;
+    /* ---- one batch of loads: the tile's pairs and proposals, the halo's pairs */
+    uint64_t pv[8], cv[8], hv[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const unsigned long long bm = __ballot((m >> k) & 1);
-            off[k] = wtot + __popcll(bm & lt);
-            wtot += __popcll(bm);
-        }
-        const int wvis = __popcll(__ballot((m >> 6) & 1));
-        if (lane == 0) { sc->tot[wave] = wtot; sc->vis[wave] = wvis; }
-        __syncthreads();
-        GIE_TS(2);
-        if (threadIdx.x == 0) {
-            int t = 0, v = 0;
-            for (int w = 0; w < GIE_WAVE_THREADS / 64; w++) { t += sc->tot[w]; v += sc->vis[w]; }
-            if (solo) { sc->base = sc->n_local; sc->n_local += t; }
-            else sc->base = t ? gie_aadd32(next_cnt, t) : 0;
-            if (v) gie_aadd32(&c.lvl_vis[level], v);
-        }
-        __syncthreads();
-        GIE_TS(3);
-        int wbase = sc->base;
-        for (int w = 0; w < wave; w++) wbase += sc->tot[w];
+    for (int j = 0; j < 8; j++) {
+        const bool in = colin && z0 + j < c.Z;
+        const size_t id = in ? (size_t)(z0 + j) * plane + col : 0;
+        pv[j] = gie_ld(&c.pair[id]);
+        cv[j] = gie_ld(&rd[id]);
+        if (!in) { pv[j] = 0ull; cv[j] = GIE_NOPROP; }                    /* a voxel outside the volume: distance 0, never improved */
+    }
+    {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z), the lane's position (a, b) on it */
+        const int a = lane & 7, b = lane >> 3;
+        const int hx[6] = { x0 - 1, x0 + 8, x0 + a, x0 + a, x0 + a, x0 + a };
+        const int hy[6] = { y0 + a, y0 + a, y0 - 1, y0 + 8, y0 + b, y0 + b };
+        const int hz[6] = { z0 + b, z0 + b, z0 + b, z0 + b, z0 - 1, z0 + 8 };
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            if ((m >> k) & 1) {
-                const int slot = wbase + off[k];
-                if (slot < c.qcap_c) gie_st(&next[slot], (int32_t)nid[k]);
-                else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+        for (int f = 0; f < 6; f++) {
+            const bool in = gie_in_loc(c, hx[f], hy[f], hz[f]);
+            hv[f] = gie_ld(&c.pair[in ? gie_lid(c, hx[f], hy[f], hz[f]) : 0]);
+            if (!in) hv[f] = 0ull;
+        }
+    }
+    if (lane == 0) gie_st(&c.wc_flag[round & 1][t], (int32_t)0);          /* may be activated again (for round + 2) from now on */
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int v = lane + 64 * j;
+        L.pair[v] = pv[j]; L.ca[v] = cv[j]; L.cb[v] = GIE_NOPROP;
+        if (cv[j] != GIE_NOPROP) gie_st(&rd[(size_t)(z0 + j) * plane + col], (uint64_t)GIE_NOPROP);      /* consumed */
+    }
+#pragma unroll
+    for (int f = 0; f < 6; f++) L.halo[f][lane] = hv[f];
+    gie_wave_sync();
+    /* ---- BFS inside the tile */
+    uint64_t *A = L.ca, *B = L.cb;
+    unsigned dirty = 0, xmask = 0;                        /* my voxels whose pair changed; neighbour tiles that received a proposal */
+    int nvis = 0;
+    for (int sub = 0;; sub++) {
+        bool pushed = false;
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            const int v = lane + 64 * j;
+            const uint64_t cd = A[v];
+            if (cd == GIE_NOPROP) continue;
+            A[v] = GIE_NOPROP;
+            const uint64_t own = L.pair[v];
+            if (!((round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(own))) continue;
+            L.pair[v] = cd;
+            dirty |= 1u << j; nvis++;
+            const uint64_t par = gie_pair_par(cd);
+            int cw[3];
+            gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
+            const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
+            const int z = z0 + j;
+            const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+                if (!gie_in_loc(c, nx, ny, nz)) continue;
+                const int d = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
+                if (d >= c.empty_value) continue;
+                const uint64_t key = gie_pair_make(d, par);
+                const int ux = lx + dx[k], uy = ly + dy[k], uz = j + dz[k];
+                if ((unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u) {
+                    const int nv = ux + 8 * uy + 64 * uz;
+                    /* (the pre-read only drops proposals that cannot improve: values only decrease) */
+                    if (d < gie_pair_dist(L.pair[nv])) { __hip_atomic_fetch_min(&B[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); pushed = true; }
+                } else {
+                    /* across the border: position on the halo face k, filtered against the neighbour's pair at the start of the round */
+                    const int hp = (k < 2) ? (ly + 8 * j) : ((k < 4) ? (lx + 8 * j) : (lx + 8 * ly));
+                    if (d < gie_pair_dist(L.halo[k][hp])) { gie_amin64(&wr[(size_t)nz * plane + (size_t)ny * c.X + nx], key); xmask |= 1u << k; }
+                }
             }
         }
-        __syncthreads();                       /* scratch is reused by the next trip */
-        GIE_TS(4);
+        gie_wave_sync();
+        if (!__any(pushed)) break;
+        uint64_t *tswap = A; A = B; B = tswap;
     }
+    /* ---- write back what changed (wave C is the only writer of these pairs; agent-scope: another XCD's wave takes the tile next time) */
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        if (!((dirty >> j) & 1u)) continue;
+        const int z = z0 + j;
+        const size_t id = (size_t)z * plane + col;
+        const uint64_t pr = L.pair[lane + 64 * j];
+        gie_st(&c.pair[id], pr);
+        if (c.fused) gie_commit_merged(c, (int)id, c.glb_type[id], c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])], x, y, z, pr);
+    }
+    /* ---- neighbour tiles that received a proposal take part in the next round */
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (__ballot((xmask >> k) & 1u) == 0ull) continue;                /* wave-uniform */
+        if (lane == 0) {
+            const int dt[6] = { -1, 1, -c.tfd[0], c.tfd[0], -c.tfd[0] * c.tfd[1], c.tfd[0] * c.tfd[1] };
+            const int nt = t + dt[k];
+            if (gie_axchg32(&c.wc_flag[(round + 1) & 1][nt], (int32_t)1) == 0) {
+                const int slot = gie_aadd32(&c.lvl_next[round + 1], 1);
+                gie_st(&c.wc_list[(round + 1) & 1][slot], (int32_t)nt);
+            }
+        }
+    }
+    {   /* visits of the tile (one atomic per wave) */
+        int s = nvis;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && s > 0) gie_aadd32(&c.lvl_vis[round], s);
+    }
+    gie_wave_sync();                                       /* the LDS block is reused for the wave's next tile */
 }
-__device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb, const int record_seeds, gie_wg_scratch &s_wg)
+
+__device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb, const int record_seeds, gie_wc_tile *tiles)
 {
-    const int gtid = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x;
-    const bool boss = (gtid == 0);
-    int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c), cur = 0, level = 0;
+    const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
+    const int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c);
     if (boss) {
         c.cnt[GIE_CNT_FRONT_C] = n;
         if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
     }
     if (n == 0) return;                        /* same n everywhere */
-    /* lvl_next[] / lvl_vis[] (one word per BFS level) were zeroed by the host before the launch,
-     * so no counter has to be reset or read back by one thread between levels */
-    while (n > 0 && !gb.failed && level < GIE_MAX_LEVELS - 1) {
-        if (n <= GIE_WAVE_SOLO) {
-            /* solo episode: workgroup 0 runs levels with block barriers while the frontier stays
-             * small, the others wait at ONE grid barrier and then pick up the published state */
-            if (blockIdx.x == 0) {
-                do {
-                    gie_wave_c_level(c, cur, level, 0, n, &s_wg, true);
-                    n = gie_clampi(s_wg.n_local, c.qcap_c); cur ^= 1; level++;
-                    __syncthreads();                   /* everybody has the size before the next level resets it */
-                } while (n > 0 && n <= GIE_WAVE_SOLO && level < GIE_MAX_LEVELS - 1);
-                if (boss) { gie_st(&c.cnt[GIE_CNT_STATE], n); gie_st(&c.cnt[GIE_CNT_STATE + 1], cur); gie_st(&c.cnt[GIE_CNT_STATE + 2], level); }
-            }
-            gie_grid_sync(gb, c);
-            n = gie_ld(&c.cnt[GIE_CNT_STATE]); cur = gie_ld(&c.cnt[GIE_CNT_STATE + 1]); level = gie_ld(&c.cnt[GIE_CNT_STATE + 2]);
-            gie_grid_sync(gb, c);              /* everybody has read the state before it can be republished */
-        } else {
-            const int share = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;      /* whole waves */
-            const int first = (int)blockIdx.x * share;
-            gie_wave_c_level(c, cur, level, first < n ? first : n, first + share < n ? first + share : n, &s_wg, false);
-            gie_grid_sync(gb, c);
-            GIE_TS(5);
-            n = gie_clampi(gie_ld(&c.lvl_next[level]), c.qcap_c);
-            GIE_TS(6);
-            cur ^= 1; level++;
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    /* the tiles of the seeds are the active tiles of round 0 (lvl_next[] / lvl_vis[] — one word per round — and the tile flags
+     * are zero when the launch starts) */
+    for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
+        const int id = gie_ld(&c.qc[0][e]);
+        const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
+        const int t = gie_tile_index(c, x, y, z);
+        if (gie_axchg32(&c.wc_flag[0][t], (int32_t)1) == 0) gie_st(&c.wc_list[0][gie_aadd32(&c.lvl_next[0], 1)], (int32_t)t);
     }
-    if (n > 0 && level >= GIE_MAX_LEVELS - 1 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    gie_grid_sync(gb, c);
+    int round = 0;
+    while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
+        const int nt = gie_ld(&c.lvl_next[round]);
+        if (nt <= 0) break;                    /* same everywhere */
+        if (wave < GIE_WC_WAVES) {
+            const int32_t *list = c.wc_list[round & 1];
+            for (int i = (int)blockIdx.x * GIE_WC_WAVES + wave; i < nt; i += (int)gridDim.x * GIE_WC_WAVES)
+                gie_wave_c_tile(c, tiles[wave], gie_ld(&list[i]), round, lane);
+        }
+        gie_grid_sync(gb, c);
+        round++;
+    }
+    if (round >= GIE_MAX_LEVELS - 2 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
     /* statistics once, after the wave */
     if (boss) {
         int lv = 0; long long vis = 0;
-        for (int l = 0; l < level; l++) { const int v = gie_ld(&c.lvl_vis[l]); if (v > 0) { lv++; vis += v; } }
+        for (int l = 0; l < round; l++) { const int v = gie_ld(&c.lvl_vis[l]); if (v > 0) { lv++; vis += v; } }
         c.cnt[GIE_CNT_VIS_C] = (int)vis; c.cnt[GIE_CNT_LVL_C] = lv;
         *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += vis;
     }
@@ -1770,7 +1838,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
 /* waves A, B (unless fast_mode / refinement) and C in one launch */
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds, const int ab_wgs)
 {
-    __shared__ gie_wg_scratch s_wg;
+    __shared__ gie_wc_tile s_tiles[GIE_WC_WAVES];         /* wave C: one 8x8x8 tile (+ halo) per wave */
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail };
@@ -1800,7 +1868,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
         gie_grid_sync(gb, c);
         GIE_TS2(9, 0);
     }
-    gie_wave_c_run(c, gb, record_seeds, s_wg);
+    gie_wave_c_run(c, gb, record_seeds, s_tiles);
     GIE_TS2(10, 0);
 }
 

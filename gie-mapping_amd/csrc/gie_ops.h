@@ -1109,67 +1109,9 @@ GIE_DEV void gie_commit_merged(const gie_ctx &c, int id, int8_t ty, int slot, in
 }
 
 /* ================================================================== wave C (lower_inside) */
-/* wave_core.cuh:353-393 with ONE grid barrier per BFS level.  Relaxations of level k do not
- * touch `pair`: they atomicMin into the candidate plane cand[k&1]; the thread that later owns
- * queue entry n merges cand[(k)&1][n] into pair[n] at the start of level k+1 (strict improvement
- * of the distance, id_atomicMin's '>' — wave_core.cuh:16) and only then expands n.  Nobody else
- * writes pair[n], so the parent an entry expands with is its level-start value without a
- * snapshot phase.  The first candidate that turns a slot from "none" into a value enqueues the
- * voxel (exactly once per level); entries whose candidate does not improve are dropped at the
- * merge.  The pre-read of pair[m] only filters candidates that cannot improve (values only
- * decrease), so a stale read costs a dropped entry, never a result.  Returns 1 when the entry
- * expanded (= one "visit" of the canonical schedule). */
-/* merge + relax of one queue entry.  Returns bit 6 = the entry expanded ("visit"), bits 0..5 =
- * neighbour k must be appended to the next queue (its id in nid_out[k]). */
-GIE_DEV int gie_wave_c_relax(const gie_ctx &c, const int32_t *cur, int level, int e, int nid_out[6])
-{
-    const int id = gie_ld(&cur[e]);
-    const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    /* every read of this entry is issued in ONE batch (each is a round trip through the fabric:
-     * own candidate, own pair and the six neighbours' pairs only depend on the voxel id) */
-    uint64_t *slot = &c.cand[(level - 1) & 1][id];
-    const uint64_t cd = gie_ld(slot);
-    const uint64_t own = gie_ld(&c.pair[id]);
-    int8_t own_ty = GIE_VOX_UNKNOWN;
-    int own_slot = -1;
-    if (c.fused) { own_ty = c.glb_type[id]; own_slot = c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])]; }   /* for the commit of the merge below */
-    uint64_t seen[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
-        nid_out[k] = gie_in_loc(c, nx, ny, nz) ? gie_lid(c, nx, ny, nz) : -1;
-        seen[k] = nid_out[k] >= 0 ? gie_ld(&c.pair[nid_out[k]]) : 0ull;
-    }
-    /* level 0: the seed pairs written by obtainFrontiers / wave B are assignments
-     * (unify_helper.cuh:334-335, wave_core.cuh:338-341); later levels: strict improvement */
-    gie_st(slot, (uint64_t)GIE_NOPROP);
-    if (level > 0 && !(gie_pair_dist(cd) < gie_pair_dist(own))) return 0;
-    const uint64_t pr = cd;
-    gie_st(&c.pair[id], pr);
-    if (c.fused) gie_commit_merged(c, id, own_ty, own_slot, x, y, z, pr);
-    const uint64_t par = gie_pair_par(pr);
-    int cw[3];
-    gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
-    const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
-    int cand[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        if (nid_out[k] < 0) continue;
-        const int d = gie_d2(cl[0], cl[1], cl[2], x + dx[k], y + dy[k], z + dz[k]);
-        if (d >= c.empty_value) { nid_out[k] = -1; continue; }
-        cand[k] = d;
-    }
-    /* stage 2: candidates that can still improve */
-    uint64_t *plane = c.cand[level & 1];
-    int mask = 64;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        if (nid_out[k] < 0 || !(cand[k] < gie_pair_dist(seen[k]))) continue;
-        if (gie_amin64(&plane[nid_out[k]], gie_pair_make(cand[k], par)) == GIE_NOPROP) mask |= 1 << k;
-    }
-    return mask;
-}
+/* wave_core.cuh:353-393 in the canonical tile-round schedule: the kernel is gie_wave_c_tile (gie_kernels.hip.h) — a wave per
+ * active 8x8x8 tile, BFS inside the tile out of LDS; the sequential statements are oracle/gie_oracle.c wave_c and
+ * tests/emu/gie_emu.cpp be_wave_c.  What the three share is gie_commit_merged above. */
 
 /* ================================================================== commit */
 /* UpdateHashBatch, unify_helper.cuh:448-523 */

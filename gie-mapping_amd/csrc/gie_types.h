@@ -143,7 +143,9 @@ typedef struct gie_ctx {
     int32_t *qc[2];
     int qcap_ab, qcap_c;
     int32_t *cnt;           /* device counters, see GIE_CNT_* */
-    int32_t *lvl_next, *lvl_vis; /* wave C: next-frontier size / visits per BFS level (GIE_MAX_LEVELS words each) */
+    int32_t *lvl_next, *lvl_vis; /* wave C: active tiles / visits per round (GIE_MAX_LEVELS words each) */
+    int32_t *wc_list[2];         /* wave C: the active tiles of a round (parity of the round) */
+    int32_t *wc_flag[2];         /*         ... and their membership flags, one word per tile */
     /* per-entry scratch of the wave phases */
     uint64_t *rec0, *rec1, *rec2;
     int32_t *rec3;

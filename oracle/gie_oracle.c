@@ -1,3 +1,4 @@
+#define _GNU_SOURCE   /* qsort_r */
 /*
  * gie_oracle.c — CPU restatement of the GIE-mapping per-frame map update.  TEST INFRASTRUCTURE.
  *
@@ -924,6 +925,20 @@ static void wave_b(gie_oracle *o, queue *front, queue *fc)
 }
 
 /* Wave C: lower_inside (wave_core.cuh:353-393). */
+/* lower_inside in the canonical TILE-ROUND schedule (DESIGN.md "Canonical wave schedule"): the volume is cut into its 8x8x8
+ * tiles; in a round every tile that holds pending voxels runs a level-synchronous BFS INSIDE itself to exhaustion (like the
+ * reference's BFS_in_block, wave_core.cuh:395-469), and what it proposes to voxels of OTHER tiles is collected — minimum
+ * (dist, parent) per voxel — and applied at the end of the round, where a voxel that improved joins the next round.  Tiles
+ * do not see each other inside a round, so their order is irrelevant.  levels_c counts rounds, visits_c expansions. */
+static int tile_of(const gie_oracle *o, int x, int y, int z)
+{ return ((z >> 3) * ((o->Y + 7) >> 3) + (y >> 3)) * ((o->X + 7) >> 3) + (x >> 3); }
+static int cmp_i3_tile(const void *a, const void *b, void *ctx)
+{
+    const gie_oracle *o = (const gie_oracle *)ctx;
+    const i3 *p = (const i3 *)a, *q = (const i3 *)b;
+    const int tp = tile_of(o, p->x, p->y, p->z), tq = tile_of(o, q->x, q->y, q->z);
+    return tp < tq ? -1 : (tp > tq ? 1 : 0);
+}
 static void wave_c(gie_oracle *o, queue *front)
 {
     /* set semantics for the seed list (lower_outside may push a voxel more than once) */
@@ -937,48 +952,82 @@ static void wave_c(gie_oracle *o, queue *front)
         front->n = m;
         for (int i = 0; i < front->n; i++) o->lprop_par[lid(o, front->d[i].x, front->d[i].y, front->d[i].z)] = 0;
     }
-    queue cur = *front, next = { 0, 0, 0 };
+    queue cur = *front;
     front->d = NULL; front->n = front->cap = 0;
-    int level = 0;
+    /* proposals across tile borders of the running round */
+    int32_t *xd = (int32_t *)malloc(sizeof(int32_t) * (size_t)o->N);
+    int64_t *xp = (int64_t *)calloc((size_t)o->N, sizeof(int64_t));
+    for (int i = 0; i < o->N; i++) xd[i] = 0x7fffffff;
     while (cur.n > 0) {
         o->st.levels_c++;
-        o->st.visits_c += cur.n;
-        const int gray = (level & 1) ? GRAY1 : GRAY0;
-        int64_t *par = (int64_t *)malloc(sizeof(int64_t) * (size_t)cur.n);
-        for (int e = 0; e < cur.n; e++) {
-            const int id = lid(o, cur.d[e].x, cur.d[e].y, cur.d[e].z);
-            o->wave_layer[id] = BLACK;
-            par[e] = o->pair_par[id];
-        }
-        queue touched = { 0, 0, 0 };
-        for (int e = 0; e < cur.n; e++) {
-            int cw[3]; unpack_wr(par[e], &cw[0], &cw[1], &cw[2]);
-            const int cl[3] = { cw[0] + o->upvt[0] - o->pvt[0], cw[1] + o->upvt[1] - o->pvt[1], cw[2] + o->upvt[2] - o->pvt[2] };
-            for (int k = 0; k < 6; k++) {
-                const int nx = cur.d[e].x + DIRS[k][0], ny = cur.d[e].y + DIRS[k][1], nz = cur.d[e].z + DIRS[k][2];
-                if (!in_loc(o, nx, ny, nz)) continue;
-                const int nid = lid(o, nx, ny, nz);
-                const int cand = d2i(cl[0], cl[1], cl[2], nx, ny, nz);
-                if (cand >= o->empty_value) continue;
-                if (pair_less(cand, par[e], o->lprop_dist[nid], o->lprop_par[nid])) { o->lprop_dist[nid] = cand; o->lprop_par[nid] = par[e]; }
-                q_push(&touched, nx, ny, nz);
+        qsort_r(cur.d, (size_t)cur.n, sizeof(i3), cmp_i3_tile, o);       /* group the pending voxels by tile */
+        queue xtouched = { 0, 0, 0 };
+        for (int b = 0; b < cur.n;) {
+            const int T = tile_of(o, cur.d[b].x, cur.d[b].y, cur.d[b].z);
+            int e1 = b;
+            while (e1 < cur.n && tile_of(o, cur.d[e1].x, cur.d[e1].y, cur.d[e1].z) == T) e1++;
+            queue L = { 0, 0, 0 };
+            for (int e = b; e < e1; e++) q_push(&L, cur.d[e].x, cur.d[e].y, cur.d[e].z);
+            b = e1;
+            while (L.n > 0) {                                             /* one level inside the tile */
+                o->st.visits_c += L.n;
+                int64_t *par = (int64_t *)malloc(sizeof(int64_t) * (size_t)L.n);
+                for (int e = 0; e < L.n; e++) {
+                    const int id = lid(o, L.d[e].x, L.d[e].y, L.d[e].z);
+                    o->wave_layer[id] = BLACK;
+                    par[e] = o->pair_par[id];
+                }
+                queue touched = { 0, 0, 0 }, Ln = { 0, 0, 0 };
+                for (int e = 0; e < L.n; e++) {
+                    int cw[3]; unpack_wr(par[e], &cw[0], &cw[1], &cw[2]);
+                    const int cl[3] = { cw[0] + o->upvt[0] - o->pvt[0], cw[1] + o->upvt[1] - o->pvt[1], cw[2] + o->upvt[2] - o->pvt[2] };
+                    for (int k = 0; k < 6; k++) {
+                        const int nx = L.d[e].x + DIRS[k][0], ny = L.d[e].y + DIRS[k][1], nz = L.d[e].z + DIRS[k][2];
+                        if (!in_loc(o, nx, ny, nz)) continue;
+                        const int nid = lid(o, nx, ny, nz);
+                        const int cand = d2i(cl[0], cl[1], cl[2], nx, ny, nz);
+                        if (cand >= o->empty_value) continue;
+                        if (tile_of(o, nx, ny, nz) == T) {
+                            if (pair_less(cand, par[e], o->lprop_dist[nid], o->lprop_par[nid])) { o->lprop_dist[nid] = cand; o->lprop_par[nid] = par[e]; }
+                            q_push(&touched, nx, ny, nz);
+                        } else {
+                            if (pair_less(cand, par[e], xd[nid], xp[nid])) { xd[nid] = cand; xp[nid] = par[e]; }
+                            q_push(&xtouched, nx, ny, nz);
+                        }
+                    }
+                }
+                for (int i = 0; i < touched.n; i++) {
+                    const int nid = lid(o, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+                    if (o->lprop_dist[nid] == 0x7fffffff) continue;
+                    if (o->pair_dist[nid] > o->lprop_dist[nid]) {
+                        o->pair_dist[nid] = o->lprop_dist[nid]; o->pair_par[nid] = o->lprop_par[nid];
+                        o->wave_layer[nid] = GRAY0;
+                        q_push(&Ln, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+                    }
+                    o->lprop_dist[nid] = 0x7fffffff; o->lprop_par[nid] = 0;
+                }
+                q_free(&touched); free(par);
+                q_free(&L); L = Ln;
             }
+            q_free(&L);
         }
-        for (int i = 0; i < touched.n; i++) {
-            const int nid = lid(o, touched.d[i].x, touched.d[i].y, touched.d[i].z);
-            if (o->lprop_dist[nid] == 0x7fffffff) continue;
-            if (o->pair_dist[nid] > o->lprop_dist[nid]) {
-                o->pair_dist[nid] = o->lprop_dist[nid]; o->pair_par[nid] = o->lprop_par[nid];
-                o->wave_layer[nid] = gray;
-                q_push(&next, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+        /* end of the round: what crossed a tile border */
+        queue next = { 0, 0, 0 };
+        for (int i = 0; i < xtouched.n; i++) {
+            const int nid = lid(o, xtouched.d[i].x, xtouched.d[i].y, xtouched.d[i].z);
+            if (xd[nid] == 0x7fffffff) continue;
+            if (o->pair_dist[nid] > xd[nid]) {
+                o->pair_dist[nid] = xd[nid]; o->pair_par[nid] = xp[nid];
+                o->wave_layer[nid] = GRAY1;
+                q_push(&next, xtouched.d[i].x, xtouched.d[i].y, xtouched.d[i].z);
             }
-            o->lprop_dist[nid] = 0x7fffffff; o->lprop_par[nid] = 0;
+            xd[nid] = 0x7fffffff; xp[nid] = 0;
         }
-        q_free(&touched); free(par);
-        q_free(&cur); cur = next; next.d = NULL; next.n = next.cap = 0;
-        level++;
+        q_free(&xtouched);
+        q_free(&cur); cur = next;
     }
     q_free(&cur);
+    free(xd); free(xp);
 }
 
 /* UpdateHashBatch, unify_helper.cuh:448-523 */

@@ -9,6 +9,7 @@
  * `pytest -m gpu` covers them.
  */
 #define GIE_HOST_EMU 1
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -170,17 +171,79 @@ static void be_wave_b(be_state *, const gie_ctx &c)
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
     }
 }
+/* wave C in the canonical tile-round schedule: sequential statement on the device data structures — the seeds are
+ * the voxels of qc[0] with their pairs in cand[1]; proposals across tile borders travel through the candidate planes (parity of
+ * the round) like on the device, proposals inside a tile through a scratch plane (the device keeps those in LDS) */
 static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
 {
-    int n = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c, cur = 0, level = 0;
-    c.cnt[GIE_CNT_FRONT_C] = n;
-    if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
-    while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0;
-        int v = 0;
-        for (int e = 0; e < n; e++) v += gie_wave_c_step(c, c.qc[cur], c.qc[cur ^ 1], &c.cnt[GIE_CNT_NEXT], level, e);
-        if (v > 0) { c.cnt[GIE_CNT_VIS_C] += v; c.cnt[GIE_CNT_LVL_C] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += v; }
-        n = c.cnt[GIE_CNT_NEXT] < c.qcap_c ? c.cnt[GIE_CNT_NEXT] : c.qcap_c; cur ^= 1; level++;
+    const int n0 = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c;
+    c.cnt[GIE_CNT_FRONT_C] = n0;
+    if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n0; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    auto tile = [&](int id) { const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y); return gie_tile_index(c, x, y, z); };
+    auto set_pair = [&](int id, uint64_t pr) {
+        c.pair[id] = pr;
+        if (c.fused) {
+            const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
+            gie_commit_merged(c, id, c.glb_type[id], c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])], x, y, z, pr);
+        }
+    };
+    std::vector<uint64_t> lp((size_t)c.N, (uint64_t)GIE_NOPROP);
+    std::vector<int> cur;
+    for (int e = 0; e < n0; e++) {                                  /* round 0: the seeds' pairs are assignments */
+        const int id = c.qc[0][e];
+        const uint64_t pr = c.cand[1][id];
+        c.cand[1][id] = GIE_NOPROP;
+        set_pair(id, pr & ~GIE_PAIR_NEW);
+        cur.push_back(id);
+    }
+    int round = 0;
+    while (!cur.empty()) {
+        c.cnt[GIE_CNT_LVL_C] += 1;
+        uint64_t *xplane = c.cand[round & 1];                       /* what crosses a tile border in this round */
+        std::vector<int> xtouched;
+        std::stable_sort(cur.begin(), cur.end(), [&](int a, int b) { return tile(a) < tile(b); });
+        for (size_t b = 0; b < cur.size();) {
+            const int T = tile(cur[b]);
+            std::vector<int> L;
+            while (b < cur.size() && tile(cur[b]) == T) L.push_back(cur[b++]);
+            while (!L.empty()) {
+                c.cnt[GIE_CNT_VIS_C] += (int)L.size(); *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += (long long)L.size();
+                std::vector<uint64_t> par(L.size());
+                for (size_t e = 0; e < L.size(); e++) par[e] = gie_pair_par(c.pair[L[e]]);
+                std::vector<int> touched, Ln;
+                for (size_t e = 0; e < L.size(); e++) {
+                    const int id = L[e], x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
+                    int cw[3];
+                    gie_unpack_wr(par[e], &cw[0], &cw[1], &cw[2]);
+                    const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
+                    for (int k = 0; k < 6; k++) {
+                        const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
+                        if (!gie_in_loc(c, nx, ny, nz)) continue;
+                        const int nid = gie_lid(c, nx, ny, nz);
+                        const int cand = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
+                        if (cand >= c.empty_value) continue;
+                        const uint64_t key = gie_pair_make(cand, par[e]);
+                        if (gie_tile_index(c, nx, ny, nz) == T) { if (key < lp[(size_t)nid]) lp[(size_t)nid] = key; touched.push_back(nid); }
+                        else { if (key < xplane[nid]) xplane[nid] = key; xtouched.push_back(nid); }
+                    }
+                }
+                for (int nid : touched) {
+                    if (lp[(size_t)nid] == GIE_NOPROP) continue;
+                    if (gie_pair_dist(c.pair[nid]) > gie_pair_dist(lp[(size_t)nid])) { set_pair(nid, lp[(size_t)nid]); Ln.push_back(nid); }
+                    lp[(size_t)nid] = GIE_NOPROP;
+                }
+                L.swap(Ln);
+            }
+        }
+        std::vector<int> next;
+        for (int nid : xtouched) {
+            if (xplane[nid] == GIE_NOPROP) continue;
+            if (gie_pair_dist(c.pair[nid]) > gie_pair_dist(xplane[nid])) { set_pair(nid, xplane[nid]); next.push_back(nid); }
+            xplane[nid] = GIE_NOPROP;
+        }
+        cur.swap(next);
+        round++;
     }
 }
 static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)

@@ -1,6 +1,6 @@
 /*
  * gie_emu_ops.h — TEST-ONLY pieces of the sequential emulation (tests/emu/gie_emu.cpp): the one-thread-per-ray
- * walk, the scan-based block allocation and the sequential wave-C step.  They restate stages the HIP product
+ * walk and the scan-based block allocation.  They restate stages the HIP product
  * runs with different kernels (k_free_rays, k_cell_alloc, k_waves) and live here, not in the product headers.
  */
 #ifndef GIE_EMU_OPS_H
@@ -66,17 +66,6 @@ GIE_DEV int gie_cell_needs_new(const gie_ctx &c, int cell)
     const int bx = cell % c.tdim[0], by = (cell / c.tdim[0]) % c.tdim[1], bz = cell / (c.tdim[0] * c.tdim[1]);
     return gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]) < 0;
 }
-
-/* sequential form (test-only emulation) */
-GIE_DEV int gie_wave_c_step(const gie_ctx &c, const int32_t *cur, int32_t *next, int32_t *next_cnt, int level, int e)
-{
-    int nid[6];
-    const int m = gie_wave_c_relax(c, cur, level, e, nid);
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) if (m & (1 << k)) gie_push32(c, next, next_cnt, c.qcap_c, nid[k]);
-    return m >> 6;
-}
-
 
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 /* block allocation (allocHashTB, glb_hash_map.cu:58-113) */
