@@ -1672,8 +1672,8 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
  *           takes the tile, set by whoever activates it for round r + 2);
  *   rule:   a proposal replaces a pair on a strict distance improvement over the value at the start of the (sub-)level,
  *           among proposals the smaller (dist, parent) wins; the seeds of round 0 are assignments. */
-#define GIE_WC_WAVES 10                                   /* waves of a workgroup that take tiles: 15 KB of LDS each */
-struct gie_wc_tile { uint64_t pair[512], ca[512], cb[512], halo[6][64]; };
+#define GIE_WC_WAVES 10                                   /* waves of a workgroup that take tiles: 14.6 KB of LDS each */
+struct gie_wc_tile { uint64_t pair[512], prop[512], halo[6][64]; uint16_t list[512], pend[2][512]; int32_t npend[2]; };   /* 14.6 KB */
 
 __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L, const int t, const int round, const int lane)
 {
@@ -1687,13 +1687,21 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
     const size_t col = (size_t)y * c.X + x;
     /* ---- one batch of loads: the tile's pairs and proposals, the halo's pairs */
     uint64_t pv[8], cv[8], hv[6];
+    uint64_t tys = 0;                                     /* the column's eight types, for the commit of what changes */
+    int slot_lo = -1, slot_hi = -1;                       /* block slots of the column's first / last voxel (at most two blocks) */
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const bool in = colin && z0 + j < c.Z;
         const size_t id = in ? (size_t)(z0 + j) * plane + col : 0;
         pv[j] = gie_ld(&c.pair[id]);
         cv[j] = gie_ld(&rd[id]);
+        if (c.fused) tys |= (uint64_t)(uint8_t)c.glb_type[id] << (8 * j);
         if (!in) { pv[j] = 0ull; cv[j] = GIE_NOPROP; }                    /* a voxel outside the volume: distance 0, never improved */
+    }
+    if (c.fused && colin) {
+        const int zl = min(z0 + 7, c.Z - 1);
+        slot_lo = c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z0 + c.pvt[2])];
+        slot_hi = c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], zl + c.pvt[2])];
     }
     {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z), the lane's position (a, b) on it */
         const int a = lane & 7, b = lane >> 3;
@@ -1708,60 +1716,93 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
         }
     }
     if (lane == 0) gie_st(&c.wc_flag[round & 1][t], (int32_t)0);          /* may be activated again (for round + 2) from now on */
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int np0 = 0;                                          /* the voxels with a proposal from the round before: the first pending list */
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int v = lane + 64 * j;
-        L.pair[v] = pv[j]; L.ca[v] = cv[j]; L.cb[v] = GIE_NOPROP;
-        if (cv[j] != GIE_NOPROP) gie_st(&rd[(size_t)(z0 + j) * plane + col], (uint64_t)GIE_NOPROP);      /* consumed */
+        L.pair[v] = pv[j]; L.prop[v] = cv[j];
+        const bool have = cv[j] != GIE_NOPROP;
+        if (have) gie_st(&rd[(size_t)(z0 + j) * plane + col], (uint64_t)GIE_NOPROP);      /* consumed */
+        const unsigned long long m = __ballot(have);
+        if (have) L.pend[0][np0 + __popcll(m & lt)] = (uint16_t)v;
+        np0 += __popcll(m);
     }
 #pragma unroll
     for (int f = 0; f < 6; f++) L.halo[f][lane] = hv[f];
+    if (lane == 0) { L.npend[0] = np0; L.npend[1] = 0; }
     gie_wave_sync();
-    /* ---- BFS inside the tile */
-    uint64_t *A = L.ca, *B = L.cb;
-    unsigned dirty = 0, xmask = 0;                        /* my voxels whose pair changed; neighbour tiles that received a proposal */
+    /* ---- BFS inside the tile, driven by lists (a level costs what its entries cost, not a scan of the tile): the PENDING
+     * list holds the voxels with a proposal; (a) one pending voxel per lane: merge, the ones that improved are compacted
+     * (ballot) into the entry list; (b) one entry per lane: expand; a proposal that turns a voxel's slot from "none" into a
+     * value appends the voxel to the other pending list (the returning LDS minimum says so). */
+    unsigned xmask = 0;                                   /* neighbour tiles that received a proposal */
     int nvis = 0;
+    int np = np0;
     for (int sub = 0;; sub++) {
-        bool pushed = false;
-#pragma unroll 1
-        for (int j = 0; j < 8; j++) {
-            const int v = lane + 64 * j;
-            const uint64_t cd = A[v];
-            if (cd == GIE_NOPROP) continue;
-            A[v] = GIE_NOPROP;
-            const uint64_t own = L.pair[v];
-            if (!((round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(own))) continue;
-            L.pair[v] = cd;
-            dirty |= 1u << j; nvis++;
-            const uint64_t par = gie_pair_par(cd);
+        const int pi = sub & 1;
+        int nent = 0;
+        for (int e0 = 0; e0 < np; e0 += 64) {
+            const int e = e0 + lane;
+            bool take = false;
+            int v = 0;
+            if (e < np) {
+                v = L.pend[pi][e];
+                const uint64_t cd = L.prop[v];
+                L.prop[v] = GIE_NOPROP;
+                take = (round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(L.pair[v]);
+                if (take) { L.pair[v] = cd; nvis++; }
+            }
+            const unsigned long long m = __ballot(take);
+            if (take) L.list[nent + __popcll(m & lt)] = (uint16_t)v;
+            nent += __popcll(m);
+        }
+        if (lane == 0) L.npend[pi] = 0;                   /* free for the level after the next */
+        if (nent == 0) break;                             /* wave-uniform */
+        gie_wave_sync();
+        for (int e = lane; e < nent; e += 64) {
+            const int v = L.list[e];
+            const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
+            const uint64_t par = gie_pair_par(L.pair[v]);
             int cw[3];
             gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
-            const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
-            const int z = z0 + j;
+            const int cx = cw[0] + c.upvt[0] - c.pvt[0] - (x0 + ex), cy = cw[1] + c.upvt[1] - c.pvt[1] - (y0 + ey), cz = cw[2] + c.upvt[2] - c.pvt[2] - (z0 + ez);
             const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+            int d[6];
+            uint64_t seen[6];
+            unsigned okm = 0, inm = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {                 /* the six neighbours' current pairs (tile or halo) in flight together */
+                const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
+                const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+                const int hp = (k < 2) ? (ey + 8 * ez) : ((k < 4) ? (ex + 8 * ez) : (ex + 8 * ey));
+                seen[k] = inside ? L.pair[ux + 8 * uy + 64 * uz] : L.halo[k][hp];
+                /* |closest obstacle - neighbour|^2 in 32 bits: wave-range coordinates are below 2^14 */
+                const int ax = cx - dx[k], ay = cy - dy[k], az = cz - dz[k];
+                d[k] = ax * ax + ay * ay + az * az;
+                if (gie_in_loc(c, x0 + ux, y0 + uy, z0 + uz) && d[k] < c.empty_value) okm |= 1u << k;
+                if (inside) inm |= 1u << k;
+            }
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
-                if (!gie_in_loc(c, nx, ny, nz)) continue;
-                const int d = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
-                if (d >= c.empty_value) continue;
-                const uint64_t key = gie_pair_make(d, par);
-                const int ux = lx + dx[k], uy = ly + dy[k], uz = j + dz[k];
-                if ((unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u) {
+                /* (the pre-read only drops proposals that cannot improve: values only decrease; a halo pair is the neighbour's at the start of the round) */
+                if (!((okm >> k) & 1u) || !(d[k] < gie_pair_dist(seen[k]))) continue;
+                const uint64_t key = gie_pair_make(d[k], par);
+                const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
+                if ((inm >> k) & 1u) {
                     const int nv = ux + 8 * uy + 64 * uz;
-                    /* (the pre-read only drops proposals that cannot improve: values only decrease) */
-                    if (d < gie_pair_dist(L.pair[nv])) { __hip_atomic_fetch_min(&B[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); pushed = true; }
-                } else {
-                    /* across the border: position on the halo face k, filtered against the neighbour's pair at the start of the round */
-                    const int hp = (k < 2) ? (ly + 8 * j) : ((k < 4) ? (lx + 8 * j) : (lx + 8 * ly));
-                    if (d < gie_pair_dist(L.halo[k][hp])) { gie_amin64(&wr[(size_t)nz * plane + (size_t)ny * c.X + nx], key); xmask |= 1u << k; }
-                }
+                    if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
+                        L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
+                } else { gie_amin64(&wr[(size_t)(z0 + uz) * plane + (size_t)(y0 + uy) * c.X + (x0 + ux)], key); xmask |= 1u << k; }
             }
         }
         gie_wave_sync();
-        if (!__any(pushed)) break;
-        uint64_t *tswap = A; A = B; B = tswap;
+        np = L.npend[pi ^ 1];
     }
+    /* which of my eight voxels changed: the pair in LDS against the one loaded */
+    unsigned dirty = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (L.pair[lane + 64 * j] != pv[j]) dirty |= 1u << j;
     /* ---- write back what changed (wave C is the only writer of these pairs; agent-scope: another XCD's wave takes the tile next time) */
 #pragma unroll 1
     for (int j = 0; j < 8; j++) {
@@ -1770,15 +1811,20 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
         const size_t id = (size_t)z * plane + col;
         const uint64_t pr = L.pair[lane + 64 * j];
         gie_st(&c.pair[id], pr);
-        if (c.fused) gie_commit_merged(c, (int)id, c.glb_type[id], c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])], x, y, z, pr);
+        if (c.fused) {
+            const int slot = (((z + c.pvt[2]) >> 3) == ((z0 + c.pvt[2]) >> 3)) ? slot_lo : slot_hi;
+            gie_commit_merged(c, (int)id, (int8_t)(tys >> (8 * j)), slot, x, y, z, pr);
+        }
     }
     /* ---- neighbour tiles that received a proposal take part in the next round */
+    {
+        unsigned any6 = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        if (__ballot((xmask >> k) & 1u) == 0ull) continue;                /* wave-uniform */
-        if (lane == 0) {
-            const int dt[6] = { -1, 1, -c.tfd[0], c.tfd[0], -c.tfd[0] * c.tfd[1], c.tfd[0] * c.tfd[1] };
-            const int nt = t + dt[k];
+        for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
+        if (lane < 6 && ((any6 >> lane) & 1u)) {            /* lane k activates the neighbour across face k: the six in flight together */
+            const int dt = (lane == 0) ? -1 : (lane == 1) ? 1 : (lane == 2) ? -c.tfd[0] : (lane == 3) ? c.tfd[0]
+                         : (lane == 4) ? -c.tfd[0] * c.tfd[1] : c.tfd[0] * c.tfd[1];
+            const int nt = t + dt;
             if (gie_axchg32(&c.wc_flag[(round + 1) & 1][nt], (int32_t)1) == 0) {
                 const int slot = gie_aadd32(&c.lvl_next[round + 1], 1);
                 gie_st(&c.wc_list[(round + 1) & 1][slot], (int32_t)nt);
@@ -1813,6 +1859,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
         if (gie_axchg32(&c.wc_flag[0][t], (int32_t)1) == 0) gie_st(&c.wc_list[0][gie_aadd32(&c.lvl_next[0], 1)], (int32_t)t);
     }
     gie_grid_sync(gb, c);
+    GIE_TS2(12, n);
     int round = 0;
     while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
         const int nt = gie_ld(&c.lvl_next[round]);
@@ -1823,6 +1870,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
                 gie_wave_c_tile(c, tiles[wave], gie_ld(&list[i]), round, lane);
         }
         gie_grid_sync(gb, c);
+        GIE_TS2(11, nt);
         round++;
     }
     if (round >= GIE_MAX_LEVELS - 2 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);

@@ -16,27 +16,35 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "c5"
 dev = torch.device("cuda", 0)
 size = (512, 512, 512)
 m = gie.Mapper(gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False))
-feed = bench.make_feed(wl, torch, scenes, dev, 0.05, size, (0, 0, 0), 8)
-feed.prepare(0, 8)
-for i in range(8):
-    feed.step_input(m, i); m.step(); m.sync()
-st = m.stats()
-row = m.read_local(vtype=False, dist_sq=False, coc=False)["edt"][size[2] // 2, size[1] // 2, :]
+feed = bench.make_feed(wl, torch, scenes, dev, 0.05, size, (0, 0, 0), 64)
+NF = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+verbose = len(sys.argv) > 4
+feed.prepare(0, NF)
 names = {0: "start", 1: "A level start", 2: "A phase 1 + barrier", 3: "A phase 2 + barrier", 4: "B start", 5: "B phase 1 (first) + barrier", 6: "B phase 2 + barrier",
-         7: "B phase 3 + next phase 1 + barrier", 8: "A done + grid barrier", 9: "B done + grid barrier", 10: "C done"}
-print("visits", st["visits_a"], st["visits_b"], st["visits_c"], "levels", st["levels_a"], st["levels_b"], st["levels_c"])
-prev = None
-tot = {}
-for k in range(0, 1000, 2):
-    t, tag = float(row[k]), int(row[k + 1])
-    if k > 0 and tag // 1000000 == 0 and t == 0:
-        break
-    tg, n = tag // 1000000, tag % 1000000
-    if prev is not None:
-        dt = (t - prev) % 16777216.0 / 100.0
-        print("%-38s n %7d   %8.2f us" % (names.get(tg, tg), n, dt))
-        tot[tg] = tot.get(tg, 0.0) + dt
-    prev = t
-    if tg == 10:
-        break
-print({names[k]: round(v, 1) for k, v in tot.items()})
+         7: "B phase 3 + next phase 1 + barrier", 8: "A done + grid barrier", 9: "B done + grid barrier", 10: "C done", 11: "C round (n = active tiles) + barrier",
+         12: "C seeds -> tiles + barrier"}
+for i in range(NF):
+    feed.step_input(m, i); m.step(); m.sync()
+    st = m.stats()
+    row = m.read_local(vtype=False, dist_sq=False, coc=False)["edt"][size[2] // 2, size[1] // 2, :]
+    prev, tot, cnt, tiles = None, {}, {}, 0
+    lines = []
+    for k in range(0, 1000, 2):
+        t, tag = float(row[k]), int(row[k + 1])
+        tg, n = tag // 1000000, tag % 1000000
+        if tg not in names or (k > 0 and tg == 0):
+            break
+        if prev is not None:
+            dt = (t - prev) % 16777216.0 / 100.0
+            lines.append("%-38s n %7d   %8.2f us" % (names[tg], n, dt))
+            tot[tg] = tot.get(tg, 0.0) + dt; cnt[tg] = cnt.get(tg, 0) + 1
+            if tg == 11:
+                tiles += n
+        prev = t
+        if tg == 10:
+            break
+    print("frame %d: visits %d %d %d  levels %d %d %d | A %.0f us, B %.0f us, C %.0f us in %d rounds (%d tile-rounds)" % (
+        i, st["visits_a"], st["visits_b"], st["visits_c"], st["levels_a"], st["levels_b"], st["levels_c"],
+        sum(tot.get(k, 0) for k in (1, 2, 3, 8)), sum(tot.get(k, 0) for k in (4, 5, 6, 7, 9)), sum(tot.get(k, 0) for k in (10, 11, 12)), cnt.get(11, 0), tiles))
+    if verbose:
+        print("\n".join(lines))
