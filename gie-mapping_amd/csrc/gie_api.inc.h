@@ -13,6 +13,7 @@
 
 enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, GIE_K_ALLOC, GIE_K_FUSE, GIE_K_EDT_Y, GIE_K_EDT_X,
        GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_EDT_ZFACES, GIE_K_MARKC, GIE_K_NUM };
+#include <cstdio>
 static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
        "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "waves", "commit", "edt_prep", "mark_commit" };
 
@@ -486,13 +487,9 @@ extern "C" int gie_merge_end(gie_mapper *m)
     m->merge_open = 0;
     be_prof(&m->be, GIE_K_FRONTIER, 0);
     be_list(&m->be, m->c, op_tile_summary(), m->c.tl_known, GIE_CNT_TL_KNOWN);   /* only tiles with a known voxel can have anything to look at */
-    /* the tiles obtainFrontiers has to look at are few even in a densely observed volume
-     * (surfaces of the known space): always from the list (0.45 -> 0.16 ms on the dense bench run) */
-    {
-        static const int staged = getenv("GIE_FRONT_STAGED") ? atoi(getenv("GIE_FRONT_STAGED")) : 0;   /* staged: 0.64 ms, voxel by voxel: 0.37 ms (C5) */
-        if (staged) be_vox_list<true>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, 1);
-        else be_vox_list<false>(&m->be, m->c, op_frontier(), m->c.tl_front, GIE_CNT_TL_FRONT, 1);
-    }
+    /* obtainFrontiers looks at surfaces of the known space: the listed tiles (tsum == 1) a wave per tile out of LDS, the voxels
+     * on the faces of the volume one per lane (k_frontier_tiles / k_frontier_faces; 0.32 -> 0.1 ms on the C5 workload) */
+    be_frontier_tiles(&m->be, m->c, m->c.tl_front, GIE_CNT_TL_FRONT);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     if (!m->c.fused) {
@@ -529,6 +526,11 @@ static int gie_fetch_counters(gie_mapper *m)
 {
     be_d2h(&m->be, m->h_cnt, m->c.cnt, sizeof(m->h_cnt));
     const int e = m->h_cnt[GIE_CNT_ERR];
+    {   /* GIE_DEBUG_COUNTS=1: the lengths of the device-side lists of the last map update, on stderr */
+        static const int dbg = getenv("GIE_DEBUG_COUNTS") ? atoi(getenv("GIE_DEBUG_COUNTS")) : 0;
+        if (dbg) fprintf(stderr, "gie counts: tiles known %d, frontier tiles %d, fuse tiles %d, seeds A/B/C %d %d %d\n", m->h_cnt[GIE_CNT_TL_KNOWN],
+                         m->h_cnt[GIE_CNT_TL_FRONT], m->h_cnt[GIE_CNT_TL_FUSE], m->h_cnt[GIE_CNT_SEED_A], m->h_cnt[GIE_CNT_SEED_B], m->h_cnt[GIE_CNT_SEED_C]);
+    }
     if (e & ~GIE_ERRF_BARRIER) {
         std::string s = "device capacity exceeded:";
         if (e & GIE_ERRF_POOL) s += " block pool (raise gie_config.max_blocks)";

@@ -195,11 +195,13 @@ struct op_tile_summary {
             v = w ? 1 : (face ? 2 : 0);
         }
         if (real) c.tsum[t] = v;
-        /* the tiles with something to look at, as a list (order is irrelevant) */
+        /* the tiles whose every voxel is looked at, as a list (order is irrelevant): k_frontier_tiles takes a tile per wave from it
+         * — a list of its own, so that consecutive entries cost the same (with the plain face tiles in between, the few waves
+         * whose stride met the tx = 0 tiles did all the work).  The voxels on the faces go by patches of the faces (tsum != 0). */
 #if defined(GIE_HOST_EMU)
-        if (v) c.tl_front[c.cnt[GIE_CNT_TL_FRONT]++] = t;
+        if (v == 1) c.tl_front[c.cnt[GIE_CNT_TL_FRONT]++] = t;
 #else
-        const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FRONT], v != 0);
+        const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FRONT], v == 1);
         if (slot >= 0) c.tl_front[slot] = t;
 #endif
     } };

@@ -1245,6 +1245,262 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
     }
 }
 
+/* ------------------------------------------------------------------ obtainFrontiers: tiles out of LDS, faces one voxel per lane */
+/* obtainFrontiers (unify_helper.cuh:275-446).  The per-voxel decisions are gie_frontier_finish_nb's (gie_ops.h); what the two
+ * kernels here change is where their inputs come from and who looks at which voxel (the thread-per-column form walked a
+ * column's eight voxels one after the other, each a chain of two or three dependent memory round trips — five to seven for a
+ * voxel on a face of the volume: 0.32 ms for 0.4 GB of traffic on the C5 workload).
+ *   k_frontier_tiles  voxels OFF the faces of the volume, over the listed tiles that have something to look at (tsum == 1): a
+ *                     WAVE takes a tile, ONE batch of loads brings the tile's types and Mark-time pairs and those of the
+ *                     one-voxel halo around it into LDS, every voxel's six neighbour types / pairs are LDS reads;
+ *   k_frontier_faces  voxels ON a face — the ones that look at hashed voxels outside the volume (gie_frontier_outside: a chain
+ *                     of dependent round trips, latency-bound) — one per lane, a wave = an 8x8 patch of a face (one tile: the
+ *                     tile summary is wave-uniform), no LDS staging, as many waves in flight as the registers allow; a
+ *                     voxel on several faces goes with the first of them.
+ * Seeds are collected per workgroup / wave in LDS and appended with one atomic each.  The order of the voxels is irrelevant:
+ * a voxel's decision reads only Mark-time state (pairs, tile flags), types up to the FREE / FNT distinction it does not look
+ * at, and the one outside voxel across its own face. */
+#define GIE_FR_CQ 256           /* C seeds a wave collects before it appends them with one atomic */
+struct gie_fr_tile { uint64_t pair[512], hpair[6][64]; int32_t cq[GIE_FR_CQ]; uint8_t typ[512], htyp[6][64]; };        /* 8.9 KB per wave */
+struct gie_nbpair_lds {
+    const gie_fr_tile *L; int ex, ey, ez;
+    __device__ __forceinline__ uint64_t operator()(int k, int) const {
+        const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+        const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
+        const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+        const int hp = (k < 2) ? (ey + 8 * ez) : ((k < 4) ? (ex + 8 * ez) : (ex + 8 * ey));
+        return inside ? L->pair[ux + 8 * uy + 64 * uz] : L->hpair[k][hp];
+    }
+};
+struct gie_absink_none { static constexpr bool outside = false; __device__ __forceinline__ void ab(const gie_ctx &, int, uint64_t, int) const {} };   /* (a voxel off the faces has no outside neighbour) */
+/* append the wave's collected C seeds: one atomic */
+__device__ __forceinline__ void gie_frontier_flush_c(const gie_ctx &c, const int32_t *cq, int &ncq, const int lane)
+{
+    if (ncq == 0) return;                                     /* wave-uniform */
+    gie_wave_sync();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&c.cnt[GIE_CNT_C], ncq);
+    base = __shfl(base, 0);
+    for (int e = lane; e < ncq; e += 64) {
+        if (base + e < c.qcap_c) c.qc[0][base + e] = cq[e];
+        else atomicOr(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    }
+    gie_wave_sync();
+    ncq = 0;
+}
+
+/* 16 when the closest obstacle of pair `pr` lies outside the local volume and inside the wave range: only such a voxel can
+ * make a neighbour a seed of wave C (gie_frontier_finish_nb tests the same again on the pair itself) */
+#define GIE_FR_SRC 16u
+__device__ __forceinline__ uint32_t gie_fr_srcbit(const gie_ctx &c, const uint64_t pr)
+{
+    int nw[3];
+    gie_unpack_wr(gie_pair_par(pr), &nw[0], &nw[1], &nw[2]);
+    const int n0 = nw[0] + c.upvt[0] - c.pvt[0], n1 = nw[1] + c.upvt[1] - c.pvt[1], n2 = nw[2] + c.upvt[2] - c.pvt[2];
+    return (!gie_in_loc(c, n0, n1, n2) && gie_in_wr(c, nw[0], nw[1], nw[2])) ? GIE_FR_SRC : 0u;
+}
+__device__ __forceinline__ void gie_frontier_tile(const gie_ctx &c, gie_fr_tile &L, const int t, const int lane, int &ncq)
+{
+    const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+    const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool colin = x < c.X && y < c.Y;
+    const size_t plane = (size_t)c.X * c.Y;
+    const size_t col = (size_t)y * c.X + x;
+    /* ---- one batch of loads: types and Mark-time pairs of the tile and of the one-voxel halo around it */
+    uint64_t pv[8], hv[6];
+    int8_t tv[8], ht[6];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const bool in = colin && z0 + j < c.Z;
+        const size_t id = in ? (size_t)(z0 + j) * plane + col : 0;
+        tv[j] = c.glb_type[id];
+        pv[j] = c.pair[id];
+        if (!in) tv[j] = -1;
+    }
+    {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z), the lane's position (a, b) on it */
+        const int a = lane & 7, b = lane >> 3;
+        const int hx[6] = { x0 - 1, x0 + 8, x0 + a, x0 + a, x0 + a, x0 + a };
+        const int hy[6] = { y0 + a, y0 + a, y0 - 1, y0 + 8, y0 + b, y0 + b };
+        const int hz[6] = { z0 + b, z0 + b, z0 + b, z0 + b, z0 - 1, z0 + 8 };
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            const bool in = gie_in_loc(c, hx[f], hy[f], hz[f]);
+            const int id = in ? gie_lid(c, hx[f], hy[f], hz[f]) : 0;
+            ht[f] = c.glb_type[id];
+            hv[f] = c.pair[id];
+            if (!in) ht[f] = -1;
+        }
+    }
+    /* staged type byte: type | GIE_FR_SRC; a position outside the volume (only ever next to a voxel on a face, which is not
+     * looked at here): UNKNOWN, no source */
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        L.pair[lane + 64 * j] = pv[j];
+        L.typ[lane + 64 * j] = tv[j] < 0 ? (uint8_t)GIE_VOX_UNKNOWN : (uint8_t)((uint32_t)(tv[j] & 15) | gie_fr_srcbit(c, pv[j]));
+    }
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+        L.hpair[f][lane] = hv[f];
+        L.htyp[f][lane] = ht[f] < 0 ? (uint8_t)GIE_VOX_UNKNOWN : (uint8_t)((uint32_t)(ht[f] & 15) | gie_fr_srcbit(c, hv[f]));
+    }
+    gie_wave_sync();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const bool xyface = x == 0 || x == c.X - 1 || y == 0 || y == c.Y - 1;
+    /* ---- the lane's column, voxels off the faces.  A voxel acts only next to a source (C seed) or, FREE itself, next to an
+     * unknown voxel (FNT): a trip none of whose voxels does is skipped, the others run the reference's decisions in full. */
+#pragma unroll 1
+    for (int ez = 0; ez < 8; ez++) {
+        const int vz = z0 + ez;
+        const bool go = colin && vz < c.Z && !xyface && vz != 0 && vz != c.Z - 1;
+        const int v = lane + 64 * ez;
+        const uint32_t own = L.typ[v];
+        uint32_t nn[6], src = 0;
+        bool unk = false;
+        const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int ux = lx + dx[k], uy = ly + dy[k], uz = ez + dz[k];
+            const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+            const int hp = (k < 2) ? (ly + 8 * ez) : ((k < 4) ? (lx + 8 * ez) : (lx + 8 * ly));
+            nn[k] = inside ? L.typ[ux + 8 * uy + 64 * uz] : L.htyp[k][hp];
+            src |= ((nn[k] >> 4) & 1u) << k;
+            unk |= (nn[k] & 15u) == (uint32_t)GIE_VOX_UNKNOWN;
+        }
+        const bool need = go && (own & 15u) != (uint32_t)GIE_VOX_UNKNOWN && (src != 0u || ((own & 15u) == (uint32_t)GIE_VOX_FREE && unk));
+        if (__ballot(need) == 0ull) continue;                 /* wave-uniform */
+        int push = 0, id = 0;
+        if (need) {
+            id = gie_lid(c, x, y, vz);
+            gie_frontier_st s;
+            s.p0 = L.pair[v];
+            s.tys = own & 15u;
+            s.tfm = src;                                       /* (the reference path gates the neighbour's pair by its TILE's flag: a superset) */
+#pragma unroll
+            for (int k = 0; k < 6; k++) s.tys |= (nn[k] & 15u) << (4 * (k + 1));
+            const gie_nbpair_lds nb = { &L, lx, ly, ez };
+            push = gie_frontier_finish_nb(c, id, x, y, vz, s, nb, gie_absink_none());
+        }
+        const unsigned long long m = __ballot(push);         /* C seeds of the trip join the wave's list */
+        if (m) {
+            if (push) L.cq[ncq + __popcll(m & lt)] = id;
+            ncq += __popcll(m);
+            if (ncq > GIE_FR_CQ - 64) gie_frontier_flush_c(c, L.cq, ncq, lane);
+        }
+    }
+    gie_wave_sync();                                            /* the LDS block is reused for the wave's next tile */
+}
+#define GIE_FR_WAVES 4
+__global__ __launch_bounds__(64 * GIE_FR_WAVES) void k_frontier_tiles(const gie_ctx c, const int32_t *list, const int count_idx)
+{
+    __shared__ gie_fr_tile s_tiles[GIE_FR_WAVES];
+    const int n = c.cnt[count_idx];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stride = gridDim.x * GIE_FR_WAVES;
+    int ncq = 0;
+    int e = blockIdx.x * GIE_FR_WAVES + wave;
+    int t = e < n ? list[e] : 0;
+    while (e < n) {
+        const int tn = e + stride < n ? list[e + stride] : 0;   /* the next entry travels with this tile's batch */
+        gie_frontier_tile(c, s_tiles[wave], t, lane, ncq);
+        t = tn; e += stride;
+    }
+    gie_frontier_flush_c(c, s_tiles[wave].cq, ncq, lane);
+}
+
+/* the seeds of waves A / B the face voxels of a workgroup produce, collected in LDS (bit 63 of the coordinate: frontier A) */
+#define GIE_FR_ABIT ((uint64_t)1 << 63)
+#define GIE_FF_WAVES 4
+#define GIE_FF_AB (64 * GIE_FF_WAVES * 3)                     /* three outside neighbours per voxel: a corner of the volume */
+struct gie_ff_wg { uint64_t ab_crd[GIE_FF_AB]; int32_t ab_addr[GIE_FF_AB]; int32_t cq[64 * GIE_FF_WAVES]; int32_t nab, ncq, base[3], pad_; };   /* 10.3 KB */
+struct gie_absink_lds {
+    static constexpr bool outside = true;
+    gie_ff_wg *L;
+    __device__ __forceinline__ void ab(const gie_ctx &c, int push, uint64_t crd, int a) const {
+        if (!push) return;
+        const int i = __hip_atomic_fetch_add(&L->nab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (i < GIE_FF_AB) { L->ab_crd[i] = crd | (push == 2 ? GIE_FR_ABIT : (uint64_t)0); L->ab_addr[i] = (int32_t)a; }
+        else if (push == 2) gie_push64a(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, crd, a);    /* (volumes one or two voxels thick: more than three outside neighbours per voxel) */
+        else gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, crd, a);
+    }
+};
+/* patches of 8x8 voxels per face: face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z) spans (Y, Z), (X, Z) or (X, Y) */
+struct gie_face_patches { int off[7], na[6]; };
+__global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_ctx c, const gie_face_patches fp)
+{
+    __shared__ gie_ff_wg W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { W.nab = 0; W.ncq = 0; }
+    __syncthreads();
+    const int p = blockIdx.x * GIE_FF_WAVES + wave;             /* the wave's patch */
+    int push = 0, id = 0;
+    if (p < fp.off[6]) {
+        int f = 0;
+#pragma unroll
+        for (int k = 1; k < 6; k++) if (p >= fp.off[k]) f = k;
+        const int q = p - fp.off[f], pa = q % fp.na[f], pb = q / fp.na[f];
+        const int a = pa * 8 + (lane & 7), b = pb * 8 + (lane >> 3);
+        const int fix = (f & 1) ? ((f == 1) ? c.X - 1 : (f == 3) ? c.Y - 1 : c.Z - 1) : 0;
+        const int vx = (f < 2) ? fix : a, vy = (f < 2) ? a : ((f < 4) ? fix : b), vz = (f < 4) ? b : fix;
+        bool go = vx < c.X && vy < c.Y && vz < c.Z;
+        const bool fx0 = vx == 0, fx1 = vx == c.X - 1, fy0 = vy == 0, fy1 = vy == c.Y - 1, fz0 = vz == 0;
+        /* on an earlier face: that face's patch has it */
+        if ((f >= 1 && fx0) || (f >= 2 && fx1) || (f >= 3 && fy0) || (f >= 4 && fy1) || (f >= 5 && fz0)) go = false;
+        if (go && c.tsum[gie_tile_index(c, vx, vy, vz)] == 0) go = false;         /* (one tile per patch: wave-uniform) */
+        if (go) {
+            id = gie_lid(c, vx, vy, vz);
+            if (c.glb_type[id] != GIE_VOX_UNKNOWN) {
+                gie_frontier_st s;
+                gie_frontier_load1(c, id, vx, vy, vz, s);
+                const gie_nbpair_mem nb = { c.pair };
+                const gie_absink_lds sink = { &W };
+                push = gie_frontier_finish_nb(c, id, vx, vy, vz, s, nb, sink);
+            }
+        }
+    }
+    if (push) W.cq[__hip_atomic_fetch_add(&W.ncq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = id;
+    __syncthreads();
+    /* ---- one atomic per list and workgroup */
+    const int nab = min(W.nab, GIE_FF_AB), ncq = W.ncq;
+    if (nab == 0 && ncq == 0) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (wave == 0) {
+        /* entries of frontier A first, then B: the ranks come from two passes of ballots over the list */
+        int na = 0;
+        for (int e0 = 0; e0 < nab; e0 += 64) na += __popcll(__ballot(e0 + lane < nab && (W.ab_crd[e0 + lane] & GIE_FR_ABIT) != 0));
+        if (lane < 3) {                                          /* the three appends in flight together */
+            const int cnt = (lane == 0) ? na : (lane == 1) ? nab - na : ncq;
+            int32_t *const ctr = &c.cnt[(lane == 0) ? GIE_CNT_A : (lane == 1) ? GIE_CNT_B : GIE_CNT_C];
+            W.base[lane] = cnt > 0 ? gie_aadd32(ctr, cnt) : 0;
+        }
+        gie_wave_sync();
+        int ra = W.base[0], rb = W.base[1];
+        for (int e0 = 0; e0 < nab; e0 += 64) {
+            const int e = e0 + lane;
+            const bool have = e < nab;
+            const uint64_t crd = have ? W.ab_crd[e] : (uint64_t)0;
+            const bool isa = have && (crd & GIE_FR_ABIT) != 0, isb = have && !isa;
+            const unsigned long long ma = __ballot(isa), mb = __ballot(isb);
+            if (isa) {
+                const int i = ra + __popcll(ma & lt);
+                if (i < c.qcap_ab) { gie_st(&c.qa[0][i], (uint64_t)(crd & ~GIE_FR_ABIT)); gie_st(&c.qa_a[0][i], W.ab_addr[e]); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+            }
+            if (isb) {
+                const int i = rb + __popcll(mb & lt);
+                if (i < c.qcap_ab) { gie_st(&c.qb[0][i], crd); gie_st(&c.qb_a[0][i], W.ab_addr[e]); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+            }
+            ra += __popcll(ma); rb += __popcll(mb);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ncq; e += 64 * GIE_FF_WAVES) {
+        const int i = W.base[2] + e;
+        if (i < c.qcap_c) c.qc[0][i] = W.cq[e];
+        else atomicOr(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    }
+}
+
 /* ------------------------------------------------------------------ block-row sweeps */
 /* The sweeps that touch the global map (fuse, Mark + commit) in their dense form.  A thread owns one
  * ROW OF A GLOBAL BLOCK — the 8 voxels (8 bx .. 8 bx + 7, gy, gz) — for the eight z layers of the block,

@@ -567,11 +567,14 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
     const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
     const int a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
     if (a < 0) return 2;
-    if (c.g_type[a] == GIE_VOX_UNKNOWN) return 2;
+    /* the neighbour's record in one batch of loads (a face voxel is a chain of dependent round trips) */
+    const int8_t nty = c.g_type[a];
     const int nd = c.g_dist[a];
+    const uint64_t ncoc = c.g_coc[a];
+    if (nty == GIE_VOX_UNKNOWN) return 2;
     if (gie_invalid_dist(c, nd)) return 0;
     int ncx, ncy, ncz;
-    gie_unpack_crd(c.g_coc[a], &ncx, &ncy, &ncz);
+    gie_unpack_crd(ncoc, &ncx, &ncy, &ncz);
     if (gie_invalid_coc(ncx, ncy, ncz)) return 0;
     const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
     const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
@@ -630,7 +633,25 @@ GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, g
     for (int k = 0; k < 6; k++) { s.tys |= (uint32_t)(ty[k + 1] & 15) << (4 * (k + 1)); s.tfm |= (tf[k] ? 1u : 0u) << k; }
 }
 
-GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s)
+/* `nb(k, nid)` = the Mark-time pair of the in-volume neighbour k (local index nid): from memory (gie_nbpair_mem), or from
+ * the tile a wave has staged in LDS (k_frontier_tiles) */
+#if defined(GIE_HOST_EMU)
+#define GIE_DEV_MEMBER inline
+#else
+#define GIE_DEV_MEMBER __device__ __forceinline__
+#endif
+struct gie_nbpair_mem { const uint64_t *pair; GIE_DEV_MEMBER uint64_t operator()(int, int nid) const { return pair[nid]; } };
+/* `sink.ab(c, push, crd, a)` = the outside neighbour at global coordinate crd (address a) joins frontier B (push == 1) or
+ * frontier A (push == 2); called by every executing lane for every direction: straight into the queues with one atomic per
+ * wave and call (gie_absink_queues), or collected per tile in LDS (k_frontier_tiles) */
+struct gie_absink_queues {
+    static constexpr bool outside = true;                  /* false: the caller only hands over voxels off the faces (no outside neighbour: that branch is not compiled) */
+    GIE_DEV_MEMBER void ab(const gie_ctx &c, int push, uint64_t crd, int a) const {
+        gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, push == 1, crd, a);
+        gie_push64a_wave(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, push == 2, crd, a);
+    } };
+template <class NB, class SINK>
+GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s, const NB &nb, const SINK &sink)
 {
     const int8_t ty = (int8_t)(s.tys & 15u);
     if (ty == GIE_VOX_UNKNOWN) return 0;
@@ -655,7 +676,7 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
              * flagged the 8x8x8 tiles that contain one */
             if (!((s.tfm >> k) & 1u)) continue;
             int nw[3];
-            gie_unpack_wr(gie_pair_par(c.pair[nid]), &nw[0], &nw[1], &nw[2]);
+            gie_unpack_wr(gie_pair_par(nb(k, nid)), &nw[0], &nw[1], &nw[2]);
             const int nl[3] = { nw[0] + c.upvt[0] - c.pvt[0], nw[1] + c.upvt[1] - c.pvt[1], nw[2] + c.upvt[2] - c.pvt[2] };
             if (!gie_in_loc(c, nl[0], nl[1], nl[2]) && gie_in_wr(c, nw[0], nw[1], nw[2])) {
                 const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
@@ -664,19 +685,18 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
                     cur_in_q = 1;
                 }
             }
-        } else {
+        } else if (SINK::outside) {
             /* a neighbour outside the volume (only voxels on the six faces get here): kept out of
              * line so that the hot interior path stays small */
             const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed, &opush[k], &oaddr[k]);
             cur_in_q |= r & 1; has_unknown |= (r >> 1) & 1;
         }
     }
-    if (!c.fast_mode && (x == 0 || y == 0 || z == 0 || x == c.X - 1 || y == c.Y - 1 || z == c.Z - 1)) {
+    if (SINK::outside && !c.fast_mode && (x == 0 || y == 0 || z == 0 || x == c.X - 1 || y == c.Y - 1 || z == c.Z - 1)) {
         GIE_UNROLL6
         for (int k = 0; k < 6; k++) {                     /* neighbours outside the volume that seed wave B / wave A */
             const uint64_t crd = gie_pack_crd(x + dx[k] + c.pvt[0], y + dy[k] + c.pvt[1], z + dz[k] + c.pvt[2]);
-            gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, opush[k] == 1, crd, oaddr[k]);
-            gie_push64a_wave(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, opush[k] == 2, crd, oaddr[k]);
+            sink.ab(c, opush[k], crd, oaddr[k]);
         }
     }
     if (cur_in_q) { c.wl[id] = GIE_WL_SEED(c); c.cand[1][id] = seed; }   /* the pair the seed enters wave C with */
@@ -688,6 +708,11 @@ GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, c
         }
     }
     return cur_in_q;
+}
+GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s)
+{
+    const gie_nbpair_mem nb = { c.pair };
+    return gie_frontier_finish_nb(c, id, x, y, z, s, nb, gie_absink_queues());
 }
 GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
 {

@@ -13,6 +13,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+if [ "${TRACE_ONLY:-0}" = "1" ]; then
+  T=$(find $OUT/trace -name "*.db" | head -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (MI355X)"; python $ROOT/tools/rocpd_summary.py stats "$T"; } > $OUT/kernel_stats.txt
+  rm -rf $OUT/trace; cat $OUT/kernel_stats.txt; exit 0
+fi
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/write.err
 cd $ROOT
