@@ -1706,8 +1706,6 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t plane = (size_t)c.X * c.Y;
-    const int kq = (((K + 3) >> 2) + 3) & ~3;              /* planes per wave, a multiple of the four reads in flight */
-    const int jlo = w * kq, jhi = min(K, jlo + kq);
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const int t = c.tl_known[e];
         const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
@@ -1719,19 +1717,47 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
         uint32_t best[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) best[k] = 0xffffffffu;
-        for (int j0 = jlo; j0 < jhi; j0 += 4) {
-            int zj[4]; uint32_t v[4];
+        /* The planes are taken outwards from the tile — first the ones at or above its lowest layer (rank js, js + 1, ...),
+         * then the ones below (js - 1, js - 2, ...), every wave each fourth plane of a side — and a side ends where the
+         * plane's distance to the tile alone (dz², nearest layer) exceeds every minimum this wave holds: such a plane can
+         * neither win nor tie, and the planes behind it are farther still.  (The wave's own minima bound the merged ones
+         * from above, so the test is conservative.)  A tile near obstacles reads a handful of planes instead of all K. */
+        int js = 0;
+        for (int lo = 0, hi = K; lo < hi;) { const int mid = (lo + hi) >> 1; if ((int)s_zl[mid] < z0) lo = mid + 1; else hi = mid; js = lo; }
+#pragma unroll 1
+        for (int side = 0; side < 2; side++) {
+            for (int i0 = 0;; i0 += 4) {
+                /* this wave's planes of the trip: ranks base +- (4 (i0 + u) + w) */
+                int jj[4], zj[4]; uint32_t v[4];
+                bool any_plane = false;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int j = j0 + u < jhi ? j0 + u : jhi - 1; zj[u] = s_zl[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; }
+                for (int u = 0; u < 4; u++) {
+                    const int r = 4 * (i0 + u) + w;
+                    const int j = side ? js - 1 - r : js + r;
+                    const bool have = side ? j >= 0 : j < K;
+                    jj[u] = have ? j : -1;
+                    any_plane |= have;
+                }
+                if (!any_plane) break;                              /* wave-uniform */
+                {   /* the nearest plane of the trip is the first one: out of reach for every voxel of the tile? */
+                    const int zn = s_zl[jj[0] >= 0 ? jj[0] : 0];
+                    const int dzn = side ? z0 - zn : max(zn - (z0 + 7), 0);
+                    uint32_t mx = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u < jhi ? j0 + u : jhi - 1;       /* a repeated site does not change a minimum */
-                const int dx = x - (int)(v[u] & 0xffffu), dy = y - (int)(v[u] >> 16);
-                const uint32_t a = (uint32_t)(dx * dx + dy * dy);
+                    for (int k = 0; k < 8; k++) mx = max(mx, best[k] >> 10);
+                    if (jj[0] < 0 || !__any((uint32_t)(dzn * dzn) <= mx)) break;
+                }
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int dz = z0 + k - zj[u];
-                    best[k] = min(best[k], ((a + (uint32_t)(dz * dz)) << 10) | (uint32_t)j);
+                for (int u = 0; u < 4; u++) { const int j = jj[u] >= 0 ? jj[u] : jj[0]; zj[u] = s_zl[j]; v[u] = c.cxy2[(size_t)zj[u] * plane + o]; jj[u] = j; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {                       /* (a repeated site does not change a minimum) */
+                    const int dx = x - (int)(v[u] & 0xffffu), dy = y - (int)(v[u] >> 16);
+                    const uint32_t a = (uint32_t)(dx * dx + dy * dy);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int dz = z0 + k - zj[u];
+                        best[k] = min(best[k], ((a + (uint32_t)(dz * dz)) << 10) | (uint32_t)jj[u]);
+                    }
                 }
             }
         }
