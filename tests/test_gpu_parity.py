@@ -281,6 +281,60 @@ def test_full_size_512_cube_hash_world(oracle_lib):
 
 
 @pytest.mark.gpu
+def test_full_size_512_cube_flood_of_wave_c(oracle_lib):
+    """A FLOOD at full size (BASELINE config 3's regime: 512^3, 16-ring lidar through the projective OGM, waves A / B / C): the
+    bench's `vlp16_projective` workload until an update in which a box of the world has vanished and wave C re-floods what it
+    shadowed — millions of visits, dozens of tile rounds (frame 7: 10 M visits in 50 rounds).  The scalar oracle needs minutes per
+    update at this size, so the result is pinned by what it has to be: every known voxel's distance is witnessed by its closest
+    obstacle; a closest obstacle inside the volume is an OCCUPIED voxel and exactly as far as the independent exact CPU EDT of
+    the volume's own obstacles says (oracle/edt_mt.c, pinned by brute force); one outside the volume is at most that far and
+    a voxel the global map believes occupied."""
+    import bench
+    from gie import scenes
+    from oracle_py import edt_mt
+    size = (512, 512, 512)
+    cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
+    rings, az, phi_min, phi_inc, bins = bench.LIDARS["vlp16_projective"]
+    kw = dict(theta_inc=2.0 * np.pi / bins, theta_min=-np.pi, phi_inc=np.radians(phi_inc), phi_min=np.radians(phi_min))
+    world = bench.lidar_world(scenes)
+    b = gie.Mapper(cfg)
+    try:
+        flooded = False
+        for k in range(12):
+            pos, q, img, _ = bench.lidar_host_frame(scenes, world, 0.05, "vlp16_projective", k)
+            b.set_pose(pos, q)
+            b.ogm_multiscan(img, **kw)
+            b.step()
+            st = b.stats()
+            if st["visits_c"] < 1000000:
+                continue
+            flooded = True
+            assert st["levels_c"] >= 10
+            rb = b.read_local(edt=False)
+            ty = rb["type"]
+            known = (ty != 0) & (rb["dist_sq"] < 4000000)
+            d_cpu, _ = edt_mt(ty, want_coc=False)
+            pv = np.array(b.pivot(), dtype=np.int64)
+            cl = rb["coc"].astype(np.int64) - pv
+            inside = ((cl >= 0) & (cl < 512)).all(-1) & known
+            outside = known & ~inside
+            assert int(known.sum()) > 20000000 and inside.any() and outside.any()
+            assert np.array_equal(rb["dist_sq"][inside], d_cpu[inside]), "%d voxels differ from the exact EDT" % int((rb["dist_sq"][inside] != d_cpu[inside]).sum())
+            ci = cl[inside]
+            assert (ty[ci[:, 2], ci[:, 1], ci[:, 0]] == 2).all()
+            assert (rb["dist_sq"][outside] <= d_cpu[outside]).all()
+            far = np.ascontiguousarray(rb["coc"][outside][::997][:4096], dtype=np.int32)
+            assert (b.query_global(far)["vox_type"] == 2).all()
+            zz, yy, xx = np.nonzero(known)
+            g = np.stack([xx, yy, zz], -1) + pv
+            assert np.array_equal(((rb["coc"][known].astype(np.int64) - g) ** 2).sum(-1), rb["dist_sq"][known])
+            break
+        assert flooded, "no flood within 12 updates"
+    finally:
+        b.close()
+
+
+@pytest.mark.gpu
 def test_full_size_512_cube_ray_casting(oracle_lib):
     """The bench's default workload at full size: 512^3 @ 0.05 m, VLP-16 cloud through parallel
     ray casting (sparse observation: tile lists, direct pass Z, scan labels on demand).  Three map
