@@ -486,10 +486,10 @@ extern "C" int gie_merge_end(gie_mapper *m)
     if (!m->merge_open) { gie_set_err("gie_merge_end: gie_merge_begin has not been called"); return GIE_ERR_INVALID; }
     m->merge_open = 0;
     be_prof(&m->be, GIE_K_FRONTIER, 0);
-    be_list(&m->be, m->c, op_tile_summary(), m->c.tl_known, GIE_CNT_TL_KNOWN);   /* only tiles with a known voxel can have anything to look at */
-    /* obtainFrontiers looks at surfaces of the known space: the listed tiles (tsum == 1) a wave per tile out of LDS, the voxels
-     * on the faces of the volume one per lane (k_frontier_tiles / k_frontier_faces; 0.32 -> 0.1 ms on the C5 workload) */
-    be_frontier_tiles(&m->be, m->c, m->c.tl_front, GIE_CNT_TL_FRONT);
+    /* obtainFrontiers looks at surfaces of the known space.  One launch: the tile summary (only tiles with a known voxel can have
+     * anything to look at) + the voxels on the faces of the volume, one per lane; then the listed tiles (tsum == 1), a wave
+     * per tile out of LDS (k_frontier_faces / k_frontier_tiles; 0.32 -> 0.15 ms on the C5 workload) */
+    be_frontier_tiles(&m->be, m->c, m->c.tl_known, GIE_CNT_TL_KNOWN, m->c.tl_front, GIE_CNT_TL_FRONT);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     if (!m->c.fused) {

@@ -174,26 +174,27 @@ struct op_frontier { static constexpr bool rolled = false;
 struct op_tile_summary {
     /* tile holds an unknown voxel: fuse said so, or fuse never looked at it (then it is all-unknown) */
     GIE_DEVM static int unk(const gie_ctx &c, int t) { return c.tunk[t] | (c.tact[t] ^ 1); }
+    /* 1: every voxel of the tile is looked at; 2: a tile on a face of the volume whose surroundings hold neither an unknown
+     * voxel nor a closest obstacle outside the volume — only the voxels on the face itself can act; 0: nothing to look at */
+    GIE_DEVM static uint8_t value(const gie_ctx &c, int t) {
+        if (!c.tknown[t]) return 0;
+        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+        const bool face = tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1;
+        const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
+        int w = unk(c, t) | c.tflag[t];
+        if (tx > 0) w |= unk(c, t - sx) | c.tflag[t - sx];
+        if (tx < c.tfd[0] - 1) w |= unk(c, t + sx) | c.tflag[t + sx];
+        if (ty > 0) w |= unk(c, t - sy) | c.tflag[t - sy];
+        if (ty < c.tfd[1] - 1) w |= unk(c, t + sy) | c.tflag[t + sy];
+        if (tz > 0) w |= unk(c, t - sz) | c.tflag[t - sz];
+        if (tz < c.tfd[2] - 1) w |= unk(c, t + sz) | c.tflag[t + sz];
+        return w ? 1 : (face ? 2 : 0);
+    }
     /* called for the tiles on tl_known (t = -1: a padding lane of the last wave) */
     GIE_DEVM void operator()(const gie_ctx &c, int t) const {
         const bool real = t >= 0;
         if (!real) t = 0;
-        const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
-        uint8_t v = 0;
-        if (real && c.tknown[t]) {
-            const bool face = tx == 0 || ty == 0 || tz == 0 || tx == c.tfd[0] - 1 || ty == c.tfd[1] - 1 || tz == c.tfd[2] - 1;
-            const int sx = 1, sy = c.tfd[0], sz = c.tfd[0] * c.tfd[1];
-            int w = unk(c, t) | c.tflag[t];
-            if (tx > 0) w |= unk(c, t - sx) | c.tflag[t - sx];
-            if (tx < c.tfd[0] - 1) w |= unk(c, t + sx) | c.tflag[t + sx];
-            if (ty > 0) w |= unk(c, t - sy) | c.tflag[t - sy];
-            if (ty < c.tfd[1] - 1) w |= unk(c, t + sy) | c.tflag[t + sy];
-            if (tz > 0) w |= unk(c, t - sz) | c.tflag[t - sz];
-            if (tz < c.tfd[2] - 1) w |= unk(c, t + sz) | c.tflag[t + sz];
-            /* 1: every voxel of the tile is looked at; 2: a tile on a face of the volume whose surroundings hold neither an
-             * unknown voxel nor a closest obstacle outside the volume — only the voxels on the face itself can act */
-            v = w ? 1 : (face ? 2 : 0);
-        }
+        const uint8_t v = real ? value(c, t) : 0;
         if (real) c.tsum[t] = v;
         /* the tiles whose every voxel is looked at, as a list (order is irrelevant): k_frontier_tiles takes a tile per wave from it
          * — a list of its own, so that consecutive entries cost the same (with the plain face tiles in between, the few waves

@@ -304,9 +304,19 @@ template <class F> static void be_range(be_state *b, const gie_ctx &c, const F &
     const int wgs = (n + 1023) / 1024;
     GIE_LAUNCH(b, k_range<F>, dim3(wgs < b->cu_total ? wgs : b->cu_total), dim3(1024), 0, c, f, n);
 }
-/* obtainFrontiers: a wave per listed tile for the voxels off the faces (tile + halo staged in LDS), then the face voxels one per lane */
-static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *list, int count_idx)
+/* obtainFrontiers: the voxels on the six faces of the volume one per lane (an 8x8 patch per wave) with the tile summary + tile
+ * list in the first workgroups of the same launch, then a wave per listed tile for the voxels off the faces (tile + halo
+ * staged in LDS) */
+static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx, const int32_t *list, int count_idx)
 {
+    gie_face_patches fp;
+    const int da[6] = { c.Y, c.Y, c.X, c.X, c.X, c.X }, db[6] = { c.Z, c.Z, c.Z, c.Z, c.Y, c.Y };
+    fp.off[0] = 0;
+    for (int f = 0; f < 6; f++) { fp.na[f] = (da[f] + 7) / 8; fp.off[f + 1] = fp.off[f] + fp.na[f] * ((db[f] + 7) / 8); }
+    const long long ntile = (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
+    int nsum = (int)((ntile + 64 * GIE_FF_WAVES - 1) / (64 * GIE_FF_WAVES));
+    if (nsum > 2 * b->cu_total) nsum = 2 * b->cu_total;
+    GIE_LAUNCH(b, k_frontier_faces, dim3(nsum + (fp.off[6] + GIE_FF_WAVES - 1) / GIE_FF_WAVES), dim3(64 * GIE_FF_WAVES), 0, c, fp, known, known_idx, nsum);
     static int mult = getenv("GIE_FRONT_MULT") ? atoi(getenv("GIE_FRONT_MULT")) : 0;
     if (mult <= 0) {    /* as many workgroups as are resident at once: every wave walks the same share of the list (a second round of workgroups would start when the first is done) */
         int per_cu = 0;
@@ -314,12 +324,6 @@ static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *list
         mult = per_cu;
     }
     GIE_LAUNCH(b, k_frontier_tiles, dim3(b->cu_total * mult), dim3(64 * GIE_FR_WAVES), 0, c, list, count_idx);
-    /* the voxels on the six faces of the volume, an 8x8 patch per wave */
-    gie_face_patches fp;
-    const int da[6] = { c.Y, c.Y, c.X, c.X, c.X, c.X }, db[6] = { c.Z, c.Z, c.Z, c.Z, c.Y, c.Y };
-    fp.off[0] = 0;
-    for (int f = 0; f < 6; f++) { fp.na[f] = (da[f] + 7) / 8; fp.off[f + 1] = fp.off[f] + fp.na[f] * ((db[f] + 7) / 8); }
-    GIE_LAUNCH(b, k_frontier_faces, dim3((fp.off[6] + GIE_FF_WAVES - 1) / GIE_FF_WAVES), dim3(64 * GIE_FF_WAVES), 0, c, fp);
 }
 static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {

@@ -1427,13 +1427,25 @@ struct gie_absink_lds {
 };
 /* patches of 8x8 voxels per face: face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z) spans (Y, Z), (X, Z) or (X, Y) */
 struct gie_face_patches { int off[7], na[6]; };
-__global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_ctx c, const gie_face_patches fp)
+/* The first `nsum` workgroups of the launch build the tile summary and the list k_frontier_tiles walks (op_tile_summary over
+ * the known tiles) — the face voxels do not wait for it: a patch is one tile, and its summary value is a dozen wave-uniform
+ * flag reads (op_tile_summary::value) — so the summary costs no launch of its own and runs under the face voxels' chains. */
+__global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_ctx c, const gie_face_patches fp, const int32_t *known, const int known_idx, const int nsum)
 {
+    if ((int)blockIdx.x < nsum) {
+        const int n = c.cnt[known_idx];
+        const op_tile_summary f;
+        for (int e0 = blockIdx.x * blockDim.x; e0 < n; e0 += nsum * blockDim.x) {     /* whole workgroups call (block barriers inside) */
+            const int e = e0 + (int)threadIdx.x;
+            f(c, e < n ? known[e] : -1);
+        }
+        return;
+    }
     __shared__ gie_ff_wg W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { W.nab = 0; W.ncq = 0; }
     __syncthreads();
-    const int p = blockIdx.x * GIE_FF_WAVES + wave;             /* the wave's patch */
+    const int p = ((int)blockIdx.x - nsum) * GIE_FF_WAVES + wave;             /* the wave's patch */
     int push = 0, id = 0;
     if (p < fp.off[6]) {
         int f = 0;
@@ -1447,7 +1459,7 @@ __global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_
         const bool fx0 = vx == 0, fx1 = vx == c.X - 1, fy0 = vy == 0, fy1 = vy == c.Y - 1, fz0 = vz == 0;
         /* on an earlier face: that face's patch has it */
         if ((f >= 1 && fx0) || (f >= 2 && fx1) || (f >= 3 && fy0) || (f >= 4 && fy1) || (f >= 5 && fz0)) go = false;
-        if (go && c.tsum[gie_tile_index(c, vx, vy, vz)] == 0) go = false;         /* (one tile per patch: wave-uniform) */
+        if (go && op_tile_summary::value(c, gie_tile_index(c, vx, vy, vz)) == 0) go = false;         /* (one tile per patch: wave-uniform) */
         if (go) {
             id = gie_lid(c, vx, vy, vz);
             if (c.glb_type[id] != GIE_VOX_UNKNOWN) {

@@ -86,7 +86,8 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
 }
 /* the device takes the listed tiles (tsum == 1) a wave per tile and the face voxels by patches of the faces; here: every voxel
  * the tile summary does not rule out (op_frontier::tile_skip / skip), same decisions per voxel */
-static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *, int) { be_vox(b, c, op_frontier()); }
+static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx, const int32_t *, int)
+{ be_list(b, c, op_tile_summary(), known, known_idx); be_vox(b, c, op_frontier()); }
 static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels) { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 template <class F> static void be_range(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
