@@ -428,15 +428,13 @@ extern "C" int gie_fuse(gie_mapper *m)
         add(c.wc_flag[0], 2 * ntile * sizeof(int32_t));          /* (zero again after every complete wave C; a wave cut short may leave flags) */
         be_clear(&m->be, l);
     }
-    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0);
-    /* the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
-     * earlier frames); fuse, Mark, commit and pass Z walk their list or sweep the volume — each kernel
-     * decides from the length of its list (gie_use_lists) */
-    be_range(&m->be, m->c, op_fuse_list(), (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
+    /* + the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
+     * earlier frames), listed in the block-initialisation launch; fuse, Mark, commit and pass Z walk their list or
+     * sweep the volume — each kernel decides from the length of its list (gie_use_lists) */
+    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0, (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     be_prof(&m->be, GIE_K_ALLOC, 1);
     be_prof(&m->be, GIE_K_FUSE, 0);
-    be_vox_list<true>(&m->be, m->c, op_fuse(), m->c.tl_front, GIE_CNT_TL_FUSE, be_rows_mode());
-    be_fuse_rows(&m->be, m->c);
+    be_fuse(&m->be, m->c, m->c.tl_front);
     be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
     return GIE_OK;

@@ -210,11 +210,14 @@ static void be_clear(be_state *b, const gie_clear_list &l)
     if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(32, l.n), dim3(256), 0, l);
 }
 /* allocHashTB + block table (see k_cell_alloc) */
-static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, int clear_list)
+/* fuse_list_ntile > 0: the fuse tile list (op_fuse_list over that many tiles) is built in the block-initialisation launch */
+static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, int clear_list, int fuse_list_ntile = 0)
 {
     if (clear_list) GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_NEWLIST], 0, sizeof(int32_t), b->stream));
     GIE_LAUNCH(b, k_cell_alloc, dim3((ncell + 255) / 256), dim3(256), 0, c, ncell);
-    GIE_LAUNCH(b, k_block_init_list, dim3(b->cu_total * 4), dim3(256), 0, c);
+    const int ninit = b->cu_total * 4;
+    int nfl = (fuse_list_ntile + 255) / 256; if (nfl > 2 * b->cu_total) nfl = 2 * b->cu_total;
+    GIE_LAUNCH(b, k_block_init_list, dim3(ninit + nfl), dim3(256), 0, c, ninit, fuse_list_ntile);
 }
 static void be_free_rays(be_state *b, const gie_ctx &c, const float *g, int n)
 {
@@ -288,10 +291,13 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
 static int be_sweep_lx(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return (v == 8 || v == 16 || v == 32) ? v : 64; }
 /* dense (block-row) form of fuse; GIE_ROWS=0 keeps the thread-per-z-column sweep */
 static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(getenv("GIE_ROWS")) : 1; return v ? 2 : 0; }
-static void be_fuse_rows(be_state *b, const gie_ctx &c)
+/* fuse: one launch — the kernel walks its tile list (a wave per tile) or sweeps the volume by block rows, whichever the list's
+ * length calls for; GIE_ROWS=0: the thread-per-z-column sweep of k_voxa instead of the block rows */
+static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list)
 {
     static const int mult = getenv("GIE_ROWS_MULT") ? atoi(getenv("GIE_ROWS_MULT")) : 16;
-    if (be_rows_mode()) GIE_LAUNCH(b, k_fuse_rows, dim3(b->cu_total * mult), dim3(256), 0, c);
+    if (be_rows_mode()) GIE_LAUNCH(b, k_fuse_rows, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
+    else be_vox_list<true>(b, c, op_fuse(), list, GIE_CNT_TL_FUSE, 0);
 }
 template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
 {

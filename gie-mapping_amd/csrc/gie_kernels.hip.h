@@ -365,12 +365,23 @@ __global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int n
         if (found >= 0) gie_cell_mark_tiles(c, i);
     }
 }
-/* initialise the 512 voxels of every block on the list (one workgroup per block, grid-stride) */
-__global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c)
+/* initialise the 512 voxels of every block on the list (one workgroup per block, grid-stride).  The workgroups behind the
+ * first `ninit` build the fuse tile list (op_fuse_list over the `ntile` tiles of the volume; 0: none): the two only read what
+ * k_cell_alloc has left and touch different data, so they share a launch. */
+__global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c, const int ninit, const int ntile)
 {
+    if ((int)blockIdx.x >= ninit) {
+        const op_fuse_list f;
+        const int nfl = (int)gridDim.x - ninit;
+        for (int i0 = ((int)blockIdx.x - ninit) * 256; i0 < ntile; i0 += nfl * 256) {      /* whole workgroups call (block barriers inside) */
+            const int i = i0 + (int)threadIdx.x;
+            f(c, i < ntile ? i : -1);
+        }
+        return;
+    }
     const int n = c.cnt[GIE_CNT_NEWLIST];
     if (blockIdx.x == 0 && threadIdx.x == 0 && *c.pool_count > c.max_blocks) *c.pool_count = c.max_blocks;
-    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    for (int e = blockIdx.x; e < n; e += ninit) {
         const int slot = c.blk_new[e];
         if (slot < 0) continue;
         gie_init_voxel(c, slot, threadIdx.x);
@@ -1617,9 +1628,21 @@ __device__ __forceinline__ void gie_row_ld32(const uint32_t *p, const long long 
 /* updateHashOGMWithPntCld / updateHashOGMWithSensor (unify_helper.cuh:35-197), dense form: the per-voxel
  * decisions are gie_fuse_finish's (shared gie_fuse_logic), the per-tile known / unknown summaries and
  * the plane flags come out the same */
-__global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c)
+/* (few tiles to look at: the list form — a wave per listed tile, the staged per-voxel functor as in k_voxa — in the same launch) */
+__global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c, const op_fuse f, const int32_t *list)
 {
-    if (gie_use_lists(c, c.cnt[GIE_CNT_TL_FUSE])) return;        /* few tiles to look at: the list form (k_voxa<op_fuse>) does the stage */
+    {
+        const int n = c.cnt[GIE_CNT_TL_FUSE];
+        if (gie_use_lists(c, n)) {
+            const int lane = threadIdx.x & 63, waves = gridDim.x * 4;
+            for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+                const int t = list[e];
+                const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+                gie_vox_column<op_fuse, true>(c, f, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8);
+            }
+            return;
+        }
+    }
     const gie_rows r = gie_rows_of(c);
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + (threadIdx.x >> 6);

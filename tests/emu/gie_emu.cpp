@@ -69,7 +69,7 @@ static void be_vox_list_col(const gie_ctx &c, const op_fuse &f, int x, int y, in
 static int be_sweep_lx(const char *, int dflt) { return dflt; }
 static int be_rows_mode() { return 0; }
                        /* the block-row kernels are device-only forms of the same functors */
-static void be_fuse_rows(be_state *, const gie_ctx &) {}
+
 template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, int always_list, int = 64)
 {
     const int n = c.cnt[count_idx];
@@ -84,6 +84,7 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
         }
     }
 }
+static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox_list<true>(b, c, op_fuse(), list, GIE_CNT_TL_FUSE, 0); }
 /* the device takes the listed tiles (tsum == 1) a wave per tile and the face voxels by patches of the faces; here: every voxel
  * the tile summary does not rule out (op_frontier::tile_skip / skip), same decisions per voxel */
 static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx, const int32_t *, int)
@@ -95,7 +96,7 @@ static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < 
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell);
 /* sequential allocHashTB: flag → rank → insert → initialise → table */
-static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *rank, int)
+static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *rank, int, int fuse_list_ntile = 0)
 {
     be_lin(b, c, op_cell_flag(), ncell);
     be_exclusive_scan(b, c.blk_new, rank, ncell);
@@ -104,6 +105,7 @@ static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *ra
     be_block_init(b, c, c.blk_new, rank, ncell);
     be_lin(b, c, op_cell_table(), ncell);
     for (int cell = 0; cell < ncell; cell++) if (c.blk_tab[cell] >= 0) gie_cell_mark_tiles(c, cell);
+    if (fuse_list_ntile > 0) be_range(b, c, op_fuse_list(), fuse_list_ntile);     /* (the device builds the list in its block-initialisation launch) */
 }
 static void be_free_rays(be_state *, const gie_ctx &c, const float *g, int n) { for (int i = 0; i < n; i++) gie_free_ray(c, g, i); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n) { int s = 0; for (int i = 0; i < n; i++) { rank[i] = s; s += flag[i]; } }

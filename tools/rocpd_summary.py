@@ -107,8 +107,18 @@ def pmc(fetch_db, write_db):
     return "\n".join(out), js
 
 
+def series(path, pat):
+    """durations (us) of the launches of the kernels whose short name matches `pat`, in launch order"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall() if _has(db, "kernels", "name") else \
+        db.execute("select kernel_name, start, end from kernels order by start").fetchall()
+    return [round((e - s0) / 1e3, 1) for n, s0, e in rows if re.search(pat, short(n))]
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "series":
+        print(" ".join(str(v) for v in series(sys.argv[2], sys.argv[3])))
+    elif sys.argv[1] == "stats":
         print(stats(sys.argv[2]))
     else:
         txt, js = pmc(sys.argv[2], sys.argv[3])
