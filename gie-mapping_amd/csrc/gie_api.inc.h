@@ -48,6 +48,10 @@ template <class T> static T *gie_dalloc(gie_mapper *m, size_t n, bool zero = tru
 {
     void *p = be_alloc(&m->be, n * sizeof(T), zero);
     if (p) m->allocs.push_back(p);
+    {   /* GIE_DEBUG_ALLOC=1: where the planes went (stderr) */
+        static const int dbg = getenv("GIE_DEBUG_ALLOC") ? atoi(getenv("GIE_DEBUG_ALLOC")) : 0;
+        if (dbg && n * sizeof(T) >= (64u << 20)) fprintf(stderr, "gie alloc %2d: %p  %8.1f MiB\n", (int)m->allocs.size(), p, (double)(n * sizeof(T)) / 1048576.0);
+    }
     return (T *)p;
 }
 
