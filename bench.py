@@ -567,6 +567,9 @@ def main():
     backend = os.environ.get("GIE_BENCH_BACKEND", "nccl")
     if os.environ.get("GIE_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+        # the wavefront kernel is persistent and takes a whole compute unit's LDS per workgroup (wave C's tiles): the grids of
+        # all ranks have to be resident side by side on the one device, or their grid barriers wait for each other until they time out
+        os.environ.setdefault("GIE_WAVE_WGS", str(max(8, 192 // max(1, world))))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:

@@ -5,6 +5,8 @@
  * synchronisation inside (the reference syncs ≥12 times per frame through thrust scalars,
  * SURVEY.md §2.3).
  */
+#include <cstdio>
+#include <unistd.h>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -153,7 +155,15 @@ static int be_prof_event(be_state *b)
     if (b->pool_used == (int)b->pool->size()) { hipEvent_t e; GIE_HIP_OK(hipEventCreate(&e)); b->pool->push_back(e); }
     return b->pool_used++;
 }
+/* GIE_TRACE_LAUNCHES=1: every kernel launch is announced on stderr (process id, kernel) and waited for — the last line a
+ * process prints before a device fault names the kernel */
+static int be_trace_on() { static const int on = getenv("GIE_TRACE_LAUNCHES") ? atoi(getenv("GIE_TRACE_LAUNCHES")) : 0; return on; }
 #define GIE_LAUNCH(b, kern, grid, block, lds, ...) do { \
+        if (be_trace_on()) { fprintf(stderr, "[%d] launch %s\n", (int)getpid(), #kern); fflush(stderr); } \
+        GIE_LAUNCH_(b, kern, grid, block, lds, __VA_ARGS__); \
+        if (be_trace_on()) { hipError_t e_ = hipStreamSynchronize((b)->stream); if (e_ != hipSuccess) { fprintf(stderr, "[%d] %s: %s\n", (int)getpid(), #kern, hipGetErrorString(e_)); fflush(stderr); } } \
+    } while (0)
+#define GIE_LAUNCH_(b, kern, grid, block, lds, ...) do { \
         if ((b)->prof_on && (b)->cur_id >= 0) { \
             const int e0_ = be_prof_event(b), e1_ = be_prof_event(b); \
             hipExtLaunchKernelGGL(kern, grid, block, lds, (b)->stream, (*(b)->pool)[e0_], (*(b)->pool)[e1_], 0, __VA_ARGS__); \
