@@ -14,6 +14,7 @@
 enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, GIE_K_ALLOC, GIE_K_FUSE, GIE_K_EDT_Y, GIE_K_EDT_X,
        GIE_K_EDT_Z, GIE_K_MARK, GIE_K_FRONTIER, GIE_K_WAVE_A, GIE_K_WAVE_B, GIE_K_WAVE_C, GIE_K_COMMIT, GIE_K_EDT_ZFACES, GIE_K_MARKC, GIE_K_NUM };
 #include <cstdio>
+#include <unistd.h>
 static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
        "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "waves", "commit", "edt_prep", "mark_commit" };
 
@@ -50,7 +51,7 @@ template <class T> static T *gie_dalloc(gie_mapper *m, size_t n, bool zero = tru
     if (p) m->allocs.push_back(p);
     {   /* GIE_DEBUG_ALLOC=1: where the planes went (stderr) */
         static const int dbg = getenv("GIE_DEBUG_ALLOC") ? atoi(getenv("GIE_DEBUG_ALLOC")) : 0;
-        if (dbg && n * sizeof(T) >= (64u << 20)) fprintf(stderr, "gie alloc %2d: %p  %8.1f MiB\n", (int)m->allocs.size(), p, (double)(n * sizeof(T)) / 1048576.0);
+        if (dbg && (dbg > 1 || n * sizeof(T) >= (64u << 20))) fprintf(stderr, "[%d] gie alloc %2d: %p  %8.1f MiB\n", (int)getpid(), (int)m->allocs.size(), p, (double)(n * sizeof(T)) / 1048576.0);
     }
     return (T *)p;
 }

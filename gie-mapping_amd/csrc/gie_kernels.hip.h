@@ -1921,6 +1921,7 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
         GIE_WAVE_SHARE(n, first, last);
         for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_a_phase1(c, cur, e);
         gie_grid_sync(gb, c);
+        if (gb.failed) break;                   /* a barrier that timed out: nothing the other workgroups share is touched again */
         GIE_TS2(2, n);
         if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
         for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_a_phase2(c, cur, next_cnt, e);
@@ -1957,6 +1958,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         GIE_WAVE_SHARE(n, first, last);
         for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase2(c, cur, next_cnt, level, rp, e);
         gie_grid_sync(gb, c);
+        if (gb.failed) break;                   /* (as in wave A) */
         GIE_TS2(6, n);
         const int nn = gie_clampi(gie_ld(next_cnt), c.qcap_ab);
         if (boss) {
@@ -2165,7 +2167,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
         c.cnt[GIE_CNT_FRONT_C] = n;
         if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
     }
-    if (n == 0) return;                        /* same n everywhere */
+    if (n == 0 || gb.failed) return;           /* same n everywhere; a barrier of waves A / B that timed out: the update is incomplete (GIE_ERR_TIMEOUT) */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     /* the tiles of the seeds are the active tiles of round 0 (lvl_next[] / lvl_vis[] — one word per round — and the tile flags
      * are zero when the launch starts) */

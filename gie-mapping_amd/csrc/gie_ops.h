@@ -912,7 +912,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {                          /* all compare-and-swaps of the entry in flight together */
         key[k] = 0; old[k] = GIE_NOPROP; d[k] = 0;
-        if (!((mask >> k) & 1u)) continue;
+        if (!((mask >> k) & 1u) || na[k] < 0) continue;   /* (na < 0 cannot happen while phase 1's lookups hold; never index a plane with it) */
         d[k] = gie_d2(lc[0], lc[1], lc[2], g[0] + dx[k], g[1] + dy[k], g[2] + dz[k]);
         key[k] = gie_pair_make(d[k], lpar);
         old[k] = gie_acas64(&c.g_prop[na[k]], key[k], GIE_NOPROP);
@@ -920,7 +920,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     unsigned win = 0;
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
-        if (!((mask >> k) & 1u) || old[k] != key[k]) continue;       /* not the (unique) winner */
+        if (!((mask >> k) & 1u) || na[k] < 0 || old[k] != key[k]) continue;       /* not the (unique) winner */
         win |= 1u << k;
         gie_st(&c.g_dist[na[k]], (int32_t)d[k]);
         gie_st(&c.g_coc[na[k]], gie_pack_crd(lc[0], lc[1], lc[2]));
