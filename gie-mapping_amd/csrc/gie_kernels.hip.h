@@ -1822,8 +1822,9 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
  * relaxed poll / acquire — cdna_hip_programming.md G16), so a whole wavefront costs one launch
  * and no host round trip (the reference pays ≈3 PCIe round trips per level, wave_helper.h:20-90).
  * Every shared word touched inside the phases goes through agent-scope accesses (gie_ld/gie_st/
- * atomics in gie_ops.h); the per-entry rec* scratch is only re-read by the thread that wrote it
- * (identical grid-stride mapping in every phase). */
+ * atomics in gie_ops.h) — the per-entry rec* records too: the workgroup that reads one is the one that wrote it while a
+ * level keeps its split, but the tail of a wave goes to workgroup 0 (wave B: records written by phase 1 on every
+ * workgroup, read by workgroup 0's phase 2), and the per-XCD L2s are not coherent for plain accesses. */
 #define GIE_WAVE_THREADS 1024
 #define GIE_BAR_SPIN_LIMIT (1 << 22)
 

@@ -815,7 +815,7 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
     int g[3];
     gie_unpack_crd(gie_ld(&c.qa[cur][e]), &g[0], &g[1], &g[2]);
     const int a = gie_ld(&c.qa_a[cur][e]);
-    c.rec0[e] = GIE_KEY_EMPTY; c.rec1[e] = GIE_NOPROP; c.rec3[e] = 0;
+    gie_st(&c.rec0[e], (uint64_t)GIE_KEY_EMPTY); gie_st(&c.rec1[e], (uint64_t)GIE_NOPROP); gie_st(&c.rec3[e], (int32_t)0);
     if (a < 0) return;
     int cd = gie_ld(&c.g_dist[a]);
     const uint64_t lcoc = gie_ld(&c.g_coc[a]);
@@ -878,10 +878,10 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
             }
         }
     }
-    c.rec0[e] = lowered ? newcoc : GIE_KEY_EMPTY;
-    c.rec1[e] = newpair;
-    c.rec2[e] = lpar;
-    c.rec3[e] = (lowered ? cd : 0) | (mask << 24);
+    gie_st(&c.rec0[e], (uint64_t)(lowered ? newcoc : GIE_KEY_EMPTY));
+    gie_st(&c.rec1[e], newpair);
+    gie_st(&c.rec2[e], lpar);
+    gie_st(&c.rec3[e], (int32_t)((lowered ? cd : 0) | (mask << 24)));
 }
 
 GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int e)
@@ -890,17 +890,19 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     int g[3];
     gie_unpack_crd(gk, &g[0], &g[1], &g[2]);
     const int a = gie_ld(&c.qa_a[cur][e]);
-    const unsigned mask = (unsigned)(c.rec3[e] >> 24) & 63u;
-    if (c.rec0[e] != GIE_KEY_EMPTY) {
-        gie_st(&c.g_dist[a], (int32_t)(c.rec3[e] & 0xffffff));
-        gie_st(&c.g_coc[a], c.rec0[e]);
+    const int32_t r3 = gie_ld(&c.rec3[e]);
+    const uint64_t r0 = gie_ld(&c.rec0[e]), r1 = gie_ld(&c.rec1[e]);
+    const unsigned mask = (unsigned)(r3 >> 24) & 63u;
+    if (r0 != GIE_KEY_EMPTY) {
+        gie_st(&c.g_dist[a], (int32_t)(r3 & 0xffffff));
+        gie_st(&c.g_coc[a], r0);
         gie_touch(c, a);
         gie_st(&c.g_wl[a], (int32_t)1);
-        if (c.rec1[e] != GIE_NOPROP) gie_st(&c.g_pair[a], c.rec1[e]);
-        gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, c.rec1[e] != GIE_NOPROP, gk, a);
+        if (r1 != GIE_NOPROP) gie_st(&c.g_pair[a], r1);
+        gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, r1 != GIE_NOPROP, gk, a);
     }
     if (!mask) return;
-    const uint64_t lpar = c.rec2[e];
+    const uint64_t lpar = gie_ld(&c.rec2[e]);
     int lw[3];
     gie_unpack_wr(lpar, &lw[0], &lw[1], &lw[2]);
     const int lc[3] = { lw[0] + c.upvt[0], lw[1] + c.upvt[1], lw[2] + c.upvt[2] };
@@ -962,7 +964,7 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e)
     uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
     int32_t *const rec3 = rp ? c.rec3b : c.rec3;
     const int a = gie_ld(&c.qb_a[cur][e]);
-    rec0[e] = GIE_NOPROP; rec3[e] = 0;
+    gie_st(&rec0[e], (uint64_t)GIE_NOPROP); gie_st(&rec3[e], (int32_t)0);
     if (a < 0) return;
     const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
     if (gie_ld(&c.g_dist[a]) > c.cutoff_sq) return;
@@ -972,20 +974,20 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e)
     gie_st(&c.g_coc[a], coc);
     gie_st(&c.g_dist[a], (int32_t)gie_pair_dist(pr));
     gie_touch(c, a);
-    rec0[e] = gie_pair_par(pr);
-    rec1[e] = coc;
+    gie_st(&rec0[e], (uint64_t)gie_pair_par(pr));
+    gie_st(&rec1[e], coc);
 }
 
 GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int level, int rp, int e)
 {
     const uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
     int32_t *const rec3 = rp ? c.rec3b : c.rec3;
-    if (rec0[e] == GIE_NOPROP) return;
+    const uint64_t par = gie_ld(&rec0[e]);               /* (phase 1 of this entry may have run on another workgroup: the tail of a wave goes to workgroup 0) */
+    if (par == GIE_NOPROP) return;
     int g[3], cc[3];
     gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
     const int a = gie_ld(&c.qb_a[cur][e]);
-    gie_unpack_crd(rec1[e], &cc[0], &cc[1], &cc[2]);
-    const uint64_t par = rec0[e];
+    gie_unpack_crd(gie_ld(&rec1[e]), &cc[0], &cc[1], &cc[2]);
     const int32_t stamp = (int32_t)(c.stamp_base + 8u + (uint32_t)(level % 4000));
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     unsigned outm = 0, inm = 0;
@@ -1056,20 +1058,20 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
             mask |= 1 << k;
         }
     }
-    rec3[e] = mask;
+    gie_st(&rec3[e], (int32_t)mask);
 }
 
 GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int rp, int e)
 {
     const uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
     const int32_t *const rec3 = rp ? c.rec3b : c.rec3;
-    if (rec0[e] == GIE_NOPROP) return;
-    const unsigned mask = (unsigned)rec3[e];
+    const uint64_t par = gie_ld(&rec0[e]);
+    if (par == GIE_NOPROP) return;
+    const unsigned mask = (unsigned)gie_ld(&rec3[e]);
     if (!mask) return;
     int g[3], cc[3];
     gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
-    gie_unpack_crd(rec1[e], &cc[0], &cc[1], &cc[2]);
-    const uint64_t par = rec0[e];
+    gie_unpack_crd(gie_ld(&rec1[e]), &cc[0], &cc[1], &cc[2]);
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     uint64_t key[6], old[6];
     int nid[6];
