@@ -476,6 +476,17 @@ def test_hip_matches_oracle_production_sequence(oracle_lib, sc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wgs", ["8", "24"])
+@pytest.mark.parametrize("name", ["c5_hash_world", "mixed", "c3_no_cutoff"])
+def test_small_wavefront_grids(oracle_lib, monkeypatch, name, wgs):
+    """GIE_WAVE_WGS shrinks the persistent grid of the wavefront kernel (processes that share a device): levels
+    and tile rounds are split over fewer workgroups, the tails of waves A / B reach workgroup 0 at other levels — same results."""
+    monkeypatch.setenv("GIE_WAVE_WGS", wgs)
+    sc = [s for s in SCENARIOS if s.name == name][0]
+    parity.run_and_compare(sc, OracleMapper, gie.Mapper, production=True)
+
+
+@pytest.mark.gpu
 def test_waves_wait_out_a_kernel_that_holds_every_compute_unit(oracle_lib):
     """The wavefront kernel meets at a hand-rolled grid barrier, so all of its workgroups have to be resident at
     once.  Here another stream fills EVERY wave slot of the device with spinning workgroups (tests/gpu_helpers)
