@@ -309,17 +309,6 @@ static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list)
     if (be_rows_mode()) GIE_LAUNCH(b, k_fuse_rows, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
     else be_vox_list<true>(b, c, op_fuse(), list, GIE_CNT_TL_FUSE, 0);
 }
-template <class F> static void be_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
-{
-    GIE_LAUNCH(b, k_list<F>, dim3(b->cu_total), dim3(1024), 0, c, f, list, count_idx);
-}
-/* f(c, i) for i < n with whole workgroups calling (see k_range) */
-template <class F> static void be_range(be_state *b, const gie_ctx &c, const F &f, int n)
-{
-    if (n <= 0) return;
-    const int wgs = (n + 1023) / 1024;
-    GIE_LAUNCH(b, k_range<F>, dim3(wgs < b->cu_total ? wgs : b->cu_total), dim3(1024), 0, c, f, n);
-}
 /* obtainFrontiers: the voxels on the six faces of the volume one per lane (an 8x8 patch per wave) with the tile summary + tile
  * list in the first workgroups of the same launch, then a wave per listed tile for the voxels off the faces (tile + halo
  * staged in LDS) */

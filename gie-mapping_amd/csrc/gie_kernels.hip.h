@@ -1166,29 +1166,6 @@ __global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx 
     if (slot >= 0) c.tl_known[slot] = t;
 }
 
-/* f(c, i) for i in [0, n), every thread of every workgroup calling f the same number of times (i = -1 past the end):
- * for functors that meet at block barriers (gie_wg_reserve) */
-template <class F>
-__global__ __launch_bounds__(1024) void k_range(const gie_ctx c, const F f, const int n)
-{
-    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
-        const int i = i0 + (int)threadIdx.x;
-        f(c, i < n ? i : -1);
-    }
-}
-
-/* f(c, list[e]) for every entry of a device-side list (fixed grid, the length lives in device memory) */
-template <class F>
-__global__ __launch_bounds__(1024) void k_list(const gie_ctx c, const F f, const int32_t *list, const int count_idx)
-{
-    const int n = c.cnt[count_idx];
-    /* whole waves run (the functor may ballot): lanes past the end get the entry -1 */
-    for (int e0 = blockIdx.x * blockDim.x; e0 < n; e0 += gridDim.x * blockDim.x) {
-        const int e = e0 + (int)threadIdx.x;
-        f(c, e < n ? list[e] : -1);
-    }
-}
-
 /* ------------------------------------------------------------------ adaptive sweeps */
 /* The per-voxel functors of fuse / Mark / obtainFrontiers / commit over either the tiles on a list
  * (one wave per 8x8x8 tile, lane = (x,y) column of the tile) or the whole volume (the geometry of
