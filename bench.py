@@ -62,6 +62,10 @@ LIDARS = {
 }
 WORKLOADS = ["c5"] + sorted(LIDARS)
 C5 = {"seed": 5, "p_occ": 0.01, "toggle_frac": 0.25, "delta_vox": 8, "yaw_deg": 2.0}
+C5_TURN = 24             # like the lidar robot below, the c5 robot drives 24 frames out (+8 voxels each) and 24 back, so the map it
+                         # leaves behind is bounded however many regions a command times (round 2: a straight line forever ran
+                         # the default block pool dry after ~157 updates and the driver's --steps 20 --warmup 5 died in it)
+MAX_REGIONS = 12         # timed regions per workload at most
 
 
 SENSORS = LIDARS
@@ -72,14 +76,46 @@ def lidar_world(scenes):
 
 
 LIDAR_TURN = 24          # the robot of the lidar workloads drives 24 frames out and 24 back: it stays inside the 12 m box world
-                         # however many regions are timed (the hash world of c5 is unbounded)
+                         # however many regions are timed
+
+
+def turn_index(i, turn):
+    """Frame i of an out-and-back drive: 0, 1, …, turn, turn-1, …, 1, 0, 1, …"""
+    j = i % (2 * turn)
+    return j if j <= turn else 2 * turn - j
+
+
+def c5_pose(scenes, i, voxel):
+    return scenes.pose(turn_index(i, C5_TURN), voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+
+
+def planned_updates(W, K, max_regions=MAX_REGIONS, with_latency=True):
+    """Upper bound of the map updates one mapper of run_workload() goes through: warm-up + every timed region + the latency pass."""
+    return W + K * max_regions + (K if with_latency else 0)
+
+
+def c5_pool_blocks(size, updates):
+    """Blocks the c5 drive can allocate in `updates` map updates (an upper bound: every 8x8x8 block the volume ever overlaps,
+    +1 per axis for a pivot that is not block-aligned, +1 for the ghost layer of a tiled run)."""
+    travel = C5["delta_vox"] * min(int(updates), C5_TURN)
+    ext = (size[0] + travel, size[1], size[2])
+    n = 1
+    for e in ext:
+        n *= (e + 7) // 8 + 2
+    return n
+
+
+def pool_blocks(workload, size, updates):
+    """gie_config.max_blocks for a bench run of `updates` map updates (0 = the library's default of 3 x the block table)."""
+    if workload != "c5":
+        return 0
+    return int(c5_pool_blocks(size, updates) * 1.05) + 4096
 
 
 def lidar_host_frame(scenes, world, voxel, sensor, i):
     """(pos, quat, cloud or range image, points in the cloud) of frame i of a lidar workload."""
     rings, az, phi_min, phi_inc, bins = LIDARS[sensor]
-    j = i % (2 * LIDAR_TURN)
-    pos, q = scenes.pose(j if j <= LIDAR_TURN else 2 * LIDAR_TURN - j, voxel, delta_vox=8, yaw_deg=2.0)
+    pos, q = scenes.pose(turn_index(i, LIDAR_TURN), voxel, delta_vox=8, yaw_deg=2.0)
     pts, _ = scenes.lidar_frame(world, i, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc, max_range=30.0)
     npts = pts.shape[0]
     if bins is not None:   # Vlp16MapMaker::convertPyntCld binning (vlp16_map_maker.cpp:73-147)
@@ -103,7 +139,7 @@ class HashWorldFeed:
         self.first, self.planes = 0, []
 
     def pose(self, i):
-        return self.scenes.pose(i, self.voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+        return c5_pose(self.scenes, i, self.voxel)
 
     def prepare(self, first, count):
         torch = self.torch
@@ -128,7 +164,7 @@ class HashWorldFeed:
 
     def describe(self):
         return ("sensor-less hash world (BASELINE config 5): occupied iff hash(x,y,z) < %.0f %%, full observation, %.0f %% of the "
-                "obstacles toggle per frame, robot +%d voxels/frame" % (100 * C5["p_occ"], 100 * C5["toggle_frac"], C5["delta_vox"]))
+                "obstacles toggle per frame, robot %d voxels/frame, %d frames out and %d back" % (100 * C5["p_occ"], 100 * C5["toggle_frac"], C5["delta_vox"], C5_TURN, C5_TURN))
 
 
 class LidarFeed:
@@ -289,16 +325,18 @@ class Runner:
 
 
 def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff_dist, W, K, rank, world, dev, local_rank, backend,
-                 min_timed_s=0.5, max_regions=12, with_latency=True, rms=False):
+                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False):
     """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
-    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank)
+    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank,
+                          max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)))
     feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
     r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend)
     first = r.warmup(W)
     st0 = r.m.stats()
     regions = []
+    PARTIAL[workload] = {"n_voxels": n_vox * world, "steps": K, "region_s": regions}    # what a failure later on still reports
     while True:
         regions.append(r.region(first, K))
         first += K
@@ -480,7 +518,7 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
     # the occupancy the EDT works on: frame W of the workload (for the hash world the fused types are the labels: a first
     # observation of an obstacle gives 250 * 0.8 = 200 > 180)
     if workload == "c5":
-        pos, _ = scenes.pose(W, voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+        pos, _ = c5_pose(scenes, W, voxel)
         pvt = scenes.local_pivot(pos, voxel, size)
         lab = scenes.hash_world_labels(pvt, size, W, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"],
                                        arange=lambda n: torch.arange(n, dtype=torch.int64, device=dev),
@@ -521,7 +559,7 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
     k = 0
     while k < 32 and (k < 3 or time.perf_counter() - t0 < 10.0):
         if workload == "c5":
-            pos, q = scenes.pose(k, voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+            pos, q = c5_pose(scenes, k, voxel)
             lab = scenes.hash_world_labels(scenes.local_pivot(pos, voxel, s2), s2, k, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"])
             om.update(pos, q, "labels", lab.astype(np.int8))
         else:
@@ -536,7 +574,31 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
     return out
 
 
+PARTIAL = {}     # per workload: the regions timed so far (printed with an "error" key if the run dies later on)
+
+
 def main():
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        run_bench()
+    except BaseException as e:          # noqa: B902 — the ONE JSON line is printed whatever happens, with what was timed
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        if rank == 0:
+            line = {"metric": "edt_map_update_throughput", "value": None, "unit": "Mvoxels/s", "higher_is_better": True,
+                    "error": "%s: %s" % (type(e).__name__, e), "partial": {}}
+            for wl, p in PARTIAL.items():
+                rs = sorted(p["region_s"])
+                if rs:
+                    med = rs[len(rs) // 2]
+                    line["partial"][wl] = {"timed_regions": len(rs), "region_ms": [round(1e3 * x, 3) for x in p["region_s"]],
+                                           "ms_per_step": round(1e3 * med / p["steps"], 4),
+                                           "value": round(p["n_voxels"] * p["steps"] / med / 1e6, 2)}
+            print(json.dumps(line), flush=True)
+        raise
+
+
+def run_bench():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
