@@ -85,8 +85,11 @@ def turn_index(i, turn):
     return j if j <= turn else 2 * turn - j
 
 
+DRIVE = {"mode": "turn", "retain": 0}      # --drive line: the c5 robot never turns back (needs --retain R or a pool for the whole drive)
+
+
 def c5_pose(scenes, i, voxel):
-    return scenes.pose(turn_index(i, C5_TURN), voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
+    return scenes.pose(turn_index(i, C5_TURN) if DRIVE["mode"] == "turn" else i, voxel, delta_vox=C5["delta_vox"], yaw_deg=C5["yaw_deg"])
 
 
 def planned_updates(W, K, max_regions=MAX_REGIONS, with_latency=True):
@@ -97,7 +100,12 @@ def planned_updates(W, K, max_regions=MAX_REGIONS, with_latency=True):
 def c5_pool_blocks(size, updates):
     """Blocks the c5 drive can allocate in `updates` map updates (an upper bound: every 8x8x8 block the volume ever overlaps,
     +1 per axis for a pivot that is not block-aligned, +1 for the ghost layer of a tiled run)."""
-    travel = C5["delta_vox"] * min(int(updates), C5_TURN)
+    if DRIVE["retain"] > 0:             # block-pool lifecycle on: the retention zone is all the map ever holds
+        n = 1
+        for e in size:
+            n *= (e + 7) // 8 + 2 + 2 * DRIVE["retain"]
+        return n + ((size[1] + 7) // 8 + 2) * ((size[2] + 7) // 8 + 2) * ((C5["delta_vox"] + 7) // 8)   # + what one step adds before the next erasure
+    travel = C5["delta_vox"] * (min(int(updates), C5_TURN) if DRIVE["mode"] == "turn" else int(updates))
     ext = (size[0] + travel, size[1], size[2])
     n = 1
     for e in ext:
@@ -164,7 +172,9 @@ class HashWorldFeed:
 
     def describe(self):
         return ("sensor-less hash world (BASELINE config 5): occupied iff hash(x,y,z) < %.0f %%, full observation, %.0f %% of the "
-                "obstacles toggle per frame, robot %d voxels/frame, %d frames out and %d back" % (100 * C5["p_occ"], 100 * C5["toggle_frac"], C5["delta_vox"], C5_TURN, C5_TURN))
+                "obstacles toggle per frame, robot %d voxels/frame, %s" % (100 * C5["p_occ"], 100 * C5["toggle_frac"], C5["delta_vox"],
+                   ("%d frames out and %d back" % (C5_TURN, C5_TURN)) if DRIVE["mode"] == "turn" else
+                   ("a straight line, blocks more than %d blocks behind the volume erased and recycled" % DRIVE["retain"] if DRIVE["retain"] else "a straight line")))
 
 
 class LidarFeed:
@@ -329,7 +339,7 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
-    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank,
+    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank, retain_radius_blocks=DRIVE["retain"],
                           max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)))
     feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
     r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend)
@@ -607,6 +617,8 @@ def run_bench():
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--workload", "--sensor", dest="workload", choices=WORKLOADS, default="c5")
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="repeat the K-step region until this much has been timed")
+    ap.add_argument("--drive", choices=["turn", "line"], default="turn", help="c5 robot: 24 frames out and 24 back (default), or a straight line forever")
+    ap.add_argument("--retain", type=int, default=0, help="gie_config.retain_radius_blocks: erase and recycle blocks more than R blocks outside the volume (0: never, the reference's rule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rms", action="store_true",
                     help="accuracy profiler (the reference's Gnd_truth_checker, gt_checker.h:30-80): RMSE of the local EDT after the last "
@@ -614,6 +626,7 @@ def run_bench():
     ap.add_argument("--no-extras", "--no-secondary", dest="no_extras", action="store_true",
                     help="skip the projective-lidar and ray-casting runs reported beside the headline")
     args = ap.parse_args()
+    DRIVE["mode"], DRIVE["retain"] = args.drive, max(0, args.retain)
 
     import torch
     import gie

@@ -18,6 +18,7 @@ enum { GIE_K_CLASSIFY = 0, GIE_K_RAY_REGISTER, GIE_K_RAY_FREE, GIE_K_RAY_FINAL, 
 static const char *const gie_kernel_names[GIE_K_NUM] = { "ogm_classify", "ray_register", "ray_free", "ray_finalize", "block_alloc", "fuse",
        "edt_pass_y", "edt_pass_x", "edt_pass_z", "mark", "frontiers", "wave_a", "wave_b", "waves", "commit", "edt_prep", "mark_commit" };
 
+#define GIE_REHASH_PERIOD 64                 /* map updates between two rebuilds of the hash table while blocks are being erased */
 static thread_local std::string g_gie_err;
 static void gie_set_err(const std::string &s) { g_gie_err = s; }
 extern "C" const char *gie_last_error(void) { return g_gie_err.c_str(); }
@@ -28,6 +29,7 @@ struct gie_mapper {
     be_state be;
     int ncell;
     int has_pose, has_ogm, merge_open;
+    int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
     int ogm_unlabelled;                   /* ray-cast scan whose _inst_type labels have not been written (gie_read_ogm does it) */
     float msg_origin[3];
@@ -83,7 +85,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -143,7 +145,9 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.hmask = (uint32_t)(hcap - 1);
     c.hkeys = gie_dalloc<uint64_t>(m, (size_t)hcap, false);
     c.hvals = gie_dalloc<int32_t>(m, (size_t)hcap, false);
-    c.pool_count = gie_dalloc<int32_t>(m, 1);
+    c.pool_count = gie_dalloc<int32_t>(m, 4);
+    c.retain = cfg->retain_radius_blocks > 0 ? cfg->retain_radius_blocks : 0;
+    c.free_list = gie_dalloc<int32_t>(m, c.retain > 0 ? (size_t)mb : 1, false);
     const size_t GV = (size_t)mb * GIE_VBSZ;
     c.g_key = gie_dalloc<uint64_t>(m, (size_t)mb, false);
     c.g_occ = gie_dalloc<uint8_t>(m, GV, false);
@@ -229,6 +233,7 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
         m->msg_origin[i] = (float)c.pvt[i] * c.voxel_width;
         c.upvt[i] = crd[i] - c.wr[i] / 2;                 /* calculate_update_pivot, :159-166 */
         c.tb0[i] = (c.pvt[i] - 1) >> 3;
+        c.vb_lo[i] = (c.pvt[i] - 1) >> 3; c.vb_hi[i] = (c.pvt[i] + sz[i]) >> 3;
     }
     const uint32_t f = (uint32_t)c.map_ct & 0x3ffffu;
     if (f == 0) {                                         /* stamp wrap: clear the stamp planes once */
@@ -415,6 +420,16 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
     be_prof(&m->be, GIE_K_ALLOC, 0);
+    if (m->c.retain > 0) {
+        /* block-pool lifecycle (gie_config.retain_radius_blocks): erase what lies too far behind, before anything is allocated;
+         * every GIE_REHASH_PERIOD-th map update the hash table is rebuilt from the live slots, which drops the tombstones */
+        be_lin(&m->be, m->c, op_evict(), m->c.max_blocks);
+        if (++m->evictions >= GIE_REHASH_PERIOD) {
+            m->evictions = 0;
+            be_memset(&m->be, m->c.hkeys, 0xff, ((size_t)m->c.hmask + 1) * sizeof(uint64_t));
+            be_lin(&m->be, m->c, op_rehash(), m->c.max_blocks);
+        }
+    }
     {   /* everything that has to be zero for this map update, in one launch.  Per-tile summaries:
          * last frame's "known" flags (tknown_prev) tell which tiles still hold stale _glb_type; the
          * ray-touch flags were consumed by the OGM stage and are cleared for the next scan. */
@@ -640,8 +655,9 @@ extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
 {
     if (!m || !s) { gie_set_err("gie_get_stats: bad arguments"); return GIE_ERR_INVALID; }
     int rc = gie_sync(m);
-    int32_t pc = 0;
-    be_d2h(&m->be, &pc, m->c.pool_count, 4);
+    int32_t pcs[2] = { 0, 0 };
+    be_d2h(&m->be, pcs, m->c.pool_count, 8);
+    const int32_t pc = pcs[0] - pcs[1];                   /* live blocks: handed out minus the ones on the free list */
     const int32_t *h = m->h_cnt;
     memset(s, 0, sizeof(*s));
     s->frame = m->c.map_ct; s->blocks_total = pc; s->blocks_new = h[GIE_CNT_NEWBLK];

@@ -346,16 +346,19 @@ __global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int n
     const unsigned long long m = __ballot(isnew);
     if (m) {
         const int lane = __lane_id(), leader = __ffsll((long long)m) - 1, cnt = __popcll(m);
-        int base = 0, lbase = 0;
+        int base = 0, lbase = 0, nf = 0, ftop = 0;
         if (lane == leader) {
-            base = atomicAdd(c.pool_count, cnt);
+            /* slots of erased blocks first (only pops happen in this launch; a count driven below zero is reset by
+             * k_block_init_list), the rest from the bump allocator */
+            if (c.retain > 0) { ftop = atomicSub(&c.pool_count[1], cnt); nf = ftop < 0 ? 0 : (ftop < cnt ? ftop : cnt); }
+            if (cnt > nf) base = atomicAdd(&c.pool_count[0], cnt - nf);
             lbase = atomicAdd(&c.cnt[GIE_CNT_NEWLIST], cnt);
             atomicAdd(&c.cnt[GIE_CNT_NEWBLK], cnt);
         }
-        base = __shfl(base, leader); lbase = __shfl(lbase, leader);
+        base = __shfl(base, leader); lbase = __shfl(lbase, leader); nf = __shfl(nf, leader); ftop = __shfl(ftop, leader);
         if (isnew) {
             const int r = __popcll(m & ((1ull << lane) - 1ull));
-            const int slot = base + r;
+            const int slot = gie_alloc_slot(c, r, nf, ftop, base);
             if (slot >= c.max_blocks) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_POOL); c.blk_new[lbase + r] = -1; }
             else { gie_cell_insert(c, i, slot); c.blk_new[lbase + r] = slot; found = slot; }
         }
@@ -380,7 +383,10 @@ __global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c, const 
         return;
     }
     const int n = c.cnt[GIE_CNT_NEWLIST];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *c.pool_count > c.max_blocks) *c.pool_count = c.max_blocks;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (c.pool_count[0] > c.max_blocks) c.pool_count[0] = c.max_blocks;
+        if (c.pool_count[1] < 0) c.pool_count[1] = 0;
+    }
     for (int e = blockIdx.x; e < n; e += ninit) {
         const int slot = c.blk_new[e];
         if (slot < 0) continue;
@@ -1926,8 +1932,9 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
         GIE_TS2(4, n);
         GIE_WAVE_SHARE(n, first, last);
-        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur, 0, e);
+        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur, 0, e, 1);
         gie_grid_sync(gb, c);                   /* (also orders the two counter resets above before the first append) */
+        if (boss) { const int dup = gie_ld(&c.cnt[GIE_CNT_SPARE0]); c.cnt[GIE_CNT_VIS_B] -= dup; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) -= dup; }   /* entries that were in the seed list twice */
         GIE_TS2(5, n);
     }
     while (n > 0 && !gb.failed) {
@@ -1946,7 +1953,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase3(c, cur, rp, e);
         {
             GIE_WAVE_SHARE(nn, first, last);
-            for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur ^ 1, rp ^ 1, e);
+            for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur ^ 1, rp ^ 1, e, 0);
         }
         gie_grid_sync(gb, c);
         GIE_TS2(7, nn);

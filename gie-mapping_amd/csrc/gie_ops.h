@@ -336,17 +336,61 @@ GIE_DEV void gie_raycast_finalize(const gie_ctx &c, int x, int y, int z)
 /* ================================================================== block allocation */
 /* TryAllocateKernel / insert_to_id (alloc_helper.cuh:30-50, vhashing.h:387-455) without locks:
  * the slot comes from an exclusive scan (deterministic), the key is claimed by CAS. */
-GIE_DEV void gie_cell_insert(const gie_ctx &c, int cell, int slot)
+GIE_DEV void gie_key_insert(const gie_ctx &c, uint64_t key, int bx, int by, int bz, int slot)
 {
-    const int bx = cell % c.tdim[0] + c.tb0[0], by = (cell / c.tdim[0]) % c.tdim[1] + c.tb0[1], bz = cell / (c.tdim[0] * c.tdim[1]) + c.tb0[2];
-    const uint64_t key = gie_pack_crd(bx, by, bz);
     uint32_t h = gie_hash_key(bx, by, bz) & c.hmask;
     for (uint32_t probes = 0; probes <= c.hmask; probes++) {
-        const uint64_t old = gie_acas64(&c.hkeys[h], GIE_KEY_EMPTY, key);
-        if (old == GIE_KEY_EMPTY) { c.hvals[h] = slot; c.g_key[slot] = key; return; }
+        /* a free cell or the cell of an erased block (the caller has looked the key up: it is not further down the chain) */
+        const uint64_t k = gie_ld(&c.hkeys[h]);
+        if (k == GIE_KEY_EMPTY || k == GIE_KEY_TOMB) {
+            if (gie_acas64(&c.hkeys[h], k, key) == k) { c.hvals[h] = slot; c.g_key[slot] = key; return; }
+        }
         h = (h + 1) & c.hmask;
     }
     gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_HASH);
+}
+GIE_DEV void gie_cell_insert(const gie_ctx &c, int cell, int slot)
+{
+    const int bx = cell % c.tdim[0] + c.tb0[0], by = (cell / c.tdim[0]) % c.tdim[1] + c.tb0[1], bz = cell / (c.tdim[0] * c.tdim[1]) + c.tb0[2];
+    gie_key_insert(c, gie_pack_crd(bx, by, bz), bx, by, bz, slot);
+}
+
+/* ---- block-pool lifecycle (gie_config.retain_radius_blocks > 0; the reference never erases: blockalloc.h:50-67) */
+/* Slot `r` of `cnt` blocks a caller allocates at once: the first `nf` come from the top of the free list (entries
+ * [ftop - nf, ftop)), the rest from the bump allocator starting at `base`. */
+GIE_DEV int gie_alloc_slot(const gie_ctx &c, int r, int nf, int ftop, int base)
+{ return r < nf ? c.free_list[ftop - 1 - r] : base + (r - nf); }
+/* erase block `slot` when it lies more than `retain` blocks outside the block box of the volume: its hash cell becomes a
+ * tombstone, the slot goes onto the free list, its voxels are re-initialised when the slot is handed out again */
+GIE_DEV int gie_evict_slot(const gie_ctx &c, int slot)
+{
+    const uint64_t key = c.g_key[slot];
+    if (key == GIE_KEY_EMPTY) return 0;                             /* already on the free list */
+    int b[3];
+    gie_unpack_crd(key, &b[0], &b[1], &b[2]);
+    int far = 0;
+    for (int i = 0; i < 3; i++) far |= (b[i] < c.vb_lo[i] - c.retain) | (b[i] > c.vb_hi[i] + c.retain);
+    if (!far) return 0;
+    uint32_t h = gie_hash_key(b[0], b[1], b[2]) & c.hmask;
+    for (uint32_t probes = 0; probes <= c.hmask; probes++) {
+        const uint64_t k = c.hkeys[h];
+        if (k == key) { c.hkeys[h] = GIE_KEY_TOMB; break; }
+        if (k == GIE_KEY_EMPTY) break;
+        h = (h + 1) & c.hmask;
+    }
+    c.g_key[slot] = GIE_KEY_EMPTY;
+    c.g_dirty[slot] = 0;                                            /* erased blocks are not streamed */
+    c.free_list[gie_aadd32(&c.pool_count[1], 1)] = slot;
+    return 1;
+}
+/* re-insert a live slot into a freshly cleared table (drops the tombstones) */
+GIE_DEV void gie_rehash_slot(const gie_ctx &c, int slot)
+{
+    const uint64_t key = c.g_key[slot];
+    if (key == GIE_KEY_EMPTY) return;
+    int b[3];
+    gie_unpack_crd(key, &b[0], &b[1], &b[2]);
+    gie_key_insert(c, key, b[0], b[1], b[2], slot);
 }
 
 /* GlbVoxel defaults (voxmap_utils.cuh:30-43) for voxel i of a fresh block */
@@ -959,13 +1003,18 @@ GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
  * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask.  The records come in two sets (rp = level
  * parity): phase 3 of a level and phase 1 of the next touch different data apart from them, so the kernel runs the two as
  * one barrier-separated phase. */
-GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e)
+/* `first`: the entries are the seeds of the wave (obtainFrontiers' lower-out voxels + the voxels wave A lowered).  The
+ * frontier is a SET (DESIGN.md "Canonical wave schedule"): a voxel that was appended twice — seeded, then raised and lowered
+ * again by wave A — is expanded once; the second entry finds the frame-unique mark the first one left and drops out. */
+#define GIE_GWL_INB(c) ((int32_t)((c).stamp_base + 1u))
+GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e, int first)
 {
     uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
     int32_t *const rec3 = rp ? c.rec3b : c.rec3;
     const int a = gie_ld(&c.qb_a[cur][e]);
     gie_st(&rec0[e], (uint64_t)GIE_NOPROP); gie_st(&rec3[e], (int32_t)0);
     if (a < 0) return;
+    if (first && gie_axchg32(&c.g_wl[a], GIE_GWL_INB(c)) == GIE_GWL_INB(c)) { gie_aadd32(&c.cnt[GIE_CNT_SPARE0], 1); return; }
     const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
     if (gie_ld(&c.g_dist[a]) > c.cutoff_sq) return;
     int cw[3];

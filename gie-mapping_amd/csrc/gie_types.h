@@ -50,6 +50,7 @@ GIE_HD uint64_t gie_pack_crd(int x, int y, int z)
 GIE_HD void gie_unpack_crd(uint64_t k, int *x, int *y, int *z)
 { *x = (int)(k & 0x1fffff) - GIE_CRD_OFF; *y = (int)((k >> 21) & 0x1fffff) - GIE_CRD_OFF; *z = (int)((k >> 42) & 0x1fffff) - GIE_CRD_OFF; }
 #define GIE_KEY_EMPTY 0xffffffffffffffffull
+#define GIE_KEY_TOMB 0xfffffffffffffffeull    /* hash cell of an erased block (gie_config.retain_radius_blocks): a probe walks past it, an insert may take it */
 
 /* batch-EDT closest obstacle in local coordinates, 10 bits per axis (dims <= 1024) */
 #define GIE_BCOC_NONE 0xffffffffu
@@ -121,7 +122,10 @@ typedef struct gie_ctx {
     int32_t *hvals;
     uint32_t hmask;
     int max_blocks;
-    int32_t *pool_count;    /* device scalar */
+    int32_t *pool_count;    /* device scalars: [0] slots handed out by the bump allocator, [1] entries on the free list */
+    int32_t *free_list;     /* slots of erased blocks (BlockAllocBase's links, blockalloc.h:69-118, as a stack) */
+    int retain;             /* gie_config.retain_radius_blocks (0: blocks are never erased) */
+    int vb_lo[3], vb_hi[3]; /* block box of the local volume +-1 voxel */
     uint64_t *g_key;        /* block key per slot */
     uint8_t *g_occ;         /* planes, 512 per slot, in-block index x | y<<3 | z<<6 */
     int8_t *g_type;

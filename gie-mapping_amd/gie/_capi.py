@@ -27,7 +27,8 @@ class Config(C.Structure):
         ("robot_r2_grids", C.c_int32),
         ("max_blocks", C.c_int32),
         ("device_id", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("retain_radius_blocks", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -32,7 +32,7 @@ def flt2grids_sq(rad, voxel_width):
 
 def make_config(voxel_width, local_size, occupancy_threshold=180, ogm_min_h=-1000.0, ogm_max_h=1000.0,
                 cutoff_dist=None, cutoff_grids_sq=None, fast_mode=False, for_motion_planner=False,
-                robot_r=0.4, max_blocks=0, device_id=0):
+                robot_r=0.4, max_blocks=0, device_id=0, retain_radius_blocks=0):
     cfg = Config()
     cfg.voxel_width = voxel_width
     cfg.local_size[:] = [int(v) for v in local_size]
@@ -47,6 +47,7 @@ def make_config(voxel_width, local_size, occupancy_threshold=180, ogm_min_h=-100
     cfg.robot_r2_grids = flt2grids_sq(robot_r, voxel_width)
     cfg.max_blocks = int(max_blocks)
     cfg.device_id = int(device_id)
+    cfg.retain_radius_blocks = int(retain_radius_blocks)
     return cfg
 
 

@@ -55,7 +55,14 @@ typedef struct gie_config {
     int32_t robot_r2_grids;       /* ceil(robot_r/voxel_width)^2                               */
     int32_t max_blocks;           /* block pool capacity (hash/block_max); 0 = size from volume */
     int32_t device_id;            /* HIP device ordinal                                         */
-    int32_t reserved[6];
+    int32_t retain_radius_blocks; /* block-pool lifecycle.  0 = the reference's rule: blocks are never freed and the pool only
+                                     shrinks (BlockAllocBase::allocate_n throws when it is empty, blockalloc.h:50-67; its free
+                                     list, blockalloc.h:69-118, is never fed).  R > 0: at the start of every gie_fuse the
+                                     blocks whose block coordinate lies more than R blocks (Chebyshev) outside the block box
+                                     of the local volume +-1 voxel are erased — their voxels revert to the defaults
+                                     (UNKNOWN, EMPTY_VALUE, EMPTY_KEY) — and go back to the pool's free list, so a robot
+                                     that drives on forever runs on a fixed pool.  Erased blocks are not streamed. */
+    int32_t reserved[5];
 } gie_config;
 
 /* MulScanParam, include/cuda_toolkit/occupancy/vlp16/multiscan_param.h:4-27 */

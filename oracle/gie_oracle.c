@@ -494,10 +494,37 @@ static void set_occ(ovox *v, float val, float a, int thresh)
 /* GlbHashMap::updateHashOGM (glb_hash_map.cu:115-143): allocHashTB (:58-113) — a block is
  * allocated for every voxel the scan observed — then updateHashOGMWithPntCld
  * (unify_helper.cuh:35-116) or updateHashOGMWithSensor (:118-197). */
+/* Block-pool lifecycle, gie_config.retain_radius_blocks = R > 0 (the reference itself never erases a block — its pool only
+ * shrinks and allocate_n throws when it is empty, blockalloc.h:50-67; the free list it declares, :69-118, is what is fed
+ * here): before anything is allocated, every block whose block coordinate lies more than R blocks (Chebyshev) outside the
+ * block box of the local volume +-1 voxel is erased; its voxels read as defaults from then on. */
+static void evict_far_blocks(gie_oracle *o)
+{
+    const int R = o->cfg.retain_radius_blocks;
+    if (R <= 0) return;
+    const int sz[3] = { o->X, o->Y, o->Z };
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; i++) { lo[i] = fdiv8(o->pvt[i] - 1) - R; hi[i] = fdiv8(o->pvt[i] + sz[i]) + R; }
+    int kept = 0;
+    for (int s = 0; s < o->nblocks; s++) {
+        oblock *b = o->blocks[s];
+        int far = 0;
+        for (int i = 0; i < 3; i++) far |= (b->key[i] < lo[i]) | (b->key[i] > hi[i]);
+        if (far) { free(b); continue; }
+        if (kept != s) for (int i = 0; i < VBSZ; i++) b->v[i].blk = kept;
+        o->blocks[kept++] = b;
+    }
+    if (kept == o->nblocks) return;
+    o->nblocks = kept;
+    for (int i = 0; i < o->hcap; i++) o->htab[i] = -1;
+    for (int i = 0; i < o->nblocks; i++) htab_insert(o, i);
+}
+
 int go_fuse(gie_oracle *o)
 {
     const float w = o->cfg.voxel_width;
     o->st.blocks_new = 0;
+    evict_far_blocks(o);
     for (int z = 0; z < o->Z; z++) for (int y = 0; y < o->Y; y++) for (int x = 0; x < o->X; x++)
         if (o->inst_type[lid(o, x, y, z)] != GIE_VOX_UNKNOWN)
             blk_get_or_alloc(o, fdiv8(x + o->pvt[0]), fdiv8(y + o->pvt[1]), fdiv8(z + o->pvt[2]));

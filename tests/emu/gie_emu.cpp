@@ -113,13 +113,14 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
 {
     for (int cell = 0; cell < ncell; cell++) {
         if (!flag[cell]) continue;
-        const int slot = *c.pool_count + rank[cell];
+        const int slot = gie_emu_slot(c, rank[cell]);
         if (slot >= c.max_blocks) continue;
         for (int i = 0; i < GIE_VBSZ; i++) gie_init_voxel(c, slot, i);
     }
     const int total = rank[ncell - 1] + flag[ncell - 1];
-    int pc = *c.pool_count + total; if (pc > c.max_blocks) pc = c.max_blocks;
-    *c.pool_count = pc; c.cnt[GIE_CNT_NEWBLK] = total;
+    const int nfree = c.retain > 0 ? c.pool_count[1] : 0, from_free = total < nfree ? total : nfree;
+    int pc = c.pool_count[0] + (total - from_free); if (pc > c.max_blocks) pc = c.max_blocks;
+    c.pool_count[0] = pc; c.pool_count[1] -= c.retain > 0 ? from_free : 0; c.cnt[GIE_CNT_NEWBLK] = total;
 }
 /* plain restatement of the closed form the HIP EDT kernels implement (see
  * tests/test_oracle_edt.py::test_meijster_tie_rule) */
@@ -171,7 +172,8 @@ static void be_wave_b(be_state *, const gie_ctx &c)
     c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
     while (n > 0) {
         c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n;
-        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, level & 1, e);
+        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, level & 1, e, level == 0);
+        if (level == 0) { const int dup = c.cnt[GIE_CNT_SPARE0]; c.cnt[GIE_CNT_VIS_B] -= dup; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) -= dup; }
         for (int e = 0; e < n; e++) gie_wave_b_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], level, level & 1, e);
         for (int e = 0; e < n; e++) gie_wave_b_phase3(c, cur, level & 1, e);
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;

@@ -67,13 +67,18 @@ GIE_DEV int gie_cell_needs_new(const gie_ctx &c, int cell)
     return gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]) < 0;
 }
 
+/* slot of the r-th new block of a map update: from the free list while it lasts, then from the bump allocator
+ * (the counters move once, after the whole batch: be_block_init) */
+GIE_DEV int gie_emu_slot(const gie_ctx &c, int r)
+{ const int nfree = c.retain > 0 ? c.pool_count[1] : 0; return gie_alloc_slot(c, r, nfree, nfree, c.pool_count[0]); }
+
 struct op_free_ray { const float *g; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_free_ray(c, g, i); } };
 /* block allocation (allocHashTB, glb_hash_map.cu:58-113) */
 struct op_cell_flag { GIE_DEVM void operator()(const gie_ctx &c, int i) const { c.blk_new[i] = gie_cell_needs_new(c, i); } };
 struct op_cell_insert { const int32_t *flag; const int32_t *rank;
     GIE_DEVM void operator()(const gie_ctx &c, int i) const {
         if (!flag[i]) return;
-        const int slot = *c.pool_count + rank[i];
+        const int slot = gie_emu_slot(c, rank[i]);
         if (slot >= c.max_blocks) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_POOL); return; }
         gie_cell_insert(c, i, slot);
     } };

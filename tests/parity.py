@@ -11,20 +11,22 @@ class Scenario:
     def __init__(self, name, size, voxel=0.1, sensor="depth", frames=6, delta_vox=5, yaw_deg=40.0, seed=2,
                  cutoff_dist=2.0, fast_mode=False, n_boxes=30, extent=(4.0, 4.0, 1.5), for_motion_planner=False,
                  img=(120, 160, 130.0), toggle=0.25, lidar_az=360, ext_boxes=False, min_h=-1000.0, max_h=1000.0,
-                 max_depth=6.0, p_occ=0.01):
+                 max_depth=6.0, p_occ=0.01, retain=0, max_blocks=0, probe_margin=12, turn=0):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
     def config(self):
         return gie.make_config(self.voxel, self.size, cutoff_dist=self.cutoff_dist, fast_mode=self.fast_mode,
-                               for_motion_planner=self.for_motion_planner, ogm_min_h=self.min_h, ogm_max_h=self.max_h)
+                               for_motion_planner=self.for_motion_planner, ogm_min_h=self.min_h, ogm_max_h=self.max_h,
+                               retain_radius_blocks=self.retain, max_blocks=self.max_blocks)
 
     def frames_iter(self):
         world = scenes.BoxWorld(self.seed, extent=self.extent, n_boxes=self.n_boxes, toggle_frac=self.toggle)
         rows, cols, f = self.img
         cx, cy = (cols - 1) / 2.0, (rows - 1) / 2.0
         for k in range(self.frames):
-            pos, q = scenes.pose(k, self.voxel, delta_vox=self.delta_vox, yaw_deg=self.yaw_deg)
+            kp = k if not self.turn else (k % (2 * self.turn) if k % (2 * self.turn) <= self.turn else 2 * self.turn - k % (2 * self.turn))
+            pos, q = scenes.pose(kp, self.voxel, delta_vox=self.delta_vox, yaw_deg=self.yaw_deg)     # turn > 0: out and back
             kind = self.sensor
             if kind == "mixed":
                 kind = ("depth", "pointcloud", "multiscan")[k % 3]
@@ -69,10 +71,10 @@ def _feed(m, kind, data, kw):
         m.ogm_labels(data)
 
 
-def probe_coords(pvt, size, rng, n=4000):
+def probe_coords(pvt, size, rng, n=4000, margin=12):
     """Global voxels in and around the local volume (margin 12 voxels)."""
-    lo = np.array(pvt) - 12
-    hi = np.array(pvt) + np.array(size) + 12
+    lo = np.array(pvt) - margin
+    hi = np.array(pvt) + np.array(size) + margin
     return rng.integers(lo, hi, size=(n, 3)).astype(np.int32)
 
 
@@ -82,14 +84,14 @@ def _compare_after_merge(sc, k, a, b, rng, check_stats):
         assert np.array_equal(ra[key], rb[key]), "%s frame %d: post-merge %s differs in %d voxels" % (
             sc.name, k, key, int((ra[key] != rb[key]).reshape(ra["type"].shape + (-1,)).any(-1).sum()))
     assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0.0), "%s frame %d: edt differs" % (sc.name, k)
-    xyz = probe_coords(a.pivot(), sc.size, rng)
+    xyz = probe_coords(a.pivot(), sc.size, rng, margin=sc.probe_margin)
     ga, gb = a.query_global(xyz), b.query_global(xyz)
     for key in ("occ_val", "vox_type", "dist_sq", "coc"):
         assert np.array_equal(ga[key], gb[key]), "%s frame %d: global %s differs in %d probes" % (
             sc.name, k, key, int((ga[key] != gb[key]).reshape(len(xyz), -1).any(-1).sum()))
     sa, sb = a.stats(), b.stats()
     if check_stats:
-        for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_c", "blocks_total"):
+        for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_b", "visits_c", "blocks_total"):
             assert sa[key] == sb[key], "%s frame %d: stat %s %d != %d" % (sc.name, k, key, sa[key], sb[key])
 
 
@@ -146,14 +148,14 @@ def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False, product
                     sc.name, k, key, int((ra[key] != rb[key]).reshape(ra["type"].shape + (-1,)).any(-1).sum()))
             # float distance: sqrtf of an int, tolerance 1e-6 relative (north_star)
             assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0.0), "%s frame %d: edt differs" % (sc.name, k)
-            xyz = probe_coords(a.pivot(), sc.size, rng)
+            xyz = probe_coords(a.pivot(), sc.size, rng, margin=sc.probe_margin)
             ga, gb = a.query_global(xyz), b.query_global(xyz)
             for key in ("occ_val", "vox_type", "dist_sq", "coc"):
                 assert np.array_equal(ga[key], gb[key]), "%s frame %d: global %s differs in %d probes" % (
                     sc.name, k, key, int((ga[key] != gb[key]).reshape(len(xyz), -1).any(-1).sum()))
             sa, sb = a.stats(), b.stats()
             if check_stats:
-                for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_c",
+                for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_b", "visits_c",
                             "blocks_total"):
                     assert sa[key] == sb[key], "%s frame %d: stat %s %d != %d" % (sc.name, k, key, sa[key], sb[key])
             if verbose:

@@ -47,12 +47,50 @@ SCENARIOS = [
                     cutoff_dist=2.0, p_occ=0.01),
     parity.Scenario("c2_256cube", (256, 256, 256), voxel=0.05, sensor="mixed", frames=4, delta_vox=4, yaw_deg=2.0,
                     extent=(6.0, 6.0, 3.0), n_boxes=60, img=(480, 640, 525.0)),
+    # block-pool lifecycle (gie_config.retain_radius_blocks): see tests/test_host_logic.py
+    parity.Scenario("retain_c5_out_and_back", (32, 32, 16), voxel=0.05, sensor="labels", frames=26, delta_vox=8, yaw_deg=2.0, seed=5,
+                    cutoff_dist=1.0, p_occ=0.01, retain=2, turn=9, probe_margin=60),
+    parity.Scenario("retain_lidar", (48, 48, 16), sensor="multiscan", frames=16, delta_vox=7, yaw_deg=10.0, retain=1, probe_margin=40),
+    parity.Scenario("retain_odd_r1", (37, 29, 11), sensor="mixed", frames=12, delta_vox=5, yaw_deg=33.0, retain=1, turn=5, probe_margin=40),
 ]
 
 
 @pytest.mark.parametrize("sc", SCENARIOS, ids=[s.name for s in SCENARIOS])
 def test_hip_matches_oracle(oracle_lib, sc):
     parity.run_and_compare(sc, OracleMapper, gie.Mapper)
+
+
+def test_long_drive_on_a_fixed_pool(oracle_lib):
+    """a 2 000-update C5 drive in a straight line at 64^3 on a FIXED pool (retain_radius_blocks = 2: the pool holds
+    the retention zone, 13^3 blocks, and nothing more — without recycling the drive would need 130 000 blocks).  HIP == oracle:
+    the local volume every 50 updates, global probes reaching past the retention zone, and the live block count; the hash table
+    goes through 31 rebuilds on the way."""
+    from gie import scenes
+    size, voxel, R = (64, 64, 64), 0.05, 2
+    cfg = gie.make_config(voxel, size, cutoff_dist=1.0, fast_mode=False, retain_radius_blocks=R, max_blocks=13 ** 3)
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    rng = np.random.default_rng(12)
+    try:
+        for i in range(2000):
+            pos, q = scenes.pose(i, voxel, delta_vox=8, yaw_deg=1.0)
+            lab = scenes.hash_world_labels(scenes.local_pivot(pos, voxel, size), size, i, seed=5, p_occ=0.01, toggle_frac=0.25).astype(np.int8)
+            for m in (a, b):
+                m.update(pos, q, "labels", lab)
+            if i % 50 == 0 or i == 1999:
+                ra, rb = a.read_local(), b.read_local()
+                for key in ("type", "dist_sq", "coc"):
+                    assert np.array_equal(ra[key], rb[key]), (i, key)
+                xyz = parity.probe_coords(a.pivot(), size, rng, n=6000, margin=64)
+                ga, gb = a.query_global(xyz), b.query_global(xyz)
+                for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+                    assert np.array_equal(ga[key], gb[key]), (i, key)
+                sa, sb = a.stats(), b.stats()
+                for key in ("blocks_total", "visits_a", "visits_b", "visits_c"):
+                    assert sa[key] == sb[key], (i, key, sa[key], sb[key])
+                assert sb["blocks_total"] <= 13 ** 3
+    finally:
+        a.close()
+        b.close()
 
 
 @pytest.mark.parametrize("shape,dens,seed", [

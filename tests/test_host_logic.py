@@ -32,6 +32,14 @@ SCENARIOS = [
                     cutoff_dist=2.0, p_occ=0.01),
     parity.Scenario("c5_dense_odd", (40, 36, 20), voxel=0.05, sensor="labels", frames=8, delta_vox=3, yaw_deg=2.0, seed=6,
                     cutoff_dist=0.5, p_occ=0.05, toggle=0.5),
+    # block-pool lifecycle (gie_config.retain_radius_blocks): blocks more than R blocks behind the volume are erased and their
+    # slots recycled.  A drive out and back over the same ground (what was erased comes back as unknown space), a lidar drive
+    # whose waves A / B walk through remembered space right up to the erased zone, and R = 1 on a misaligned volume; the probes
+    # reach well past the retention zone
+    parity.Scenario("retain_c5_out_and_back", (32, 32, 16), voxel=0.05, sensor="labels", frames=26, delta_vox=8, yaw_deg=2.0, seed=5,
+                    cutoff_dist=1.0, p_occ=0.01, retain=2, turn=9, probe_margin=60),
+    parity.Scenario("retain_lidar", (48, 48, 16), sensor="multiscan", frames=16, delta_vox=7, yaw_deg=10.0, retain=1, probe_margin=40),
+    parity.Scenario("retain_odd_r1", (37, 29, 11), sensor="mixed", frames=12, delta_vox=5, yaw_deg=33.0, retain=1, turn=5, probe_margin=40),
 ]
 
 
@@ -54,6 +62,38 @@ def test_waves_are_exercised(oracle_lib):
     assert sum(s["visits_a"] for s in stats) > 0
     assert sum(s["visits_b"] for s in stats) > 0
     assert sum(s["visits_c"] for s in stats) > 0
+
+
+def test_long_drive_on_a_fixed_pool_emulation(oracle_lib):
+    """2 000 map updates of the c5 world in a straight line on a pool that holds the retention zone and nothing more: without
+    recycling the drive needs ~18 000 blocks, the pool has 400.  The map equals the oracle's wherever it is probed, the live
+    block count is bounded and equal on both sides, and the hash table survives its periodic rebuilds (every 64 updates)."""
+    import numpy as np
+    import gie as _gie
+    from gie import scenes
+    size, voxel, R = (16, 16, 16), 0.05, 2
+    cfg = _gie.make_config(voxel, size, cutoff_dist=0.5, fast_mode=False, retain_radius_blocks=R, max_blocks=400)
+    a, b = OracleMapper(cfg), EmuMapper(cfg)
+    rng = np.random.default_rng(11)
+    peak = 0
+    for i in range(2000):
+        pos, q = scenes.pose(i, voxel, delta_vox=8, yaw_deg=1.0)
+        lab = scenes.hash_world_labels(scenes.local_pivot(pos, voxel, size), size, i, seed=5, p_occ=0.02, toggle_frac=0.25).astype(np.int8)
+        for m in (a, b):
+            m.update(pos, q, "labels", lab)
+        if i % 97 == 0 or i == 1999:
+            xyz = parity.probe_coords(a.pivot(), size, rng, n=3000, margin=48)
+            ga, gb = a.query_global(xyz), b.query_global(xyz)
+            for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+                assert np.array_equal(ga[key], gb[key]), (i, key)
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), (i, key)
+            sa, sb = a.stats(), b.stats()
+            assert sa["blocks_total"] == sb["blocks_total"]
+            peak = max(peak, sb["blocks_total"])
+    assert peak <= (3 + 2 * R + 1) ** 3          # the retention zone: (2 + 1 blocks of volume +-1 voxel, + R on either side)^3
+    a.close(); b.close()
 
 
 def test_block_pool_overflow_fails_loudly_emulation():
