@@ -30,6 +30,8 @@ struct gie_mapper {
     int ncell;
     int has_pose, has_ogm, merge_open;
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
+    int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
+    int commit_pvt[3], commit_upvt[3], commit_tb0[3];   /* pivots / block-table origin of that merge */
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
     int ogm_unlabelled;                   /* ray-cast scan whose _inst_type labels have not been written (gie_read_ogm does it) */
     float msg_origin[3];
@@ -85,7 +87,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -420,6 +422,26 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
     be_prof(&m->be, GIE_K_ALLOC, 0);
+    if (m->deferred) {
+        /* the stored pairs the last (fused) merge left out, for the voxels that are not in this volume any more; before
+         * anything of that update — types, pairs, block table — is overwritten, and before blocks are erased */
+        const gie_ctx &c = m->c;
+        op_pair_flush op;
+        const int sz[3] = { c.X, c.Y, c.Z };
+        int w[3];
+        for (int i = 0; i < 3; i++) {
+            op.b.opvt[i] = m->commit_pvt[i]; op.b.oupvt[i] = m->commit_upvt[i]; op.b.otb0[i] = m->commit_tb0[i];
+            const long long s = (long long)m->commit_pvt[i] - c.pvt[i];          /* old local + s = new local */
+            long long lo = -s > 0 ? -s : 0, hi = sz[i] - s < sz[i] ? sz[i] - s : sz[i];
+            if (hi < lo) hi = lo;
+            if (lo > sz[i]) { lo = sz[i]; hi = sz[i]; }
+            op.b.lo[i] = (int)lo; op.b.hi[i] = (int)hi; w[i] = (int)(hi - lo);
+        }
+        if (w[0] == 0 || w[1] == 0 || w[2] == 0) { for (int i = 0; i < 3; i++) { op.b.lo[i] = op.b.hi[i] = 0; w[i] = 0; } }   /* nothing stays */
+        op.b.n0 = (c.X - w[0]) * c.Y * c.Z; op.b.n1 = w[0] * (c.Y - w[1]) * c.Z; op.b.n2 = w[0] * w[1] * (c.Z - w[2]);
+        be_lin(&m->be, c, op, op.b.n0 + op.b.n1 + op.b.n2);
+        m->deferred = 0;
+    }
     if (m->c.retain > 0) {
         /* block-pool lifecycle (gie_config.retain_radius_blocks): erase what lies too far behind, before anything is allocated;
          * every GIE_REHASH_PERIOD-th map update the hash table is rebuilt from the live slots, which drops the tombstones */
@@ -495,6 +517,7 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
     m->merge_open = 1;
+    if (m->c.fused) { m->deferred = 1; for (int i = 0; i < 3; i++) { m->commit_pvt[i] = m->c.pvt[i]; m->commit_upvt[i] = m->c.upvt[i]; m->commit_tb0[i] = m->c.tb0[i]; } }
     return GIE_OK;
 }
 /* second half: obtainFrontiers, waves A / B / C, commit */

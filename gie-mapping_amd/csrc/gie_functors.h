@@ -235,6 +235,7 @@ struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
         if (slot >= 0) c.tl_front[slot] = t;
 #endif
     } };
+struct op_pair_flush { gie_flush_boxes b; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_pair_flush_voxel(c, b, i); } };
 struct op_evict { GIE_DEVM void operator()(const gie_ctx &c, int slot) const { if (slot < c.pool_count[0]) gie_evict_slot(c, slot); } };
 struct op_rehash { GIE_DEVM void operator()(const gie_ctx &c, int slot) const { if (slot < c.pool_count[0]) gie_rehash_slot(c, slot); } };
 struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };

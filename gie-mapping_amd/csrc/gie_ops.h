@@ -1156,6 +1156,17 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int rp, int e)
  * AGENT: the stores go through agent-scope (write-through) accesses — wave C may commit the same
  * voxel again one BFS level later from a workgroup on another XCD, and the per-XCD L2s are not
  * coherent: two plain stores would reach memory in either order. */
+/* DEFERRED dist_id_pair (fused mode only — this function's only callers): UpdateHashBatch also stores the pair in the
+ * GlbVoxel (`C.pair = pair[v]`, unify_helper.cuh:448-523).  The stored copy of a voxel INSIDE the volume is never read — the
+ * waves work on the local plane there, and Mark rewrites it next map update — it only matters once the voxel has left the
+ * volume (wave B's atomic minimum compares a proposal with it, wave_core.cuh:300-330).  So the 8-byte store per voxel and map
+ * update is left out here and made up for when the voxel leaves: the next gie_fuse writes the pairs of the voxels that
+ * are in this map update's volume and not in the next one's (gie_pair_flush_voxel below; 8 of 512 layers on the C5 drive).
+ * Bit 63 of the stored closest obstacle (spare: the packed coordinate has 63 bits, gie_unpack_crd masks it) says "the stored pair
+ * is older than this record": set by this commit, cleared by whoever stores a pair for real.  It settles the one case the
+ * local plane cannot — a voxel whose pair was EMPTY (not committed) when it left: flag set = its last commit happened
+ * during this stay in the volume and the pair of that commit is (stored distance, stored closest obstacle). */
+#define GIE_COC_STALEPAIR (1ull << 63)
 template <bool AGENT>
 GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
 {
@@ -1167,11 +1178,52 @@ GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
     if (a < 0) return;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
-    const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
+    const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]) | GIE_COC_STALEPAIR;
     if (AGENT) {
-        gie_st(&c.g_coc[a], ncoc); gie_st(&c.g_dist[a], (int32_t)d); gie_st(&c.edt[id], sqrtf((float)d)); gie_st(&c.g_pair[a], pr);
+        gie_st(&c.g_coc[a], ncoc); gie_st(&c.g_dist[a], (int32_t)d); gie_st(&c.edt[id], sqrtf((float)d));
     } else {
-        c.g_coc[a] = ncoc; c.g_dist[a] = d; c.edt[id] = sqrtf((float)d); c.g_pair[a] = pr;     /* (nontemporal stores: no gain measured) */
+        c.g_coc[a] = ncoc; c.g_dist[a] = d; c.edt[id] = sqrtf((float)d);     /* (nontemporal stores: no gain measured) */
+    }
+}
+/* The voxels of the LAST fused map update's volume (pivot opvt, wave-range pivot oupvt, block table still that update's)
+ * that the next volume (pivot c.pvt) no longer holds, enumerated as three slabs: item i -> old local coordinate. */
+struct gie_flush_boxes { int opvt[3], oupvt[3], otb0[3]; int lo[3], hi[3]; int n0, n1, n2; };   /* [lo, hi) = old local range that stays, per axis */
+GIE_DEV int gie_flush_skipax(int i, int lo, int hi) { return i < lo ? i : i + (hi - lo); }        /* i-th coordinate outside [lo, hi) */
+GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, int i)
+{
+    int x, y, z;
+    const int w0 = b.hi[0] - b.lo[0], w1 = b.hi[1] - b.lo[1];
+    if (i < b.n0) {                                   /* x leaves: every y, z */
+        const int nx = c.X - w0;
+        x = gie_flush_skipax(i % nx, b.lo[0], b.hi[0]); y = (i / nx) % c.Y; z = i / (nx * c.Y);
+    } else if (i < b.n0 + b.n1) {                     /* x stays, y leaves */
+        const int j = i - b.n0, ny = c.Y - w1;
+        x = b.lo[0] + j % w0; y = gie_flush_skipax((j / w0) % ny, b.lo[1], b.hi[1]); z = j / (w0 * ny);
+    } else {                                          /* x, y stay, z leaves */
+        const int j = i - b.n0 - b.n1;
+        x = b.lo[0] + j % w0; y = b.lo[1] + (j / w0) % w1; z = gie_flush_skipax(j / (w0 * w1), b.lo[2], b.hi[2]);
+    }
+    const int id = gie_lid(c, x, y, z);
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;    /* (still the last update's types: fuse has not run yet) */
+    const int gx = x + b.opvt[0], gy = y + b.opvt[1], gz = z + b.opvt[2];
+    const int cell = (((gz >> 3) - b.otb0[2]) * c.tdim[1] + ((gy >> 3) - b.otb0[1])) * c.tdim[0] + ((gx >> 3) - b.otb0[0]);
+    const int slot = c.blk_tab[cell];
+    if (slot < 0) return;
+    const int a = slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+    const uint64_t pr = c.pair[id];
+    if (gie_pair_dist(pr) != c.empty_value) {         /* committed by that update: the pair it would have stored */
+        int cw[3];
+        gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+        c.g_pair[a] = pr;
+        c.g_coc[a] = gie_pack_crd(cw[0] + b.oupvt[0], cw[1] + b.oupvt[1], cw[2] + b.oupvt[2]);
+    } else {
+        const uint64_t cc = c.g_coc[a];
+        if (cc & GIE_COC_STALEPAIR) {                 /* not committed by that update, but by an earlier one of this stay */
+            int ox, oy, oz;
+            gie_unpack_crd(cc, &ox, &oy, &oz);
+            c.g_pair[a] = gie_pair_make(c.g_dist[a], gie_pack_wr((ox - b.oupvt[0]) & 0x3fff, (oy - b.oupvt[1]) & 0x3fff, (oz - b.oupvt[2]) & 0x1fff));   /* (only the distance of a stored pair is ever compared) */
+            c.g_coc[a] = cc & ~GIE_COC_STALEPAIR;
+        }
     }
 }
 /* wave C merged `pr` into pair[id] (fused mode): commit it on the spot */
@@ -1214,7 +1266,7 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
     const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
-    if (c.track && (c.g_dist[a] != d || c.g_coc[a] != ncoc || (ty == GIE_VOX_FNT && c.g_type[a] != GIE_VOX_FNT))) gie_touch(c, a);
+    if (c.track && (c.g_dist[a] != d || (c.g_coc[a] & ~GIE_COC_STALEPAIR) != ncoc || (ty == GIE_VOX_FNT && c.g_type[a] != GIE_VOX_FNT))) gie_touch(c, a);
     c.g_coc[a] = ncoc;
     c.g_dist[a] = d;
     c.edt[id] = sqrtf((float)d);
