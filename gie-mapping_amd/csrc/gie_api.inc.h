@@ -123,6 +123,9 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tflag = gie_dalloc<uint8_t>(m, 7 * ntile);     /* tflag | tunk | tsum | tray | tact | tknown (this frame / previous frame) */
     c.tunk = c.tflag + ntile; c.tsum = c.tflag + 2 * ntile; c.tray = c.tflag + 3 * ntile; c.tact = c.tflag + 4 * ntile;
     c.tknown = c.tflag + 5 * ntile; c.tknown_prev = c.tflag + 6 * ntile;
+    c.tmax = gie_dalloc<int32_t>(m, 2 * ntile);
+    c.tmax_prev = c.tmax ? c.tmax + ntile : nullptr;
+    c.tskip = gie_dalloc<uint8_t>(m, ntile);
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
     c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
@@ -422,6 +425,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
     be_prof(&m->be, GIE_K_ALLOC, 0);
+    const int was_fused = m->deferred;    /* the map update before this one ran fused (and nothing has been merged since) */
     if (m->deferred) {
         /* the stored pairs the last (fused) merge left out, for the voxels that are not in this volume any more; before
          * anything of that update — types, pairs, block table — is overwritten, and before blocks are erased */
@@ -458,11 +462,18 @@ extern "C" int gie_fuse(gie_mapper *m)
         gie_ctx &c = m->c;
         const size_t ntile = (size_t)c.tfd[0] * c.tfd[1] * c.tfd[2];
         uint8_t *t = c.tknown; c.tknown = c.tknown_prev; c.tknown_prev = t;
+        {   /* the bounds of what the previous map update committed per tile (gie_tile_oldskip): valid when that update ran fused */
+            int32_t *tm = c.tmax; c.tmax = c.tmax_prev; c.tmax_prev = tm;
+            c.prev_valid = was_fused;
+            for (int i = 0; i < 3; i++) c.prev_shift[i] = c.pvt[i] - m->commit_pvt[i];
+        }
         gie_clear_list l; l.n = 0;
         auto add = [&l](void *p, size_t bytes) { l.p[l.n] = p; l.bytes[l.n] = (uint32_t)bytes; l.n++; };
         add(c.tflag, 5 * ntile);                                   /* tflag | tunk | tsum | tray | tact */
         add(c.tknown, ntile);
         add(c.zocc, (size_t)c.Z);
+        add(c.tmax, ntile * sizeof(int32_t));
+        add(c.tskip, ntile);
         add(c.cnt, GIE_CNT_ERR * sizeof(int32_t));                 /* per-frame counters (the sticky error flag survives) */
         add(c.cnt + GIE_CNT_ERR + 1, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
         add(c.cnt + GIE_CNT_BAR_B, (GIE_CNT_AUX_END - GIE_CNT_BAR_B) * sizeof(int32_t));
@@ -513,6 +524,7 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     m->c.fused = gie_fused_mode(m);
     const int kmark = m->c.fused ? GIE_K_MARKC : GIE_K_MARK;
     be_prof(&m->be, kmark, 0);
+    if (m->c.fused && m->c.prev_valid) be_lin(&m->be, m->c, op_tile_oldskip(), m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]);   /* (tskip is zero otherwise) */
     if (m->c.fused) be_vox_list<true>(&m->be, m->c, op_markc(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0, be_sweep_lx("GIE_MARKC_LX", 32));
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
@@ -569,8 +581,8 @@ static int gie_fetch_counters(gie_mapper *m)
     const int e = m->h_cnt[GIE_CNT_ERR];
     {   /* GIE_DEBUG_COUNTS=1: the lengths of the device-side lists of the last map update, on stderr */
         static const int dbg = getenv("GIE_DEBUG_COUNTS") ? atoi(getenv("GIE_DEBUG_COUNTS")) : 0;
-        if (dbg) fprintf(stderr, "gie counts: tiles known %d, frontier tiles %d, fuse tiles %d, seeds A/B/C %d %d %d\n", m->h_cnt[GIE_CNT_TL_KNOWN],
-                         m->h_cnt[GIE_CNT_TL_FRONT], m->h_cnt[GIE_CNT_TL_FUSE], m->h_cnt[GIE_CNT_SEED_A], m->h_cnt[GIE_CNT_SEED_B], m->h_cnt[GIE_CNT_SEED_C]);
+        if (dbg) fprintf(stderr, "gie counts: tiles known %d, frontier tiles %d, fuse tiles %d, seeds A/B/C %d %d %d, tiles without a read of the stored records %d\n", m->h_cnt[GIE_CNT_TL_KNOWN],
+                         m->h_cnt[GIE_CNT_TL_FRONT], m->h_cnt[GIE_CNT_TL_FUSE], m->h_cnt[GIE_CNT_SEED_A], m->h_cnt[GIE_CNT_SEED_B], m->h_cnt[GIE_CNT_SEED_C], m->h_cnt[GIE_CNT_TSKIP]);
     }
     if (e & ~GIE_ERRF_BARRIER) {
         std::string s = "device capacity exceeded:";

@@ -119,8 +119,11 @@ struct op_markc { static constexpr bool rolled = false;
     GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_markc_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &c, int, int, int, int, st &s) const { gie_markc_load2(c, s); }
-    GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { gie_markc_finish(c, id, x, y, z, s); return 0; }
-    GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { gie_markc_voxel(c, x, y, z); } };
+    GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { return gie_markc_finish(c, id, x, y, z, s); }
+    /* per z-column: which voxels were committed and the largest value finish() returned (the tile's bound for the next map update) */
+    GIE_DEVM void column_max(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax) const { gie_markc_column(c, x, y, z0, known, valid, vmax); }
+    GIE_DEVM int operator()(const gie_ctx &c, int x, int y, int z) const { return gie_markc_voxel(c, x, y, z); } };
+struct op_tile_oldskip { GIE_DEVM void operator()(const gie_ctx &c, int t) const { gie_tile_oldskip(c, t); } };
 struct op_commit { static constexpr bool rolled = false;
     typedef gie_commit_st st;
     /* a map update whose waves were cut short by a barrier timeout commits nothing (GIE_ERR_TIMEOUT, include/gie.h) */

@@ -32,6 +32,10 @@
 template <class F> __device__ __forceinline__ auto gie_column_hook_impl(const F &f, const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int)
     -> decltype(f.column(c, x, y, z0, known, valid), void()) { f.column(c, x, y, z0, known, valid); }
 template <class F> __device__ __forceinline__ void gie_column_hook_impl(const F &, const gie_ctx &, int, int, int, unsigned, unsigned, long) {}
+/* ... or column_max(c, x, y, z0, committed mask, valid mask, largest value finish() returned) (op_markc) */
+template <class F> __device__ __forceinline__ auto gie_column_max_hook_impl(const F &f, const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax, int)
+    -> decltype(f.column_max(c, x, y, z0, known, valid, vmax), void()) { f.column_max(c, x, y, z0, known, valid, vmax); }
+template <class F> __device__ __forceinline__ void gie_column_max_hook_impl(const F &, const gie_ctx &, int, int, int, unsigned, unsigned, int, long) {}
 template <class F>
 __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c, const F f)
 {
@@ -1197,12 +1201,14 @@ __device__ __forceinline__ void gie_vox_column(const gie_ctx &c, const F &f, con
 #pragma unroll
         for (int k = 0; k < 8; k++) if (!sk[k]) f.load2(c, id[k], x, y, z0 + k, s[k]);
         unsigned known = 0, valid = 0;
+        int vmax = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (z0 + k < c.Z) valid |= 1u << k;
-            if (!sk[k]) known |= (unsigned)(f.finish(c, id[k], x, y, z0 + k, s[k]) != 0) << k;
+            if (!sk[k]) { const int r = f.finish(c, id[k], x, y, z0 + k, s[k]); known |= (unsigned)(r != 0) << k; vmax = r > vmax ? r : vmax; }
         }
         gie_column_hook_impl(f, c, x, y, z0, known, valid, 0);
+        gie_column_max_hook_impl(f, c, x, y, z0, known, valid, vmax, 0);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; k++) if (!sk[k]) f(c, x, y, z0 + k);

@@ -1292,16 +1292,74 @@ GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
  * block-table lookup per voxel, and the previous frame's pair is read only in the one branch that
  * needs it.  Not used while the changed-block flags are on (gie_stream_enable): a pair that is
  * committed twice could flag a block the reference's single commit would not. */
-struct gie_markc_st { uint32_t bc; int a; int dold; uint64_t ococ; };
+struct gie_markc_st { uint32_t bc; int a; int dold; uint64_t ococ; int skipold; };
+
+/* ---- which stored global records Mark has to read at all.  MarkLimitedObserve compares the batch distance with the voxel's
+ * stored (distance, closest obstacle) and keeps the stored one when it is smaller AND its obstacle lies outside the (whole)
+ * volume.  A stored obstacle is at most sqrt(stored distance) away from its voxel, so for a tile that lies deeper inside the
+ * whole volume than the square root of the largest distance stored in it, no stored obstacle can be outside: the 12 bytes per
+ * voxel need not be read (every voxel of the C5 volume more than ~15 voxels from the faces).  What is stored in the tile's voxels is what
+ * the map update before this one committed there — the sweep below records, per tile, 1 + the largest committed distance
+ * (wave C only lowers what it commits later; nothing else writes voxels inside the volume) — so the bound is only used when
+ * that update was the previous one, ran fused, and covered every voxel of the tile (a voxel it did not commit may hold
+ * anything: its tile's bound is "infinite"). */
+#define GIE_TMAX_INF 0x7fffffff
+GIE_DEV void gie_tile_oldskip(const gie_ctx &c, int t)
+{
+    const int tc[3] = { t % c.tfd[0], (t / c.tfd[0]) % c.tfd[1], t / (c.tfd[0] * c.tfd[1]) };
+    const int sz[3] = { c.X, c.Y, c.Z };
+    int o0[3], o1[3];
+    long long reach2 = 0x7fffffffffffll;              /* (smallest distance to a face of the whole volume)^2, conservative per axis */
+    for (int a = 0; a < 3; a++) {
+        const int v0 = tc[a] * 8, v1 = (v0 + 7 < sz[a] ? v0 + 7 : sz[a] - 1);
+        o0[a] = (v0 + c.prev_shift[a]) >> 3; o1[a] = (v1 + c.prev_shift[a]) >> 3;      /* the previous update's tiles that hold these voxels */
+        if (v0 + c.prev_shift[a] < 0 || v1 + c.prev_shift[a] >= sz[a]) { c.tskip[t] = 0; return; }   /* (partly) new in the volume */
+        const long long m = (long long)(v0 - c.whole_lo[a] < c.whole_hi[a] - 1 - v1 ? v0 - c.whole_lo[a] : c.whole_hi[a] - 1 - v1);
+        if (m < 0) { c.tskip[t] = 0; return; }
+        if (m * m < reach2) reach2 = m * m;
+    }
+    long long d = 0;
+    for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++) {
+        const int v = c.tmax_prev[(z * c.tfd[1] + y) * c.tfd[0] + x];
+        if (v <= 0 || v == GIE_TMAX_INF) { c.tskip[t] = 0; return; }
+        if (v - 1 > d) d = v - 1;
+    }
+    c.tskip[t] = (uint8_t)(d < reach2 ? 1 : 0);      /* |obstacle - voxel| <= sqrt(d) < distance to the nearest face, on every axis */
+#if defined(GIE_HOST_EMU)
+    if (d < reach2) c.cnt[GIE_CNT_TSKIP] += 1;
+#endif
+}
+/* the column's share of its tile's bound (known != valid: a voxel of the column was not committed) */
+GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax)
+{
+    const int t = gie_tile_index(c, x, y, z0);
+    int v = (known != valid) ? GIE_TMAX_INF : vmax;
+#if defined(GIE_HOST_EMU)
+    if (v > c.tmax[t]) c.tmax[t] = v;
+#else
+    /* the eight lanes of a wave that share (lane >> 3) hold one row of one tile in every form of the sweep (inactive ones are the
+     * row's upper end, past the volume); lane ^ 32 is the same tile two (sweep, 32 lanes along x) or four (list) rows on */
+    const int lane = __lane_id();
+    const unsigned long long ex = __ballot(1);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { const int ov = __shfl_xor(v, o); if ((ex >> (lane ^ o)) & 1ull) v = v > ov ? v : ov; }
+    const int ov = __shfl_xor(v, 32), ot = __shfl_xor(t, 32);
+    const bool paired = ((ex >> (lane ^ 32)) & 1ull) && ot == t;
+    if (paired) v = v > ov ? v : ov;
+    if ((lane & 7) == 0 && !(paired && lane >= 32) && v > 0) __hip_atomic_fetch_max(&c.tmax[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 
 GIE_DEV void gie_markc_load1(const gie_ctx &c, int id, int x, int y, int z, gie_markc_st &s)
 {
     s.bc = c.bcoc[id];
     s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    s.skipold = c.tskip[gie_tile_index(c, x, y, z)];
 }
 GIE_DEV void gie_markc_load2(const gie_ctx &c, gie_markc_st &s)
 {
     if (s.a < 0) return;
+    if (s.skipold) { s.dold = GIE_TMAX_INF; s.ococ = 0; return; }     /* no stored record can win (gie_tile_oldskip): never "dn > dold" */
     s.dold = c.g_dist[s.a];
     s.ococ = c.g_coc[s.a];
 }
@@ -1337,23 +1395,26 @@ GIE_DEV uint64_t gie_mark_logic(const gie_ctx &c, int x, int y, int z, uint32_t 
     *flag_tile = !gie_in_loc(c, cn0, cn1, cn2);
     return gie_pair_make(auxv, gie_pack_wr(wx, wy, wz));
 }
-GIE_DEV void gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_markc_st &s)
+/* returns the voxel's share of its tile's bound: 1 + the committed distance, GIE_TMAX_INF when nothing was committed */
+GIE_DEV int gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_markc_st &s)
 {
-    if (s.a < 0) { gie_commit_pair<false>(c, id, -1, c.pair[id]); return; }   /* (a known voxel always has its block) */
+    if (s.a < 0) { gie_commit_pair<false>(c, id, -1, c.pair[id]); return GIE_TMAX_INF; }   /* (a known voxel always has its block) */
     int flag_tile;
     const uint64_t pr = gie_mark_logic(c, x, y, z, s.bc, s.dold, s.ococ, &c.pair[id], &flag_tile);
     if (flag_tile) c.tflag[gie_tile_index(c, x, y, z)] = 1;
     c.pair[id] = pr;
     gie_commit_pair<false>(c, id, s.a, pr);
+    const int d = gie_pair_dist(pr);
+    return d == c.empty_value ? GIE_TMAX_INF : d + 1;
 }
-GIE_DEV void gie_markc_voxel(const gie_ctx &c, int x, int y, int z)
+GIE_DEV int gie_markc_voxel(const gie_ctx &c, int x, int y, int z)
 {
     const int id = gie_lid(c, x, y, z);
-    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;
+    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return 0;
     gie_markc_st s;
     gie_markc_load1(c, id, x, y, z, s);
     gie_markc_load2(c, s);
-    gie_markc_finish(c, id, x, y, z, s);
+    return gie_markc_finish(c, id, x, y, z, s);
 }
 /* ================================================================== halo exchange between tiles */
 /* face f: axis f/2, side f%2.  Layer index i ↔ the two remaining axes (a fastest). */

@@ -102,6 +102,11 @@ typedef struct gie_ctx {
     uint8_t *tray;          /* per tile: a ray touched it this scan (ray-casting OGM) */
     uint8_t *tact;          /* per tile: fuse has to look at it (overlaps an existing block, or held a known voxel last frame) */
     uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
+    int32_t *tmax, *tmax_prev; /* per tile: 1 + the largest distance this / the previous (fused) map update committed in it; 0x7fffffff: a voxel of
+                                * the tile was not committed; 0: the tile was not looked at */
+    uint8_t *tskip;         /* per tile: Mark need not read the stored global records of this tile (gie_tile_oldskip) */
+    int prev_valid;         /* tmax_prev describes the map update right before this one */
+    int prev_shift[3];      /* previous local coordinate = local coordinate + prev_shift */
     uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */
     uint64_t *zneed;        /* per (x,y) tile column: bit tz set = somebody reads the batch EDT of tile (tx,ty,tz) */
     uint16_t *zlist;        /* the planes with obstacles, ascending */
@@ -177,7 +182,8 @@ enum {
     GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
     GIE_CNT_BAR_AB2 = 39,                       /* barrier word of wave B's workgroups */
     GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
-    GIE_CNT_AUX_END = 41,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_TSKIP = 41,                         /* tiles whose stored records Mark does not read (counted by the test-only emulation) */
+    GIE_CNT_AUX_END = 42,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096
@@ -187,7 +193,7 @@ enum {
 #define GIE_ERRF_BARRIER 8
 
 /* regions zeroed by one launch at the start of a map update */
-#define GIE_CLEAR_MAX 8
+#define GIE_CLEAR_MAX 12
 typedef struct gie_clear_list { void *p[GIE_CLEAR_MAX]; uint32_t bytes[GIE_CLEAR_MAX]; int n; } gie_clear_list;
 
 /* stamps in ctx.wl (local) */

@@ -55,6 +55,16 @@ static void be_vox(be_state *, const gie_ctx &c, const op_fuse &f)
         f.column(c, x, y, z0, known, valid);
     }
 }
+/* ... and the Mark + commit sweep the bound of what it committed per tile */
+static void be_vox(be_state *, const gie_ctx &c, const op_markc &f)
+{
+    for (int z0 = 0; z0 < c.Z; z0 += 8) for (int y = 0; y < c.Y; y++) for (int x = 0; x < c.X; x++) {
+        if (f.tile_skip(c, x, y, z0)) continue;
+        unsigned known = 0, valid = 0; int vmax = 0;
+        for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f.skip(c, gie_lid(c, x, y, z), x, y, z)) continue; const int r = f(c, x, y, z); if (r) known |= 1u << (z - z0); if (r > vmax) vmax = r; }
+        f.column_max(c, x, y, z0, known, valid, vmax);
+    }
+}
 template <class F> static void be_list(be_state *, const gie_ctx &c, const F &f, const int32_t *list, int count_idx)
 { const int n = c.cnt[count_idx]; for (int e = 0; e < n; e++) f(c, list[e]); }
 /* the list form: only the listed tiles, one (x,y) column of a tile at a time like a device lane */
@@ -65,6 +75,12 @@ static void be_vox_list_col(const gie_ctx &c, const op_fuse &f, int x, int y, in
     unsigned known = 0, valid = 0;
     for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f(c, x, y, z)) known |= 1u << (z - z0); }
     f.column(c, x, y, z0, known, valid);
+}
+static void be_vox_list_col(const gie_ctx &c, const op_markc &f, int x, int y, int z0)
+{
+    unsigned known = 0, valid = 0; int vmax = 0;
+    for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f.skip(c, gie_lid(c, x, y, z), x, y, z)) continue; const int r = f(c, x, y, z); if (r) known |= 1u << (z - z0); if (r > vmax) vmax = r; }
+    f.column_max(c, x, y, z0, known, valid, vmax);
 }
 static int be_sweep_lx(const char *, int dflt) { return dflt; }
 static int be_rows_mode() { return 0; }

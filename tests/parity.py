@@ -50,6 +50,14 @@ class Scenario:
                 pvt = scenes.local_pivot(pos, self.voxel, self.size, getattr(self, "tile_off", (0, 0, 0)))
                 yield pos, q, "labels", scenes.hash_world_labels(pvt, self.size, k, seed=self.seed, p_occ=self.p_occ,
                                                                  toggle_frac=self.toggle).astype(np.int8), {}
+            elif kind == "labels_blink":
+                # the hash world with every third scan free of obstacles altogether: in those map updates the batch EDT has nothing
+                # (pairs EMPTY, nothing committed) except where limited observation keeps an old obstacle outside the volume
+                pvt = scenes.local_pivot(pos, self.voxel, self.size)
+                lab = scenes.hash_world_labels(pvt, self.size, k, seed=self.seed, p_occ=self.p_occ, toggle_frac=self.toggle).astype(np.int8)
+                if k % 3 == 2:
+                    lab[:] = 1
+                yield pos, q, "labels", lab, {}
             elif kind == "scan2d":
                 pts, rng = scenes.lidar_frame(world, k, pos, q, rings=1, az=360, phi_min_deg=0.0, max_range=30.0)
                 r = np.where(np.isfinite(rng[0]), rng[0], np.nan).astype(np.float32)

@@ -38,6 +38,10 @@ SCENARIOS = [
     # reach well past the retention zone
     parity.Scenario("retain_c5_out_and_back", (32, 32, 16), voxel=0.05, sensor="labels", frames=26, delta_vox=8, yaw_deg=2.0, seed=5,
                     cutoff_dist=1.0, p_occ=0.01, retain=2, turn=9, probe_margin=60),
+    # obstacle-free scans in between, on the move: known voxels that are not committed (EMPTY pairs) while their stored pair is
+    # still owed from an earlier update of the same stay in the volume (gie_commit_pair / gie_pair_flush_voxel)
+    parity.Scenario("blink_empty_scans", (32, 28, 12), voxel=0.05, sensor="labels_blink", frames=18, delta_vox=5, yaw_deg=2.0, seed=9,
+                    cutoff_dist=1.0, p_occ=0.004, toggle=0.3, probe_margin=30),
     parity.Scenario("retain_lidar", (48, 48, 16), sensor="multiscan", frames=16, delta_vox=7, yaw_deg=10.0, retain=1, probe_margin=40),
     parity.Scenario("retain_odd_r1", (37, 29, 11), sensor="mixed", frames=12, delta_vox=5, yaw_deg=33.0, retain=1, turn=5, probe_margin=40),
 ]
