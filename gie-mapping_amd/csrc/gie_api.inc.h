@@ -524,8 +524,9 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     m->c.fused = gie_fused_mode(m);
     const int kmark = m->c.fused ? GIE_K_MARKC : GIE_K_MARK;
     be_prof(&m->be, kmark, 0);
-    if (m->c.fused && m->c.prev_valid) be_lin(&m->be, m->c, op_tile_oldskip(), m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]);   /* (tskip is zero otherwise) */
-    if (m->c.fused) be_vox_list<true>(&m->be, m->c, op_markc(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0, be_sweep_lx("GIE_MARKC_LX", 32));
+    static const int use_bound = getenv("GIE_MARKC_BOUND") ? atoi(getenv("GIE_MARKC_BOUND")) : 1;     /* 0: always read the stored records (measurements) */
+    if (m->c.fused && m->c.prev_valid && use_bound) be_lin(&m->be, m->c, op_tile_oldskip(), m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]);   /* (tskip is zero otherwise) */
+    if (m->c.fused) be_markc(&m->be, m->c, m->c.tl_known);
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
     m->merge_open = 1;

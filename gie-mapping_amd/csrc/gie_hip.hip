@@ -297,6 +297,18 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
     else if (lx == 8) GIE_LAUNCH(b, (k_voxa<F, STAGED, 8>), g, t, 0, c, f, list, count_idx, always_list);
     else GIE_LAUNCH(b, (k_voxa<F, STAGED, 64>), g, t, 0, c, f, list, count_idx, always_list);
 }
+/* Mark + commit as one sweep: its own kernel (k_markc); GIE_MARKC_GENERIC=1 keeps the staged functor sweep (tests run both) */
+static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
+{
+    static const int generic = getenv("GIE_MARKC_GENERIC") ? atoi(getenv("GIE_MARKC_GENERIC")) : 0;
+    static const int lx = getenv("GIE_MARKC_LX") ? atoi(getenv("GIE_MARKC_LX")) : 32;
+    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
+    if (generic) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0, lx == 16 || lx == 8 || lx == 32 ? lx : 64); return; }
+    const dim3 g(b->cu_total * mult), t(256);
+    if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list);
+    else if (lx == 64) GIE_LAUNCH(b, k_markc<64>, g, t, 0, c, list);
+    else GIE_LAUNCH(b, k_markc<32>, g, t, 0, c, list);
+}
 /* lanes of a wave along x in the sweep form of the kernels that touch the global block planes */
 static int be_sweep_lx(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return (v == 8 || v == 16 || v == 32) ? v : 64; }
 /* dense (block-row) form of fuse; GIE_ROWS=0 keeps the thread-per-z-column sweep */

@@ -1245,6 +1245,92 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
     }
 }
 
+/* ------------------------------------------------------------------ Mark + commit, the dense sweep's own kernel */
+/* MarkLimitedObserve + UpdateHashBatch as one sweep (gie_ops.h "Mark + commit"): the same per-voxel functions as op_markc
+ * under k_voxa (gie_mark_logic, gie_commit_pair, gie_markc_column) and the same geometry (thread = z-column of one tile, lanes LX
+ * along x), but every load of a column's batch goes out BEFORE anything is tested: types, batch obstacles, the two block slots a
+ * column can touch and the tile's skip flag in one batch, the stored records in a second one, then arithmetic and stores.  The
+ * generic staged sweep tests the type first and loads behind the branch — four dependent round trips per column instead of
+ * two; on the C5 volume the sweep is bound by how many bytes it keeps in flight, and by its stores (tools/sweep_probe.hip:
+ * this device writes at ~4.1 TB/s and reads at ~6.5, one after the other). */
+__device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const int x, const int y, const int z0)
+{
+    if (x >= c.X || y >= c.Y) return;
+    const int t = gie_tile_index(c, x, y, z0);
+    if (!c.tknown[t]) return;
+    const size_t plane = (size_t)c.X * c.Y;
+    const size_t id0 = ((size_t)z0 * c.Y + y) * c.X + x;
+    const int nz = min(8, c.Z - z0);
+    const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz0 = z0 + c.pvt[2];
+    int8_t ty[8]; uint32_t bc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const size_t id = id0 + (size_t)(k < nz ? k : 0) * plane;
+        ty[k] = c.glb_type[id]; bc[k] = c.bcoc[id];
+    }
+    const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
+    const int slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
+    const int skipold = c.tskip[t];
+    int a[8]; int dold[8]; uint64_t oc[8];
+    unsigned want = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int gz = gz0 + k;
+        const int slot = ((gz >> 3) == (gz0 >> 3)) ? slot_lo : slot_hi;
+        a[k] = slot < 0 ? -1 : slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+        if (k < nz && ty[k] != GIE_VOX_UNKNOWN) want |= 1u << k;
+        dold[k] = GIE_TMAX_INF; oc[k] = 0;
+    }
+    if (!skipold) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && a[k] >= 0) { dold[k] = c.g_dist[a[k]]; oc[k] = c.g_coc[a[k]]; }
+    }
+    unsigned known = 0, valid = 0;
+    int vmax = 0, flag = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < nz) valid |= 1u << k;
+        if (!((want >> k) & 1u)) continue;
+        const size_t id = id0 + (size_t)k * plane;
+        int r;
+        if (a[k] < 0) { gie_commit_pair<false>(c, (int)id, -1, c.pair[id]); r = GIE_TMAX_INF; }      /* (a known voxel always has its block) */
+        else {
+            int ft;
+            const uint64_t pr = gie_mark_logic(c, x, y, z0 + k, bc[k], dold[k], oc[k], &c.pair[id], &ft);
+            flag |= ft;
+            c.pair[id] = pr;
+            gie_commit_pair<false>(c, (int)id, a[k], pr);
+            const int d = gie_pair_dist(pr);
+            r = d == c.empty_value ? GIE_TMAX_INF : d + 1;
+        }
+        known |= 1u << k; vmax = r > vmax ? r : vmax;
+    }
+    if (flag) c.tflag[t] = 1;
+    gie_markc_column(c, x, y, z0, known, valid, vmax);
+}
+template <int LX>
+__global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *list)
+{
+    const int n = c.cnt[GIE_CNT_TL_KNOWN];
+    const int lane = threadIdx.x & 63;
+    if (gie_use_lists(c, n)) {
+        const int waves = gridDim.x * 4;
+        for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+            const int t = list[e];
+            const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+            gie_markc_column_fast(c, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8);
+        }
+    } else {
+        constexpr int LY = 64 / LX, WY = 4 * LY;
+        const int gx = (c.X + LX - 1) / LX, gy = (c.Y + WY - 1) / WY, gz = (c.Z + 7) / 8;
+        const int nv = gx * gy * gz;
+        const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
+        for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++)
+            gie_markc_column_fast(c, (v % gx) * LX + lx, ((v / gx) % gy) * WY + ly, (v / (gx * gy)) * 8);
+    }
+}
+
 /* ------------------------------------------------------------------ obtainFrontiers: tiles out of LDS, faces one voxel per lane */
 /* obtainFrontiers (unify_helper.cuh:275-446).  The per-voxel decisions are gie_frontier_finish_nb's (gie_ops.h); what the two
  * kernels here change is where their inputs come from and who looks at which voxel (the thread-per-column form walked a

@@ -1332,6 +1332,9 @@ GIE_DEV void gie_tile_oldskip(const gie_ctx &c, int t)
 /* the column's share of its tile's bound (known != valid: a voxel of the column was not committed) */
 GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax)
 {
+#if defined(GIE_ABL_NOTMAX)
+    return;
+#endif
     const int t = gie_tile_index(c, x, y, z0);
     int v = (known != valid) ? GIE_TMAX_INF : vmax;
 #if defined(GIE_HOST_EMU)
@@ -1354,7 +1357,13 @@ GIE_DEV void gie_markc_load1(const gie_ctx &c, int id, int x, int y, int z, gie_
 {
     s.bc = c.bcoc[id];
     s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+#if defined(GIE_ABL_NOSKIPLOAD)
+    s.skipold = 0;
+#elif defined(GIE_ABL_ALLSKIP)
+    s.skipold = 1;
+#else
     s.skipold = c.tskip[gie_tile_index(c, x, y, z)];
+#endif
 }
 GIE_DEV void gie_markc_load2(const gie_ctx &c, gie_markc_st &s)
 {
