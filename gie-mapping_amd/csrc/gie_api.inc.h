@@ -157,7 +157,6 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.g_key = gie_dalloc<uint64_t>(m, (size_t)mb, false);
     c.g_occ = gie_dalloc<uint8_t>(m, GV, false);
     c.g_type = gie_dalloc<int8_t>(m, GV, false);
-    c.g_dist = gie_dalloc<int32_t>(m, GV, false);
     c.g_coc = gie_dalloc<uint64_t>(m, GV, false);
     c.g_pair = gie_dalloc<uint64_t>(m, GV, false);
     c.g_prop = gie_dalloc<uint64_t>(m, GV, false);

@@ -1283,7 +1283,9 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     }
     if (!skipold) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && a[k] >= 0) { dold[k] = c.g_dist[a[k]]; oc[k] = c.g_coc[a[k]]; }
+        for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && a[k] >= 0) oc[k] = c.g_coc[a[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && a[k] >= 0) dold[k] = gie_gdist(c, oc[k], gx, gy, gz0 + k);
     }
     unsigned known = 0, valid = 0;
     int vmax = 0, flag = 0;

@@ -159,6 +159,22 @@ GIE_DEV int gie_gvox_hash(const gie_ctx &c, int gx, int gy, int gz)
     return s < 0 ? -1 : s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
 }
 
+/* The stored squared distance of a global voxel is not a plane of its own: every writer of the reference stores dist_sq and
+ * coc_glb together, and dist_sq is |coc_glb - voxel|^2 whenever the obstacle is valid (MarkLimitedObserve keeps an old pair
+ * whole, obtainFrontiers / raise_outside / lower_outside / UpdateHashBatch compute the distance from the obstacle they store;
+ * tests: every stored record is a witness), EMPTY_VALUE next to EMPTY_KEY otherwise.  So GlbVoxel.dist_sq is derived from the
+ * stored obstacle where it is read — 4 bytes per voxel less to write in the commit sweep, which is bound by its stores. */
+#define GIE_COC_STALEPAIR (1ull << 63)            /* bit 63 of a stored obstacle: see gie_commit_pair */
+#define GIE_COC_EMPTY ((uint64_t)(uint32_t)(GIE_EMPTY_VALUE + GIE_CRD_OFF) | ((uint64_t)(uint32_t)(GIE_EMPTY_VALUE + GIE_CRD_OFF) << 21) | ((uint64_t)(uint32_t)(GIE_EMPTY_VALUE + GIE_CRD_OFF) << 42))
+GIE_DEV int gie_gdist(const gie_ctx &c, uint64_t coc, int gx, int gy, int gz)
+{
+    coc &= ~GIE_COC_STALEPAIR;
+    if (coc == GIE_COC_EMPTY) return c.empty_value;
+    int cx, cy, cz;
+    gie_unpack_crd(coc, &cx, &cy, &cz);
+    return gie_d2(cx, cy, cz, gx, gy, gz);
+}
+
 /* ================================================================== OGM: projective */
 GIE_DEV int gie_robot_sphere(const gie_ctx &c, int x, int y, int z)
 {   /* pntcld_raycast.cu:33-41, vlp16_fast.cu:30-40: |crd - _half_shift|² <= rbt_r2_grids */
@@ -398,7 +414,6 @@ GIE_DEV void gie_init_voxel(const gie_ctx &c, int slot, int i)
 {
     const int a = slot * GIE_VBSZ + i;
     c.g_occ[a] = 0; c.g_type[a] = GIE_VOX_UNKNOWN;
-    c.g_dist[a] = c.empty_value;
     c.g_coc[a] = gie_pack_crd(GIE_EMPTY_VALUE, GIE_EMPTY_VALUE, GIE_EMPTY_VALUE);
     c.g_pair[a] = 0; c.g_prop[a] = GIE_NOPROP; c.g_wl[a] = -1;
 }
@@ -537,7 +552,7 @@ GIE_DEV int gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
 /* Split in stages so that a thread can keep the loads of several voxels in flight (the sweep is
  * latency-bound): load1 = independent reads, load2 = reads that need load1's block slot,
  * finish = arithmetic + writes.  gie_mark_voxel chains them for one voxel. */
-struct gie_mark_st { uint32_t bc; uint64_t pr; int a; int dold; uint64_t ococ; };
+struct gie_mark_st { uint32_t bc; uint64_t pr; int a; uint64_t ococ; };
 
 GIE_DEV void gie_mark_load1(const gie_ctx &c, int id, int x, int y, int z, gie_mark_st &s)
 {
@@ -548,7 +563,6 @@ GIE_DEV void gie_mark_load1(const gie_ctx &c, int id, int x, int y, int z, gie_m
 GIE_DEV void gie_mark_load2(const gie_ctx &c, gie_mark_st &s)
 {
     if (s.a < 0) return;
-    s.dold = c.g_dist[s.a];
     s.ococ = c.g_coc[s.a];
 }
 GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_mark_st &s)
@@ -565,7 +579,7 @@ GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         auxv = c.empty_value;
         cn[0] = cn[2] = 0; cn[1] = 16383;          /* the oracle's invalid marker: outside every wave range */
     } else { cn[0] = (int)(bc & 1023u); cn[1] = (int)((bc >> 10) & 1023u); cn[2] = (int)(bc >> 20); }
-    const int dold = s.dold;
+    const int dold = gie_gdist(c, s.ococ, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     int ox, oy, oz;
     gie_unpack_crd(s.ococ, &ox, &oy, &oz);
     const int ol[3] = { ox - c.pvt[0], oy - c.pvt[1], oz - c.pvt[2] };
@@ -613,8 +627,8 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
     if (a < 0) return 2;
     /* the neighbour's record in one batch of loads (a face voxel is a chain of dependent round trips) */
     const int8_t nty = c.g_type[a];
-    const int nd = c.g_dist[a];
     const uint64_t ncoc = c.g_coc[a];
+    const int nd = gie_gdist(c, ncoc, ng[0], ng[1], ng[2]);
     if (nty == GIE_VOX_UNKNOWN) return 2;
     if (gie_invalid_dist(c, nd)) return 0;
     int ncx, ncy, ncz;
@@ -643,8 +657,7 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
     } else if (c2n > nd && n_local) {                     /* raise out → frontier A */
         /* the reference reads the live _glb_type here; FNT never aliases OCCUPIED */
         if (c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
-            c.g_dist[a] = c2n;
-            c.g_coc[a] = gie_pack_crd(cl[0] + c.pvt[0], cl[1] + c.pvt[1], cl[2] + c.pvt[2]);
+            c.g_coc[a] = gie_pack_crd(cl[0] + c.pvt[0], cl[1] + c.pvt[1], cl[2] + c.pvt[2]);     /* (its distance to the neighbour is c2n) */
             gie_touch(c, a);
             c.g_wl[a] = -c.map_ct;
             c.g_pair[a] = gie_pair_make(c2n, gie_pack_wr(cw[0], cw[1], cw[2]));
@@ -861,8 +874,8 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
     const int a = gie_ld(&c.qa_a[cur][e]);
     gie_st(&c.rec0[e], (uint64_t)GIE_KEY_EMPTY); gie_st(&c.rec1[e], (uint64_t)GIE_NOPROP); gie_st(&c.rec3[e], (int32_t)0);
     if (a < 0) return;
-    int cd = gie_ld(&c.g_dist[a]);
     const uint64_t lcoc = gie_ld(&c.g_coc[a]);
+    int cd = gie_gdist(c, lcoc, g[0], g[1], g[2]);
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     unsigned want = 0;
     GIE_UNROLL6
@@ -878,7 +891,8 @@ GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {      /* straight-line code: a neighbour that does not exist re-reads the entry's own record (ignored below) */
         const int ak = na[k] >= 0 ? na[k] : a;
-        nty[k] = gie_ld(&c.g_type[ak]); ncc[k] = gie_ld(&c.g_coc[ak]); nd[k] = gie_ld(&c.g_dist[ak]); nwl[k] = gie_ld(&c.g_wl[ak]);
+        nty[k] = gie_ld(&c.g_type[ak]); ncc[k] = gie_ld(&c.g_coc[ak]); nwl[k] = gie_ld(&c.g_wl[ak]);
+        nd[k] = gie_gdist(c, ncc[k], g[0] + dx[k], g[1] + dy[k], g[2] + dz[k]);
     }
     int lc[3];
     gie_unpack_crd(lcoc, &lc[0], &lc[1], &lc[2]);
@@ -938,8 +952,7 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     const uint64_t r0 = gie_ld(&c.rec0[e]), r1 = gie_ld(&c.rec1[e]);
     const unsigned mask = (unsigned)(r3 >> 24) & 63u;
     if (r0 != GIE_KEY_EMPTY) {
-        gie_st(&c.g_dist[a], (int32_t)(r3 & 0xffffff));
-        gie_st(&c.g_coc[a], r0);
+        gie_st(&c.g_coc[a], r0);                            /* (its distance to this voxel is r3's low bits) */
         gie_touch(c, a);
         gie_st(&c.g_wl[a], (int32_t)1);
         if (r1 != GIE_NOPROP) gie_st(&c.g_pair[a], r1);
@@ -968,7 +981,6 @@ GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     for (int k = 0; k < 6; k++) {
         if (!((mask >> k) & 1u) || na[k] < 0 || old[k] != key[k]) continue;       /* not the (unique) winner */
         win |= 1u << k;
-        gie_st(&c.g_dist[na[k]], (int32_t)d[k]);
         gie_st(&c.g_coc[na[k]], gie_pack_crd(lc[0], lc[1], lc[2]));
         gie_touch(c, na[k]);
         gie_st(&c.g_wl[na[k]], (int32_t)-c.map_ct);
@@ -1016,12 +1028,15 @@ GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e, int fir
     if (a < 0) return;
     if (first && gie_axchg32(&c.g_wl[a], GIE_GWL_INB(c)) == GIE_GWL_INB(c)) { gie_aadd32(&c.cnt[GIE_CNT_SPARE0], 1); return; }
     const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
-    if (gie_ld(&c.g_dist[a]) > c.cutoff_sq) return;
+    {   /* the cut-off looks at the distance stored BEFORE the pair is committed (wave_core.cuh:262-266) */
+        int g[3];
+        gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
+        if (gie_gdist(c, gie_ld(&c.g_coc[a]), g[0], g[1], g[2]) > c.cutoff_sq) return;
+    }
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
     const uint64_t coc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
-    gie_st(&c.g_coc[a], coc);
-    gie_st(&c.g_dist[a], (int32_t)gie_pair_dist(pr));
+    gie_st(&c.g_coc[a], coc);                               /* (its distance to this voxel is the pair's) */
     gie_touch(c, a);
     gie_st(&rec0[e], (uint64_t)gie_pair_par(pr));
     gie_st(&rec1[e], coc);
@@ -1166,7 +1181,6 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int rp, int e)
  * is older than this record": set by this commit, cleared by whoever stores a pair for real.  It settles the one case the
  * local plane cannot — a voxel whose pair was EMPTY (not committed) when it left: flag set = its last commit happened
  * during this stay in the volume and the pair of that commit is (stored distance, stored closest obstacle). */
-#define GIE_COC_STALEPAIR (1ull << 63)
 template <bool AGENT>
 GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
 {
@@ -1180,9 +1194,9 @@ GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
     const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]) | GIE_COC_STALEPAIR;
     if (AGENT) {
-        gie_st(&c.g_coc[a], ncoc); gie_st(&c.g_dist[a], (int32_t)d); gie_st(&c.edt[id], sqrtf((float)d));
+        gie_st(&c.g_coc[a], ncoc); gie_st(&c.edt[id], sqrtf((float)d));
     } else {
-        c.g_coc[a] = ncoc; c.g_dist[a] = d; c.edt[id] = sqrtf((float)d);     /* (nontemporal stores: no gain measured) */
+        c.g_coc[a] = ncoc; c.edt[id] = sqrtf((float)d);     /* (nontemporal stores: no gain measured) */
     }
 }
 /* The voxels of the LAST fused map update's volume (pivot opvt, wave-range pivot oupvt, block table still that update's)
@@ -1221,7 +1235,7 @@ GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, in
         if (cc & GIE_COC_STALEPAIR) {                 /* not committed by that update, but by an earlier one of this stay */
             int ox, oy, oz;
             gie_unpack_crd(cc, &ox, &oy, &oz);
-            c.g_pair[a] = gie_pair_make(c.g_dist[a], gie_pack_wr((ox - b.oupvt[0]) & 0x3fff, (oy - b.oupvt[1]) & 0x3fff, (oz - b.oupvt[2]) & 0x1fff));   /* (only the distance of a stored pair is ever compared) */
+            c.g_pair[a] = gie_pair_make(gie_gdist(c, cc, gx, gy, gz), gie_pack_wr((ox - b.oupvt[0]) & 0x3fff, (oy - b.oupvt[1]) & 0x3fff, (oz - b.oupvt[2]) & 0x1fff));   /* (only the distance of a stored pair is ever compared) */
             c.g_coc[a] = cc & ~GIE_COC_STALEPAIR;
         }
     }
@@ -1266,9 +1280,8 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
     const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
-    if (c.track && (c.g_dist[a] != d || (c.g_coc[a] & ~GIE_COC_STALEPAIR) != ncoc || (ty == GIE_VOX_FNT && c.g_type[a] != GIE_VOX_FNT))) gie_touch(c, a);
+    if (c.track && ((c.g_coc[a] & ~GIE_COC_STALEPAIR) != ncoc || (ty == GIE_VOX_FNT && c.g_type[a] != GIE_VOX_FNT))) gie_touch(c, a);   /* (same obstacle: same distance) */
     c.g_coc[a] = ncoc;
-    c.g_dist[a] = d;
     c.edt[id] = sqrtf((float)d);
     c.g_pair[a] = pr;
     if (ty == GIE_VOX_FNT) c.g_type[a] = GIE_VOX_FNT;
@@ -1292,7 +1305,7 @@ GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
  * block-table lookup per voxel, and the previous frame's pair is read only in the one branch that
  * needs it.  Not used while the changed-block flags are on (gie_stream_enable): a pair that is
  * committed twice could flag a block the reference's single commit would not. */
-struct gie_markc_st { uint32_t bc; int a; int dold; uint64_t ococ; int skipold; };
+struct gie_markc_st { uint32_t bc; int a; int dold; uint64_t ococ; int skipold; int g[3]; };
 
 /* ---- which stored global records Mark has to read at all.  MarkLimitedObserve compares the batch distance with the voxel's
  * stored (distance, closest obstacle) and keeps the stored one when it is smaller AND its obstacle lies outside the (whole)
@@ -1356,7 +1369,8 @@ GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned k
 GIE_DEV void gie_markc_load1(const gie_ctx &c, int id, int x, int y, int z, gie_markc_st &s)
 {
     s.bc = c.bcoc[id];
-    s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    s.g[0] = x + c.pvt[0]; s.g[1] = y + c.pvt[1]; s.g[2] = z + c.pvt[2];
+    s.a = gie_gvox_tab(c, s.g[0], s.g[1], s.g[2]);
 #if defined(GIE_ABL_NOSKIPLOAD)
     s.skipold = 0;
 #elif defined(GIE_ABL_ALLSKIP)
@@ -1369,8 +1383,8 @@ GIE_DEV void gie_markc_load2(const gie_ctx &c, gie_markc_st &s)
 {
     if (s.a < 0) return;
     if (s.skipold) { s.dold = GIE_TMAX_INF; s.ococ = 0; return; }     /* no stored record can win (gie_tile_oldskip): never "dn > dold" */
-    s.dold = c.g_dist[s.a];
     s.ococ = c.g_coc[s.a];
+    s.dold = gie_gdist(c, s.ococ, s.g[0], s.g[1], s.g[2]);
 }
 /* MarkLimitedObserve for one voxel on values in registers: batch closest obstacle `bc`, the stored global
  * (dold, ococ); last frame's pair is read through `old_pair` only in the one branch that needs it.
@@ -1450,7 +1464,8 @@ GIE_DEV void gie_halo_export_voxel(const gie_ctx &c, int face, int i, gie_halo_v
     if (a < 0 || c.g_type[a] == GIE_VOX_UNKNOWN) {
         h.vox_type = GIE_VOX_UNKNOWN; h.dist_sq = c.empty_value; h.coc[0] = h.coc[1] = h.coc[2] = GIE_EMPTY_VALUE;
     } else {
-        h.vox_type = c.g_type[a]; h.dist_sq = c.g_dist[a]; h.occ_val = c.g_occ[a];
+        h.vox_type = c.g_type[a]; h.occ_val = c.g_occ[a];
+        h.dist_sq = gie_gdist(c, c.g_coc[a], x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
         gie_unpack_crd(c.g_coc[a], &h.coc[0], &h.coc[1], &h.coc[2]);
     }
     out[i] = h;
@@ -1473,8 +1488,7 @@ GIE_DEV void gie_halo_import_voxel(const gie_ctx &c, int face, int i, const gie_
     if (a < 0) return;
     c.g_type[a] = in[i].vox_type;
     c.g_occ[a] = in[i].occ_val;
-    c.g_dist[a] = in[i].dist_sq;
-    c.g_coc[a] = gie_pack_crd(in[i].coc[0], in[i].coc[1], in[i].coc[2]);
+    c.g_coc[a] = gie_pack_crd(in[i].coc[0], in[i].coc[1], in[i].coc[2]);      /* (in[i].dist_sq is this obstacle's distance: the owner's record is a witness) */
     gie_touch(c, a);
 }
 /* obtainFrontiers' C-seed rule (unify_helper.cuh:365-399) for a face voxel against its ghost
@@ -1494,7 +1508,7 @@ GIE_DEV int gie_refine_voxel(const gie_ctx &c, int id)
         if (gie_in_loc(c, nx, ny, nz)) continue;
         const int a = gie_gvox_tab(c, nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]);
         if (a < 0 || c.g_type[a] == GIE_VOX_UNKNOWN) continue;
-        if (gie_invalid_dist(c, c.g_dist[a])) continue;
+        if (gie_invalid_dist(c, gie_gdist(c, c.g_coc[a], nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]))) continue;
         int ncx, ncy, ncz;
         gie_unpack_crd(c.g_coc[a], &ncx, &ncy, &ncz);
         if (gie_invalid_coc(ncx, ncy, ncz)) continue;
@@ -1559,7 +1573,13 @@ GIE_DEV void gie_stream_gather(const gie_ctx &c, const int32_t *list, int first,
     const int slot = list[first + (i >> 9)], j = i & 511;
     const int a = slot * GIE_VBSZ + ((j >> 6) | (((j >> 3) & 7) << 3) | ((j & 7) << 6));
     gie_voxel v;
-    v.occ_val = c.g_occ[a]; v.vox_type = c.g_type[a]; v.pad = 0; v.dist_sq = c.g_dist[a];
+    v.occ_val = c.g_occ[a]; v.vox_type = c.g_type[a]; v.pad = 0;
+    {   /* the voxel's global coordinate: block key * 8 + in-block position */
+        int k[3];
+        gie_unpack_crd(c.g_key[slot], &k[0], &k[1], &k[2]);
+        const int ib = a & (GIE_VBSZ - 1);
+        v.dist_sq = gie_gdist(c, c.g_coc[a], k[0] * 8 + (ib & 7), k[1] * 8 + ((ib >> 3) & 7), k[2] * 8 + (ib >> 6));
+    }
     gie_unpack_crd(c.g_coc[a], &v.coc[0], &v.coc[1], &v.coc[2]);
     out[i] = v;
     if (j < 3) {
@@ -1578,7 +1598,7 @@ GIE_DEV void gie_query_voxel(const gie_ctx &c, const int32_t *xyz, int i, gie_vo
         out[i].occ_val = 0; out[i].vox_type = GIE_VOX_UNKNOWN; out[i].dist_sq = c.empty_value;
         out[i].coc[0] = out[i].coc[1] = out[i].coc[2] = GIE_EMPTY_VALUE;
     } else {
-        out[i].occ_val = c.g_occ[a]; out[i].vox_type = c.g_type[a]; out[i].dist_sq = c.g_dist[a];
+        out[i].occ_val = c.g_occ[a]; out[i].vox_type = c.g_type[a]; out[i].dist_sq = gie_gdist(c, c.g_coc[a], xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
         gie_unpack_crd(c.g_coc[a], &out[i].coc[0], &out[i].coc[1], &out[i].coc[2]);
     }
 }

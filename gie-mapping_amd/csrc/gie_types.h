@@ -134,7 +134,6 @@ typedef struct gie_ctx {
     uint64_t *g_key;        /* block key per slot */
     uint8_t *g_occ;         /* planes, 512 per slot, in-block index x | y<<3 | z<<6 */
     int8_t *g_type;
-    int32_t *g_dist;
     uint64_t *g_coc;        /* packed global coord */
     uint64_t *g_pair;
     uint64_t *g_prop;
