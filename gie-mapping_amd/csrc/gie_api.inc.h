@@ -29,6 +29,7 @@ struct gie_mapper {
     be_state be;
     int ncell;
     int has_pose, has_ogm, merge_open;
+    int fuse_fresh;                       /* gie_fuse has run and no merge has consumed it yet (a merge needs the frame clear of its own map update) */
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
     int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
     int commit_pvt[3], commit_upvt[3], commit_tb0[3];   /* pivots / block-table origin of that merge */
@@ -72,6 +73,16 @@ static void *gie_scratch(gie_mapper *m, int i, size_t bytes, const char *who)
     return m->scratch[i];
 }
 
+/* the full-volume debug readers (gie_read_local / _batch_edt / _costmap) export through buffers of 4-12 bytes per voxel — 2 GB at
+ * 512^3: those go back to the device when the call is over (eight mappers on one device is a supported test configuration);
+ * the small buffers of the per-update readers (halo layers, point queries) are kept and reused */
+#define GIE_SCRATCH_KEEP ((size_t)64 << 20)
+static void gie_scratch_trim(gie_mapper *m)
+{
+    for (int i = 0; i < 2; i++)
+        if (m->scratch[i] && m->scratch_cap[i] > GIE_SCRATCH_KEEP) { be_free(&m->be, m->scratch[i]); m->scratch[i] = nullptr; m->scratch_cap[i] = 0; }
+}
+
 static int gie_pow2_ge(long long v) { int p = 1; while ((long long)p < v) p <<= 1; return p; }
 
 extern "C" gie_mapper *gie_create(const gie_config *cfg)
@@ -87,7 +98,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0; m->fuse_fresh = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -420,6 +431,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     if (!m->has_ogm) { gie_set_err("gie_fuse: no scan has been fed since the last fuse (call gie_ogm_* first)"); return GIE_ERR_INVALID; }
     m->has_ogm = 0;
     m->ogm_unlabelled = 0;                /* fuse consumes the scan */
+    m->fuse_fresh = 1;
     be_time(&m->be, 2);
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
@@ -519,6 +531,10 @@ static int gie_fused_mode(const gie_mapper *m)
 extern "C" int gie_merge_begin(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_merge"); if (rc) return rc;
+    /* the seed counters, the barrier words of the waves and the per-round arrays are zeroed by gie_fuse's frame clear: a second
+     * merge of the same map update would append to what the first one left */
+    if (!m->fuse_fresh) { gie_set_err("gie_merge: no gie_fuse since the last merge (one merge per map update)"); return GIE_ERR_INVALID; }
+    m->fuse_fresh = 0;
     be_time(&m->be, 6);
     m->c.fused = gie_fused_mode(m);
     const int kmark = m->c.fused ? GIE_K_MARKC : GIE_K_MARK;
@@ -625,6 +641,7 @@ extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *
         be_lin(&m->be, m->c, op, m->c.N);
         if (dd) be_d2h(&m->be, dist_sq, dd, N * 4);
         if (dc) be_d2h(&m->be, coc_xyz, dc, N * 12);
+        gie_scratch_trim(m);
     }
     return gie_sync(m);
 }
@@ -652,6 +669,7 @@ extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
         be_lin(&m->be, m->c, op, m->c.N);
         if (dd) be_d2h(&m->be, dist_sq, dd, N * 4);
         if (dc) be_d2h(&m->be, coc, dc, N * 12);
+        gie_scratch_trim(m);
     }
     return gie_sync(m);
 }
@@ -665,6 +683,7 @@ extern "C" int gie_read_costmap(gie_mapper *m, gie_seendist *payload, gie_costma
         op_costmap op; op.out = d;
         be_lin(&m->be, m->c, op, m->c.N);
         be_d2h(&m->be, payload, d, N * sizeof(gie_seendist));
+        gie_scratch_trim(m);
     }
     if (hdr) {
         hdr->x_size = m->c.X; hdr->y_size = m->c.Y; hdr->z_size = m->c.Z;
@@ -889,7 +908,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
     c.fused = gie_fused_mode(m);
-    be_waves(&m->be, c, 0, 0, 0);
+    be_waves(&m->be, c, 0, 0, 0);                        /* (its own clear above) */
     if (!c.fused) be_vox_list<true>(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, 0);   /* fused: wave C has committed what it merged */
     if (!seeded) return GIE_OK;          /* enqueue only: a fixed number of exchange rounds needs no answer */
     rc = gie_sync(m);

@@ -126,8 +126,10 @@ struct op_markc { static constexpr bool rolled = false;
 struct op_tile_oldskip { GIE_DEVM void operator()(const gie_ctx &c, int t) const { gie_tile_oldskip(c, t); } };
 struct op_commit { static constexpr bool rolled = false;
     typedef gie_commit_st st;
-    /* a map update whose waves were cut short by a barrier timeout commits nothing (GIE_ERR_TIMEOUT, include/gie.h) */
-    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return (c.cnt[GIE_CNT_ERR] & GIE_ERRF_BARRIER) || !c.tknown[gie_tile_index(c, x, y, z0)]; }
+    /* a map update whose waves were cut short by a barrier timeout commits nothing (GIE_ERR_TIMEOUT, include/gie.h): the flag of
+     * THIS update (cleared with the frame), not the sticky one the host fetches — an enqueue-only pipeline that never
+     * synchronises must not lose every later commit to one timeout */
+    GIE_DEVM bool tile_skip(const gie_ctx &c, int x, int y, int z0) const { return c.cnt[GIE_CNT_BARFAIL] != 0 || !c.tknown[gie_tile_index(c, x, y, z0)]; }
     GIE_DEVM bool skip(const gie_ctx &c, int id, int, int, int) const { return c.glb_type[id] == GIE_VOX_UNKNOWN; }
     GIE_DEVM void load1(const gie_ctx &c, int id, int x, int y, int z, st &s) const { gie_commit_load1(c, id, x, y, z, s); }
     GIE_DEVM void load2(const gie_ctx &, int, int, int, int, st &) const {}

@@ -1935,7 +1935,7 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
         int spins = 0;
         while (__hip_atomic_load(gb.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); break; }
+            if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); gie_st(&c.cnt[GIE_CNT_BARFAIL], (int32_t)1); break; }
         }
         /* a timed-out barrier poisons the launch: this block leaves; the others time out at their
          * next barrier (bounded spin), so nobody hangs */

@@ -171,7 +171,7 @@ enum {
     GIE_CNT_LVL_A, GIE_CNT_LVL_B, GIE_CNT_LVL_C,
     GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
-    GIE_CNT_SPARE0,
+    GIE_CNT_SPARE0,                             /* wave B: entries that were in its seed list twice */
     GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (n, cur, level) published after a solo episode */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
@@ -181,8 +181,9 @@ enum {
     GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
     GIE_CNT_BAR_AB2 = 39,                       /* barrier word of wave B's workgroups */
     GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
+    GIE_CNT_BARFAIL = 42,                       /* a grid barrier of THIS map update timed out (the sticky GIE_ERRF_BARRIER is the host's copy) */
     GIE_CNT_TSKIP = 41,                         /* tiles whose stored records Mark does not read (counted by the test-only emulation) */
-    GIE_CNT_AUX_END = 42,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_AUX_END = 43,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096

@@ -28,8 +28,11 @@ extern "C" {
 #define GIE_ERR_TIMEOUT 4   /* the wavefront kernel's grid barrier timed out: its workgroups were kept off the device for
                                seconds (another process's kernels holding the compute units).  The map update that hit it is
                                incomplete (waves cut short, distances may be over-estimates until the region is observed
-                               again); the condition is reported once and cleared — the next update runs normally.  One
-                               process per device is the supported configuration. */
+                               again); the condition is reported once and cleared — the next update runs normally.  What the
+                               incomplete update leaves in the map: Mark's own distances are committed (Mark and commit are one
+                               sweep unless the changed-block flags are on — then nothing of that update is committed), what the
+                               waves would have lowered or raised behind them is not.  One process per device is the supported
+                               configuration. */
 
 /* voxel types, local_batch.h:7-10 */
 #define GIE_VOX_UNKNOWN 0
@@ -166,11 +169,14 @@ int gie_ogm_labels_dev(gie_mapper *h, const int8_t *d_labels);
  * "fence". n = 0 clears. */
 int gie_set_ext_boxes(gie_mapper *h, const float *ll, const float *ur, const uint8_t *active, int n);
 
-/* GlbHashMap::updateHashOGM (glb_hash_map.cu:115-143): allocHashTB + updateHashOGMWith*. */
+/* GlbHashMap::updateHashOGM (glb_hash_map.cu:115-143): allocHashTB + updateHashOGMWith*.  Needs a scan: GIE_ERR_INVALID when no
+ * gie_ogm_* call has been made since the last gie_fuse (an update that only changes the external boxes feeds an empty scan:
+ * gie_ogm_pointcloud(h, NULL, 0)). */
 int gie_fuse(gie_mapper *h);
 /* EDT_OCC::batchEDTUpdate (local_edt.cu:7-28). */
 int gie_batch_edt(gie_mapper *h);
-/* GlbHashMap::mergeNewObsv (glb_hash_map.cu:146-207). */
+/* GlbHashMap::mergeNewObsv (glb_hash_map.cu:146-207).  One merge per map update: GIE_ERR_INVALID without a gie_fuse since the
+ * last merge (the seed counters and barrier words of the wavefront kernel are cleared with the frame). */
 int gie_merge(gie_mapper *h);
 /* The two halves of gie_merge for a TILED run (gie_set_tile): gie_merge_begin_tiled = MarkLimitedObserve + commit of the
  * Mark-time pairs, so that the face layers exported next are THIS map update's state; gie_merge_end = obtainFrontiers +

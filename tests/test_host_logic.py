@@ -100,6 +100,27 @@ def test_long_drive_on_a_fixed_pool_emulation(oracle_lib):
     a.close(); b.close()
 
 
+def test_one_merge_per_map_update_emulation():
+    """gie_merge without a gie_fuse since the last merge is a call-order error (the seed counters and the wavefront kernel's
+    barrier words belong to the frame clear), and it leaves the mapper usable."""
+    import numpy as np
+    import gie as _gie
+    sc = parity.Scenario("twice", (24, 24, 8), sensor="labels", voxel=0.05, frames=2, delta_vox=4, p_occ=0.02)
+    m = EmuMapper(sc.config())
+    frames = list(sc.frames_iter())
+    pos, q, kind, data, kw = frames[0]
+    m.set_pose(pos, q); m.ogm_labels(data); m.fuse(); m.batch_edt(); m.merge()
+    with pytest.raises(RuntimeError) as e:
+        m.merge()
+    assert "no gie_fuse since the last merge" in str(e.value)
+    with pytest.raises(RuntimeError):
+        m.fuse()                                          # and no scan, no fuse
+    pos, q, kind, data, kw = frames[1]
+    m.update(pos, q, kind, data)
+    m.sync()
+    m.close()
+
+
 def test_block_pool_overflow_fails_loudly_emulation():
     """A pool that is too small is a sticky, reported error (never a silent wrong map)."""
     import gie as _gie
