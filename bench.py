@@ -241,8 +241,10 @@ def percentile(xs, p):
 class Runner:
     """One mapper + its feed + (N > 1) the halo exchange after every update."""
 
-    def __init__(self, torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, exchange=True):
+    def __init__(self, torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, exchange=True, group=None):
         self.torch, self.dist, self.feed, self.rank, self.world, self.dev, self.backend = torch, dist, feed, rank, world, dev, backend
+        self.group = group                                 # the RCCL group of the face-layer exchange (None: the default gloo group)
+        self.fallback_note = None
         self.tiling = tiling
         self.m = gie.Mapper(cfg)
         self.exchange = exchange and world > 1
@@ -276,13 +278,15 @@ class Runner:
             elif self.halo_mode == "stream":
                 # one exchange round per map update, enqueued on the mapper's own stream (RCCL included): the host never waits
                 try:
-                    self.rounds_total += t.exchange_rounds_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, rounds=self.halo_rounds)
+                    self.rounds_total += t.exchange_rounds_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, rounds=self.halo_rounds, group=self.group)
                 except Exception as e:                                  # e.g. no external-stream support: host-synchronised rounds
-                    sys.stderr.write("bench: stream-ordered exchange failed (%s); falling back to synchronised rounds\n" % e)
+                    self.fallback_note = "stream-ordered exchange failed (%s: %s): host-synchronised rounds" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
+                    sys.stderr.write("bench: %s\n" % self.fallback_note)
                     self.halo_mode = "stable"
-                    self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs)
+                    self.halo_bufs = {}
+                    self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, group=self.group)
             else:
-                self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs)
+                self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, group=self.group)
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -292,7 +296,7 @@ class Runner:
     def max_over_ranks(self, v):
         if self.dist is None:
             return v
-        t = self.torch.tensor([v], device=self.dev if self.backend == "nccl" else "cpu", dtype=self.torch.float64)
+        t = self.torch.tensor([v], device="cpu", dtype=self.torch.float64)       # control plane: the default (gloo) group
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -335,14 +339,14 @@ class Runner:
 
 
 def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff_dist, W, K, rank, world, dev, local_rank, backend,
-                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False):
+                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False, group=None, transport_note=None):
     """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
     cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank, retain_radius_blocks=DRIVE["retain"],
                           max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)))
     feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
-    r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend)
+    r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, group=group)
     first = r.warmup(W)
     st0 = r.m.stats()
     regions = []
@@ -370,16 +374,20 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         kt = np.pad(kn, pad).reshape((Zs + pad[0][1]) // 8, 8, (Ys + pad[1][1]) // 8, 8, (Xs + pad[2][1]) // 8, 8).any(axis=(1, 3, 5))
         # the units one launch works on (per-unit bytes x units per launch): observed voxels for the sweeps,
         # the planes that hold obstacles for EDT passes Y / X, the tiles Mark reads for pass Z; all = N under full observation
-        units = {"fuse": n_known, "mark": n_known, "mark_commit": n_known, "frontiers": n_known, "commit": n_known,
+        # obtainFrontiers examines the voxels on the six faces of the volume and, voxel by voxel, only the tiles its summary lists
+        face = np.zeros_like(kn); face[0] = face[-1] = True; face[:, 0] = face[:, -1] = True; face[:, :, 0] = face[:, :, -1] = True
+        n_front = int((kn & face).sum()) + 512 * int(st1.get("frontier_tiles", 0))
+        units = {"fuse": n_known, "mark": n_known, "mark_commit": n_known, "frontiers": min(n_known, n_front), "commit": n_known,
                  "edt_pass_y": planes * Ys * Xs, "edt_pass_x": planes * Ys * Xs, "edt_pass_z": int(kt.sum()) * 512,
                  "ogm_classify": n_vox}
         known = n_known / float(n_vox)
         ray_cells = None
-        del ty, kn, kt
+        del ty, kn, kt, face
         res = {"known": known, "units": units}
     blocks = st1["blocks_total"]
     rounds_per_step = r.rounds_total / float(max(1, r.updates))
     halo_mode = r.halo_mode
+    notes = [n for n in (transport_note, r.fallback_note) if n]
     r.close()
     if rank != 0:
         return None
@@ -431,22 +439,32 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         ach = b / (avg_ms * 1e-3) / 1e9
         o = {"kernel": name, "avg_launch_ms": round(avg_ms, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": int(b)}
         o.update(what)
+        # what the kernel PHYSICALLY moved (rocprofv3 PMC, committed profile of this command): a kernel that fuses stages or
+        # skips what nobody reads moves fewer bytes than the reference's field widths add up to — the algorithmic figure can then
+        # exceed the peak; the physical one is the device's view
+        tb = (traffic or {}).get("kernels", {}).get(name)
+        if tb:
+            o["traffic"] = int(tb); o["achieved_physical"] = round(tb / (avg_ms * 1e-3) / 1e9, 1); o["frac_physical"] = round(tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         return o
 
+    traffic = load_traffic(workload, size, world)
     sweeps = {k: kernel_roof(k) for k in prof}
     sweeps = {k: v for k, v in sweeps.items() if v}
     dom = max(prof, key=lambda k: prof[k][0])
-    traffic = load_traffic(workload, size, world)
     dom_roof = sweeps.get(dom)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_roof["achieved"] if dom_roof else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom_roof["frac"] if dom_roof else None,
                 "traffic": (traffic or {}).get("kernels", {}).get(dom), "traffic_source": (traffic or {}).get("source"),
                 "avg_launch_ms": round(prof[dom][0] / prof[dom][1], 4)}
     if dom_roof:
-        roofline.update({k: v for k, v in dom_roof.items() if k not in ("kernel", "achieved", "frac", "avg_launch_ms")})
-    roofline["note"] = ("achieved = SURVEY 8(d)'s bytes per unit x the units one launch works on / the kernel's average duration from HIP events on its "
-                        "own dispatch (the mapper's stream); traffic = rocprofv3 PMC bytes per launch from the committed profile named in "
-                        "traffic_source (null when no profile of this exact workload is committed) — it is not measured in this run")
+        roofline.update({k: v for k, v in dom_roof.items() if k not in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic")})
+    roofline["note"] = ("achieved = SURVEY 8(d)'s ALGORITHMIC bytes per unit (the reference's field widths: Mark 33 B + commit 37 B per voxel for the fused "
+                        "sweep) x the units one launch works on / the kernel's average duration from HIP events on its own dispatch (the mapper's "
+                        "stream); frac = achieved / peak and can exceed what the memory system delivers when the kernel moves fewer bytes than the "
+                        "reference's layout implies; traffic = rocprofv3 PMC bytes per launch from the committed profile named in traffic_source "
+                        "(null when no profile of this exact workload is committed — it is not measured in this run), achieved_physical / "
+                        "frac_physical = traffic / duration: the device's view (this device streams reads at 6.5 TB/s and writes at 4.1 TB/s, "
+                        "one after the other: tools/sweep_probe.hip)")
     # the wavefront sweep the north-star target names: Mark + obtainFrontiers + waves A/B/C + commit
     ws = [sweeps[k] for k in WAVEFRONT_SWEEP if k in sweeps]
     ws_ms = sum(prof[k][0] / prof[k][1] for k in WAVEFRONT_SWEEP if k in prof)
@@ -454,7 +472,11 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     wavefront = {"kernels": [k for k in WAVEFRONT_SWEEP if k in prof], "ms_per_step": round(ws_ms, 4), "alg_bytes_per_step": int(ws_bytes),
                  "achieved": round(ws_bytes / (ws_ms * 1e-3) / 1e9, 1) if ws_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(ws_bytes / (ws_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ws_ms > 0 else None,
-                 "per_kernel_frac": {k: sweeps[k]["frac"] for k in WAVEFRONT_SWEEP if k in sweeps}}
+                 "per_kernel_ms": {k: sweeps[k]["avg_launch_ms"] for k in WAVEFRONT_SWEEP if k in sweeps},
+                 "per_kernel_frac_physical": {k: sweeps[k].get("frac_physical") for k in WAVEFRONT_SWEEP if k in sweeps}}
+    ws_traffic = [sweeps[k].get("traffic") for k in WAVEFRONT_SWEEP if k in sweeps]
+    if ws_ms > 0 and ws_traffic and all(ws_traffic):
+        wavefront["traffic"] = int(sum(ws_traffic)); wavefront["frac_physical"] = round(sum(ws_traffic) / (ws_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     all_bytes = sum(s["alg_bytes_per_launch"] for s in sweeps.values())
     update = {"alg_bytes_per_step": int(all_bytes), "ms_per_step": round(ms_per_step, 4),
               "achieved": round(all_bytes / (ms_per_step * 1e-3) / 1e9, 1), "frac": round(all_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -468,9 +490,10 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         "config": {"workload": "%dx%dx%d local grid @ %.2f m, %s, OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m, fast_mode off"
                                % (size[0], size[1], size[2], voxel, feed2.describe(), cutoff_dist),
                    "preset": workload,
-                   "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement (%.1f rounds/step, %s)"
-                             % (tgrid + tuple(size) + (rounds_per_step, "stream-ordered, fixed" if (halo_mode == "stream" and backend == "nccl")
-                                                       else "until no tile changes"))) if world > 1 else "single volume",
+                   "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement over %s (%.1f rounds/step, %s)%s"
+                             % (tgrid + tuple(size) + ("RCCL" if backend == "nccl" else "gloo with host staging", rounds_per_step,
+                                                       "stream-ordered, fixed" if (halo_mode == "stream" and backend == "nccl") else "until no tile changes",
+                                                       ("; " + "; ".join(notes)) if notes else ""))) if world > 1 else "single volume",
                    "known_voxel_fraction": round(res["known"], 4),
                    "wave_visits_per_step": [round(visits[k], 1) for k in "abc"],
                    "wave_levels_last_step": [st1["levels_a"], st1["levels_b"], st1["levels_c"]],
@@ -506,8 +529,8 @@ def accuracy_check(m, voxel):
 
 
 def load_traffic(workload, size, world):
-    """PMC bytes per launch from the committed profile of this exact workload (profiles/traffic_r02.json), or None."""
-    tp = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    """PMC bytes per launch from the committed profile of this exact workload and command (profiles/traffic_r03.json), or None."""
+    tp = os.path.join(ROOT, "profiles", "traffic_r03.json")
     if world != 1 or not os.path.exists(tp):
         return None
     try:
@@ -647,20 +670,22 @@ def run_bench():
         os.environ.setdefault("GIE_WAVE_WGS", str(max(8, 192 // max(1, world))))
     torch.cuda.set_device(local_rank)
     dist = None
+    group, transport_note = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # control plane on gloo; the face layers over RCCL if its pre-flight passes on every rank, else staged through the host
+        tr = tiling.init_transport(torch, dist, rank, world, torch.device("cuda", local_rank), want=backend)
+        backend, group, transport_note = tr["backend"], tr["group"], tr["note"]
+        if transport_note and rank == 0:
+            sys.stderr.write("bench: %s\n" % transport_note)
 
     size = tuple(args.size)
     cutoff_dist = 2.0
     dev = torch.device("cuda", local_rank)
     W, K = args.warmup, args.steps
     main_res = run_workload(torch, gie, scenes, tiling, dist, args.workload, size, args.voxel, cutoff_dist, W, K, rank, world, dev,
-                            local_rank, backend, min_timed_s=args.min_timed_s, rms=args.rms)
+                            local_rank, backend, min_timed_s=args.min_timed_s, rms=args.rms, group=group, transport_note=transport_note)
     if rank == 0:
         line = {"metric": "edt_map_update_throughput", "value": main_res["value"], "unit": "Mvoxels/s", "n_gpus": world, "steps": K, "warmup": W,
                 "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
@@ -681,6 +706,7 @@ def run_bench():
             line["extra_runs"] = extras
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scenes, torch, dev, args.voxel, size, cutoff_dist, args.workload, W)
+            line["config"]["cpu_baseline_stage"] = line["cpu_baseline"]["stage"] + " (the whole map update on one core: cpu_baseline.full_update_1core)"
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()                                    # rank 0's instrumented pass is over

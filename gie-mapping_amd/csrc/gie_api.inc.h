@@ -720,6 +720,7 @@ extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
     s->visits_a = h[GIE_CNT_VIS_A]; s->visits_b = h[GIE_CNT_VIS_B]; s->visits_c = h[GIE_CNT_VIS_C];
     s->levels_a = h[GIE_CNT_LVL_A]; s->levels_b = h[GIE_CNT_LVL_B]; s->levels_c = h[GIE_CNT_LVL_C];
     be_times(&m->be, &s->us_ogm, &s->us_fuse, &s->us_edt, &s->us_merge);
+    s->known_tiles = h[GIE_CNT_TL_KNOWN]; s->frontier_tiles = h[GIE_CNT_TL_FRONT];
     memcpy(&s->total_visits_a, &h[GIE_CNT_TOT_A], 8); memcpy(&s->total_visits_b, &h[GIE_CNT_TOT_B], 8); memcpy(&s->total_visits_c, &h[GIE_CNT_TOT_C], 8);
     return rc;
 }

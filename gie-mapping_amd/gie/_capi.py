@@ -67,7 +67,8 @@ class FrameStats(C.Structure):
                 ("levels_a", C.c_int32), ("levels_b", C.c_int32), ("levels_c", C.c_int32),
                 ("us_ogm", C.c_float), ("us_fuse", C.c_float), ("us_edt", C.c_float),
                 ("us_merge", C.c_float),
-                ("total_visits_a", C.c_int64), ("total_visits_b", C.c_int64), ("total_visits_c", C.c_int64)]
+                ("total_visits_a", C.c_int64), ("total_visits_b", C.c_int64), ("total_visits_c", C.c_int64),
+                ("known_tiles", C.c_int32), ("frontier_tiles", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -147,7 +147,7 @@ def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64, buf
     return rounds
 
 
-def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=None, max_rounds=64):
+def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=None, max_rounds=64, group=None):
     """Device-resident form of exchange_until_stable for backend "nccl" (RCCL over xGMI): the
     face layers are written by the export kernel straight into the send tensors and read by the
     import kernel from the receive tensors; nothing crosses PCIe except the seed count."""
@@ -165,8 +165,8 @@ def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=No
         for face, nb in sorted(nbs.items()):
             snd, rcv = bufs[face]
             mapper.halo_export_dev(face, snd.data_ptr())
-            ops.append(dist.P2POp(dist.isend, snd, nb))
-            ops.append(dist.P2POp(dist.irecv, rcv, nb))
+            ops.append(dist.P2POp(dist.isend, snd, nb, group=group))
+            ops.append(dist.P2POp(dist.irecv, rcv, nb, group=group))
         mapper.sync()                                   # export kernels ran on the mapper's own stream
         if ops:
             for w in dist.batch_isend_irecv(ops):
@@ -178,14 +178,14 @@ def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=No
             mapper.merge_end()
             continue
         n = torch.tensor([mapper.refine()], dtype=torch.int64, device=device)
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
         rounds += 1
         if int(n.item()) == 0:
             break
     return rounds
 
 
-def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=1):
+def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=1, group=None):
     """A fixed number of exchange rounds, ordered ON THE MAPPER'S STREAM: export kernels, the RCCL
     send / receive of the face layers, ghost import and refinement are enqueued back to back and
     the host never waits (no seed count comes back, so there is no convergence test: information
@@ -202,8 +202,8 @@ def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=
         ops = []
         for face, nb in sorted(nbs.items()):
             snd, rcv = bufs[face]
-            ops.append(dist.P2POp(dist.isend, snd, nb))
-            ops.append(dist.P2POp(dist.irecv, rcv, nb))
+            ops.append(dist.P2POp(dist.isend, snd, nb, group=group))
+            ops.append(dist.P2POp(dist.irecv, rcv, nb, group=group))
         bufs["ops"] = ops
     ops = bufs["ops"]
     with torch.cuda.stream(bufs["stream"]):
@@ -262,7 +262,7 @@ def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
     return rounds
 
 
-def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64):
+def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64, group=None):
     """One tile per rank: face layers travel with torch.distributed point-to-point ops (RCCL over
     xGMI with backend "nccl", gloo on CPU); a 1-int all-reduce(sum) of the seed counts is the
     convergence test.  Returns the refinement rounds run."""
@@ -279,8 +279,8 @@ def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_round
             if device is not None:
                 t, r = t.to(device), r.to(device)
             sends[face], recvs[face] = t, r
-            ops.append(dist.P2POp(dist.isend, t, nb))
-            ops.append(dist.P2POp(dist.irecv, r, nb))
+            ops.append(dist.P2POp(dist.isend, t, nb, group=group))
+            ops.append(dist.P2POp(dist.irecv, r, nb, group=group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
@@ -290,8 +290,45 @@ def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_round
             mapper.merge_end()
             continue
         n = torch.tensor([mapper.refine()], dtype=torch.int64, device=device if device is not None else "cpu")
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
         rounds += 1
         if int(n.item()) == 0:
             break
     return rounds
+
+
+def init_transport(torch, dist, rank, world_size, device, want="nccl", preflight_timeout_s=120):
+    """The process group(s) of a tiled run.  The control plane (barriers, timing reductions, the agreement below) is always a
+    gloo group — it exists wherever torch.distributed does.  The data plane is RCCL (backend "nccl", over xGMI) when `want`
+    says so AND a PRE-FLIGHT on every rank succeeds: group creation, one all-reduce and one ring send / receive of a device
+    buffer, checked.  Every rank then learns over gloo whether ANY rank failed, so that all of them take the same path: RCCL, or
+    the face layers staged through the host over gloo with the reason recorded.  Returns {"backend", "group", "note"}: `group`
+    is what the exchange functions above take (None = the default gloo group)."""
+    import datetime
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+    info = {"backend": "gloo", "group": None, "note": None}
+    if want != "nccl" or world_size < 2:
+        return info
+    err, g = None, None
+    try:
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=preflight_timeout_s))
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t, group=g)
+        snd = torch.full((4096,), rank % 251, dtype=torch.uint8, device=device)
+        rcv = torch.empty_like(snd)
+        ops = [dist.P2POp(dist.isend, snd, (rank + 1) % world_size, group=g), dist.P2POp(dist.irecv, rcv, (rank - 1) % world_size, group=g)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        torch.cuda.synchronize(device)
+        if int(t.item()) != world_size or int(rcv[0].item()) != ((rank - 1) % world_size) % 251 or int(rcv[-1].item()) != int(rcv[0].item()):
+            err = "pre-flight data mismatch"
+    except Exception as e:            # noqa: BLE001 — whatever RCCL raises (no xGMI, IPC refused, a peer that never arrives) is a reason to fall back
+        err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # over gloo: one answer for everybody
+    if int(flag.item()) == 0:
+        info.update(backend="nccl", group=g)
+    else:
+        info["note"] = "RCCL pre-flight failed (%s): face layers staged through the host over gloo" % (err or "on another rank")
+    return info

@@ -124,6 +124,8 @@ typedef struct gie_frame_stats {
     int32_t levels_a, levels_b, levels_c;
     float us_ogm, us_fuse, us_edt, us_merge; /* device time of the last step's stages; filled while gie_profile_enable is on, else 0 */
     int64_t total_visits_a, total_visits_b, total_visits_c; /* since gie_create */
+    int32_t known_tiles;      /* 8x8x8 tiles of the local volume that hold a known voxel (what Mark / commit sweep) */
+    int32_t frontier_tiles;   /* tiles obtainFrontiers looks at voxel by voxel (the voxels on the six faces come on top) */
 } gie_frame_stats;
 
 const char *gie_last_error(void);

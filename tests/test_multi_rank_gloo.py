@@ -124,6 +124,42 @@ def test_two_ranks_halo_exchange_matches_in_process_exchange(oracle_lib):
             assert np.array_equal(g_coc, reads[t]["coc"])
 
 
+def _worker_transport(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
+    import torch
+    import torch.distributed as dist
+    from gie import tiling
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    # no GPU here: the RCCL pre-flight fails on every rank, and every rank must come back with the same answer
+    info = tiling.init_transport(torch, dist, rank, world, torch.device("cuda", 0), want="nccl", preflight_timeout_s=20)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # the control plane works
+    out.put((rank, info["backend"], info["group"] is None, info["note"], float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_preflight_falls_back_on_every_rank_alike():
+    """bench.py --gpus N: the face layers go over RCCL only if a pre-flight (group creation, an all-reduce, a ring send / receive)
+    passes on EVERY rank; otherwise all ranks stage them through the host over gloo and say why (the first
+    execution of the RCCL path must not be able to kill the driver's run)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_transport, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, backend, no_group, note, mx in got:
+        assert backend == "gloo" and no_group and mx == 1.0
+        assert note and "RCCL pre-flight failed" in note
+
+
 def test_tile_layouts():
     from gie import tiling
     assert tiling.tile_grid(1) == (1, 1, 1) and tiling.tile_grid(2) == (2, 1, 1)

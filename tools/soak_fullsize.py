@@ -30,8 +30,8 @@ def main():
 
     size = tuple(args.size)
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
-    fr = {"r": bench.make_frames(scenes, 0.05, args.frames, 5, args.ray_sensor, delta_vox=args.delta),
-          "p": bench.make_frames(scenes, 0.05, args.frames, 5, "vlp16_projective", delta_vox=args.delta)}
+    fr = {"r": bench.make_frames(scenes, 0.05, args.frames, 5, args.ray_sensor),
+          "p": bench.make_frames(scenes, 0.05, args.frames, 5, "vlp16_projective")}
     rings, az, phi_min, phi_inc, bins = bench.SENSORS["vlp16_projective"]
     kw = dict(theta_inc=2.0 * np.pi / bins, theta_min=-np.pi, phi_inc=np.radians(phi_inc), phi_min=np.radians(phi_min))
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
