@@ -638,7 +638,11 @@ GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int
     const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
     const int n_valid = gie_in_wr(c, nw[0], nw[1], nw[2]);
     const int n_local = gie_in_loc(c, nl[0], nl[1], nl[2]);
-    if (!n_local && n_valid) {
+    /* tiling: a ghost (another tile's voxel, refreshed this update) vouches for its obstacle wherever it lies outside this tile; a
+     * remembered voxel outside the WHOLE volume only for an obstacle outside the whole volume too — one inside it belongs to
+     * another tile and may have vanished since (only the owner knows).  Without tiling whole = local: the reference's test. */
+    const int n_hidden = gie_in_whole(c, nx, ny, nz) ? !n_local : !gie_in_whole(c, nl[0], nl[1], nl[2]);
+    if (n_hidden && n_valid) {
         const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
         if (d < cd) {
             *seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
@@ -1109,6 +1113,10 @@ GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int
     for (int k = 0; k < 6; k++) if (((imp >> k) & 1u) && ow[k] != stamp) pm |= 1u << k;
     gie_push_nbrs(c, c.qb[cur ^ 1], c.qb_a[cur ^ 1], next_cnt, g, pm, na);
     int mask = 0;
+    {   /* tiling: an obstacle inside the whole volume but not in this tile is its owner's to vouch for (gie_frontier_outside) */
+        const int cl3[3] = { cc[0] - c.pvt[0], cc[1] - c.pvt[1], cc[2] - c.pvt[2] };
+        if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) inm = 0;
+    }
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
         if (!((inm >> k) & 1u)) continue;
@@ -1514,7 +1522,10 @@ GIE_DEV int gie_refine_voxel(const gie_ctx &c, int id)
         if (gie_invalid_coc(ncx, ncy, ncz)) continue;
         const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
         const int nl[3] = { ncx - c.pvt[0], ncy - c.pvt[1], ncz - c.pvt[2] };
-        if (gie_in_loc(c, nl[0], nl[1], nl[2]) || !gie_in_wr(c, nw[0], nw[1], nw[2])) continue;
+        /* a ghost vouches for an obstacle anywhere outside this tile, a remembered voxel outside the whole volume only for one
+         * outside the whole volume (gie_frontier_outside) */
+        const int hidden = gie_in_whole(c, nx, ny, nz) ? !gie_in_loc(c, nl[0], nl[1], nl[2]) : !gie_in_whole(c, nl[0], nl[1], nl[2]);
+        if (!hidden || !gie_in_wr(c, nw[0], nw[1], nw[2])) continue;
         const int d = gie_d2(nl[0], nl[1], nl[2], x, y, z);
         if (d < cd) { seed = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2])); hit = 1; }
     }

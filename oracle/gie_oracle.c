@@ -735,7 +735,12 @@ static void obtain_frontiers(gie_oracle *o, queue *fa, queue *fb, queue *fc)
                 const int nl[3] = { nv->coc[0] - o->pvt[0], nv->coc[1] - o->pvt[1], nv->coc[2] - o->pvt[2] };
                 const int n_valid = in_wr(o, nw[0], nw[1], nw[2]);
                 const int n_local = in_loc(o, nl[0], nl[1], nl[2]);
-                if (!n_local && n_valid) {
+                /* tiling: the neighbour is either a ghost (another tile's voxel, refreshed this update: its obstacle counts
+                 * wherever it lies outside this tile) or a remembered voxel outside the WHOLE volume — and what that one
+                 * remembers about an obstacle inside the whole volume is another tile's business (it may have vanished since:
+                 * only the owner knows); without tiling whole = local and this is the reference's test */
+                const int n_hidden = in_whole(o, nx, ny, nz) ? !n_local : !in_whole(o, nl[0], nl[1], nl[2]);
+                if (n_hidden && n_valid) {
                     const int d = d2i(nl[0], nl[1], nl[2], x, y, z);
                     if (d < cd) {
                         o->pair_dist[id] = d; o->pair_par[id] = pack_wr(nw[0], nw[1], nw[2]);
@@ -917,6 +922,10 @@ static void wave_b(gie_oracle *o, queue *front, queue *fc)
                     props[np].v = nv; props[np].g[0] = ng[0]; props[np].g[1] = ng[1]; props[np].g[2] = ng[2]; np++;
                 } else {
                     const int nid = lid(o, nb[0], nb[1], nb[2]);
+                    {   /* tiling: an obstacle inside the whole volume but not in this tile is its owner's to vouch for (see obtain_frontiers) */
+                        const int cl3[3] = { sn[e].coc[0] - o->pvt[0], sn[e].coc[1] - o->pvt[1], sn[e].coc[2] - o->pvt[2] };
+                        if (in_whole(o, cl3[0], cl3[1], cl3[2]) && !in_loc(o, cl3[0], cl3[1], cl3[2])) continue;
+                    }
                     if (o->aux[nid] > cand) {
                         if (pair_less(cand, sn[e].par, o->lprop_dist[nid], o->lprop_par[nid])) { o->lprop_dist[nid] = cand; o->lprop_par[nid] = sn[e].par; }
                         q_push(&inl, nb[0], nb[1], nb[2]);
@@ -1185,7 +1194,10 @@ int go_refine(gie_oracle *o, int32_t *seeded)
             if (invalid_dist_glb(o, nv->dist_sq) || invalid_coc_glb(nv->coc)) continue;
             const int nw[3] = { nv->coc[0] - o->upvt[0], nv->coc[1] - o->upvt[1], nv->coc[2] - o->upvt[2] };
             const int nl[3] = { nv->coc[0] - o->pvt[0], nv->coc[1] - o->pvt[1], nv->coc[2] - o->pvt[2] };
-            if (in_loc(o, nl[0], nl[1], nl[2]) || !in_wr(o, nw[0], nw[1], nw[2])) continue;
+            /* a ghost vouches for an obstacle anywhere outside this tile, a remembered voxel outside the whole volume only for
+             * one outside the whole volume (obtain_frontiers) */
+            const int hidden = in_whole(o, nx, ny, nz) ? !in_loc(o, nl[0], nl[1], nl[2]) : !in_whole(o, nl[0], nl[1], nl[2]);
+            if (!hidden || !in_wr(o, nw[0], nw[1], nw[2])) continue;
             const int d = d2i(nl[0], nl[1], nl[2], x, y, z);
             if (d < cd) { sd = d; sp = pack_wr(nw[0], nw[1], nw[2]); hit = 1; }
         }

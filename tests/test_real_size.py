@@ -63,6 +63,7 @@ def test_c5_1024_cube_as_eight_tiles_of_512_on_one_gpu(oracle_lib):
                 m.set_pose(pos, q)
                 assert tuple(m.pivot()) == tuple(pvt)
                 lab = _labels_dev(torch, dev, pvt, tile, k).contiguous()
+                torch.cuda.synchronize(dev)                # torch built the plane on ITS stream; the mapper reads it on its own
                 m.ogm_labels_dev(lab.data_ptr())
                 m.step_begin_tiled()
                 m.sync()
@@ -81,10 +82,12 @@ def test_c5_1024_cube_as_eight_tiles_of_512_on_one_gpu(oracle_lib):
             for r in range(8):
                 o = pvts[r] - pvw
                 world_lab[o[2]:o[2] + 512, o[1]:o[1] + 512, o[0]:o[0] + 512] = ms[r].read_local(edt=False, dist_sq=False, coc=False)["type"]
-            assert (world_lab != 0).all()
+            assert (world_lab != 0).all(), "unknown voxels after full observation: %s" % (
+                [(r, int((world_lab[tuple(slice(int(v), int(v) + 512) for v in (pvts[r] - pvw)[::-1])] == 0).sum()),
+                  int((ms[r].read_local(edt=False, dist_sq=False, coc=False)["type"] == 0).sum())) for r in range(8)],)
             exact, _ = edt_mt(world_lab, want_coc=False)
             faces = {}
-            n_equal = n_total = n_outside = 0
+            n_equal = n_total = n_outside = n_below = 0
             for r, m in enumerate(ms):
                 rb = m.read_local(edt=False)
                 st = m.stats()
@@ -101,7 +104,13 @@ def test_c5_1024_cube_as_eight_tiles_of_512_on_one_gpu(oracle_lib):
                 inside = np.ones(d.shape, bool)
                 for i in range(3):
                     inside &= (c[..., i] >= pvw[i]) & (c[..., i] < pvw[i] + whole[i])
-                assert (d[inside] >= ex[inside]).all(), "tile %d update %d: a distance below the exact one" % (r, k)
+                below = inside & (d < ex)
+                if below.any():
+                    zz, yy, xx = np.nonzero(below)
+                    print("tile", r, "update", k, "below exact:", int(below.sum()), "local bbox", (xx.min(), yy.min(), zz.min()), (xx.max(), yy.max(), zz.max()),
+                          "examples", [(int(xx[i]), int(yy[i]), int(zz[i]), int(d[zz[i], yy[i], xx[i]]), int(ex[zz[i], yy[i], xx[i]]), (c[zz[i], yy[i], xx[i]] - pv).tolist(),
+                                        int(world_lab[tuple((c[zz[i], yy[i], xx[i]] - pvw)[::-1])])) for i in range(0, len(xx), max(1, len(xx) // 6))][:6])
+                n_below += int(below.sum())
                 if k == 0:
                     assert inside.all()
                 n_equal += int((d[inside] == ex[inside]).sum()); n_total += int(inside.sum()); n_outside += int((~inside).sum())
@@ -117,6 +126,7 @@ def test_c5_1024_cube_as_eight_tiles_of_512_on_one_gpu(oracle_lib):
                 faces[r] = {f: (np.take(d, -1 if f & 1 else 0, axis=2 - (f >> 1)).astype(np.int64), np.take(c, -1 if f & 1 else 0, axis=2 - (f >> 1)).astype(np.int64))
                             for f in range(6)}
                 del rb, d, c, inside, ex
+            assert n_below == 0, (k, n_below)
             assert n_equal >= 0.999 * n_total, (k, n_equal, n_total)
             if k == 1:
                 assert 0 < n_outside < 0.05 * n_total
