@@ -29,7 +29,6 @@ struct gie_mapper {
     be_state be;
     int ncell;
     int has_pose, has_ogm, merge_open;
-    int overlap;                          /* gie_merge_begin is the first step of the overlapped merge: Mark of the shell only */
     int fuse_fresh;                       /* gie_fuse has run and no merge has consumed it yet (a merge needs the frame clear of its own map update) */
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
     int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
@@ -99,7 +98,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0; m->fuse_fresh = 0; m->overlap = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0; m->fuse_fresh = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -542,7 +541,7 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     be_prof(&m->be, kmark, 0);
     static const int use_bound = getenv("GIE_MARKC_BOUND") ? atoi(getenv("GIE_MARKC_BOUND")) : 1;     /* 0: always read the stored records (measurements) */
     if (m->c.fused && m->c.prev_valid && use_bound) be_lin(&m->be, m->c, op_tile_oldskip(), m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]);   /* (tskip is zero otherwise) */
-    if (m->c.fused) be_markc(&m->be, m->c, m->c.tl_known, m->overlap ? 1 : 0);      /* overlapped merge: the shell first (gie_merge) */
+    if (m->c.fused) be_markc(&m->be, m->c, m->c.tl_known);
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
     m->merge_open = 1;
@@ -561,9 +560,7 @@ extern "C" int gie_merge_end(gie_mapper *m)
      * per tile out of LDS (k_frontier_faces / k_frontier_tiles; 0.32 -> 0.15 ms on the C5 workload) */
     be_frontier_tiles(&m->be, m->c, m->c.tl_known, GIE_CNT_TL_KNOWN, m->c.tl_front, GIE_CNT_TL_FRONT);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
-    be_prof(&m->be, GIE_K_WAVE_C, 0);
-    be_waves(&m->be, m->c, (m->c.fast_mode ? GIE_WAVES_REC_AB : GIE_WAVES_AB) | GIE_WAVES_C | GIE_WAVES_REC_C, 0);
-    be_prof(&m->be, GIE_K_WAVE_C, 1);
+    be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
     if (!m->c.fused) {
         be_prof(&m->be, GIE_K_COMMIT, 0);
         be_vox_list<true>(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
@@ -581,41 +578,8 @@ extern "C" int gie_merge_begin_tiled(gie_mapper *m)
     return GIE_OK;
 }
 
-/* The merge of an untiled map update with Mark of the volume's INTERIOR running beside waves A / B.  The waves are ~35 dependent
- * phases of a few thousand entries each (latency: the device idles), the sweep streams 3.4 GB (bandwidth); and what the face voxels
- * of obtainFrontiers and waves A / B read of Mark's results lies in the two tile layers behind the faces.  So: Mark + commit of that
- * shell; then, on the mapper's side stream, the face voxels of obtainFrontiers and waves A / B — while the main stream sweeps the
- * interior; when both are done, obtainFrontiers of the voxels off the faces and wave C.  Every kernel writes what it writes in
- * the one-stream order too (Mark: voxels inside the volume; waves A / B: hashed voxels outside it, proposals to face voxels), so
- * the result is the same — the tests run both (GIE_OVERLAP=0). */
-static int gie_merge_overlapped(gie_mapper *m)
-{
-    m->overlap = 1;
-    int rc = gie_merge_begin(m);                           /* the tile bounds' kernel + Mark + commit of the shell */
-    m->overlap = 0;
-    if (rc) return rc;
-    m->merge_open = 0;
-    be_state *b = &m->be;
-    be_fork(b);
-    be_side(b, 1);
-    be_prof(b, GIE_K_FRONTIER, 0); be_frontier_faces(b, m->c, m->c.tl_known, GIE_CNT_TL_KNOWN); be_prof(b, GIE_K_FRONTIER, 2);
-    be_prof(b, GIE_K_WAVE_C, 0); be_waves(b, m->c, GIE_WAVES_AB, 0); be_prof(b, GIE_K_WAVE_C, 2);
-    be_side(b, 0);
-    be_prof(b, GIE_K_MARKC, 0); be_markc(b, m->c, m->c.tl_known, 2); be_prof(b, GIE_K_MARKC, 2);      /* beside them: the interior */
-    be_join(b);
-    be_prof(b, GIE_K_FRONTIER, 0); be_frontier_rest(b, m->c, m->c.tl_known, GIE_CNT_TL_KNOWN, m->c.tl_front, GIE_CNT_TL_FRONT); be_prof(b, GIE_K_FRONTIER, 1);
-    be_prof(b, GIE_K_WAVE_C, 0); be_waves(b, m->c, GIE_WAVES_C | GIE_WAVES_REC_C, 0); be_prof(b, GIE_K_WAVE_C, 1);
-    be_time(b, 7);
-    return GIE_OK;
-}
-
 extern "C" int gie_merge(gie_mapper *m)
 {
-    if (m && m->has_pose && be_can_overlap(&m->be) && gie_fused_mode(m) && !m->c.fast_mode
-        && m->c.whole_lo[0] == 0 && m->c.whole_lo[1] == 0 && m->c.whole_lo[2] == 0
-        && m->c.whole_hi[0] == m->c.X && m->c.whole_hi[1] == m->c.Y && m->c.whole_hi[2] == m->c.Z
-        && m->c.tfd[0] > 4 && m->c.tfd[1] > 4 && m->c.tfd[2] > 4)                    /* (a volume that is all shell has nothing to run beside) */
-        return gie_merge_overlapped(m);
     int rc = gie_merge_begin(m); if (rc) return rc;
     return gie_merge_end(m);
 }
@@ -945,7 +909,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
     c.fused = gie_fused_mode(m);
-    be_waves(&m->be, c, GIE_WAVES_C, 0);                 /* (its own clear above) */
+    be_waves(&m->be, c, 0, 0, 0);                        /* (its own clear above) */
     if (!c.fused) be_vox_list<true>(&m->be, c, op_commit(), c.tl_known, GIE_CNT_TL_KNOWN, 0);   /* fused: wave C has committed what it merged */
     if (!seeded) return GIE_OK;          /* enqueue only: a fixed number of exchange rounds needs no answer */
     rc = gie_sync(m);

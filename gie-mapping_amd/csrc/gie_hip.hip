@@ -22,9 +22,7 @@ struct be_state {
     int device;
     int num_cu;     /* workgroups of the persistent wave kernels */
     int cu_total;   /* CUs of the device */
-    hipStream_t stream;                 /* the stream the next launch goes to: main, or side while be_side(b, 1) */
-    hipStream_t main_stream, side_stream;   /* side: waves A / B beside Mark of the interior (gie_merge), higher priority */
-    hipEvent_t ev_fork, ev_join;
+    hipStream_t stream;
     hipEvent_t ev[GIE_NEV];
     int ev_set[GIE_NEV];
     void *scan_tmp; size_t scan_bytes;
@@ -71,15 +69,7 @@ static int be_init(be_state *b, int device)
         }
         if (b->num_cu > per_cu * b->cu_total) b->num_cu = per_cu * b->cu_total;
     }
-    {
-        int lo = 0, hi = 0;                                  /* (numerically lower = higher priority) */
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&b->main_stream, hipStreamNonBlocking, lo) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
-        if (hipStreamCreateWithPriority(&b->side_stream, hipStreamNonBlocking, hi) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
-        b->stream = b->main_stream;
-        GIE_HIP_OK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-        GIE_HIP_OK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-    }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
     b->scan_tmp = nullptr; b->scan_bytes = 0;
     for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
@@ -99,9 +89,7 @@ static void be_fini(be_state *b)
     delete b->pool; delete b->pending;
     for (int i = 0; i < GIE_NEV; i++) (void)hipEventDestroy(b->ev[i]);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(b->copy_ev[i]);
-    (void)hipEventDestroy(b->ev_fork); (void)hipEventDestroy(b->ev_join);
-    (void)hipStreamDestroy(b->side_stream);
-    (void)hipStreamDestroy(b->main_stream);
+    (void)hipStreamDestroy(b->stream);
 }
 static void *be_alloc(be_state *b, size_t bytes, bool zero)
 {
@@ -132,14 +120,7 @@ static void be_d2h_async(be_state *b, void *h, const void *d, size_t bytes, int 
     GIE_HIP_OK(hipEventRecord(b->copy_ev[slot], b->stream));
 }
 static void be_wait(be_state *b, int slot) { GIE_HIP_OK(hipEventSynchronize(b->copy_ev[slot])); }
-static void *be_stream_handle(be_state *b) { return (void *)b->main_stream; }
-/* Two things of one map update side by side: be_fork = "what is enqueued on the side stream from here on starts when
- * everything enqueued on the main stream so far is done"; be_side(b, 1 / 0) routes the launches; be_join = "the main stream goes
- * on when the side stream has drained".  GIE_OVERLAP=0 keeps everything on one stream. */
-static int be_can_overlap(be_state *) { static const int on = getenv("GIE_OVERLAP") ? atoi(getenv("GIE_OVERLAP")) : 1; return on; }
-static void be_fork(be_state *b) { GIE_HIP_OK(hipEventRecord(b->ev_fork, b->main_stream)); GIE_HIP_OK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0)); }
-static void be_side(be_state *b, int on) { b->stream = on ? b->side_stream : b->main_stream; }
-static void be_join(be_state *b) { GIE_HIP_OK(hipEventRecord(b->ev_join, b->side_stream)); GIE_HIP_OK(hipStreamWaitEvent(b->main_stream, b->ev_join, 0)); }
+static void *be_stream_handle(be_state *b) { return (void *)b->stream; }
 static int be_sync(be_state *b)
 {
     hipError_t e = hipStreamSynchronize(b->stream);
@@ -207,7 +188,7 @@ static void be_prof(be_state *b, int id, int end)
     if (!end) {
         if (b->pool_used > 4000) be_prof_resolve(b);
         b->cur_id = id;
-    } else { b->cur_id = -1; if (end == 1) b->acc_n[id] += 1; }       /* acc_n counts brackets (end == 2: a further piece of a bracket already counted), acc_ms sums the kernels launched inside them */
+    } else { b->cur_id = -1; b->acc_n[id] += 1; }       /* acc_n counts brackets, acc_ms sums the kernels launched inside them */
 }
 static void be_prof_enable(be_state *b, int on) { be_prof_resolve(b); b->prof_on = on; b->cur_id = -1; }
 static void be_prof_collect(be_state *b, float *ms, int *n, int num)
@@ -317,16 +298,16 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
     else GIE_LAUNCH(b, (k_voxa<F, STAGED, 64>), g, t, 0, c, f, list, count_idx, always_list);
 }
 /* Mark + commit as one sweep: its own kernel (k_markc); GIE_MARKC_GENERIC=1 keeps the staged functor sweep (tests run both) */
-static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list, int part = 0)
+static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
 {
     static const int generic = getenv("GIE_MARKC_GENERIC") ? atoi(getenv("GIE_MARKC_GENERIC")) : 0;
     static const int lx = getenv("GIE_MARKC_LX") ? atoi(getenv("GIE_MARKC_LX")) : 32;
     static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
-    if (generic) { if (part != 2) be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0, lx == 16 || lx == 8 || lx == 32 ? lx : 64); return; }   /* (the functor sweep has no parts: everything with the shell) */
+    if (generic) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0, lx == 16 || lx == 8 || lx == 32 ? lx : 64); return; }
     const dim3 g(b->cu_total * mult), t(256);
-    if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list, part);
-    else if (lx == 64) GIE_LAUNCH(b, k_markc<64>, g, t, 0, c, list, part);
-    else GIE_LAUNCH(b, k_markc<32>, g, t, 0, c, list, part);
+    if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list);
+    else if (lx == 64) GIE_LAUNCH(b, k_markc<64>, g, t, 0, c, list);
+    else GIE_LAUNCH(b, k_markc<32>, g, t, 0, c, list);
 }
 /* lanes of a wave along x in the sweep form of the kernels that touch the global block planes */
 static int be_sweep_lx(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return (v == 8 || v == 16 || v == 32) ? v : 64; }
@@ -355,33 +336,6 @@ static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *know
     GIE_LAUNCH(b, k_frontier_faces, dim3(nsum + (fp.off[6] + GIE_FF_WAVES - 1) / GIE_FF_WAVES), dim3(64 * GIE_FF_WAVES), 0, c, fp, known, known_idx, nsum);
     static int mult = getenv("GIE_FRONT_MULT") ? atoi(getenv("GIE_FRONT_MULT")) : 0;
     if (mult <= 0) {    /* as many workgroups as are resident at once: every wave walks the same share of the list (a second round of workgroups would start when the first is done) */
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_frontier_tiles), 64 * GIE_FR_WAVES, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        mult = per_cu;
-    }
-    GIE_LAUNCH(b, k_frontier_tiles, dim3(b->cu_total * mult), dim3(64 * GIE_FR_WAVES), 0, c, list, count_idx);
-}
-/* the two halves of be_frontier_tiles for the overlapped merge: the voxels on the faces (they only need Mark's results of the shell) ... */
-static void be_frontier_faces(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx)
-{
-    gie_face_patches fp;
-    const int da[6] = { c.Y, c.Y, c.X, c.X, c.X, c.X }, db[6] = { c.Z, c.Z, c.Z, c.Z, c.Y, c.Y };
-    fp.off[0] = 0;
-    for (int f = 0; f < 6; f++) { fp.na[f] = (da[f] + 7) / 8; fp.off[f + 1] = fp.off[f] + fp.na[f] * ((db[f] + 7) / 8); }
-    GIE_LAUNCH(b, k_frontier_faces, dim3((fp.off[6] + GIE_FF_WAVES - 1) / GIE_FF_WAVES), dim3(64 * GIE_FF_WAVES), 0, c, fp, known, known_idx, 0);
-}
-/* ... and, when Mark is complete, the tile summary + the list of the tiles to look at voxel by voxel, then those tiles */
-static void be_frontier_rest(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx, const int32_t *list, int count_idx)
-{
-    gie_face_patches fp;
-    for (int f = 0; f < 7; f++) fp.off[f] = 0;
-    for (int f = 0; f < 6; f++) fp.na[f] = 1;
-    const long long ntile = (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
-    int nsum = (int)((ntile + 64 * GIE_FF_WAVES - 1) / (64 * GIE_FF_WAVES));
-    if (nsum > 2 * b->cu_total) nsum = 2 * b->cu_total;
-    GIE_LAUNCH(b, k_frontier_faces, dim3(nsum), dim3(64 * GIE_FF_WAVES), 0, c, fp, known, known_idx, nsum);       /* summary workgroups only */
-    static int mult = 0;
-    if (mult <= 0) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_frontier_tiles), 64 * GIE_FR_WAVES, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         mult = per_cu;
@@ -437,7 +391,7 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
  * different mappers on the same device at the same time need not be.  Waves launches of one
  * device are therefore chained through an event: a launch waits for the previous one, whichever
  * mapper (stream) it came from. */
-static void be_waves(be_state *b, const gie_ctx &c, int mode, int clear_first)
+static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
     std::lock_guard<std::mutex> lock(g_waves_mutex);
     const int dv = b->device & 63;
@@ -454,7 +408,7 @@ static void be_waves(be_state *b, const gie_ctx &c, int mode, int clear_first)
     /* workgroups that run waves A / B (the rest wait at the barrier behind them): 8 / 16 / 32 / 64 / 128 measured 0.83 / 0.74 / 0.73 /
      * 0.76 / 0.70 ms of waves per C5 map update — a phase is a chain of ~7 dependent fabric round trips, not barrier fan-in */
     static const int ab_wgs = getenv("GIE_WAVE_AB_WGS") ? atoi(getenv("GIE_WAVE_AB_WGS")) : 1024;
-    GIE_LAUNCH(b, k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, mode, ab_wgs > 0 ? ab_wgs : 1);
+    GIE_LAUNCH(b, k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, with_ab, record_seeds, ab_wgs > 0 ? ab_wgs : 1);
     if (chain) GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
 }
 

@@ -1253,18 +1253,9 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
  * generic staged sweep tests the type first and loads behind the branch — four dependent round trips per column instead of
  * two; on the C5 volume the sweep is bound by how many bytes it keeps in flight, and by its stores (tools/sweep_probe.hip:
  * this device writes at ~4.1 TB/s and reads at ~6.5, one after the other). */
-/* part: 0 = every tile; 1 = only the SHELL — the two tile layers behind every face of the volume: what the face voxels of
- * obtainFrontiers and waves A / B read of Mark's results (pairs of face voxels and of their neighbours inside, the flags of their tiles
- * and of those tiles' neighbours) —; 2 = only the interior, which runs beside them on the mapper's second stream */
-__device__ __forceinline__ bool gie_tile_in_shell(const gie_ctx &c, const int x, const int y, const int z0)
-{
-    const int tx = x >> 3, ty = y >> 3, tz = z0 >> 3;
-    return tx < 2 || ty < 2 || tz < 2 || tx >= c.tfd[0] - 2 || ty >= c.tfd[1] - 2 || tz >= c.tfd[2] - 2;
-}
-__device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const int x, const int y, const int z0, const int part)
+__device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const int x, const int y, const int z0)
 {
     if (x >= c.X || y >= c.Y) return;
-    if (part && (gie_tile_in_shell(c, x, y, z0) != (part == 1))) return;
     const int t = gie_tile_index(c, x, y, z0);
     if (!c.tknown[t]) return;
     const size_t plane = (size_t)c.X * c.Y;
@@ -1320,7 +1311,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     gie_markc_column(c, x, y, z0, known, valid, vmax);
 }
 template <int LX>
-__global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *list, const int part)
+__global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *list)
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
     const int lane = threadIdx.x & 63;
@@ -1329,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *l
         for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
             const int t = list[e];
             const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
-            gie_markc_column_fast(c, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8, part);
+            gie_markc_column_fast(c, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8);
         }
     } else {
         constexpr int LY = 64 / LX, WY = 4 * LY;
@@ -1338,7 +1329,7 @@ __global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *l
         const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
         for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++)
-            gie_markc_column_fast(c, (v % gx) * LX + lx, ((v / gx) % gy) * WY + ly, (v / (gx * gy)) * 8, part);
+            gie_markc_column_fast(c, (v % gx) * LX + lx, ((v / gx) % gy) * WY + ly, (v / (gx * gy)) * 8);
     }
 }
 
@@ -2027,7 +2018,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
 {
     const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
     int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
-    if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+    if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
     const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
     if ((int)blockIdx.x >= nwg) return;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_AB2], 0, gb_all.failed, nwg, s_fail };
@@ -2247,14 +2238,13 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
     gie_wave_sync();                                       /* the LDS block is reused for the wave's next tile */
 }
 
-__device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb, const int mode, gie_wc_tile *tiles)
+__device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb, const int record_seeds, gie_wc_tile *tiles)
 {
     const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
     const int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_C]), c.qcap_c);
     if (boss) {
         c.cnt[GIE_CNT_FRONT_C] = n;
-        if (mode & GIE_WAVES_REC_C) c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]) - gie_ld(&c.cnt[GIE_CNT_BPUSH]);    /* obtainFrontiers' own seeds: the queue minus what wave B appended */
-        if (mode & GIE_WAVES_REC_AB) { c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
+        if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n; c.cnt[GIE_CNT_SEED_A] = gie_ld(&c.cnt[GIE_CNT_A]); c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
     }
     if (n == 0 || gb.failed) return;           /* same n everywhere; a barrier of waves A / B that timed out: the update is incomplete (GIE_ERR_TIMEOUT) */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2291,27 +2281,22 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
     }
 }
 
-/* waves A, B and / or C in one launch (mode: GIE_WAVES_*).  A map update runs them as ONE launch (A, B, C) or — Mark of the
- * volume's interior running beside waves A / B on a second stream, gie_merge — as two: A + B, then C. */
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int mode, const int ab_wgs)
+/* waves A, B (unless fast_mode / refinement) and C in one launch */
+__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds, const int ab_wgs)
 {
     __shared__ gie_wc_tile s_tiles[GIE_WC_WAVES];         /* wave C: one 8x8x8 tile (+ halo) per wave */
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
-    const int run_ab = mode & GIE_WAVES_AB, run_c = mode & GIE_WAVES_C;
-    gie_gridbar gb = { &c.cnt[run_c ? GIE_CNT_BAR_C : GIE_CNT_BAR_AB], 0, 0, (int)gridDim.x, &s_fail };
-    {   /* nothing seeded for what this launch runs (the usual case of a sparse scan over a settled map): nothing can be
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail };
+    {   /* nothing seeded anywhere (the usual case of a sparse scan over a settled map): nothing can be
          * produced either, so the launch ends here — same counters for every workgroup, no barrier */
         const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);
-        if (((run_ab ? (na | nb) : 0) | (run_c ? nc : 0)) == 0) {
+        if ((with_ab ? (na | nb | nc) : nc) == 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
-                if (run_ab) { c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0;
-                              gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-                if (run_c) {
-                    c.cnt[GIE_CNT_FRONT_C] = 0;
-                    if (mode & GIE_WAVES_REC_C) c.cnt[GIE_CNT_SEED_C] = 0;
-                    if (mode & GIE_WAVES_REC_AB) { c.cnt[GIE_CNT_SEED_A] = na; c.cnt[GIE_CNT_SEED_B] = nb; }
-                }
+                if (with_ab) { c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0; c.cnt[GIE_CNT_SEED_C] = 0;
+                               gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+                c.cnt[GIE_CNT_FRONT_C] = 0;
+                if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = 0; c.cnt[GIE_CNT_SEED_A] = na; c.cnt[GIE_CNT_SEED_B] = nb; }
             }
             return;
         }
@@ -2321,16 +2306,15 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     if (blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
 #endif
     GIE_TS2(0, 0);
-    if (run_ab) {
+    if (with_ab) {
         gie_wave_a_run(c, gb, ab_wgs, &s_fail);
         gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
         GIE_TS2(8, 0);
         gie_wave_b_run(c, gb, ab_wgs, &s_fail);
-        if (!run_c) return;
         gie_grid_sync(gb, c);
         GIE_TS2(9, 0);
     }
-    gie_wave_c_run(c, gb, mode, s_tiles);
+    gie_wave_c_run(c, gb, record_seeds, s_tiles);
     GIE_TS2(10, 0);
 }
 

@@ -103,17 +103,6 @@ GIE_DEV void gie_push32_wave(const gie_ctx &c, int32_t *q, int32_t *counter, int
 #endif
 }
 
-/* counter += lanes with `flag` set, one atomic per wave (only executing lanes are looked at) */
-GIE_DEV void gie_count_wave(int32_t *counter, bool flag)
-{
-#if defined(GIE_HOST_EMU)
-    if (flag) *counter += 1;
-#else
-    const unsigned long long m = __ballot(flag);
-    if (m && __lane_id() == __ffsll((long long)m) - 1) gie_aadd32(counter, __popcll(m));
-#endif
-}
-
 /* ray_count[id] += val for every lane with id >= 0, with equal targets of NEIGHBOURING lanes merged
  * into one atomic: lanes are rays adjacent in the scan, which cross the same cells at the same
  * step near the sensor, so equal targets come as contiguous runs of lanes (unmerged, thousands of
@@ -1183,7 +1172,6 @@ GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int rp, int e)
         const bool push = ((win >> k) & 1u) && !(w[k] == GIE_WL_SEED(c) || w[k] == GIE_WL_PUSHED(c));
         if (push) gie_st(&c.wl[nid[k]], GIE_WL_PUSHED(c)); /* this thread is the only writer of nid in this phase */
         gie_push32_wave(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, push, nid[k]);
-        gie_count_wave(&c.cnt[GIE_CNT_BPUSH], push);
     }
 }
 

@@ -183,18 +183,10 @@ enum {
     GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
     GIE_CNT_BARFAIL = 42,                       /* a grid barrier of THIS map update timed out (the sticky GIE_ERRF_BARRIER is the host's copy) */
     GIE_CNT_TSKIP = 41,                         /* tiles whose stored records Mark does not read (counted by the test-only emulation) */
-    GIE_CNT_BPUSH = 43,                         /* voxels wave B appended to the C queue (seeds of obtainFrontiers = queue length - this) */
-    GIE_CNT_BAR_AB = 44,                        /* grid-barrier word of a waves launch that runs A / B only (Mark of the interior runs beside it) */
-    GIE_CNT_AUX_END = 45,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_AUX_END = 43,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096
-/* what a waves launch runs: waves A and B, wave C, "record the seed counts of A / B at wave C" (fast mode: no A / B), "this is a map
- * update's wave C" (it records obtainFrontiers' C seeds; a refinement round of the tiled exchange does not) */
-#define GIE_WAVES_AB 1
-#define GIE_WAVES_C 2
-#define GIE_WAVES_REC_AB 4
-#define GIE_WAVES_REC_C 8
 #define GIE_ERRF_POOL 1
 #define GIE_ERRF_QUEUE 2
 #define GIE_ERRF_HASH 4

@@ -100,9 +100,7 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
         }
     }
 }
-static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list, int = 0) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0); }
-static void be_frontier_faces(be_state *, const gie_ctx &, const int32_t *, int) {}                    /* (only the overlapped form of the device calls the halves) */
-static void be_frontier_rest(be_state *, const gie_ctx &, const int32_t *, int, const int32_t *, int) {}
+static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0); }
 static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox_list<true>(b, c, op_fuse(), list, GIE_CNT_TL_FUSE, 0); }
 /* the device takes the listed tiles (tsum == 1) a wave per tile and the face voxels by patches of the faces; here: every voxel
  * the tile summary does not rule out (op_frontier::tile_skip / skip), same decisions per voxel */
@@ -188,7 +186,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
 static void be_wave_b(be_state *, const gie_ctx &c)
 {
     int n = c.cnt[GIE_CNT_B] < c.qcap_ab ? c.cnt[GIE_CNT_B] : c.qcap_ab, cur = 0, level = 0;
-    c.cnt[GIE_CNT_FRONT_B] = n;
+    c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
     while (n > 0) {
         c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n;
         for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, level & 1, e, level == 0);
@@ -201,12 +199,11 @@ static void be_wave_b(be_state *, const gie_ctx &c)
 /* wave C in the canonical tile-round schedule: sequential statement on the device data structures — the seeds are
  * the voxels of qc[0] with their pairs in cand[1]; proposals across tile borders travel through the candidate planes (parity of
  * the round) like on the device, proposals inside a tile through a scratch plane (the device keeps those in LDS) */
-static void be_wave_c(be_state *, const gie_ctx &c, int mode, int)
+static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
 {
     const int n0 = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c;
     c.cnt[GIE_CNT_FRONT_C] = n0;
-    if (mode & GIE_WAVES_REC_C) c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C] - c.cnt[GIE_CNT_BPUSH];
-    if (mode & GIE_WAVES_REC_AB) { c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
+    if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n0; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     auto tile = [&](int id) { const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y); return gie_tile_index(c, x, y, z); };
     auto set_pair = [&](int id, uint64_t pr) {
@@ -274,14 +271,10 @@ static void be_wave_c(be_state *, const gie_ctx &c, int mode, int)
         round++;
     }
 }
-static void be_waves(be_state *b, const gie_ctx &c, int mode, int clear_first)
+static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
-    if (mode & GIE_WAVES_AB) { be_wave_a(b, c); be_wave_b(b, c); }
-    if (mode & GIE_WAVES_C) be_wave_c(b, c, mode, clear_first);
+    if (with_ab) { be_wave_a(b, c); be_wave_b(b, c); }
+    be_wave_c(b, c, record_seeds, clear_first);
 }
-static int be_can_overlap(be_state *) { return 0; }          /* (one thing after the other here) */
-static void be_fork(be_state *) {}
-static void be_side(be_state *, int) {}
-static void be_join(be_state *) {}
 
 #include "../../gie-mapping_amd/csrc/gie_api.inc.h"
