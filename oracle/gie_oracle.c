@@ -55,6 +55,8 @@ typedef struct {
     int32_t prop_dist; /* best proposal of the running level (scratch) */
     int32_t blk;       /* slot of the owning block (for the changed-block flags) */
     int64_t prop_par;
+    int32_t xprop_dist; /* best proposal from ANOTHER block in the running round (scratch of the block-round schedule) */
+    int64_t xprop_par;
 } ovox;
 
 typedef struct { int32_t key[3]; int32_t dirty; ovox v[VBSZ]; } oblock;
@@ -170,6 +172,7 @@ static oblock *blk_get_or_alloc(gie_oracle *o, int bx, int by, int bz)
         v->dist_sq = GIE_EMPTY_VALUE; v->wave_layer = -1;
         v->pair_dist = 0; v->pair_par = 0;
         v->prop_dist = 0x7fffffff; v->prop_par = 0; v->blk = o->nblocks;
+        v->xprop_dist = 0x7fffffff; v->xprop_par = 0;
     }
     if (o->wide) for (int i = 0; i < VBSZ; i++) b->v[i].dist_sq = o->empty_value;
     o->blocks[o->nblocks] = b;
@@ -873,91 +876,131 @@ static void dedupe_global(gie_oracle *o, queue *q)
     for (int i = 0; i < q->n; i++) vox_find(o, q->d[i].x, q->d[i].y, q->d[i].z)->prop_par = 0;
 }
 
-/* Wave B: lower_outside (wave_core.cuh:229-350). */
+/* Wave B: lower_outside (wave_core.cuh:229-350) in the canonical BLOCK-ROUND schedule (DESIGN.md "Canonical wave schedule", the
+ * twin of wave C's tile rounds): the hashed voxels are taken 8x8x8 block by block.  In a round every block that holds pending
+ * voxels — the seeds, or voxels that received a proposal from another block in the round before — runs a level-synchronous
+ * BFS INSIDE itself to exhaustion (the reference's BFS_in_block idea, wave_core.cuh:395-469); what it proposes to voxels of OTHER blocks
+ * is collected — minimum (dist, parent) per voxel — and applied at the end of the round, where a voxel that improved joins the next
+ * round.  Blocks do not see each other inside a round, so their order is irrelevant.  What the wave proposes to voxels INSIDE the
+ * volume is collected over the whole wave — minimum per voxel — and stored when the wave is over (the reference's plain,
+ * unconditional store, :336-346: any of the proposers may be the last writer; the canonical one is the smallest).
+ * levels_b counts rounds, visits_b the voxels taken up (expanded or cut off). */
+static int cmp_i3_block(const void *a, const void *b)
+{
+    const i3 *p = (const i3 *)a, *q = (const i3 *)b;
+    const int kp[3] = { fdiv8(p->z), fdiv8(p->y), fdiv8(p->x) }, kq[3] = { fdiv8(q->z), fdiv8(q->y), fdiv8(q->x) };
+    for (int i = 0; i < 3; i++) if (kp[i] != kq[i]) return kp[i] < kq[i] ? -1 : 1;
+    return 0;
+}
+static int same_block(const i3 *p, int x, int y, int z) { return fdiv8(p->x) == fdiv8(x) && fdiv8(p->y) == fdiv8(y) && fdiv8(p->z) == fdiv8(z); }
+
 static void wave_b(gie_oracle *o, queue *front, queue *fc)
 {
-    const int ct = o->map_ct;
     dedupe_global(o, front);
-    queue cur = *front, next = { 0, 0, 0 };
+    queue cur = *front;
     front->d = NULL; front->n = front->cap = 0;
-    int level = 0;
+    queue inl = { 0, 0, 0 };                                  /* voxels inside the volume that received a proposal */
+    typedef struct { int active; int coc[3]; int64_t par; } snap;
     while (cur.n > 0) {
         o->st.levels_b++;
-        o->st.visits_b += cur.n;
-        const int gray = (level & 1) ? GRAY1 : GRAY0;
-        typedef struct { int active; int coc[3]; int64_t par; } snap;
-        snap *sn = (snap *)calloc((size_t)cur.n, sizeof(snap));
-        /* phase 1: snapshot own pair, cut-off test on the not-yet-committed dist, commit */
-        for (int e = 0; e < cur.n; e++) {
-            ovox *c = vox_find(o, cur.d[e].x, cur.d[e].y, cur.d[e].z);
-            if (!c) continue;
-            if (c->dist_sq > o->cfg.cutoff_grids_sq) continue;
-            c->wave_layer = BLACK;
-            int cw[3]; unpack_wr(c->pair_par, &cw[0], &cw[1], &cw[2]);
-            c->coc[0] = cw[0] + o->upvt[0]; c->coc[1] = cw[1] + o->upvt[1]; c->coc[2] = cw[2] + o->upvt[2];
-            c->dist_sq = c->pair_dist;
-            touch(o, c);
-            sn[e].active = 1; sn[e].par = c->pair_par;
-            sn[e].coc[0] = c->coc[0]; sn[e].coc[1] = c->coc[1]; sn[e].coc[2] = c->coc[2];
-        }
-        /* phase 2: proposals */
-        prop_rec *props = NULL; int np = 0, pcap = 0;
-        queue inl = { 0, 0, 0 };
-        for (int e = 0; e < cur.n; e++) {
-            if (!sn[e].active) continue;
-            const int g[3] = { cur.d[e].x, cur.d[e].y, cur.d[e].z };
-            for (int k = 0; k < 6; k++) {
-                const int ng[3] = { g[0] + DIRS[k][0], g[1] + DIRS[k][1], g[2] + DIRS[k][2] };
-                const int nb[3] = { ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2] };
-                const int cand = d2i(sn[e].coc[0], sn[e].coc[1], sn[e].coc[2], ng[0], ng[1], ng[2]);
-                if (!in_loc(o, nb[0], nb[1], nb[2])) {
-                    if (in_whole(o, nb[0], nb[1], nb[2])) continue;   /* tiling: not into another tile's territory */
-                    ovox *nv = vox_find(o, ng[0], ng[1], ng[2]);
-                    if (!nv) continue;
-                    if (nv->vox_type == GIE_VOX_UNKNOWN) continue;
-                    if (invalid_coc_glb(nv->coc)) continue;
-                    if (cand >= o->empty_value) continue;
-                    if (pair_less(cand, sn[e].par, nv->prop_dist, nv->prop_par)) { nv->prop_dist = cand; nv->prop_par = sn[e].par; }
-                    if (np == pcap) { pcap = pcap ? pcap * 2 : 256; props = (prop_rec *)realloc(props, sizeof(prop_rec) * (size_t)pcap); }
-                    props[np].v = nv; props[np].g[0] = ng[0]; props[np].g[1] = ng[1]; props[np].g[2] = ng[2]; np++;
-                } else {
-                    const int nid = lid(o, nb[0], nb[1], nb[2]);
-                    {   /* tiling: an obstacle inside the whole volume but not in this tile is its owner's to vouch for (see obtain_frontiers) */
-                        const int cl3[3] = { sn[e].coc[0] - o->pvt[0], sn[e].coc[1] - o->pvt[1], sn[e].coc[2] - o->pvt[2] };
-                        if (in_whole(o, cl3[0], cl3[1], cl3[2]) && !in_loc(o, cl3[0], cl3[1], cl3[2])) continue;
-                    }
-                    if (o->aux[nid] > cand) {
-                        if (pair_less(cand, sn[e].par, o->lprop_dist[nid], o->lprop_par[nid])) { o->lprop_dist[nid] = cand; o->lprop_par[nid] = sn[e].par; }
-                        q_push(&inl, nb[0], nb[1], nb[2]);
+        qsort(cur.d, (size_t)cur.n, sizeof(i3), cmp_i3_block);            /* group the pending voxels by block */
+        queue xtouched = { 0, 0, 0 };
+        for (int b0 = 0; b0 < cur.n;) {
+            int e1 = b0;
+            while (e1 < cur.n && same_block(&cur.d[b0], cur.d[e1].x, cur.d[e1].y, cur.d[e1].z)) e1++;
+            const i3 blk = cur.d[b0];
+            queue L = { 0, 0, 0 };
+            for (int e = b0; e < e1; e++) q_push(&L, cur.d[e].x, cur.d[e].y, cur.d[e].z);
+            b0 = e1;
+            while (L.n > 0) {                                             /* one level inside the block */
+                o->st.visits_b += L.n;
+                snap *sn = (snap *)calloc((size_t)L.n, sizeof(snap));
+                /* the cut-off looks at the distance stored BEFORE the pair is committed (:262-266); then commit */
+                for (int e = 0; e < L.n; e++) {
+                    ovox *c = vox_find(o, L.d[e].x, L.d[e].y, L.d[e].z);
+                    if (!c) continue;
+                    if (c->dist_sq > o->cfg.cutoff_grids_sq) continue;
+                    c->wave_layer = BLACK;
+                    int cw[3]; unpack_wr(c->pair_par, &cw[0], &cw[1], &cw[2]);
+                    c->coc[0] = cw[0] + o->upvt[0]; c->coc[1] = cw[1] + o->upvt[1]; c->coc[2] = cw[2] + o->upvt[2];
+                    c->dist_sq = c->pair_dist;
+                    touch(o, c);
+                    sn[e].active = 1; sn[e].par = c->pair_par;
+                    sn[e].coc[0] = c->coc[0]; sn[e].coc[1] = c->coc[1]; sn[e].coc[2] = c->coc[2];
+                }
+                queue touched = { 0, 0, 0 }, Ln = { 0, 0, 0 };
+                for (int e = 0; e < L.n; e++) {
+                    if (!sn[e].active) continue;
+                    const int g[3] = { L.d[e].x, L.d[e].y, L.d[e].z };
+                    for (int k = 0; k < 6; k++) {
+                        const int ng[3] = { g[0] + DIRS[k][0], g[1] + DIRS[k][1], g[2] + DIRS[k][2] };
+                        const int nb[3] = { ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2] };
+                        const int cand = d2i(sn[e].coc[0], sn[e].coc[1], sn[e].coc[2], ng[0], ng[1], ng[2]);
+                        if (!in_loc(o, nb[0], nb[1], nb[2])) {
+                            if (in_whole(o, nb[0], nb[1], nb[2])) continue;   /* tiling: not into another tile's territory */
+                            ovox *nv = vox_find(o, ng[0], ng[1], ng[2]);
+                            if (!nv) continue;
+                            if (nv->vox_type == GIE_VOX_UNKNOWN) continue;
+                            if (invalid_coc_glb(nv->coc)) continue;
+                            if (cand >= o->empty_value) continue;
+                            if (same_block(&blk, ng[0], ng[1], ng[2])) {
+                                if (pair_less(cand, sn[e].par, nv->prop_dist, nv->prop_par)) { nv->prop_dist = cand; nv->prop_par = sn[e].par; }
+                                q_push(&touched, ng[0], ng[1], ng[2]);
+                            } else {
+                                if (pair_less(cand, sn[e].par, nv->xprop_dist, nv->xprop_par)) { nv->xprop_dist = cand; nv->xprop_par = sn[e].par; }
+                                q_push(&xtouched, ng[0], ng[1], ng[2]);
+                            }
+                        } else {
+                            const int nid = lid(o, nb[0], nb[1], nb[2]);
+                            {   /* tiling: an obstacle inside the whole volume but not in this tile is its owner's to vouch for (see obtain_frontiers) */
+                                const int cl3[3] = { sn[e].coc[0] - o->pvt[0], sn[e].coc[1] - o->pvt[1], sn[e].coc[2] - o->pvt[2] };
+                                if (in_whole(o, cl3[0], cl3[1], cl3[2]) && !in_loc(o, cl3[0], cl3[1], cl3[2])) continue;
+                            }
+                            if (o->aux[nid] > cand) {
+                                if (o->lprop_dist[nid] == 0x7fffffff) q_push(&inl, nb[0], nb[1], nb[2]);
+                                if (pair_less(cand, sn[e].par, o->lprop_dist[nid], o->lprop_par[nid])) { o->lprop_dist[nid] = cand; o->lprop_par[nid] = sn[e].par; }
+                            }
+                        }
                     }
                 }
+                /* strict improvement over the pair at the start of the level (id_atomicMin, wave_core.cuh:9-22) */
+                for (int i = 0; i < touched.n; i++) {
+                    ovox *nv = vox_find(o, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+                    if (nv->prop_dist == 0x7fffffff) continue;
+                    if (nv->pair_dist > nv->prop_dist) {
+                        nv->pair_dist = nv->prop_dist; nv->pair_par = nv->prop_par;
+                        q_push(&Ln, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+                    }
+                    nv->prop_dist = 0x7fffffff; nv->prop_par = 0;
+                }
+                q_free(&touched); free(sn);
+                q_free(&L); L = Ln;
             }
+            q_free(&L);
         }
-        /* phase 3: apply.  Outside: strict improvement over the level-start pair
-         * (id_atomicMin, wave_core.cuh:9-22), one enqueue per level (:323-329).
-         * Inside: the reference stores the pair unconditionally (:336-346). */
-        for (int i = 0; i < np; i++) {
-            ovox *nv = props[i].v;
-            if (nv->prop_dist == 0x7fffffff) continue;
-            if (nv->pair_dist > nv->prop_dist) {
-                nv->pair_dist = nv->prop_dist; nv->pair_par = nv->prop_par;
-                nv->wave_layer = gray; nv->update_ct = ct;
-                q_push(&next, props[i].g[0], props[i].g[1], props[i].g[2]);
+        /* end of the round: what crossed a block border */
+        queue next = { 0, 0, 0 };
+        for (int i = 0; i < xtouched.n; i++) {
+            ovox *nv = vox_find(o, xtouched.d[i].x, xtouched.d[i].y, xtouched.d[i].z);
+            if (nv->xprop_dist == 0x7fffffff) continue;
+            if (nv->pair_dist > nv->xprop_dist) {
+                nv->pair_dist = nv->xprop_dist; nv->pair_par = nv->xprop_par;
+                q_push(&next, xtouched.d[i].x, xtouched.d[i].y, xtouched.d[i].z);
             }
-            nv->prop_dist = 0x7fffffff; nv->prop_par = 0;
+            nv->xprop_dist = 0x7fffffff; nv->xprop_par = 0;
         }
-        for (int i = 0; i < inl.n; i++) {
-            const int nid = lid(o, inl.d[i].x, inl.d[i].y, inl.d[i].z);
-            if (o->lprop_dist[nid] == 0x7fffffff) continue;
-            o->pair_dist[nid] = o->lprop_dist[nid]; o->pair_par[nid] = o->lprop_par[nid];
-            o->lprop_dist[nid] = 0x7fffffff; o->lprop_par[nid] = 0;
-            if (o->wave_layer[nid] != 1) q_push(fc, inl.d[i].x, inl.d[i].y, inl.d[i].z);
-        }
-        q_free(&inl); free(props); free(sn);
-        q_free(&cur); cur = next; next.d = NULL; next.n = next.cap = 0;
-        level++;
+        q_free(&xtouched);
+        q_free(&cur); cur = next;
     }
     q_free(&cur);
+    /* the stores into the volume (the reference stores the pair unconditionally, :336-346) */
+    for (int i = 0; i < inl.n; i++) {
+        const int nid = lid(o, inl.d[i].x, inl.d[i].y, inl.d[i].z);
+        o->pair_dist[nid] = o->lprop_dist[nid]; o->pair_par[nid] = o->lprop_par[nid];
+        o->lprop_dist[nid] = 0x7fffffff; o->lprop_par[nid] = 0;
+        if (o->wave_layer[nid] != 1) q_push(fc, inl.d[i].x, inl.d[i].y, inl.d[i].z);
+    }
+    q_free(&inl);
 }
 
 /* Wave C: lower_inside (wave_core.cuh:353-393). */

@@ -183,17 +183,110 @@ static void be_wave_a(be_state *, const gie_ctx &c)
         n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1;
     }
 }
+/* wave B in the canonical block-round schedule (oracle/gie_oracle.c wave_b): sequential statement on the device data
+ * structures.  Proposals inside a block and across block borders travel through host maps here (the device keeps the former in
+ * LDS, the latter in the two proposal planes of the global map). */
 static void be_wave_b(be_state *, const gie_ctx &c)
 {
-    int n = c.cnt[GIE_CNT_B] < c.qcap_ab ? c.cnt[GIE_CNT_B] : c.qcap_ab, cur = 0, level = 0;
-    c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
-    while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n;
-        for (int e = 0; e < n; e++) gie_wave_b_phase1(c, cur, level & 1, e, level == 0);
-        if (level == 0) { const int dup = c.cnt[GIE_CNT_SPARE0]; c.cnt[GIE_CNT_VIS_B] -= dup; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) -= dup; }
-        for (int e = 0; e < n; e++) gie_wave_b_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], level, level & 1, e);
-        for (int e = 0; e < n; e++) gie_wave_b_phase3(c, cur, level & 1, e);
-        n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1; level++;
+    const int n0 = c.cnt[GIE_CNT_B] < c.qcap_ab ? c.cnt[GIE_CNT_B] : c.qcap_ab;
+    c.cnt[GIE_CNT_FRONT_B] = n0; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    struct ent { int a; int g[3]; };
+    std::vector<ent> cur;
+    {
+        std::vector<int> seen;
+        for (int e = 0; e < n0; e++) {
+            const int a = c.qb_a[0][e];
+            if (a < 0 || std::find(seen.begin(), seen.end(), a) != seen.end()) continue;      /* the frontier is a set */
+            seen.push_back(a);
+            ent t; t.a = a; gie_unpack_crd(c.qb[0][e], &t.g[0], &t.g[1], &t.g[2]);
+            cur.push_back(t);
+        }
+    }
+    std::vector<int> inl;                                           /* voxels inside the volume that received a proposal */
+    auto pdist = [](uint64_t p) { return gie_pair_dist(p); };
+    while (!cur.empty()) {
+        c.cnt[GIE_CNT_LVL_B] += 1;
+        std::stable_sort(cur.begin(), cur.end(), [](const ent &p, const ent &q) { return (p.a >> 9) < (q.a >> 9); });
+        std::vector<std::pair<ent, uint64_t>> xprops;               /* proposals across block borders of the running round (min per voxel) */
+        auto xfind = [&](int a) { for (auto &x : xprops) if (x.first.a == a) return &x; return (std::pair<ent, uint64_t> *)nullptr; };
+        for (size_t b0 = 0; b0 < cur.size();) {
+            const int slot = cur[b0].a >> 9;
+            std::vector<ent> L;
+            while (b0 < cur.size() && (cur[b0].a >> 9) == slot) L.push_back(cur[b0++]);
+            while (!L.empty()) {                                    /* one level inside the block */
+                c.cnt[GIE_CNT_VIS_B] += (int)L.size(); *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += (long long)L.size();
+                struct snap { bool active; uint64_t par; int cc[3]; };
+                std::vector<snap> sn(L.size());
+                for (size_t e = 0; e < L.size(); e++) {
+                    const int a = L[e].a;
+                    sn[e].active = false;
+                    if (gie_gdist(c, c.g_coc[a], L[e].g[0], L[e].g[1], L[e].g[2]) > c.cutoff_sq) continue;     /* (the distance stored BEFORE the commit) */
+                    const uint64_t pr = c.g_pair[a] & ~GIE_PAIR_NEW;
+                    int cw[3];
+                    gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+                    sn[e].cc[0] = cw[0] + c.upvt[0]; sn[e].cc[1] = cw[1] + c.upvt[1]; sn[e].cc[2] = cw[2] + c.upvt[2];
+                    c.g_coc[a] = gie_pack_crd(sn[e].cc[0], sn[e].cc[1], sn[e].cc[2]);
+                    gie_touch(c, a);
+                    sn[e].active = true; sn[e].par = gie_pair_par(pr);
+                }
+                std::vector<std::pair<ent, uint64_t>> props;
+                for (size_t e = 0; e < L.size(); e++) {
+                    if (!sn[e].active) continue;
+                    const int *g = L[e].g;
+                    for (int k = 0; k < 6; k++) {
+                        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
+                        const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
+                        const int cand = gie_d2(sn[e].cc[0], sn[e].cc[1], sn[e].cc[2], ng[0], ng[1], ng[2]);
+                        if (!gie_in_loc(c, nb[0], nb[1], nb[2])) {
+                            if (gie_in_whole(c, nb[0], nb[1], nb[2])) continue;
+                            const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+                            if (na < 0 || c.g_type[na] == GIE_VOX_UNKNOWN) continue;
+                            int nc[3];
+                            gie_unpack_crd(c.g_coc[na], &nc[0], &nc[1], &nc[2]);
+                            if (gie_invalid_coc(nc[0], nc[1], nc[2]) || cand >= c.empty_value) continue;
+                            const uint64_t key = gie_pair_make(cand, sn[e].par);
+                            ent t; t.a = na; t.g[0] = ng[0]; t.g[1] = ng[1]; t.g[2] = ng[2];
+                            if ((na >> 9) == slot) {
+                                bool found = false;
+                                for (auto &x : props) if (x.first.a == na) { if (key < x.second) x.second = key; found = true; break; }
+                                if (!found) props.push_back(std::make_pair(t, key));
+                            } else {
+                                auto *x = xfind(na);
+                                if (x) { if (key < x->second) x->second = key; } else xprops.push_back(std::make_pair(t, key));
+                            }
+                        } else {
+                            const int cl3[3] = { sn[e].cc[0] - c.pvt[0], sn[e].cc[1] - c.pvt[1], sn[e].cc[2] - c.pvt[2] };
+                            if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) continue;   /* (tiling: gie_frontier_outside) */
+                            const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
+                            const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? pdist(c.pair[nid]) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
+                            if (ref > cand) {
+                                uint64_t *lp = &c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])];
+                                if (*lp == GIE_NOPROP) inl.push_back(nid);
+                                const uint64_t key = gie_pair_make(cand, sn[e].par);
+                                if (key < *lp) *lp = key;
+                            }
+                        }
+                    }
+                }
+                std::vector<ent> Ln;
+                for (auto &x : props)
+                    if (pdist(c.g_pair[x.first.a]) > pdist(x.second)) { c.g_pair[x.first.a] = x.second; Ln.push_back(x.first); }
+                L.swap(Ln);
+            }
+        }
+        std::vector<ent> next;
+        for (auto &x : xprops)
+            if (pdist(c.g_pair[x.first.a]) > pdist(x.second)) { c.g_pair[x.first.a] = x.second; next.push_back(x.first); }
+        cur.swap(next);
+    }
+    /* the stores into the volume: the smallest proposal of the whole wave, stored unconditionally (wave_core.cuh:336-346) */
+    for (int nid : inl) {
+        const int x = nid % c.X, y = (nid / c.X) % c.Y, z = nid / (c.X * c.Y);
+        uint64_t *lp = &c.lprop[gie_bdr_index(c, x, y, z)];
+        c.cand[1][nid] = *lp; *lp = GIE_NOPROP;
+        const uint32_t w = c.wl[nid];
+        if (!(w == GIE_WL_SEED(c) || w == GIE_WL_PUSHED(c))) { c.wl[nid] = GIE_WL_PUSHED(c); gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, nid); }
     }
 }
 /* wave C in the canonical tile-round schedule: sequential statement on the device data structures — the seeds are
