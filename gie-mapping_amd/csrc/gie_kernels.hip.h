@@ -2011,50 +2011,254 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     gb_all.failed |= gb.failed;
 }
 
-/* Wave B: per level phase 2 (relax the neighbours) and, as ONE phase, phase 3 of this level (the winners among the inside
- * voxels) together with phase 1 of the next (commit + snapshot of the entries phase 2 appended) — they touch different data
- * apart from the per-entry records, which come in two sets.  Two barriers per level instead of three. */
-__device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
+/* ------------------------------------------------------------------ wave B: block rounds */
+/* lower_outside (wave_core.cuh:229-350) in the canonical BLOCK-ROUND schedule (the twin of wave C's tile rounds, over
+ * the hashed 8x8x8 blocks of the global map): in a round every ACTIVE block — one that holds proposals from the round before, or
+ * seeds — is taken by ONE WAVE: its pairs, its proposals, the distances stored in it and which of its voxels may be lowered go into
+ * LDS together with the pairs of the one-voxel halo around it (the six neighbour blocks are looked up ONCE per block and round: six
+ * hash probes instead of six per entry and level), a level-synchronous BFS runs inside the block to exhaustion out of LDS, what
+ * it proposes to a voxel of a neighbouring block is min-resolved in that voxel's slot of the other proposal plane and activates the
+ * neighbour for the next round; what it proposes to voxels INSIDE the volume is min-resolved in the face table (lprop) over the
+ * whole wave and stored when the wave is over.  A front needs one grid barrier per BLOCK it crosses, not two per voxel.
+ *   planes: round r reads P[(r + 1) & 1] (the seeds come in P[1] = g_prop) and proposes into P[r & 1] (P[0] = g_prop2);
+ *   blocks: list wb_list[r & 1] with lvlb_next[r] entries, membership flag wb_flag[r & 1][slot];
+ *   rule:   a proposal replaces a pair on a strict distance improvement over the value at the start of the (sub-)level, among
+ *           proposals the smaller (dist, parent) wins; the seeds of round 0 enter with the pair they hold; a voxel that is
+ *           taken up is committed and expanded unless the distance stored in it BEFORE the commit exceeds the cut-off (:262-266). */
+struct gie_wb_tile { uint64_t pair[512], prop[512], halo[6][64]; uint32_t sdist[512]; uint8_t flag[512], hflag[6][64];
+                     uint16_t list[512], pend[2][512]; int32_t npend[2], nslot[6]; };                                   /* 17.3 KB */
+#define GIE_WB_WAVES 9                                    /* waves of a workgroup that take blocks */
+#define GIE_WB_OK 1u                                      /* the voxel may be lowered: known, and its stored obstacle is valid */
+#define GIE_WB_DONE 2u                                    /* committed in this round */
+
+__device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &L, const int slot, const int round, const int lane)
+{
+    int bk[3];
+    gie_unpack_crd(gie_ld(&c.g_key[slot]), &bk[0], &bk[1], &bk[2]);
+    const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };              /* global coordinate of the block's first voxel */
+    uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
+    const int base = slot * GIE_VBSZ;
+    /* ---- the six neighbour blocks (lane k < 6 probes for block k), then one batch of loads */
+    if (lane < 6) {
+        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
+        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
+    }
+    uint64_t pv[8], cv[8], cc8[8];
+    int8_t ty8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {                                       /* voxel lane + 64 j = (x, y) = lane, z = j */
+        const int a = base + lane + 64 * j;
+        pv[j] = gie_ld(&c.g_pair[a]) & ~GIE_PAIR_NEW; cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]); ty8[j] = gie_ld(&c.g_type[a]);
+    }
+    if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);     /* may be activated again (for round + 2) from now on */
+    gie_wave_sync();                                                    /* the neighbour slots */
+    {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the lane's position (a, b) on it -> in-block index of the voxel across the face */
+        const int a = lane & 7, b = lane >> 3;
+        const int hidx[6] = { 7 | (a << 3) | (b << 6), 0 | (a << 3) | (b << 6), a | (7 << 3) | (b << 6), a | (0 << 3) | (b << 6), a | (b << 3) | (7 << 6), a | (b << 3) | (0 << 6) };
+        uint64_t hp[6], hc[6]; int8_t ht[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            const int ns = L.nslot[f];
+            const int an = (ns < 0 ? base : ns * GIE_VBSZ) + hidx[f];
+            hp[f] = gie_ld(&c.g_pair[an]) & ~GIE_PAIR_NEW; hc[f] = gie_ld(&c.g_coc[an]); ht[f] = gie_ld(&c.g_type[an]);
+        }
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            int ncx, ncy, ncz;
+            gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
+            const bool ok = L.nslot[f] >= 0 && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz);
+            L.halo[f][lane] = hp[f]; L.hflag[f][lane] = ok ? GIE_WB_OK : 0u;
+        }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int np0 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int v = lane + 64 * j;
+        int ncx, ncy, ncz;
+        gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
+        L.pair[v] = pv[j]; L.prop[v] = cv[j];
+        L.flag[v] = (ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)) ? GIE_WB_OK : 0u;
+        L.sdist[v] = (uint32_t)gie_gdist(c, cc8[j], g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j);
+        const bool have = cv[j] != GIE_NOPROP;
+        if (have) gie_st(&rd[base + v], (uint64_t)GIE_NOPROP);         /* consumed */
+        const unsigned long long m = __ballot(have);
+        if (have) L.pend[0][np0 + __popcll(m & lt)] = (uint16_t)v;
+        np0 += __popcll(m);
+    }
+    if (lane == 0) { L.npend[0] = np0; L.npend[1] = 0; }
+    gie_wave_sync();
+    /* ---- BFS inside the block (see gie_wave_c_tile): pending voxels -> merge -> the ones taken up are committed (or cut off) -> entries expand */
+    unsigned xmask = 0;
+    int nvis = 0;
+    int np = np0;
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    for (int sub = 0;; sub++) {
+        const int pi = sub & 1;
+        int nent = 0;
+        for (int e0 = 0; e0 < np; e0 += 64) {
+            const int e = e0 + lane;
+            bool entry = false;
+            int v = 0;
+            if (e < np) {
+                v = L.pend[pi][e];
+                const uint64_t cd = L.prop[v];
+                L.prop[v] = GIE_NOPROP;
+                const bool take = (round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(L.pair[v]);
+                if (take) {
+                    if (!(round == 0 && sub == 0)) L.pair[v] = cd;                  /* (a seed enters with the pair it holds) */
+                    nvis++;
+                    if ((int)L.sdist[v] <= c.cutoff_sq) {                        /* the distance stored before the commit */
+                        L.sdist[v] = (uint32_t)gie_pair_dist(L.pair[v]);
+                        L.flag[v] |= GIE_WB_DONE;
+                        entry = true;
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(entry);
+            if (entry) L.list[nent + __popcll(m & lt)] = (uint16_t)v;
+            nent += __popcll(m);
+        }
+        if (lane == 0) L.npend[pi] = 0;
+        if (nent == 0) break;                             /* wave-uniform */
+        gie_wave_sync();
+        for (int e = lane; e < nent; e += 64) {
+            const int v = L.list[e];
+            const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
+            const uint64_t par = gie_pair_par(L.pair[v]);
+            int cw[3];
+            gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
+            const int cg[3] = { cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2] };          /* the entry's closest obstacle, global */
+            unsigned inm = 0;
+            int cand[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
+                const int ng[3] = { g0[0] + ux, g0[1] + uy, g0[2] + uz };
+                const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
+                const int ax = cg[0] - ng[0], ay = cg[1] - ng[1], az = cg[2] - ng[2];
+                cand[k] = gie_d2(cg[0], cg[1], cg[2], ng[0], ng[1], ng[2]);
+                (void)ax; (void)ay; (void)az;
+                if (gie_in_loc(c, nb[0], nb[1], nb[2])) { inm |= 1u << k; continue; }
+                if (gie_in_whole(c, nb[0], nb[1], nb[2])) continue;                              /* (tiling: not into another tile's territory) */
+                const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+                const int hp = (k < 2) ? (ey + 8 * ez) : ((k < 4) ? (ex + 8 * ez) : (ex + 8 * ey));
+                const int nv = (ux & 7) + 8 * (uy & 7) + 64 * (uz & 7);
+                const uint64_t seen = inside ? L.pair[nv] : L.halo[k][hp];
+                const unsigned okf = inside ? (L.flag[nv] & GIE_WB_OK) : (L.hflag[k][hp] & GIE_WB_OK);
+                if (!okf || cand[k] >= c.empty_value || !(cand[k] < gie_pair_dist(seen))) continue;
+                const uint64_t key = gie_pair_make(cand[k], par);
+                if (inside) {
+                    if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
+                        L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
+                } else { gie_amin64(&wr[L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
+            }
+            if (inm) {      /* neighbours inside the volume (only blocks at its faces get here): the face table takes the minimum of the whole wave */
+                const int cl3[3] = { cg[0] - c.pvt[0], cg[1] - c.pvt[1], cg[2] - c.pvt[2] };
+                if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) inm = 0;      /* (tiling: gie_frontier_outside) */
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if (!((inm >> k) & 1u)) continue;
+                    const int nb[3] = { g0[0] + ex + dx[k] - c.pvt[0], g0[1] + ey + dy[k] - c.pvt[1], g0[2] + ez + dz[k] - c.pvt[2] };
+                    const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
+                    /* `_aux[n]` (wave_core.cuh:334): the Mark-time pair's distance of an observed voxel, the batch distance of an unknown one */
+                    const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? gie_pair_dist(gie_ld(&c.pair[nid])) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
+                    if (ref > cand[k]) {
+                        if (gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand[k], par)) == GIE_NOPROP)
+                            gie_push32(c, c.qc[1], &c.cnt[GIE_CNT_INL], c.qcap_c, nid);
+                    }
+                }
+            }
+        }
+        gie_wave_sync();
+        np = L.npend[pi ^ 1];
+    }
+    /* ---- write back: changed pairs, the closest obstacle of every voxel committed in this round */
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        const int v = lane + 64 * j;
+        const uint64_t pr = L.pair[v];
+        if (pr != pv[j]) gie_st(&c.g_pair[base + v], pr);
+        if (L.flag[v] & GIE_WB_DONE) {
+            int cw[3];
+            gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+            gie_st(&c.g_coc[base + v], gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]));
+            gie_touch(c, base + v);
+        }
+    }
+    /* ---- neighbour blocks that received a proposal take part in the next round */
+    {
+        unsigned any6 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
+        if (lane < 6 && ((any6 >> lane) & 1u)) {
+            const int ns = L.nslot[lane];
+            if (gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0)
+                gie_st(&c.wb_list[(round + 1) & 1][gie_aadd32(&c.lvlb_next[round + 1], 1)], (int32_t)ns);
+        }
+    }
+    {
+        int sv = nvis;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sv += __shfl_xor(sv, o);
+        if (lane == 0 && sv > 0) gie_aadd32(&c.lvlb_vis[round], sv);
+    }
+    gie_wave_sync();                                       /* the LDS block is reused for the wave's next block */
+}
+
+__device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb, gie_wb_tile *tiles)
 {
     const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
-    int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab), cur = 0, level = 0;
-    if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-    const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
-    if ((int)blockIdx.x >= nwg) return;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_AB2], 0, gb_all.failed, nwg, s_fail };
-    if (n > 0) {
-        if (boss) { c.cnt[GIE_CNT_VIS_B] += n; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += n; }
-        GIE_TS2(4, n);
-        GIE_WAVE_SHARE(n, first, last);
-        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur, 0, e, 1);
-        gie_grid_sync(gb, c);                   /* (also orders the two counter resets above before the first append) */
-        if (boss) { const int dup = gie_ld(&c.cnt[GIE_CNT_SPARE0]); c.cnt[GIE_CNT_VIS_B] -= dup; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) -= dup; }   /* entries that were in the seed list twice */
-        GIE_TS2(5, n);
+    const int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_B]), c.qcap_ab);
+    if (boss) { c.cnt[GIE_CNT_FRONT_B] = n; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]); }
+    if (n == 0 || gb.failed) return;               /* same n everywhere */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    /* the seeds mark themselves in the plane round 0 reads, their blocks are its active blocks (a voxel that was appended twice
+     * marks itself twice: the frontier is a set) */
+    for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
+        const int a = gie_ld(&c.qb_a[0][e]);
+        if (a < 0) continue;
+        gie_st(&c.g_prop[a], (uint64_t)0);
+        if (gie_axchg32(&c.wb_flag[0][a >> 9], (int32_t)1) == 0) gie_st(&c.wb_list[0][gie_aadd32(&c.lvlb_next[0], 1)], (int32_t)(a >> 9));
     }
-    while (n > 0 && !gb.failed) {
-        const int rp = level & 1;
-        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + rp];
-        GIE_WAVE_SHARE(n, first, last);
-        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase2(c, cur, next_cnt, level, rp, e);
-        gie_grid_sync(gb, c);
-        if (gb.failed) break;                   /* (as in wave A) */
-        GIE_TS2(6, n);
-        const int nn = gie_clampi(gie_ld(next_cnt), c.qcap_ab);
-        if (boss) {
-            gie_st(&c.cnt[GIE_CNT_NEXT + (rp ^ 1)], 0);             /* the next level's append counter (its last reader is long past) */
-            if (nn > 0) { c.cnt[GIE_CNT_VIS_B] += nn; c.cnt[GIE_CNT_LVL_B] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += nn; }
-        }
-        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase3(c, cur, rp, e);
-        {
-            GIE_WAVE_SHARE(nn, first, last);
-            for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_b_phase1(c, cur ^ 1, rp ^ 1, e, 0);
+    gie_grid_sync(gb, c);
+    GIE_TS2(4, n);
+    int round = 0;
+    while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
+        const int nt = gie_ld(&c.lvlb_next[round]);
+        if (nt <= 0) break;                        /* same everywhere */
+        if (wave < GIE_WB_WAVES) {
+            const int32_t *list = c.wb_list[round & 1];
+            for (int i = (int)blockIdx.x * GIE_WB_WAVES + wave; i < nt; i += (int)gridDim.x * GIE_WB_WAVES)
+                gie_wave_b_block(c, tiles[wave], gie_ld(&list[i]), round, lane);
         }
         gie_grid_sync(gb, c);
-        GIE_TS2(7, nn);
-        n = nn; cur ^= 1; level++;
-        GIE_WAVE_GO_SOLO(n);
+        GIE_TS2(6, nt);
+        round++;
     }
-    gb_all.failed |= gb.failed;
+    if (round >= GIE_MAX_LEVELS - 2 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    /* the stores into the volume: the smallest proposal of the whole wave, stored unconditionally (wave_core.cuh:336-346), applied
+     * when wave C starts; a voxel that is not a seed of wave C yet becomes one */
+    {
+        const int ni = gie_clampi(gie_ld(&c.cnt[GIE_CNT_INL]), c.qcap_c);
+        for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < ni; e += gridDim.x * GIE_WAVE_THREADS) {
+            const int nid = gie_ld(&c.qc[1][e]);
+            const int x = nid % c.X, y = (nid / c.X) % c.Y, z = nid / (c.X * c.Y);
+            uint64_t *lp = &c.lprop[gie_bdr_index(c, x, y, z)];
+            gie_st(&c.cand[1][nid], gie_ld(lp));
+            gie_st(lp, (uint64_t)GIE_NOPROP);
+            const uint32_t w = gie_ld(&c.wl[nid]);
+            const bool push = !(w == GIE_WL_SEED(c) || w == GIE_WL_PUSHED(c));
+            if (push) gie_st(&c.wl[nid], GIE_WL_PUSHED(c));
+            gie_push32_wave(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, push, nid);
+        }
+    }
+    if (boss) {
+        int lv = 0; long long vis = 0;
+        for (int l = 0; l < round; l++) { const int v = gie_ld(&c.lvlb_vis[l]); if (v > 0) { lv++; vis += v; } }
+        c.cnt[GIE_CNT_VIS_B] = (int)vis; c.cnt[GIE_CNT_LVL_B] = lv;
+        *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_B]) += vis;
+    }
 }
 
 /* ------------------------------------------------------------------ wave C: tile rounds */
@@ -2284,7 +2488,9 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
 /* waves A, B (unless fast_mode / refinement) and C in one launch */
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds, const int ab_wgs)
 {
-    __shared__ gie_wc_tile s_tiles[GIE_WC_WAVES];         /* wave C: one 8x8x8 tile (+ halo) per wave */
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[sizeof(gie_wc_tile) * GIE_WC_WAVES > sizeof(gie_wb_tile) * GIE_WB_WAVES ? sizeof(gie_wc_tile) * GIE_WC_WAVES : sizeof(gie_wb_tile) * GIE_WB_WAVES];
+    gie_wc_tile *const s_tiles = reinterpret_cast<gie_wc_tile *>(s_lds);      /* wave C: one 8x8x8 tile (+ halo) per wave */
+    gie_wb_tile *const s_blocks = reinterpret_cast<gie_wb_tile *>(s_lds);     /* wave B: one 8x8x8 block of the global map (+ halo) per wave */
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail };
@@ -2310,7 +2516,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
         gie_wave_a_run(c, gb, ab_wgs, &s_fail);
         gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
         GIE_TS2(8, 0);
-        gie_wave_b_run(c, gb, ab_wgs, &s_fail);
+        gie_wave_b_run(c, gb, s_blocks);
         gie_grid_sync(gb, c);
         GIE_TS2(9, 0);
     }

@@ -415,7 +415,7 @@ GIE_DEV void gie_init_voxel(const gie_ctx &c, int slot, int i)
     const int a = slot * GIE_VBSZ + i;
     c.g_occ[a] = 0; c.g_type[a] = GIE_VOX_UNKNOWN;
     c.g_coc[a] = gie_pack_crd(GIE_EMPTY_VALUE, GIE_EMPTY_VALUE, GIE_EMPTY_VALUE);
-    c.g_pair[a] = 0; c.g_prop[a] = GIE_NOPROP; c.g_wl[a] = -1;
+    c.g_pair[a] = 0; c.g_prop[a] = GIE_NOPROP; c.g_prop2[a] = GIE_NOPROP; c.g_wl[a] = -1;
 }
 
 /* an existing block makes the (up to eight) local tiles it overlaps interesting for fuse */

@@ -136,7 +136,11 @@ typedef struct gie_ctx {
     int8_t *g_type;
     uint64_t *g_coc;        /* packed global coord */
     uint64_t *g_pair;
-    uint64_t *g_prop;
+    uint64_t *g_prop;       /* proposals to hashed voxels: wave A's raises; wave B's block rounds (plane of odd rounds + the seeds) */
+    uint64_t *g_prop2;      /*   ... and the plane of wave B's even rounds */
+    int32_t *wb_list[2];    /* wave B: the active blocks (slots) of a round, by round parity */
+    int32_t *wb_flag[2];    /*         ... and their membership flags, one word per slot */
+    int32_t *lvlb_next, *lvlb_vis; /* wave B: active blocks / voxels taken up per round (GIE_MAX_LEVELS words each) */
     int32_t *g_wl;          /* wave_layer (-map_ct raise stamp / level stamps) */
     int track;              /* changed-block flags on (gie_stream_enable) */
     int fused;              /* Mark and commit run as one sweep, wave C commits what it merges (gie_ops.h "Mark + commit") */
@@ -183,7 +187,8 @@ enum {
     GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
     GIE_CNT_BARFAIL = 42,                       /* a grid barrier of THIS map update timed out (the sticky GIE_ERRF_BARRIER is the host's copy) */
     GIE_CNT_TSKIP = 41,                         /* tiles whose stored records Mark does not read (counted by the test-only emulation) */
-    GIE_CNT_AUX_END = 43,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_INL = 43,                           /* wave B: voxels inside the volume that received a proposal (listed in qc[1]) */
+    GIE_CNT_AUX_END = 44,                       /* [BAR_B, AUX_END) is zeroed every frame too */
     GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096
