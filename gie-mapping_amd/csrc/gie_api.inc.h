@@ -200,9 +200,10 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     for (int i = 0; i < 2; i++) c.wc_list[i] = gie_dalloc<int32_t>(m, ntile, false);
     c.wc_flag[0] = gie_dalloc<int32_t>(m, 2 * ntile);          /* one allocation: cleared as one region with the frame */
     c.wc_flag[1] = c.wc_flag[0] ? c.wc_flag[0] + ntile : nullptr;
-    c.lvl_next = gie_dalloc<int32_t>(m, 4 * GIE_MAX_LEVELS);
+    c.lvl_next = gie_dalloc<int32_t>(m, 6 * GIE_MAX_LEVELS);
     c.lvl_vis = c.lvl_next + GIE_MAX_LEVELS;
     c.lvlb_next = c.lvl_next + 2 * GIE_MAX_LEVELS; c.lvlb_vis = c.lvl_next + 3 * GIE_MAX_LEVELS;
+    c.lvla_next = c.lvl_next + 4 * GIE_MAX_LEVELS; c.lvla_vis = c.lvl_next + 5 * GIE_MAX_LEVELS;
     bool ok = c.cnt != nullptr;
     for (void *p : m->allocs) ok = ok && p != nullptr;
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
@@ -493,7 +494,7 @@ extern "C" int gie_fuse(gie_mapper *m)
         add(c.cnt, GIE_CNT_ERR * sizeof(int32_t));                 /* per-frame counters (the sticky error flag survives) */
         add(c.cnt + GIE_CNT_ERR + 1, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));
         add(c.cnt + GIE_CNT_BAR_B, (GIE_CNT_AUX_END - GIE_CNT_BAR_B) * sizeof(int32_t));
-        add(c.lvl_next, 4 * GIE_MAX_LEVELS * sizeof(int32_t));    /* waves C and B */
+        add(c.lvl_next, 6 * GIE_MAX_LEVELS * sizeof(int32_t));    /* waves C, B and A */
         add(c.wc_flag[0], 2 * ntile * sizeof(int32_t));          /* (zero again after every complete wave C; a wave cut short may leave flags) */
         if (!c.fast_mode) add(c.wb_flag[0], 2 * (size_t)c.max_blocks * sizeof(int32_t));      /* (likewise for wave B) */
         be_clear(&m->be, l);

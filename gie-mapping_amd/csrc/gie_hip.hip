@@ -65,7 +65,7 @@ static int be_init(be_state *b, int device)
          * bounded spin and GIE_ERR_TIMEOUT (include/gie.h). */
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_waves), GIE_WAVE_THREADS, 0) != hipSuccess || per_cu < 1) {
-            gie_set_err("the wavefront kernel (1024 threads per workgroup) cannot be resident on this device"); return 1;
+            gie_set_err("the wavefront kernel cannot be resident on this device"); return 1;
         }
         if (b->num_cu > per_cu * b->cu_total) b->num_cu = per_cu * b->cu_total;
     }

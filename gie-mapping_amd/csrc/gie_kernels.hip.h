@@ -1902,7 +1902,11 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
  * atomics in gie_ops.h) — the per-entry rec* records too: the workgroup that reads one is the one that wrote it while a
  * level keeps its split, but the tail of a wave goes to workgroup 0 (wave B: records written by phase 1 on every
  * workgroup, read by workgroup 0's phase 2), and the per-XCD L2s are not coherent for plain accesses. */
-#define GIE_WAVE_THREADS 1024
+#ifndef GIE_WAVE_THREADS
+#define GIE_WAVE_THREADS 512          /* 8 waves: each takes one block / tile at a time out of its own ~19 KB of LDS, with a register budget of 256 (1024 threads: 128,
+                                       * and the block routines spilled 127 registers) */
+#endif
+#define GIE_WAVE_SLOTS(want) ((want) < GIE_WAVE_THREADS / 64 ? (want) : GIE_WAVE_THREADS / 64)
 #define GIE_BAR_SPIN_LIMIT (1 << 22)
 
 /* Frontiers this small are finished by workgroup 0 alone (block barriers only).  A solo level costs
@@ -1960,8 +1964,31 @@ __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : h
         float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * g_ts_i; \
         p_[0] = (float)(wall_clock64() & 0xffffff); p_[1] = (float)((tag) * 1000000 + ((n) < 999999 ? (n) : 999999)); g_ts_i++; } } while (0)
 static __device__ int g_ts_i;
+/* ... and per-section clock sums of the block routines (wave A: 0-7, wave B: 8-15): [base + i] = ticks between marks i and i + 1, [base + 6] = levels inside
+ * blocks, [base + 7] = blocks */
+static __device__ unsigned int g_wprof[256 * 16][16];          /* one row per (workgroup, wave): no atomics, nothing shared while the waves run */
+#define GIE_WPROF_DECL unsigned long long wp_t_ = wall_clock64(), wp_s_ = 0; const unsigned long long wp_t0_ = wp_t_; int wp_i_ = 0; unsigned int *const wp_ = g_wprof[blockIdx.x * 16 + (threadIdx.x >> 6)]
+#define GIE_WPROF_MARK(base) do { const unsigned long long n_ = wall_clock64(); if (lane == 0) wp_[(base) + wp_i_] += (unsigned int)(n_ - wp_t_); wp_i_++; wp_t_ = n_; } while (0)
+#define GIE_WPROF_ADD(i, v) do { if (lane == 0) wp_[i] += (unsigned int)(v); } while (0)
+#define GIE_WPROF_END(base) do { const unsigned int d_ = (unsigned int)(wall_clock64() - wp_t0_); if (lane == 0) { if (d_ > wp_[(base) + 4]) wp_[(base) + 4] = d_; wp_[(base) + 5] += d_; } } while (0)
+#define GIE_WPROF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GIE_WPROF_SUBSTART() wp_s_ = wall_clock64()
+#define GIE_WPROF_SUB(i) do { const unsigned long long n_ = wall_clock64(); if (lane == 0) wp_[i] += (unsigned int)(n_ - wp_s_); wp_s_ = n_; } while (0)
+#define GIE_WPROF_DUMP() do { gie_grid_sync(gb, c); if (blockIdx.x == 0 && threadIdx.x < 16) { unsigned long long s_ = 0; \
+        const bool mx_ = (threadIdx.x & 7) == 4 || (threadIdx.x & 7) == 5; \
+        for (int r_ = 0; r_ < 256 * 16; r_++) { const unsigned int v_ = __hip_atomic_load(&g_wprof[r_][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (mx_) { if (16ull * v_ > s_) s_ = 16ull * v_; } else s_ += v_; __hip_atomic_store(&g_wprof[r_][threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } \
+        float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * (g_ts_i + (int)threadIdx.x); \
+        p_[0] = 0.0f; p_[1] = (float)((20 + (int)threadIdx.x) * 1000000 + (int)((s_ / 16) < 999999 ? (s_ / 16) : 999999)); } } while (0)
 #else
 #define GIE_TS2(tag, n) do { } while (0)
+#define GIE_WPROF_DECL do { } while (0)
+#define GIE_WPROF_MARK(base) do { } while (0)
+#define GIE_WPROF_ADD(i, v) do { } while (0)
+#define GIE_WPROF_END(base) do { } while (0)
+#define GIE_WPROF_DRAIN() do { } while (0)
+#define GIE_WPROF_SUB(i) do { } while (0)
+#define GIE_WPROF_SUBSTART() do { } while (0)
+#define GIE_WPROF_DUMP() do { } while (0)
 #endif
 
 /* the tail of a wave: once a level is this small, workgroup 0 finishes the wave alone (block barriers only: a phase
@@ -1984,31 +2011,301 @@ static __device__ int g_ts_i;
     const int share_ = (((n) + gb.nwg - 1) / gb.nwg + 63) & ~63; \
     const int first = min((n), (int)blockIdx.x * share_), last = min((n), (int)blockIdx.x * share_ + share_)
 
-__device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb_all, const int ab_wgs, int *s_fail)
+/* ------------------------------------------------------------------ wave A: checkerboard block rounds */
+/* raise_outside (wave_core.cuh:103-224) in the canonical CHECKERBOARD BLOCK-ROUND schedule (oracle/gie_oracle.c wave_a):
+ * the hashed 8x8x8 blocks are coloured by the parity of bx + by + bz and the rounds alternate between the colours, so the blocks
+ * of a round are never 6-adjacent: what a block reads of its neighbours (closest obstacle, raised-or-not) is stable while it
+ * runs, although the wave both reads and rewrites those records.  In a round every ACTIVE block of the round's colour — one
+ * that holds seeds or raises proposed by a neighbour in the round before — is taken by ONE WAVE: closest obstacles, stamps and
+ * proposals of the block and the obstacles of the one-voxel halo around it go into LDS (six hash probes per block and round),
+ * level after level runs inside the block to exhaustion out of LDS — per level: the pending voxels are raised (min-resolved
+ * proposal) and become entries, every entry reads the level-start state of its six neighbours, proposes raises (LDS minimum
+ * inside the block, agent-scope minimum into the other proposal plane across a block border) and computes its own lowering,
+ * and the lowerings are applied behind a wave barrier — and the records that changed are written back once.
+ *   planes: round h reads P[(h + 1) & 1] and proposes into P[h & 1] (P[1] = g_prop, P[0] = g_prop2); the seeds mark themselves
+ *           with key 0 in the plane their colour reads first (colour 0: P[1], colour 1: P[0]);
+ *   blocks: list wb_list[h & 1] with lvla_next[h] entries, membership flag wb_flag[h & 1][slot] (shared with wave B, which
+ *           starts behind this wave with all flags cleared by the waves that took the blocks). */
+struct gie_wa_tile { uint64_t coc[512], pair[512], prop[512], halo[6][64]; uint8_t flag[512], hflag[6][64];
+                     uint16_t list[512], pend[2][512]; int32_t npend[2], nslot[6]; };                                   /* 18.9 KB */
+#define GIE_WA_WAVES GIE_WAVE_SLOTS(8)                                    /* waves of a workgroup that take blocks */
+#define GIE_WA_OK 1u                                      /* known, stored obstacle and distance valid: may be raised, may lower an entry */
+#define GIE_WA_RAISED 2u                                  /* raised in this map update (stamp -map_ct) */
+#define GIE_WA_DIRTY 4u                                   /* obstacle / stamp changed in this round */
+#define GIE_WA_PAIR 8u                                    /* ... and the pair */
+#define GIE_WA_PUSHB 16u                                  /* lowered to an obstacle inside the wave range: joins wave B's seeds */
+#define GIE_WA_VANISHED 32u                               /* its stored obstacle lies inside the volume and is not OCCUPIED any more (looked up once, when the
+                                                           * block is loaded: a voxel that is lowered takes over an obstacle that has NOT vanished, a raised
+                                                           * one is not looked at again) */
+/* `_aux[coc] != 0` (wave_core.cuh:177-178): the batch distance of a voxel is 0 iff it is OCCUPIED, and Mark never turns a non-zero value into 0 */
+__device__ __forceinline__ int gie_wa_vanish_lid(const gie_ctx &c, const uint64_t coc)
+{
+    int x, y, z;
+    gie_unpack_crd(coc, &x, &y, &z);
+    x -= c.pvt[0]; y -= c.pvt[1]; z -= c.pvt[2];
+    return gie_in_loc(c, x, y, z) ? gie_lid(c, x, y, z) : -1;
+}
+
+__device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &L, const int slot, const int round, const int lane)
+{
+    int bk[3];
+    gie_unpack_crd(gie_ld(&c.g_key[slot]), &bk[0], &bk[1], &bk[2]);
+    const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };
+    uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
+    const int base = slot * GIE_VBSZ;
+    if (lane < 6) {
+        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
+        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
+    }
+    GIE_WPROF_DECL;
+    uint64_t cv[8], cc8[8];
+    int8_t ty8[8];
+    int32_t wl8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {                                       /* voxel lane + 64 j = (x, y) = lane, z = j */
+        const int a = base + lane + 64 * j;
+        cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]) & ~GIE_COC_STALEPAIR; ty8[j] = gie_ld(&c.g_type[a]); wl8[j] = gie_ld(&c.g_wl[a]);
+    }
+    if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);
+    int vl8[8]; int8_t vt8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) vl8[j] = gie_wa_vanish_lid(c, cc8[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) vt8[j] = c.glb_type[vl8[j] < 0 ? 0 : vl8[j]];              /* one batch, in flight with the neighbour lookups */
+    gie_wave_sync();
+    GIE_WPROF_MARK(0);                                                   /* 0: neighbour lookups (own loads in flight) */
+    {
+        const int p = lane & 7, q = lane >> 3;
+        const int hidx[6] = { 7 | (p << 3) | (q << 6), 0 | (p << 3) | (q << 6), p | (7 << 3) | (q << 6), p | (0 << 3) | (q << 6), p | (q << 3) | (7 << 6), p | (q << 3) | (0 << 6) };
+        const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
+        uint64_t hc[6]; int8_t ht[6]; int32_t hw[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            const int ns = L.nslot[f];
+            const int an = (ns < 0 ? base : ns * GIE_VBSZ) + hidx[f];
+            hc[f] = gie_ld(&c.g_coc[an]) & ~GIE_COC_STALEPAIR; ht[f] = gie_ld(&c.g_type[an]); hw[f] = gie_ld(&c.g_wl[an]);
+        }
+        int hl[6]; int8_t hv[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++) hl[f] = gie_wa_vanish_lid(c, hc[f]);
+#pragma unroll
+        for (int f = 0; f < 6; f++) hv[f] = c.glb_type[hl[f] < 0 ? 0 : hl[f]];          /* one batch */
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            int ncx, ncy, ncz;
+            gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
+            const bool ok = L.nslot[f] >= 0 && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+                            && !gie_invalid_dist(c, gie_gdist(c, hc[f], g0[0] + hx[f], g0[1] + hy[f], g0[2] + hz[f]));
+            L.halo[f][lane] = hc[f];
+            L.hflag[f][lane] = (uint8_t)((ok ? GIE_WA_OK : 0u) | (hw[f] == -c.map_ct ? GIE_WA_RAISED : 0u) | ((hl[f] >= 0 && hv[f] != GIE_VOX_OCCUPIED) ? GIE_WA_VANISHED : 0u));
+        }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int np = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int v = lane + 64 * j;
+        int ncx, ncy, ncz;
+        gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
+        const bool ok = ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+                        && !gie_invalid_dist(c, gie_gdist(c, cc8[j], g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j));
+        L.coc[v] = cc8[j]; L.prop[v] = cv[j];
+        L.flag[v] = (uint8_t)((ok ? GIE_WA_OK : 0u) | (wl8[j] == -c.map_ct ? GIE_WA_RAISED : 0u) | ((vl8[j] >= 0 && vt8[j] != GIE_VOX_OCCUPIED) ? GIE_WA_VANISHED : 0u));
+        const bool have = cv[j] != GIE_NOPROP;
+        if (have) gie_st(&rd[base + v], (uint64_t)GIE_NOPROP);         /* consumed */
+        const unsigned long long m = __ballot(have);
+        if (have) L.pend[0][np + __popcll(m & lt)] = (uint16_t)v;
+        np += __popcll(m);
+    }
+    if (lane == 0) { L.npend[0] = np; L.npend[1] = 0; }
+    gie_wave_sync();
+    GIE_WPROF_MARK(0);                                                   /* 1: halo + own records into LDS */
+    unsigned xmask = 0;
+    int nvis = 0;
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    for (int sub = 0; np > 0; sub++) {
+        GIE_WPROF_ADD(6, 1);
+        const int pi = sub & 1;
+        /* ---- the pending voxels: a seed (key 0) enters as it is, a proposal raises its voxel; both are entries of this level */
+        for (int e = lane; e < np; e += 64) {
+            const int v = L.pend[pi][e];
+            const uint64_t key = L.prop[v];
+            L.prop[v] = GIE_NOPROP;
+            if (key != 0ull) {
+                int lw[3];
+                gie_unpack_wr(gie_pair_par(key), &lw[0], &lw[1], &lw[2]);
+                L.coc[v] = gie_pack_crd(lw[0] + c.upvt[0], lw[1] + c.upvt[1], lw[2] + c.upvt[2]);
+                L.pair[v] = key;
+                L.flag[v] |= (uint8_t)(GIE_WA_RAISED | GIE_WA_DIRTY | GIE_WA_PAIR);
+            }
+            L.list[e] = (uint16_t)v;
+            nvis++;
+        }
+        const int nent = np;
+        if (lane == 0) L.npend[pi] = 0;
+        gie_wave_sync();
+        /* ---- every entry against the level-start state of its six neighbours: one LANE per (entry, direction) — a level holds a
+         * dozen entries, and a lane that walks all six directions of one entry is six times the instructions on the critical path */
+        for (int idx = lane; idx < nent * 6; idx += 64) {
+            const int e = idx / 6, k = idx - 6 * e;
+            const int v = L.list[e];
+            const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
+            const int g[3] = { g0[0] + ex, g0[1] + ey, g0[2] + ez };
+            const uint64_t lcoc = L.coc[v];
+            const int cd = gie_gdist(c, lcoc, g[0], g[1], g[2]);
+            if (cd > c.cutoff_sq) continue;
+            const int ax = k >> 1, sg = (k & 1) ? 1 : -1;
+            const int ux = ex + (ax == 0 ? sg : 0), uy = ey + (ax == 1 ? sg : 0), uz = ez + (ax == 2 ? sg : 0);
+            const int nb[3] = { g0[0] + ux - c.pvt[0], g0[1] + uy - c.pvt[1], g0[2] + uz - c.pvt[2] };
+            if (gie_in_loc(c, nb[0], nb[1], nb[2]) || gie_in_whole(c, nb[0], nb[1], nb[2])) continue;     /* (tiling: not into another tile's territory) */
+            const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+            const int hp = (ax == 0) ? (ey + 8 * ez) : ((ax == 1) ? (ex + 8 * ez) : (ex + 8 * ey));
+            const int nv = (ux & 7) + 8 * (uy & 7) + 64 * (uz & 7);
+            const uint64_t ncoc = inside ? L.coc[nv] : L.halo[k][hp];
+            const unsigned nf = inside ? L.flag[nv] : L.hflag[k][hp];
+            if (!(nf & GIE_WA_OK) || (nf & GIE_WA_RAISED) || ncoc == lcoc) continue;
+            if (nf & GIE_WA_VANISHED) {
+                int lc[3];
+                gie_unpack_crd(lcoc, &lc[0], &lc[1], &lc[2]);
+                const uint64_t key = gie_pair_make(gie_d2(lc[0], lc[1], lc[2], g0[0] + ux, g0[1] + uy, g0[2] + uz),
+                                                   gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]));
+                if (inside) {
+                    if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
+                        L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
+                } else { gie_amin64(&wr[L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
+            } else {
+                /* the entry's own lowering: the nearest of the obstacles its neighbours hold, the first direction among equals
+                 * (the reference walks the directions in order and replaces on a strict improvement).  Nobody proposes to an
+                 * entry — it is raised — so its proposal slot is free to collect the minimum over its six lanes. */
+                int nc[3];
+                gie_unpack_crd(ncoc, &nc[0], &nc[1], &nc[2]);
+                const int d = gie_d2(nc[0], nc[1], nc[2], g[0], g[1], g[2]);
+                if (d < cd) __hip_atomic_fetch_min(&L.prop[v], ((uint64_t)(uint32_t)d << 3) | (uint64_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        gie_wave_sync();
+        /* ---- the lowerings (the neighbour an entry takes its obstacle from is not an entry: it is not raised) */
+        for (int e = lane; e < nent; e += 64) {
+            const int v = L.list[e];
+            const uint64_t t = L.prop[v];
+            if (t == GIE_NOPROP) continue;
+            L.prop[v] = GIE_NOPROP;
+            const int k = (int)(t & 7u), ax = k >> 1, sg = (k & 1) ? 1 : -1;
+            const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
+            const int ux = ex + (ax == 0 ? sg : 0), uy = ey + (ax == 1 ? sg : 0), uz = ez + (ax == 2 ? sg : 0);
+            const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+            const int hp = (ax == 0) ? (ey + 8 * ez) : ((ax == 1) ? (ex + 8 * ez) : (ex + 8 * ey));
+            const uint64_t ncoc = inside ? L.coc[(ux & 7) + 8 * (uy & 7) + 64 * (uz & 7)] : L.halo[k][hp];
+            L.coc[v] = ncoc;
+            unsigned f = (L.flag[v] & ~(GIE_WA_RAISED | GIE_WA_VANISHED)) | GIE_WA_DIRTY;
+            int ncx, ncy, ncz;
+            gie_unpack_crd(ncoc, &ncx, &ncy, &ncz);
+            const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
+            if (gie_in_wr(c, nw[0], nw[1], nw[2])) {
+                L.pair[v] = gie_pair_make((int)(t >> 3), gie_pack_wr(nw[0], nw[1], nw[2]));
+                f |= GIE_WA_PAIR | GIE_WA_PUSHB;
+            }
+            L.flag[v] = (uint8_t)f;
+        }
+        gie_wave_sync();
+        np = L.npend[pi ^ 1];
+    }
+    GIE_WPROF_MARK(0);                                                   /* 2: levels inside the block */
+    /* ---- write back what changed; the voxels that were lowered with a pair join wave B's seeds (one counter update per block) */
+    {
+        int npush = 0;
+        unsigned f8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            f8[j] = L.flag[lane + 64 * j];
+            npush += __popcll(__ballot((f8[j] & GIE_WA_PUSHB) != 0u));
+        }
+        int qbase = 0;
+        if (npush > 0) {
+            if (lane == 0) qbase = gie_aadd32(&c.cnt[GIE_CNT_B], npush);
+            qbase = __shfl(qbase, 0);
+        }
+        int before = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int v = lane + 64 * j;
+            const unsigned f = f8[j];
+            if (f & GIE_WA_DIRTY) {
+                gie_st(&c.g_coc[base + v], L.coc[v]);
+                gie_st(&c.g_wl[base + v], (f & GIE_WA_RAISED) ? (int32_t)-c.map_ct : (int32_t)1);
+                if (f & GIE_WA_PAIR) gie_st(&c.g_pair[base + v], L.pair[v]);
+                gie_touch(c, base + v);
+            }
+            const unsigned long long m = __ballot((f & GIE_WA_PUSHB) != 0u);
+            if (f & GIE_WA_PUSHB) {
+                const int i = qbase + before + __popcll(m & lt);
+                if (i < c.qcap_ab) { gie_st(&c.qb[0][i], gie_pack_crd(g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j)); gie_st(&c.qb_a[0][i], (int32_t)(base + v)); }
+                else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+            }
+            before += __popcll(m);
+        }
+    }
+    {
+        unsigned any6 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
+        if (lane < 6 && ((any6 >> lane) & 1u)) {
+            const int ns = L.nslot[lane];
+            if (gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0)
+                gie_st(&c.wb_list[(round + 1) & 1][gie_aadd32(&c.lvla_next[round + 1], 1)], (int32_t)ns);
+        }
+    }
+    {
+        int sv = nvis;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sv += __shfl_xor(sv, o);
+        if (lane == 0 && sv > 0) gie_aadd32(&c.lvla_vis[round], sv);
+    }
+    GIE_WPROF_DRAIN();
+    GIE_WPROF_MARK(0);                                                   /* 3: write-back, activation (drained) */
+    GIE_WPROF_ADD(7, 1);
+    GIE_WPROF_END(0);
+    gie_wave_sync();                                       /* the LDS block is reused for the wave's next block */
+}
+
+__device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb, gie_wa_tile *tiles)
 {
     const bool boss = (blockIdx.x == 0 && threadIdx.x == 0);
-    int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab), cur = 0, level = 0;
-    if (boss) { c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
-    const int nwg = (n <= GIE_WAVE_SOLO_AB) ? 1 : min((int)gridDim.x, ab_wgs);
-    if ((int)blockIdx.x >= nwg) return;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_B], 0, gb_all.failed, nwg, s_fail };
-    while (n > 0 && !gb.failed) {
-        int32_t *next_cnt = &c.cnt[GIE_CNT_NEXT + (level & 1)];
-        if (boss) { c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n; }
-        GIE_TS2(1, n);
-        GIE_WAVE_SHARE(n, first, last);
-        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_a_phase1(c, cur, e);
-        gie_grid_sync(gb, c);
-        if (gb.failed) break;                   /* a barrier that timed out: nothing the other workgroups share is touched again */
-        GIE_TS2(2, n);
-        if (boss) gie_st(&c.cnt[GIE_CNT_NEXT + ((level + 1) & 1)], 0);
-        for (int e = first + (int)threadIdx.x; e < last; e += GIE_WAVE_THREADS) gie_wave_a_phase2(c, cur, next_cnt, e);
-        gie_grid_sync(gb, c);
-        GIE_TS2(3, n);
-        n = gie_clampi(gie_ld(next_cnt), c.qcap_ab); cur ^= 1; level++;
-        GIE_WAVE_GO_SOLO(n);
+    const int n = gie_clampi(gie_ld(&c.cnt[GIE_CNT_A]), c.qcap_ab);
+    if (boss) { c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = gie_ld(&c.cnt[GIE_CNT_B]); }
+    if (n == 0 || gb.failed) return;               /* same n everywhere */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
+        const int a = gie_ld(&c.qa_a[0][e]);
+        if (a < 0) continue;
+        int g[3];
+        gie_unpack_crd(gie_ld(&c.qa[0][e]), &g[0], &g[1], &g[2]);
+        const int col = ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1;
+        gie_st(col ? &c.g_prop2[a] : &c.g_prop[a], (uint64_t)0);
+        if (gie_axchg32(&c.wb_flag[col][a >> 9], (int32_t)1) == 0) gie_st(&c.wb_list[col][gie_aadd32(&c.lvla_next[col], 1)], (int32_t)(a >> 9));
     }
-    gb_all.failed |= gb.failed;
+    gie_grid_sync(gb, c);
+    GIE_TS2(1, n);
+    int round = 0;
+    while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
+        const int nt = gie_ld(&c.lvla_next[round]);
+        if (nt <= 0) { if (round == 0) { round++; continue; } break; }      /* (colour 0 may have no seeds) same everywhere */
+        if (wave < GIE_WA_WAVES) {
+            const int32_t *list = c.wb_list[round & 1];
+            for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WA_WAVES)      /* (spread over the workgroups first) */
+                gie_wave_a_block(c, tiles[wave], gie_ld(&list[i]), round, lane);
+        }
+        gie_grid_sync(gb, c);
+        GIE_TS2(3, nt);
+        round++;
+    }
+    if (round >= GIE_MAX_LEVELS - 2 && boss) gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    if (boss) {
+        int lv = 0; long long vis = 0;
+        for (int l = 0; l < round; l++) { const int v = gie_ld(&c.lvla_vis[l]); if (v > 0) { lv++; vis += v; } }
+        c.cnt[GIE_CNT_VIS_A] = (int)vis; c.cnt[GIE_CNT_LVL_A] = lv;
+        *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += vis;
+    }
 }
 
 /* ------------------------------------------------------------------ wave B: block rounds */
@@ -2027,10 +2324,13 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
  *           taken up is committed and expanded unless the distance stored in it BEFORE the commit exceeds the cut-off (:262-266). */
 struct gie_wb_tile { uint64_t pair[512], prop[512], halo[6][64]; uint32_t sdist[512]; uint8_t flag[512], hflag[6][64];
                      uint16_t list[512], pend[2][512]; int32_t npend[2], nslot[6]; };                                   /* 17.3 KB */
-#define GIE_WB_WAVES 9                                    /* waves of a workgroup that take blocks */
+#define GIE_WB_WAVES GIE_WAVE_SLOTS(9)                                    /* waves of a workgroup that take blocks */
 #define GIE_WB_OK 1u                                      /* the voxel may be lowered: known, and its stored obstacle is valid */
 #define GIE_WB_DONE 2u                                    /* committed in this round */
 
+#define GIE_WB_INVOL 4u                                   /* the position lies inside the volume: its slot holds the distance a proposal has to beat
+                                                           * (`_aux[n]`, wave_core.cuh:334: the Mark-time pair's distance of an observed voxel, the batch
+                                                           * distance of an unknown one), fetched with the block — the levels never wait for memory */
 __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &L, const int slot, const int round, const int lane)
 {
     int bk[3];
@@ -2043,30 +2343,52 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
         const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
         L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
     }
+    GIE_WPROF_DECL;
     uint64_t pv[8], cv[8], cc8[8];
     int8_t ty8[8];
+    unsigned inv8 = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {                                       /* voxel lane + 64 j = (x, y) = lane, z = j */
         const int a = base + lane + 64 * j;
-        pv[j] = gie_ld(&c.g_pair[a]) & ~GIE_PAIR_NEW; cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]); ty8[j] = gie_ld(&c.g_type[a]);
+        const int nb[3] = { g0[0] + (lane & 7) - c.pvt[0], g0[1] + (lane >> 3) - c.pvt[1], g0[2] + j - c.pvt[2] };
+        const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
+        const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
+        if (inv) inv8 |= 1u << j;
+        pv[j] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[a]) & ~GIE_PAIR_NEW; cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]);
+        ty8[j] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[a]);
     }
     if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);     /* may be activated again (for round + 2) from now on */
     gie_wave_sync();                                                    /* the neighbour slots */
+    GIE_WPROF_MARK(8);
     {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the lane's position (a, b) on it -> in-block index of the voxel across the face */
-        const int a = lane & 7, b = lane >> 3;
-        const int hidx[6] = { 7 | (a << 3) | (b << 6), 0 | (a << 3) | (b << 6), a | (7 << 3) | (b << 6), a | (0 << 3) | (b << 6), a | (b << 3) | (7 << 6), a | (b << 3) | (0 << 6) };
+        const int p = lane & 7, q = lane >> 3;
+        const int hidx[6] = { 7 | (p << 3) | (q << 6), 0 | (p << 3) | (q << 6), p | (7 << 3) | (q << 6), p | (0 << 3) | (q << 6), p | (q << 3) | (7 << 6), p | (q << 3) | (0 << 6) };
+        const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
         uint64_t hp[6], hc[6]; int8_t ht[6];
+        unsigned hinv = 0;
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const int ns = L.nslot[f];
             const int an = (ns < 0 ? base : ns * GIE_VBSZ) + hidx[f];
-            hp[f] = gie_ld(&c.g_pair[an]) & ~GIE_PAIR_NEW; hc[f] = gie_ld(&c.g_coc[an]); ht[f] = gie_ld(&c.g_type[an]);
+            const int nb[3] = { g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2] };
+            const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
+            const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
+            if (inv) hinv |= 1u << f;
+            hp[f] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[an]) & ~GIE_PAIR_NEW; hc[f] = gie_ld(&c.g_coc[an]);
+            ht[f] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[an]);
         }
 #pragma unroll
         for (int f = 0; f < 6; f++) {
+            if ((hinv >> f) & 1u) {
+                if (ht[f] == GIE_VOX_UNKNOWN)
+                    hp[f] = gie_pair_make(gie_batch_dist_direct(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]), 0);
+                L.halo[f][lane] = hp[f]; L.hflag[f][lane] = GIE_WB_INVOL;
+                continue;
+            }
             int ncx, ncy, ncz;
             gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
-            const bool ok = L.nslot[f] >= 0 && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz);
+            const bool ok = L.nslot[f] >= 0 && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+                            && !gie_in_whole(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]);   /* (tiling: not into another tile's territory) */
             L.halo[f][lane] = hp[f]; L.hflag[f][lane] = ok ? GIE_WB_OK : 0u;
         }
     }
@@ -2075,12 +2397,23 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int v = lane + 64 * j;
+        const int nb[3] = { g0[0] + (lane & 7) - c.pvt[0], g0[1] + (lane >> 3) - c.pvt[1], g0[2] + j - c.pvt[2] };
+        L.prop[v] = GIE_NOPROP;
+        if ((inv8 >> j) & 1u) {
+            if (ty8[j] == GIE_VOX_UNKNOWN) pv[j] = gie_pair_make(gie_batch_dist_direct(c, nb[0], nb[1], nb[2]), 0);
+            L.pair[v] = pv[j]; L.flag[v] = GIE_WB_INVOL; L.sdist[v] = 0u;
+            continue;
+        }
         int ncx, ncy, ncz;
         gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
         L.pair[v] = pv[j]; L.prop[v] = cv[j];
-        L.flag[v] = (ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)) ? GIE_WB_OK : 0u;
+        L.flag[v] = (ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz) && !gie_in_whole(c, nb[0], nb[1], nb[2])) ? GIE_WB_OK : 0u;
         L.sdist[v] = (uint32_t)gie_gdist(c, cc8[j], g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j);
-        const bool have = cv[j] != GIE_NOPROP;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int v = lane + 64 * j;
+        const bool have = !((inv8 >> j) & 1u) && cv[j] != GIE_NOPROP;
         if (have) gie_st(&rd[base + v], (uint64_t)GIE_NOPROP);         /* consumed */
         const unsigned long long m = __ballot(have);
         if (have) L.pend[0][np0 + __popcll(m & lt)] = (uint16_t)v;
@@ -2088,11 +2421,11 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
     }
     if (lane == 0) { L.npend[0] = np0; L.npend[1] = 0; }
     gie_wave_sync();
+    GIE_WPROF_MARK(8);
     /* ---- BFS inside the block (see gie_wave_c_tile): pending voxels -> merge -> the ones taken up are committed (or cut off) -> entries expand */
     unsigned xmask = 0;
     int nvis = 0;
     int np = np0;
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     for (int sub = 0;; sub++) {
         const int pi = sub & 1;
         int nent = 0;
@@ -2104,6 +2437,7 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
                 v = L.pend[pi][e];
                 const uint64_t cd = L.prop[v];
                 L.prop[v] = GIE_NOPROP;
+                GIE_WPROF_ADD(14, e == 0 ? 1 : 0);
                 const bool take = (round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(L.pair[v]);
                 if (take) {
                     if (!(round == 0 && sub == 0)) L.pair[v] = cd;                  /* (a seed enters with the pair it holds) */
@@ -2122,61 +2456,50 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
         if (lane == 0) L.npend[pi] = 0;
         if (nent == 0) break;                             /* wave-uniform */
         gie_wave_sync();
-        for (int e = lane; e < nent; e += 64) {
+        /* one lane per (entry, direction): see gie_wave_a_block */
+        for (int idx = lane; idx < nent * 6; idx += 64) {
+            const int e = idx / 6, k = idx - 6 * e;
             const int v = L.list[e];
             const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
             const uint64_t par = gie_pair_par(L.pair[v]);
             int cw[3];
             gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
             const int cg[3] = { cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2] };          /* the entry's closest obstacle, global */
-            unsigned inm = 0;
-            int cand[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
-                const int ng[3] = { g0[0] + ux, g0[1] + uy, g0[2] + uz };
-                const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
-                const int ax = cg[0] - ng[0], ay = cg[1] - ng[1], az = cg[2] - ng[2];
-                cand[k] = gie_d2(cg[0], cg[1], cg[2], ng[0], ng[1], ng[2]);
-                (void)ax; (void)ay; (void)az;
-                if (gie_in_loc(c, nb[0], nb[1], nb[2])) { inm |= 1u << k; continue; }
-                if (gie_in_whole(c, nb[0], nb[1], nb[2])) continue;                              /* (tiling: not into another tile's territory) */
-                const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
-                const int hp = (k < 2) ? (ey + 8 * ez) : ((k < 4) ? (ex + 8 * ez) : (ex + 8 * ey));
-                const int nv = (ux & 7) + 8 * (uy & 7) + 64 * (uz & 7);
-                const uint64_t seen = inside ? L.pair[nv] : L.halo[k][hp];
-                const unsigned okf = inside ? (L.flag[nv] & GIE_WB_OK) : (L.hflag[k][hp] & GIE_WB_OK);
-                if (!okf || cand[k] >= c.empty_value || !(cand[k] < gie_pair_dist(seen))) continue;
-                const uint64_t key = gie_pair_make(cand[k], par);
-                if (inside) {
-                    if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
-                        L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
-                } else { gie_amin64(&wr[L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
-            }
-            if (inm) {      /* neighbours inside the volume (only blocks at its faces get here): the face table takes the minimum of the whole wave */
+            const int ax = k >> 1, sg = (k & 1) ? 1 : -1;
+            const int ux = ex + (ax == 0 ? sg : 0), uy = ey + (ax == 1 ? sg : 0), uz = ez + (ax == 2 ? sg : 0);
+            const int ng[3] = { g0[0] + ux, g0[1] + uy, g0[2] + uz };
+            const int cand = gie_d2(cg[0], cg[1], cg[2], ng[0], ng[1], ng[2]);
+            const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+            const int hp = (ax == 0) ? (ey + 8 * ez) : ((ax == 1) ? (ex + 8 * ez) : (ex + 8 * ey));
+            const int nv = (ux & 7) + 8 * (uy & 7) + 64 * (uz & 7);
+            const uint64_t seen = inside ? L.pair[nv] : L.halo[k][hp];
+            const unsigned nf = inside ? L.flag[nv] : L.hflag[k][hp];
+            const uint64_t key = gie_pair_make(cand, par);
+            if (nf & GIE_WB_INVOL) {
+                /* a neighbour inside the volume (only blocks at its faces get here): the face table takes the minimum of the whole wave */
                 const int cl3[3] = { cg[0] - c.pvt[0], cg[1] - c.pvt[1], cg[2] - c.pvt[2] };
-                if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) inm = 0;      /* (tiling: gie_frontier_outside) */
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    if (!((inm >> k) & 1u)) continue;
-                    const int nb[3] = { g0[0] + ex + dx[k] - c.pvt[0], g0[1] + ey + dy[k] - c.pvt[1], g0[2] + ez + dz[k] - c.pvt[2] };
-                    const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
-                    /* `_aux[n]` (wave_core.cuh:334): the Mark-time pair's distance of an observed voxel, the batch distance of an unknown one */
-                    const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? gie_pair_dist(gie_ld(&c.pair[nid])) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
-                    if (ref > cand[k]) {
-                        if (gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand[k], par)) == GIE_NOPROP)
-                            gie_push32(c, c.qc[1], &c.cnt[GIE_CNT_INL], c.qcap_c, nid);
-                    }
-                }
+                if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) continue;      /* (tiling: gie_frontier_outside) */
+                /* the slot holds the distance to beat; a proposal (marked: GIE_PAIR_NEW) that beats it replaces it — the running minimum
+                 * of this block-run, handed to the face table once, with the write-back */
+                if (gie_pair_dist(seen) >= cand)             /* (at equal distance the stored reference — no mark — stays below every proposal; among proposals the parent decides) */
+                    __hip_atomic_fetch_min(inside ? &L.pair[nv] : &L.halo[k][hp], key | GIE_PAIR_NEW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
             }
+            if (!(nf & GIE_WB_OK) || cand >= c.empty_value || !(cand < gie_pair_dist(seen))) continue;
+            if (inside) {
+                if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
+                    L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
+            } else { gie_amin64(&wr[L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
         }
         gie_wave_sync();
         np = L.npend[pi ^ 1];
     }
+    GIE_WPROF_MARK(8);
     /* ---- write back: changed pairs, the closest obstacle of every voxel committed in this round */
 #pragma unroll 1
     for (int j = 0; j < 8; j++) {
         const int v = lane + 64 * j;
+        if ((inv8 >> j) & 1u) continue;
         const uint64_t pr = L.pair[v];
         if (pr != pv[j]) gie_st(&c.g_pair[base + v], pr);
         if (L.flag[v] & GIE_WB_DONE) {
@@ -2197,12 +2520,56 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
                 gie_st(&c.wb_list[(round + 1) & 1][gie_aadd32(&c.lvlb_next[round + 1], 1)], (int32_t)ns);
         }
     }
+    /* ---- what the block-run proposes to voxels inside the volume: the face table takes the minimum of the whole wave; whoever
+     * finds a voxel's slot empty lists the voxel (all of the block-run's minima in flight together, one list append per block-run) */
+    {
+        const int p = lane & 7, q = lane >> 3;
+        const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
+        uint64_t key[14], old[14];
+        int nid[14], bi[14];
+        unsigned hitm = 0;
+#pragma unroll
+        for (int t = 0; t < 14; t++) {
+            const uint64_t pr = t < 8 ? (((inv8 >> t) & 1u) ? L.pair[lane + 64 * t] : 0ull) : ((L.hflag[t - 8][lane] & GIE_WB_INVOL) ? L.halo[t - 8][lane] : 0ull);
+            key[t] = pr & ~GIE_PAIR_NEW; nid[t] = 0; bi[t] = 0; old[t] = 0;
+            if (!(pr & GIE_PAIR_NEW)) continue;
+            const int x = g0[0] + (t < 8 ? (lane & 7) : hx[t < 8 ? 0 : t - 8]) - c.pvt[0], y = g0[1] + (t < 8 ? (lane >> 3) : hy[t < 8 ? 0 : t - 8]) - c.pvt[1],
+                      z = g0[2] + (t < 8 ? t : hz[t < 8 ? 0 : t - 8]) - c.pvt[2];
+            nid[t] = gie_lid(c, x, y, z); bi[t] = gie_bdr_index(c, x, y, z);
+            hitm |= 1u << t;
+        }
+        if (__ballot(hitm != 0u) != 0ull) {
+#pragma unroll
+            for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) old[t] = gie_amin64(&c.lprop[bi[t]], key[t]);
+            int mine = 0;
+#pragma unroll
+            for (int t = 0; t < 14; t++) if (((hitm >> t) & 1u) && old[t] == GIE_NOPROP) mine++; else hitm &= ~(1u << t);
+            int incl = mine;                                /* inclusive prefix sum over the lanes */
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            const int total = __shfl(incl, 63);
+            if (total > 0) {
+                int qb = 0;
+                if (lane == 0) qb = gie_aadd32(&c.cnt[GIE_CNT_INL], total);
+                qb = __shfl(qb, 0) + incl - mine;
+#pragma unroll
+                for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) {
+                    if (qb < c.qcap_c) gie_st(&c.qc[1][qb], (int32_t)nid[t]); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+                    qb++;
+                }
+            }
+        }
+    }
     {
         int sv = nvis;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sv += __shfl_xor(sv, o);
         if (lane == 0 && sv > 0) gie_aadd32(&c.lvlb_vis[round], sv);
     }
+    GIE_WPROF_DRAIN();
+    GIE_WPROF_MARK(8);
+    GIE_WPROF_ADD(15, 1);
+    GIE_WPROF_END(8);
     gie_wave_sync();                                       /* the LDS block is reused for the wave's next block */
 }
 
@@ -2229,7 +2596,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         if (nt <= 0) break;                        /* same everywhere */
         if (wave < GIE_WB_WAVES) {
             const int32_t *list = c.wb_list[round & 1];
-            for (int i = (int)blockIdx.x * GIE_WB_WAVES + wave; i < nt; i += (int)gridDim.x * GIE_WB_WAVES)
+            for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WB_WAVES)      /* (spread over the workgroups first) */
                 gie_wave_b_block(c, tiles[wave], gie_ld(&list[i]), round, lane);
         }
         gie_grid_sync(gb, c);
@@ -2274,7 +2641,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
  *           takes the tile, set by whoever activates it for round r + 2);
  *   rule:   a proposal replaces a pair on a strict distance improvement over the value at the start of the (sub-)level,
  *           among proposals the smaller (dist, parent) wins; the seeds of round 0 are assignments. */
-#define GIE_WC_WAVES 10                                   /* waves of a workgroup that take tiles: 14.6 KB of LDS each */
+#define GIE_WC_WAVES GIE_WAVE_SLOTS(10)                                   /* waves of a workgroup that take tiles: 14.6 KB of LDS each */
 struct gie_wc_tile { uint64_t pair[512], prop[512], halo[6][64]; uint16_t list[512], pend[2][512]; int32_t npend[2]; };   /* 14.6 KB */
 
 __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L, const int t, const int round, const int lane)
@@ -2468,7 +2835,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
         if (nt <= 0) break;                    /* same everywhere */
         if (wave < GIE_WC_WAVES) {
             const int32_t *list = c.wc_list[round & 1];
-            for (int i = (int)blockIdx.x * GIE_WC_WAVES + wave; i < nt; i += (int)gridDim.x * GIE_WC_WAVES)
+            for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WC_WAVES)      /* (spread over the workgroups first) */
                 gie_wave_c_tile(c, tiles[wave], gie_ld(&list[i]), round, lane);
         }
         gie_grid_sync(gb, c);
@@ -2488,7 +2855,9 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
 /* waves A, B (unless fast_mode / refinement) and C in one launch */
 __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds, const int ab_wgs)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_lds[sizeof(gie_wc_tile) * GIE_WC_WAVES > sizeof(gie_wb_tile) * GIE_WB_WAVES ? sizeof(gie_wc_tile) * GIE_WC_WAVES : sizeof(gie_wb_tile) * GIE_WB_WAVES];
+    constexpr size_t lds_a = sizeof(gie_wa_tile) * GIE_WA_WAVES, lds_b = sizeof(gie_wb_tile) * GIE_WB_WAVES, lds_c = sizeof(gie_wc_tile) * GIE_WC_WAVES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[lds_a > lds_b ? (lds_a > lds_c ? lds_a : lds_c) : (lds_b > lds_c ? lds_b : lds_c)];
+    gie_wa_tile *const s_ablocks = reinterpret_cast<gie_wa_tile *>(s_lds);    /* wave A: one 8x8x8 block of the global map (+ halo) per wave */
     gie_wc_tile *const s_tiles = reinterpret_cast<gie_wc_tile *>(s_lds);      /* wave C: one 8x8x8 tile (+ halo) per wave */
     gie_wb_tile *const s_blocks = reinterpret_cast<gie_wb_tile *>(s_lds);     /* wave B: one 8x8x8 block of the global map (+ halo) per wave */
     __shared__ int s_fail;
@@ -2513,7 +2882,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
 #endif
     GIE_TS2(0, 0);
     if (with_ab) {
-        gie_wave_a_run(c, gb, ab_wgs, &s_fail);
+        gie_wave_a_run(c, gb, s_ablocks);
         gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
         GIE_TS2(8, 0);
         gie_wave_b_run(c, gb, s_blocks);
@@ -2522,6 +2891,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     }
     gie_wave_c_run(c, gb, record_seeds, s_tiles);
     GIE_TS2(10, 0);
+    GIE_WPROF_DUMP();
 }
 
 #endif /* GIE_KERNELS_HIP_H */

@@ -141,6 +141,7 @@ typedef struct gie_ctx {
     int32_t *wb_list[2];    /* wave B: the active blocks (slots) of a round, by round parity */
     int32_t *wb_flag[2];    /*         ... and their membership flags, one word per slot */
     int32_t *lvlb_next, *lvlb_vis; /* wave B: active blocks / voxels taken up per round (GIE_MAX_LEVELS words each) */
+    int32_t *lvla_next, *lvla_vis; /* wave A: likewise (its rounds alternate between the two colours of the blocks) */
     int32_t *g_wl;          /* wave_layer (-map_ct raise stamp / level stamps) */
     int track;              /* changed-block flags on (gie_stream_enable) */
     int fused;              /* Mark and commit run as one sweep, wave C commits what it merges (gie_ops.h "Mark + commit") */

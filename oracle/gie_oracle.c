@@ -775,90 +775,138 @@ static void obtain_frontiers(gie_oracle *o, queue *fa, queue *fb, queue *fc)
 /* ------------------------------------------------------------------ waves (canonical schedule) */
 typedef struct { ovox *v; int g[3]; int dist; int64_t par; } prop_rec;
 
-/* Wave A: raise_outside (wave_core.cuh:103-224) under parWave/BFS level loop
- * (wave_helper.h:8-93, wave_core.cuh:395-523). */
+/* Wave A: raise_outside (wave_core.cuh:103-224) in the canonical CHECKERBOARD BLOCK-ROUND schedule: the 8x8x8
+ * blocks are coloured by the parity of bx+by+bz, and rounds alternate between the colours, starting with colour 0.  In a
+ * round every block of the round's colour that holds pending voxels — seeds, or voxels a neighbouring block proposed to raise
+ * in the round before — runs level after level INSIDE itself to exhaustion.  Blocks that run in the same round are never
+ * 6-adjacent, so what a block reads of its neighbours is stable while it runs, and the order of the blocks does not matter.
+ * Inside a block every entry of a level reads the state at the START of the level; raise proposals are min-resolved per
+ * target voxel — (dist, parent) — and applied by the unique winner when the level is over (same block) or when the round is
+ * over (a voxel of a neighbouring block, which then is pending in the next round); an entry's own lowering is applied when
+ * its level is over.  levels_a counts the rounds that had work, visits_a the voxels taken up. */
+static int cmp_i3_block(const void *a, const void *b)
+{
+    const i3 *p = (const i3 *)a, *q = (const i3 *)b;
+    const int kp[3] = { fdiv8(p->z), fdiv8(p->y), fdiv8(p->x) }, kq[3] = { fdiv8(q->z), fdiv8(q->y), fdiv8(q->x) };
+    for (int i = 0; i < 3; i++) if (kp[i] != kq[i]) return kp[i] < kq[i] ? -1 : 1;
+    return 0;
+}
+static int same_block(const i3 *p, int x, int y, int z) { return fdiv8(p->x) == fdiv8(x) && fdiv8(p->y) == fdiv8(y) && fdiv8(p->z) == fdiv8(z); }
+static int block_colour(int x, int y, int z) { return (fdiv8(x) + fdiv8(y) + fdiv8(z)) & 1; }
+
 static void wave_a(gie_oracle *o, queue *front, queue *fb)
 {
     const int ct = o->map_ct;
-    queue cur = *front, next = { 0, 0, 0 };
-    front->d = NULL; front->n = front->cap = 0;
+    queue pend[2] = { { 0, 0, 0 }, { 0, 0, 0 } };
+    for (int i = 0; i < front->n; i++) q_push(&pend[block_colour(front->d[i].x, front->d[i].y, front->d[i].z)], front->d[i].x, front->d[i].y, front->d[i].z);
+    q_free(front);
     typedef struct { int lowered; int dist; int coc[3]; int pair_set; int pair_dist; int64_t pair_par; } low_rec;
-    while (cur.n > 0) {
+    for (int h = 0; pend[0].n + pend[1].n > 0; h++) {
+        queue cur = pend[h & 1];
+        pend[h & 1].d = NULL; pend[h & 1].n = pend[h & 1].cap = 0;
+        if (cur.n == 0) continue;
         o->st.levels_a++;
-        o->st.visits_a += cur.n;
-        low_rec *low = (low_rec *)calloc((size_t)cur.n, sizeof(low_rec));
-        prop_rec *props = NULL; int np = 0, pcap = 0;
-        /* phase 1: every entry reads the level-start state; writes only proposals */
-        for (int e = 0; e < cur.n; e++) {
-            const int g[3] = { cur.d[e].x, cur.d[e].y, cur.d[e].z };
-            ovox *c = vox_find(o, g[0], g[1], g[2]);
-            if (!c) continue;
-            if (c->dist_sq > o->cfg.cutoff_grids_sq) continue;
-            const int lc[3] = { c->coc[0], c->coc[1], c->coc[2] };
-            const int lcw[3] = { lc[0] - o->upvt[0], lc[1] - o->upvt[1], lc[2] - o->upvt[2] };
-            int cd = c->dist_sq;
-            low_rec *lr = &low[e];
-            for (int k = 0; k < 6; k++) {
-                const int ng[3] = { g[0] + DIRS[k][0], g[1] + DIRS[k][1], g[2] + DIRS[k][2] };
-                if (in_loc(o, ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2])) continue;
-                if (in_whole(o, ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2])) continue;   /* tiling: not into another tile's territory */
-                ovox *nv = vox_find(o, ng[0], ng[1], ng[2]);
-                if (!nv) continue;
-                if (nv->vox_type == GIE_VOX_UNKNOWN || invalid_coc_glb(nv->coc) || invalid_dist_glb(o, nv->dist_sq)) continue;
-                if (nv->wave_layer == -ct || nv->update_ct == -ct) continue;
-                if (nv->coc[0] == lc[0] && nv->coc[1] == lc[1] && nv->coc[2] == lc[2]) continue;
-                int raised = 0;
-                const int nl[3] = { nv->coc[0] - o->pvt[0], nv->coc[1] - o->pvt[1], nv->coc[2] - o->pvt[2] };
-                if (in_loc(o, nl[0], nl[1], nl[2]) && o->aux[lid(o, nl[0], nl[1], nl[2])] != 0) {
-                    const int d = d2i(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
-                    const int64_t par = pack_wr(lcw[0], lcw[1], lcw[2]);
-                    if (pair_less(d, par, nv->prop_dist, nv->prop_par)) { nv->prop_dist = d; nv->prop_par = par; }
-                    if (np == pcap) { pcap = pcap ? pcap * 2 : 256; props = (prop_rec *)realloc(props, sizeof(prop_rec) * (size_t)pcap); }
-                    props[np].v = nv; props[np].g[0] = ng[0]; props[np].g[1] = ng[1]; props[np].g[2] = ng[2];
-                    props[np].dist = d; props[np].par = par; np++;
-                    raised = 1;
-                }
-                if (!raised) {
-                    const int d = d2i(nv->coc[0], nv->coc[1], nv->coc[2], g[0], g[1], g[2]);
-                    if (cd > d) {
-                        cd = d;
-                        lr->lowered = 1; lr->dist = d; lr->coc[0] = nv->coc[0]; lr->coc[1] = nv->coc[1]; lr->coc[2] = nv->coc[2];
-                        const int nw[3] = { nv->coc[0] - o->upvt[0], nv->coc[1] - o->upvt[1], nv->coc[2] - o->upvt[2] };
-                        if (!in_wr(o, nw[0], nw[1], nw[2])) continue;
-                        lr->pair_set = 1; lr->pair_dist = d; lr->pair_par = pack_wr(nw[0], nw[1], nw[2]);
+        qsort(cur.d, (size_t)cur.n, sizeof(i3), cmp_i3_block);
+        queue xtouched = { 0, 0, 0 };
+        for (int b0 = 0; b0 < cur.n;) {
+            int e1 = b0;
+            while (e1 < cur.n && same_block(&cur.d[b0], cur.d[e1].x, cur.d[e1].y, cur.d[e1].z)) e1++;
+            const i3 blk = cur.d[b0];
+            queue L = { 0, 0, 0 };
+            for (int e = b0; e < e1; e++) q_push(&L, cur.d[e].x, cur.d[e].y, cur.d[e].z);
+            b0 = e1;
+            while (L.n > 0) {                                             /* one level inside the block */
+                o->st.visits_a += L.n;
+                low_rec *low = (low_rec *)calloc((size_t)L.n, sizeof(low_rec));
+                queue touched = { 0, 0, 0 }, Ln = { 0, 0, 0 };
+                /* phase 1: every entry reads the level-start state; writes only proposals */
+                for (int e = 0; e < L.n; e++) {
+                    const int g[3] = { L.d[e].x, L.d[e].y, L.d[e].z };
+                    ovox *c = vox_find(o, g[0], g[1], g[2]);
+                    if (!c) continue;
+                    if (c->dist_sq > o->cfg.cutoff_grids_sq) continue;
+                    const int lc[3] = { c->coc[0], c->coc[1], c->coc[2] };
+                    const int lcw[3] = { lc[0] - o->upvt[0], lc[1] - o->upvt[1], lc[2] - o->upvt[2] };
+                    int cd = c->dist_sq;
+                    low_rec *lr = &low[e];
+                    for (int k = 0; k < 6; k++) {
+                        const int ng[3] = { g[0] + DIRS[k][0], g[1] + DIRS[k][1], g[2] + DIRS[k][2] };
+                        if (in_loc(o, ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2])) continue;
+                        if (in_whole(o, ng[0] - o->pvt[0], ng[1] - o->pvt[1], ng[2] - o->pvt[2])) continue;   /* tiling: not into another tile's territory */
+                        ovox *nv = vox_find(o, ng[0], ng[1], ng[2]);
+                        if (!nv) continue;
+                        if (nv->vox_type == GIE_VOX_UNKNOWN || invalid_coc_glb(nv->coc) || invalid_dist_glb(o, nv->dist_sq)) continue;
+                        if (nv->wave_layer == -ct) continue;
+                        if (nv->coc[0] == lc[0] && nv->coc[1] == lc[1] && nv->coc[2] == lc[2]) continue;
+                        const int nl[3] = { nv->coc[0] - o->pvt[0], nv->coc[1] - o->pvt[1], nv->coc[2] - o->pvt[2] };
+                        if (in_loc(o, nl[0], nl[1], nl[2]) && o->aux[lid(o, nl[0], nl[1], nl[2])] != 0) {
+                            const int d = d2i(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
+                            const int64_t par = pack_wr(lcw[0], lcw[1], lcw[2]);
+                            if (same_block(&blk, ng[0], ng[1], ng[2])) {
+                                if (pair_less(d, par, nv->prop_dist, nv->prop_par)) { nv->prop_dist = d; nv->prop_par = par; }
+                                q_push(&touched, ng[0], ng[1], ng[2]);
+                            } else {
+                                if (pair_less(d, par, nv->xprop_dist, nv->xprop_par)) { nv->xprop_dist = d; nv->xprop_par = par; }
+                                q_push(&xtouched, ng[0], ng[1], ng[2]);
+                            }
+                        } else {
+                            const int d = d2i(nv->coc[0], nv->coc[1], nv->coc[2], g[0], g[1], g[2]);
+                            if (cd > d) {
+                                cd = d;
+                                lr->lowered = 1; lr->dist = d; lr->coc[0] = nv->coc[0]; lr->coc[1] = nv->coc[1]; lr->coc[2] = nv->coc[2];
+                                const int nw[3] = { nv->coc[0] - o->upvt[0], nv->coc[1] - o->upvt[1], nv->coc[2] - o->upvt[2] };
+                                lr->pair_set = 0;
+                                if (!in_wr(o, nw[0], nw[1], nw[2])) continue;
+                                lr->pair_set = 1; lr->pair_dist = d; lr->pair_par = pack_wr(nw[0], nw[1], nw[2]);
+                            }
+                        }
                     }
                 }
+                /* phase 2: apply */
+                for (int e = 0; e < L.n; e++) {
+                    if (!low[e].lowered) continue;
+                    ovox *c = vox_find(o, L.d[e].x, L.d[e].y, L.d[e].z);
+                    c->dist_sq = low[e].dist; c->coc[0] = low[e].coc[0]; c->coc[1] = low[e].coc[1]; c->coc[2] = low[e].coc[2];
+                    touch(o, c);
+                    c->wave_layer = 1; c->update_ct = ct;
+                    if (low[e].pair_set) {
+                        c->pair_dist = low[e].pair_dist; c->pair_par = low[e].pair_par;
+                        q_push(fb, L.d[e].x, L.d[e].y, L.d[e].z);
+                    }
+                }
+                for (int i = 0; i < touched.n; i++) {
+                    ovox *nv = vox_find(o, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+                    if (nv->prop_dist == 0x7fffffff) continue;               /* already applied */
+                    int lw[3]; unpack_wr(nv->prop_par, &lw[0], &lw[1], &lw[2]);
+                    nv->dist_sq = nv->prop_dist;
+                    nv->coc[0] = lw[0] + o->upvt[0]; nv->coc[1] = lw[1] + o->upvt[1]; nv->coc[2] = lw[2] + o->upvt[2];
+                    touch(o, nv);
+                    nv->wave_layer = -ct; nv->update_ct = -ct;
+                    nv->pair_dist = nv->prop_dist; nv->pair_par = nv->prop_par;
+                    nv->prop_dist = 0x7fffffff; nv->prop_par = 0;
+                    q_push(&Ln, touched.d[i].x, touched.d[i].y, touched.d[i].z);
+                }
+                free(low); q_free(&touched);
+                q_free(&L); L = Ln;
             }
+            q_free(&L);
         }
-        /* phase 2: apply */
-        for (int e = 0; e < cur.n; e++) {
-            if (!low[e].lowered) continue;
-            ovox *c = vox_find(o, cur.d[e].x, cur.d[e].y, cur.d[e].z);
-            c->dist_sq = low[e].dist; c->coc[0] = low[e].coc[0]; c->coc[1] = low[e].coc[1]; c->coc[2] = low[e].coc[2];
-            touch(o, c);
-            c->wave_layer = 1; c->update_ct = ct;
-            if (low[e].pair_set) {
-                c->pair_dist = low[e].pair_dist; c->pair_par = low[e].pair_par;
-                q_push(fb, cur.d[e].x, cur.d[e].y, cur.d[e].z);
-            }
-        }
-        for (int i = 0; i < np; i++) {
-            ovox *nv = props[i].v;
-            if (nv->prop_dist == 0x7fffffff) continue;               /* already applied */
-            if (props[i].dist != nv->prop_dist || props[i].par != nv->prop_par) continue;
-            int lw[3]; unpack_wr(nv->prop_par, &lw[0], &lw[1], &lw[2]);
-            nv->dist_sq = nv->prop_dist;
+        /* end of the round: the raises proposed into the neighbouring blocks (none of which ran in this round) */
+        for (int i = 0; i < xtouched.n; i++) {
+            ovox *nv = vox_find(o, xtouched.d[i].x, xtouched.d[i].y, xtouched.d[i].z);
+            if (nv->xprop_dist == 0x7fffffff) continue;
+            int lw[3]; unpack_wr(nv->xprop_par, &lw[0], &lw[1], &lw[2]);
+            nv->dist_sq = nv->xprop_dist;
             nv->coc[0] = lw[0] + o->upvt[0]; nv->coc[1] = lw[1] + o->upvt[1]; nv->coc[2] = lw[2] + o->upvt[2];
             touch(o, nv);
             nv->wave_layer = -ct; nv->update_ct = -ct;
-            nv->pair_dist = nv->prop_dist; nv->pair_par = nv->prop_par;
-            nv->prop_dist = 0x7fffffff; nv->prop_par = 0;
-            q_push(&next, props[i].g[0], props[i].g[1], props[i].g[2]);
+            nv->pair_dist = nv->xprop_dist; nv->pair_par = nv->xprop_par;
+            nv->xprop_dist = 0x7fffffff; nv->xprop_par = 0;
+            q_push(&pend[(h & 1) ^ 1], xtouched.d[i].x, xtouched.d[i].y, xtouched.d[i].z);
         }
-        free(low); free(props);
-        q_free(&cur); cur = next; next.d = NULL; next.n = next.cap = 0;
+        q_free(&xtouched);
+        q_free(&cur);
     }
-    q_free(&cur);
 }
 
 /* first face of the volume a boundary voxel lies on → dense slot in a 2(XY+YZ+XZ) table;
@@ -885,15 +933,6 @@ static void dedupe_global(gie_oracle *o, queue *q)
  * volume is collected over the whole wave — minimum per voxel — and stored when the wave is over (the reference's plain,
  * unconditional store, :336-346: any of the proposers may be the last writer; the canonical one is the smallest).
  * levels_b counts rounds, visits_b the voxels taken up (expanded or cut off). */
-static int cmp_i3_block(const void *a, const void *b)
-{
-    const i3 *p = (const i3 *)a, *q = (const i3 *)b;
-    const int kp[3] = { fdiv8(p->z), fdiv8(p->y), fdiv8(p->x) }, kq[3] = { fdiv8(q->z), fdiv8(q->y), fdiv8(q->x) };
-    for (int i = 0; i < 3; i++) if (kp[i] != kq[i]) return kp[i] < kq[i] ? -1 : 1;
-    return 0;
-}
-static int same_block(const i3 *p, int x, int y, int z) { return fdiv8(p->x) == fdiv8(x) && fdiv8(p->y) == fdiv8(y) && fdiv8(p->z) == fdiv8(z); }
-
 static void wave_b(gie_oracle *o, queue *front, queue *fc)
 {
     dedupe_global(o, front);

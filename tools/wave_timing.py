@@ -42,6 +42,17 @@ for i in range(NF):
                 tiles += n
         prev = t
         if tg == 10:
+            prof = []
+            for k2 in range(k + 2, k + 2 + 32, 2):
+                tag2 = int(row[k2 + 1])
+                if tag2 // 1000000 < 20:
+                    break
+                prof.append((tag2 % 1000000) * 16)
+            if len(prof) == 16:
+                for nm, b in (("A", 0), ("B", 8)):
+                    nb = max(1, prof[b + 7])
+                    lines.append("wave %s blocks: %d block-runs, %.1f levels inside each; per block-run: lookups %.2f us, fill %.2f us, levels %.2f us, write-back %.2f us; the longest block-run %.1f us, the busiest wave %.1f us" % (
+                        nm, prof[b + 7], prof[b + 6] / nb, prof[b] / nb / 100.0, prof[b + 1] / nb / 100.0, prof[b + 2] / nb / 100.0, prof[b + 3] / nb / 100.0, prof[b + 4] / 1600.0, prof[b + 5] / 1600.0))
             break
     print("frame %d: visits %d %d %d  levels %d %d %d | A %.0f us, B %.0f us, C %.0f us in %d rounds (%d tile-rounds)" % (
         i, st["visits_a"], st["visits_b"], st["visits_c"], st["levels_a"], st["levels_b"], st["levels_c"],
