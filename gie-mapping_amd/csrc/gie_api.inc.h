@@ -181,21 +181,11 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     long long qab = 16ll * bdr; if (qab < 65536) qab = 65536; if (qab > (16 << 20)) qab = 16 << 20;
     long long qc = (long long)c.N; if (qc < 4096) qc = 4096; if (qc > (16 << 20)) qc = 16 << 20;
     c.qcap_ab = (int)qab; c.qcap_c = (int)qc;
-    for (int i = 0; i < 2; i++) {
-        c.qa[i] = gie_dalloc<uint64_t>(m, (size_t)qab, false);
-        c.qb[i] = gie_dalloc<uint64_t>(m, (size_t)qab, false);
-        c.qa_a[i] = gie_dalloc<int32_t>(m, (size_t)qab, false);
-        c.qb_a[i] = gie_dalloc<int32_t>(m, (size_t)qab, false);
-        c.qc[i] = gie_dalloc<int32_t>(m, (size_t)qc, false);
-    }
-    const size_t rec = (size_t)qab;                       /* per-entry records of waves A / B */
-    c.rec0 = gie_dalloc<uint64_t>(m, rec, false);
-    c.rec1 = gie_dalloc<uint64_t>(m, rec, false);
-    c.rec2 = gie_dalloc<uint64_t>(m, rec, false);
-    c.rec3 = gie_dalloc<int32_t>(m, rec, false);
-    c.rec0b = gie_dalloc<uint64_t>(m, rec, false);
-    c.rec1b = gie_dalloc<uint64_t>(m, rec, false);
-    c.rec3b = gie_dalloc<int32_t>(m, rec, false);
+    c.qa = gie_dalloc<uint64_t>(m, (size_t)qab, false);
+    c.qb = gie_dalloc<uint64_t>(m, (size_t)qab, false);
+    c.qa_a = gie_dalloc<int32_t>(m, (size_t)qab, false);
+    c.qb_a = gie_dalloc<int32_t>(m, (size_t)qab, false);
+    for (int i = 0; i < 2; i++) c.qc[i] = gie_dalloc<int32_t>(m, (size_t)qc, false);
     c.cnt = gie_dalloc<int32_t>(m, GIE_CNT_NUM);
     for (int i = 0; i < 2; i++) c.wc_list[i] = gie_dalloc<int32_t>(m, ntile, false);
     c.wc_flag[0] = gie_dalloc<int32_t>(m, 2 * ntile);          /* one allocation: cleared as one region with the frame */

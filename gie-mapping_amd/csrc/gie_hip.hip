@@ -405,10 +405,7 @@ static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seed
         GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
         GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     }
-    /* workgroups that run waves A / B (the rest wait at the barrier behind them): 8 / 16 / 32 / 64 / 128 measured 0.83 / 0.74 / 0.73 /
-     * 0.76 / 0.70 ms of waves per C5 map update — a phase is a chain of ~7 dependent fabric round trips, not barrier fan-in */
-    static const int ab_wgs = getenv("GIE_WAVE_AB_WGS") ? atoi(getenv("GIE_WAVE_AB_WGS")) : 1024;
-    GIE_LAUNCH(b, k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, with_ab, record_seeds, ab_wgs > 0 ? ab_wgs : 1);
+    GIE_LAUNCH(b, k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, with_ab, record_seeds);
     if (chain) GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
 }
 

@@ -1509,8 +1509,8 @@ struct gie_absink_lds {
         if (!push) return;
         const int i = __hip_atomic_fetch_add(&L->nab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (i < GIE_FF_AB) { L->ab_crd[i] = crd | (push == 2 ? GIE_FR_ABIT : (uint64_t)0); L->ab_addr[i] = (int32_t)a; }
-        else if (push == 2) gie_push64a(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, crd, a);    /* (volumes one or two voxels thick: more than three outside neighbours per voxel) */
-        else gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, crd, a);
+        else if (push == 2) gie_push64a(c, c.qa, c.qa_a, &c.cnt[GIE_CNT_A], c.qcap_ab, crd, a);    /* (volumes one or two voxels thick: more than three outside neighbours per voxel) */
+        else gie_push64a(c, c.qb, c.qb_a, &c.cnt[GIE_CNT_B], c.qcap_ab, crd, a);
     }
 };
 /* patches of 8x8 voxels per face: face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z) spans (Y, Z), (X, Z) or (X, Y) */
@@ -1584,11 +1584,11 @@ __global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_
             const unsigned long long ma = __ballot(isa), mb = __ballot(isb);
             if (isa) {
                 const int i = ra + __popcll(ma & lt);
-                if (i < c.qcap_ab) { gie_st(&c.qa[0][i], (uint64_t)(crd & ~GIE_FR_ABIT)); gie_st(&c.qa_a[0][i], W.ab_addr[e]); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+                if (i < c.qcap_ab) { gie_st(&c.qa[i], (uint64_t)(crd & ~GIE_FR_ABIT)); gie_st(&c.qa_a[i], W.ab_addr[e]); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
             }
             if (isb) {
                 const int i = rb + __popcll(mb & lt);
-                if (i < c.qcap_ab) { gie_st(&c.qb[0][i], crd); gie_st(&c.qb_a[0][i], W.ab_addr[e]); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+                if (i < c.qcap_ab) { gie_st(&c.qb[i], crd); gie_st(&c.qb_a[i], W.ab_addr[e]); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
             }
             ra += __popcll(ma); rb += __popcll(mb);
         }
@@ -1894,32 +1894,17 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
 
 
 /* ------------------------------------------------------------------ persistent BFS waves */
-/* One launch per wave type, one workgroup per CU, all co-resident; BFS levels and the phases
- * inside a level are separated by a grid barrier (monotonic counter, agent-scope release /
- * relaxed poll / acquire — cdna_hip_programming.md G16), so a whole wavefront costs one launch
- * and no host round trip (the reference pays ≈3 PCIe round trips per level, wave_helper.h:20-90).
- * Every shared word touched inside the phases goes through agent-scope accesses (gie_ld/gie_st/
- * atomics in gie_ops.h) — the per-entry rec* records too: the workgroup that reads one is the one that wrote it while a
- * level keeps its split, but the tail of a wave goes to workgroup 0 (wave B: records written by phase 1 on every
- * workgroup, read by workgroup 0's phase 2), and the per-XCD L2s are not coherent for plain accesses. */
+/* One launch for the three waves, all workgroups co-resident; the rounds of a wave are separated by a grid barrier
+ * (monotonic counter, agent-scope release / relaxed poll / acquire — cdna_hip_programming.md G16), so a whole wavefront
+ * costs one launch and no host round trip (the reference pays ≈3 PCIe round trips per level, wave_helper.h:20-90).
+ * Every shared word touched inside a round goes through agent-scope accesses (gie_ld / gie_st / atomics in gie_ops.h):
+ * the per-XCD L2s are not coherent for plain accesses. */
 #ifndef GIE_WAVE_THREADS
 #define GIE_WAVE_THREADS 512          /* 8 waves: each takes one block / tile at a time out of its own ~19 KB of LDS, with a register budget of 256 (1024 threads: 128,
                                        * and the block routines spilled 127 registers) */
 #endif
 #define GIE_WAVE_SLOTS(want) ((want) < GIE_WAVE_THREADS / 64 ? (want) : GIE_WAVE_THREADS / 64)
 #define GIE_BAR_SPIN_LIMIT (1 << 22)
-
-/* Frontiers this small are finished by workgroup 0 alone (block barriers only).  A solo level costs
- * one chain of round trips per 1024 entries, a level of all workgroups one chain + the grid barrier:
- * measured on the dense-observation run, wave C at 0 / 128 / 512 / 1024 / 2048 / 4096 / 8192:
- * 1.05 / 1.06 / 1.07 / 1.09 / 1.13 / 1.29 / 1.82 ms per map update, and on a 256^3 volume (small
- * waves only) 0.104 / 0.084 / 0.082 / 0.087 / 0.085 / 0.084 / 0.083 ms. */
-#ifndef GIE_WAVE_SOLO
-#define GIE_WAVE_SOLO 512
-#endif
-#ifndef GIE_WAVE_SOLO_AB
-#define GIE_WAVE_SOLO_AB 4096 /* waves A / B decide once, from their seed count (512 / 2048 / 4096 measure the same) */
-#endif
 
 struct gie_gridbar { int32_t *word; int epoch; int failed; int nwg; int *s_fail; };   /* nwg = workgroups that meet at this barrier */
 
@@ -1952,11 +1937,7 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
 __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : hi; }
 
 /* The three waves run inside ONE launch (k_waves), separated by grid barriers of all workgroups: a wave
- * without seeds costs a counter read instead of a launch.  Waves A and B expand a few thousand entries
- * per phase — a chain of dependent round trips, then a barrier — so they run on the first `ab_wgs`
- * workgroups only (a barrier's cost grows with the workgroups that meet at it; one workgroup alone,
- * block barriers only, below GIE_WAVE_SOLO_AB seeds) with a barrier word of their own, while the others
- * fall through to the barrier that separates the wave from the next one. */
+ * without seeds costs a counter read instead of a launch. */
 /* measurement only (tools/wave_timing.py): the boss thread stamps the wall clock (10 ns ticks, 24 bits) and the level size at
  * every phase boundary of waves A / B / C into the middle row of the edt plane (interior voxels: no wave writes there) */
 #if defined(GIE_WAVE_TIMING)
@@ -1990,26 +1971,6 @@ static __device__ unsigned int g_wprof[256 * 16][16];          /* one row per (w
 #define GIE_WPROF_SUBSTART() do { } while (0)
 #define GIE_WPROF_DUMP() do { } while (0)
 #endif
-
-/* the tail of a wave: once a level is this small, workgroup 0 finishes the wave alone (block barriers only: a phase
- * of a few hundred entries costs its chain of round trips, not a grid barrier on top); the others leave for the
- * barrier behind the wave.  Same n in every workgroup (read behind the level's last barrier). */
-#ifndef GIE_WAVE_TAIL_SOLO
-#define GIE_WAVE_TAIL_SOLO 768
-#endif
-#define GIE_WAVE_GO_SOLO(n) \
-    if (gb.nwg > 1 && (n) > 0 && (n) <= GIE_WAVE_TAIL_SOLO) { \
-        if (blockIdx.x != 0) break;                     /* leaves the level loop */ \
-        gb.nwg = 1; \
-    }
-
-/* entries [first, last) of a level belong to this workgroup: the level is split EVENLY over the workgroups that run the wave
- * (whole waves each).  Every entry issues dozens of scattered 8-byte fabric transactions, and a compute unit's own request
- * queue — not the fabric — is what a phase waits for: with consecutive entries on consecutive threads a level of a few
- * thousand entries sat on a handful of compute units (33 us per phase whatever its size; evenly split: see DESIGN.md). */
-#define GIE_WAVE_SHARE(n, first, last) \
-    const int share_ = (((n) + gb.nwg - 1) / gb.nwg + 63) & ~63; \
-    const int first = min((n), (int)blockIdx.x * share_), last = min((n), (int)blockIdx.x * share_ + share_)
 
 /* ------------------------------------------------------------------ wave A: checkerboard block rounds */
 /* raise_outside (wave_core.cuh:103-224) in the canonical CHECKERBOARD BLOCK-ROUND schedule (oracle/gie_oracle.c wave_a):
@@ -2239,7 +2200,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
             const unsigned long long m = __ballot((f & GIE_WA_PUSHB) != 0u);
             if (f & GIE_WA_PUSHB) {
                 const int i = qbase + before + __popcll(m & lt);
-                if (i < c.qcap_ab) { gie_st(&c.qb[0][i], gie_pack_crd(g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j)); gie_st(&c.qb_a[0][i], (int32_t)(base + v)); }
+                if (i < c.qcap_ab) { gie_st(&c.qb[i], gie_pack_crd(g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j)); gie_st(&c.qb_a[i], (int32_t)(base + v)); }
                 else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
             }
             before += __popcll(m);
@@ -2276,10 +2237,10 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     if (n == 0 || gb.failed) return;               /* same n everywhere */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
-        const int a = gie_ld(&c.qa_a[0][e]);
+        const int a = gie_ld(&c.qa_a[e]);
         if (a < 0) continue;
         int g[3];
-        gie_unpack_crd(gie_ld(&c.qa[0][e]), &g[0], &g[1], &g[2]);
+        gie_unpack_crd(gie_ld(&c.qa[e]), &g[0], &g[1], &g[2]);
         const int col = ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1;
         gie_st(col ? &c.g_prop2[a] : &c.g_prop[a], (uint64_t)0);
         if (gie_axchg32(&c.wb_flag[col][a >> 9], (int32_t)1) == 0) gie_st(&c.wb_list[col][gie_aadd32(&c.lvla_next[col], 1)], (int32_t)(a >> 9));
@@ -2583,7 +2544,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     /* the seeds mark themselves in the plane round 0 reads, their blocks are its active blocks (a voxel that was appended twice
      * marks itself twice: the frontier is a set) */
     for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
-        const int a = gie_ld(&c.qb_a[0][e]);
+        const int a = gie_ld(&c.qb_a[e]);
         if (a < 0) continue;
         gie_st(&c.g_prop[a], (uint64_t)0);
         if (gie_axchg32(&c.wb_flag[0][a >> 9], (int32_t)1) == 0) gie_st(&c.wb_list[0][gie_aadd32(&c.lvlb_next[0], 1)], (int32_t)(a >> 9));
@@ -2853,7 +2814,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
 }
 
 /* waves A, B (unless fast_mode / refinement) and C in one launch */
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds, const int ab_wgs)
+__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds)
 {
     constexpr size_t lds_a = sizeof(gie_wa_tile) * GIE_WA_WAVES, lds_b = sizeof(gie_wb_tile) * GIE_WB_WAVES, lds_c = sizeof(gie_wc_tile) * GIE_WC_WAVES;
     __shared__ __attribute__((aligned(16))) unsigned char s_lds[lds_a > lds_b ? (lds_a > lds_c ? lds_a : lds_c) : (lds_b > lds_c ? lds_b : lds_c)];
@@ -2868,8 +2829,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
         const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);
         if ((with_ab ? (na | nb | nc) : nc) == 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
-                if (with_ab) { c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0; c.cnt[GIE_CNT_SEED_C] = 0;
-                               gie_st(&c.cnt[GIE_CNT_NEXT], 0); gie_st(&c.cnt[GIE_CNT_NEXT + 1], 0); }
+                if (with_ab) { c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0; c.cnt[GIE_CNT_SEED_C] = 0; }
                 c.cnt[GIE_CNT_FRONT_C] = 0;
                 if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = 0; c.cnt[GIE_CNT_SEED_A] = na; c.cnt[GIE_CNT_SEED_B] = nb; }
             }

@@ -708,8 +708,8 @@ struct gie_nbpair_mem { const uint64_t *pair; GIE_DEV_MEMBER uint64_t operator()
 struct gie_absink_queues {
     static constexpr bool outside = true;                  /* false: the caller only hands over voxels off the faces (no outside neighbour: that branch is not compiled) */
     GIE_DEV_MEMBER void ab(const gie_ctx &c, int push, uint64_t crd, int a) const {
-        gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, push == 1, crd, a);
-        gie_push64a_wave(c, c.qa[0], c.qa_a[0], &c.cnt[GIE_CNT_A], c.qcap_ab, push == 2, crd, a);
+        gie_push64a_wave(c, c.qb, c.qb_a, &c.cnt[GIE_CNT_B], c.qcap_ab, push == 1, crd, a);
+        gie_push64a_wave(c, c.qa, c.qa_a, &c.cnt[GIE_CNT_A], c.qcap_ab, push == 2, crd, a);
     } };
 template <class NB, class SINK>
 GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s, const NB &nb, const SINK &sink)
@@ -784,215 +784,9 @@ GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
     return gie_frontier_finish(c, id, x, y, z, s);
 }
 
-/* ================================================================== waves A / B: shared pieces */
-/* Addresses of the face neighbours k (bit k of `want`) of global voxel g, which is stored at address a.
- * A neighbour inside g's own block shares its slot; the others are looked up TOGETHER: the first
- * probes of all of them go out as one batch of loads, then the slots as another — a BFS phase is a
- * chain of dependent memory round trips, and six lookups one after the other were most of it.
- * Read-only (HashTableBase::get_alloc_blk_id, vhashing.h:125-134): nothing is inserted while the waves run. */
-GIE_DEV void gie_nbr_addr6(const gie_ctx &c, const int g[3], int a, unsigned want, int na[6])
-{
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    uint64_t key[6];
-    uint32_t h[6];
-    int hit[6], inb[6];
-    unsigned pend = 0;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        na[k] = -1; hit[k] = -1; key[k] = 0; h[k] = 0;
-        const int nx = g[0] + dx[k], ny = g[1] + dy[k], nz = g[2] + dz[k];
-        inb[k] = gie_vox_in_blk(nx, ny, nz);
-        if (!((want >> k) & 1u)) continue;
-        if ((nx >> 3) == (g[0] >> 3) && (ny >> 3) == (g[1] >> 3) && (nz >> 3) == (g[2] >> 3)) { na[k] = (a & ~(GIE_VBSZ - 1)) + inb[k]; continue; }
-        key[k] = gie_pack_crd(nx >> 3, ny >> 3, nz >> 3);
-        h[k] = gie_hash_key(nx >> 3, ny >> 3, nz >> 3) & c.hmask;
-        pend |= 1u << k;
-    }
-    while (pend) {
-        uint64_t kk[6];
-        GIE_UNROLL6
-        for (int k = 0; k < 6; k++) kk[k] = ((pend >> k) & 1u) ? c.hkeys[h[k]] : 0ull;
-        GIE_UNROLL6
-        for (int k = 0; k < 6; k++) {
-            if (!((pend >> k) & 1u)) continue;
-            if (kk[k] == key[k]) { hit[k] = (int)h[k]; pend &= ~(1u << k); }
-            else if (kk[k] == GIE_KEY_EMPTY) pend &= ~(1u << k);
-            else h[k] = (h[k] + 1) & c.hmask;
-        }
-    }
-    int sl[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) sl[k] = hit[k] >= 0 ? c.hvals[hit[k]] : -1;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) if (hit[k] >= 0 && sl[k] >= 0) na[k] = sl[k] * GIE_VBSZ + inb[k];
-}
-/* append the neighbours k in `pm` (their addresses in na[]) of g to a frontier: ONE returning atomic per WAVE (the
- * lanes' counts are ranked with one ballot per direction) */
-GIE_DEV void gie_push_nbrs(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, const int g[3], unsigned pm, const int na[6])
-{
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-#if defined(GIE_HOST_EMU)
-    int n = 0;
-    for (int k = 0; k < 6; k++) n += (int)((pm >> k) & 1u);
-    if (!n) return;
-    int slot = gie_aadd32(counter, n);
-    for (int k = 0; k < 6; k++) {
-        if (!((pm >> k) & 1u)) continue;
-        if (slot < c.qcap_ab) { gie_st(&q[slot], gie_pack_crd(g[0] + dx[k], g[1] + dy[k], g[2] + dz[k])); gie_st(&qaddr[slot], (int32_t)na[k]); }
-        else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
-        slot++;
-    }
-#else
-    unsigned long long mk[6];
-    int tot = 0;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) { mk[k] = __ballot((pm >> k) & 1u); tot += __popcll(mk[k]); }
-    if (!tot) return;
-    const int lane = __lane_id(), leader = __ffsll((long long)__ballot(1)) - 1;
-    int base = 0;
-    if (lane == leader) base = gie_aadd32(counter, tot);
-    base = __shfl(base, leader);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        if ((pm >> k) & 1u) {
-            const int slot = base + __popcll(mk[k] & lt);
-            if (slot < c.qcap_ab) { gie_st(&q[slot], gie_pack_crd(g[0] + dx[k], g[1] + dy[k], g[2] + dz[k])); gie_st(&qaddr[slot], (int32_t)na[k]); }
-            else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
-        }
-        base += __popcll(mk[k]);
-    }
-#endif
-}
-
-/* ================================================================== wave A (raise_outside) */
-/* wave_core.cuh:103-224, two phases per BFS level.  Per entry e: rec0[e] = packed new coc (or
- * GIE_KEY_EMPTY = not lowered), rec1[e] = pair to store (or GIE_NOPROP), rec2[e] = the entry's closest
- * obstacle as a parent id, rec3[e] = new dist | raise-direction mask << 24.  Every phase issues the
- * reads that do not depend on each other as one batch (own record + neighbour lookups, then the
- * neighbours' records, then the local types those point at). */
-GIE_DEV void gie_wave_a_phase1(const gie_ctx &c, int cur, int e)
-{
-    int g[3];
-    gie_unpack_crd(gie_ld(&c.qa[cur][e]), &g[0], &g[1], &g[2]);
-    const int a = gie_ld(&c.qa_a[cur][e]);
-    gie_st(&c.rec0[e], (uint64_t)GIE_KEY_EMPTY); gie_st(&c.rec1[e], (uint64_t)GIE_NOPROP); gie_st(&c.rec3[e], (int32_t)0);
-    if (a < 0) return;
-    const uint64_t lcoc = gie_ld(&c.g_coc[a]);
-    int cd = gie_gdist(c, lcoc, g[0], g[1], g[2]);
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    unsigned want = 0;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++)       /* neighbours outside the volume — with tiling: outside the whole volume (see gie_frontier_outside) */
-        if (!gie_in_whole(c, g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2])
-            && !gie_in_loc(c, g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2])) want |= 1u << k;
-    int na[6];
-    gie_nbr_addr6(c, g, a, want, na);
-    if (cd > c.cutoff_sq) return;
-    int8_t nty[6];
-    uint64_t ncc[6];
-    int nd[6], nwl[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {      /* straight-line code: a neighbour that does not exist re-reads the entry's own record (ignored below) */
-        const int ak = na[k] >= 0 ? na[k] : a;
-        nty[k] = gie_ld(&c.g_type[ak]); ncc[k] = gie_ld(&c.g_coc[ak]); nwl[k] = gie_ld(&c.g_wl[ak]);
-        nd[k] = gie_gdist(c, ncc[k], g[0] + dx[k], g[1] + dy[k], g[2] + dz[k]);
-    }
-    int lc[3];
-    gie_unpack_crd(lcoc, &lc[0], &lc[1], &lc[2]);
-    const uint64_t lpar = gie_pack_wr(lc[0] - c.upvt[0], lc[1] - c.upvt[1], lc[2] - c.upvt[2]);
-    unsigned ok = 0, vanished = 0;
-    int nc[6][3], lidk[6];
-    int8_t lt[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        nc[k][0] = nc[k][1] = nc[k][2] = 0; lidk[k] = 0;
-        if (na[k] < 0 || nty[k] == GIE_VOX_UNKNOWN) continue;
-        gie_unpack_crd(ncc[k], &nc[k][0], &nc[k][1], &nc[k][2]);
-        if (gie_invalid_coc(nc[k][0], nc[k][1], nc[k][2]) || gie_invalid_dist(c, nd[k])) continue;
-        if (nwl[k] == -c.map_ct) continue;
-        if (nc[k][0] == lc[0] && nc[k][1] == lc[1] && nc[k][2] == lc[2]) continue;
-        ok |= 1u << k;
-        /* `_aux[coc] != 0` (wave_core.cuh:177-178): the batch distance of a voxel is 0 iff it is
-         * OCCUPIED, and Mark never turns a non-zero value into 0 */
-        const int nl[3] = { nc[k][0] - c.pvt[0], nc[k][1] - c.pvt[1], nc[k][2] - c.pvt[2] };
-        if (gie_in_loc(c, nl[0], nl[1], nl[2])) { lidk[k] = gie_lid(c, nl[0], nl[1], nl[2]); vanished |= 1u << k; }
-    }
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) lt[k] = c.glb_type[lidk[k]];         /* one batch (voxel 0 stands in where there is nothing to look up) */
-    int mask = 0, lowered = 0;
-    uint64_t newcoc = GIE_KEY_EMPTY, newpair = GIE_NOPROP;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        if (!((ok >> k) & 1u)) continue;
-        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
-        if (((vanished >> k) & 1u) && lt[k] != GIE_VOX_OCCUPIED) {
-            const int d = gie_d2(lc[0], lc[1], lc[2], ng[0], ng[1], ng[2]);
-            gie_amin64(&c.g_prop[na[k]], gie_pair_make(d, lpar));
-            mask |= 1 << k;
-        } else {
-            const int d = gie_d2(nc[k][0], nc[k][1], nc[k][2], g[0], g[1], g[2]);
-            if (cd > d) {
-                cd = d; lowered = 1;
-                newcoc = gie_pack_crd(nc[k][0], nc[k][1], nc[k][2]);
-                const int nw[3] = { nc[k][0] - c.upvt[0], nc[k][1] - c.upvt[1], nc[k][2] - c.upvt[2] };
-                if (gie_in_wr(c, nw[0], nw[1], nw[2])) newpair = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
-            }
-        }
-    }
-    gie_st(&c.rec0[e], (uint64_t)(lowered ? newcoc : GIE_KEY_EMPTY));
-    gie_st(&c.rec1[e], newpair);
-    gie_st(&c.rec2[e], lpar);
-    gie_st(&c.rec3[e], (int32_t)((lowered ? cd : 0) | (mask << 24)));
-}
-
-GIE_DEV void gie_wave_a_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int e)
-{
-    const uint64_t gk = gie_ld(&c.qa[cur][e]);
-    int g[3];
-    gie_unpack_crd(gk, &g[0], &g[1], &g[2]);
-    const int a = gie_ld(&c.qa_a[cur][e]);
-    const int32_t r3 = gie_ld(&c.rec3[e]);
-    const uint64_t r0 = gie_ld(&c.rec0[e]), r1 = gie_ld(&c.rec1[e]);
-    const unsigned mask = (unsigned)(r3 >> 24) & 63u;
-    if (r0 != GIE_KEY_EMPTY) {
-        gie_st(&c.g_coc[a], r0);                            /* (its distance to this voxel is r3's low bits) */
-        gie_touch(c, a);
-        gie_st(&c.g_wl[a], (int32_t)1);
-        if (r1 != GIE_NOPROP) gie_st(&c.g_pair[a], r1);
-        gie_push64a_wave(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, r1 != GIE_NOPROP, gk, a);
-    }
-    if (!mask) return;
-    const uint64_t lpar = gie_ld(&c.rec2[e]);
-    int lw[3];
-    gie_unpack_wr(lpar, &lw[0], &lw[1], &lw[2]);
-    const int lc[3] = { lw[0] + c.upvt[0], lw[1] + c.upvt[1], lw[2] + c.upvt[2] };
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    int na[6];
-    gie_nbr_addr6(c, g, a, mask, na);
-    uint64_t key[6], old[6];
-    int d[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {                          /* all compare-and-swaps of the entry in flight together */
-        key[k] = 0; old[k] = GIE_NOPROP; d[k] = 0;
-        if (!((mask >> k) & 1u) || na[k] < 0) continue;   /* (na < 0 cannot happen while phase 1's lookups hold; never index a plane with it) */
-        d[k] = gie_d2(lc[0], lc[1], lc[2], g[0] + dx[k], g[1] + dy[k], g[2] + dz[k]);
-        key[k] = gie_pair_make(d[k], lpar);
-        old[k] = gie_acas64(&c.g_prop[na[k]], key[k], GIE_NOPROP);
-    }
-    unsigned win = 0;
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        if (!((mask >> k) & 1u) || na[k] < 0 || old[k] != key[k]) continue;       /* not the (unique) winner */
-        win |= 1u << k;
-        gie_st(&c.g_coc[na[k]], gie_pack_crd(lc[0], lc[1], lc[2]));
-        gie_touch(c, na[k]);
-        gie_st(&c.g_wl[na[k]], (int32_t)-c.map_ct);
-        gie_st(&c.g_pair[na[k]], key[k]);
-    }
-    gie_push_nbrs(c, c.qa[cur ^ 1], c.qa_a[cur ^ 1], next_cnt, g, win, na);
-}
-
+/* ================================================================== waves A / B */
+/* raise_outside / lower_outside (wave_core.cuh:103-350) run in block rounds out of LDS: gie_wave_a_block / gie_wave_b_block in
+ * gie_kernels.hip.h (the emulation states the same schedule sequentially: tests/emu/gie_emu.cpp be_wave_a / be_wave_b). */
 /* batch EDT distance of ONE voxel straight from the pass-X planes: min over the planes with
  * obstacles of (in-plane distance)² + (z - plane)².  A few dozen reads — for rare lookups only. */
 GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
@@ -1012,167 +806,6 @@ GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
     }
     return best;
 #endif
-}
-
-/* ================================================================== wave B (lower_outside) */
-/* wave_core.cuh:229-350, three phases per level. rec0[e] = snapshot parent (GIE_NOPROP =
- * inactive), rec1[e] = packed committed coc, rec3[e] = inside-direction mask.  The records come in two sets (rp = level
- * parity): phase 3 of a level and phase 1 of the next touch different data apart from them, so the kernel runs the two as
- * one barrier-separated phase. */
-/* `first`: the entries are the seeds of the wave (obtainFrontiers' lower-out voxels + the voxels wave A lowered).  The
- * frontier is a SET (DESIGN.md "Canonical wave schedule"): a voxel that was appended twice — seeded, then raised and lowered
- * again by wave A — is expanded once; the second entry finds the frame-unique mark the first one left and drops out. */
-#define GIE_GWL_INB(c) ((int32_t)((c).stamp_base + 1u))
-GIE_DEV void gie_wave_b_phase1(const gie_ctx &c, int cur, int rp, int e, int first)
-{
-    uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
-    int32_t *const rec3 = rp ? c.rec3b : c.rec3;
-    const int a = gie_ld(&c.qb_a[cur][e]);
-    gie_st(&rec0[e], (uint64_t)GIE_NOPROP); gie_st(&rec3[e], (int32_t)0);
-    if (a < 0) return;
-    if (first && gie_axchg32(&c.g_wl[a], GIE_GWL_INB(c)) == GIE_GWL_INB(c)) { gie_aadd32(&c.cnt[GIE_CNT_SPARE0], 1); return; }
-    const uint64_t pr = gie_aand64(&c.g_pair[a], ~GIE_PAIR_NEW) & ~GIE_PAIR_NEW;
-    {   /* the cut-off looks at the distance stored BEFORE the pair is committed (wave_core.cuh:262-266) */
-        int g[3];
-        gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
-        if (gie_gdist(c, gie_ld(&c.g_coc[a]), g[0], g[1], g[2]) > c.cutoff_sq) return;
-    }
-    int cw[3];
-    gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
-    const uint64_t coc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
-    gie_st(&c.g_coc[a], coc);                               /* (its distance to this voxel is the pair's) */
-    gie_touch(c, a);
-    gie_st(&rec0[e], (uint64_t)gie_pair_par(pr));
-    gie_st(&rec1[e], coc);
-}
-
-GIE_DEV void gie_wave_b_phase2(const gie_ctx &c, int cur, int32_t *next_cnt, int level, int rp, int e)
-{
-    const uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
-    int32_t *const rec3 = rp ? c.rec3b : c.rec3;
-    const uint64_t par = gie_ld(&rec0[e]);               /* (phase 1 of this entry may have run on another workgroup: the tail of a wave goes to workgroup 0) */
-    if (par == GIE_NOPROP) return;
-    int g[3], cc[3];
-    gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
-    const int a = gie_ld(&c.qb_a[cur][e]);
-    gie_unpack_crd(gie_ld(&rec1[e]), &cc[0], &cc[1], &cc[2]);
-    const int32_t stamp = (int32_t)(c.stamp_base + 8u + (uint32_t)(level % 4000));
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    unsigned outm = 0, inm = 0;
-    int cand[6], nid[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
-        const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
-        cand[k] = gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]);
-        nid[k] = 0;
-        if (gie_in_loc(c, nb[0], nb[1], nb[2])) { inm |= 1u << k; nid[k] = gie_lid(c, nb[0], nb[1], nb[2]); }
-        else if (!gie_in_whole(c, nb[0], nb[1], nb[2])) outm |= 1u << k;      /* (tiling: not into another tile's territory) */
-    }
-    int na[6];
-    gie_nbr_addr6(c, g, a, outm, na);
-    /* one batch: the records of the outside neighbours, type + pair of the inside ones */
-    int8_t nty[6];
-    uint64_t ncc[6], npr[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {      /* straight-line code: both records of every direction, the one that does not apply read at a stand-in address */
-        const bool out = ((outm >> k) & 1u) && na[k] >= 0;
-        const int ak = out ? na[k] : a;
-        const int8_t oty = gie_ld(&c.g_type[ak]);
-        const uint64_t occ = gie_ld(&c.g_coc[ak]), opr = gie_ld(&c.g_pair[ak]);
-        const int8_t ity = c.glb_type[nid[k]];
-        const uint64_t ipr = gie_ld(&c.pair[nid[k]]);
-        const bool in = (inm >> k) & 1u;
-        nty[k] = out ? oty : (in ? ity : (int8_t)GIE_VOX_UNKNOWN);
-        ncc[k] = out ? occ : 0ull;
-        npr[k] = out ? opr : (in ? ipr : 0ull);
-    }
-    unsigned tryo = 0;
-    uint64_t key[6], old[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        key[k] = 0; old[k] = 0;
-        if (!((outm >> k) & 1u) || na[k] < 0 || nty[k] == GIE_VOX_UNKNOWN) continue;
-        int nc[3];
-        gie_unpack_crd(ncc[k], &nc[0], &nc[1], &nc[2]);
-        if (gie_invalid_coc(nc[0], nc[1], nc[2])) continue;
-        if (cand[k] >= c.empty_value) continue;
-        key[k] = gie_pair_make(cand[k], par) | GIE_PAIR_NEW;
-        if (npr[k] <= key[k]) continue;                   /* values only decrease: the atomic could not win */
-        tryo |= 1u << k;
-    }
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) if ((tryo >> k) & 1u) old[k] = gie_amin64(&c.g_pair[na[k]], key[k]);
-    unsigned imp = 0, pm = 0;
-    int32_t ow[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) { ow[k] = stamp; if (((tryo >> k) & 1u) && gie_pair_dist(old[k]) > cand[k]) imp |= 1u << k; }
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) if ((imp >> k) & 1u) ow[k] = gie_axchg32(&c.g_wl[na[k]], stamp);
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) if (((imp >> k) & 1u) && ow[k] != stamp) pm |= 1u << k;
-    gie_push_nbrs(c, c.qb[cur ^ 1], c.qb_a[cur ^ 1], next_cnt, g, pm, na);
-    int mask = 0;
-    {   /* tiling: an obstacle inside the whole volume but not in this tile is its owner's to vouch for (gie_frontier_outside) */
-        const int cl3[3] = { cc[0] - c.pvt[0], cc[1] - c.pvt[1], cc[2] - c.pvt[2] };
-        if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) inm = 0;
-    }
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        if (!((inm >> k) & 1u)) continue;
-        const int nb[3] = { g[0] + dx[k] - c.pvt[0], g[1] + dy[k] - c.pvt[1], g[2] + dz[k] - c.pvt[2] };
-        /* `_aux[n]` (wave_core.cuh:334): for an observed voxel Mark left it equal to the pair's
-         * distance (nothing writes `pair` between Mark and wave B); for an unknown voxel it is
-         * still the batch distance */
-        const int ref = (nty[k] != GIE_VOX_UNKNOWN) ? gie_pair_dist(npr[k]) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
-        if (ref > cand[k]) {
-            gie_amin64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], gie_pair_make(cand[k], par));
-            mask |= 1 << k;
-        }
-    }
-    gie_st(&rec3[e], (int32_t)mask);
-}
-
-GIE_DEV void gie_wave_b_phase3(const gie_ctx &c, int cur, int rp, int e)
-{
-    const uint64_t *const rec0 = rp ? c.rec0b : c.rec0, *const rec1 = rp ? c.rec1b : c.rec1;
-    const int32_t *const rec3 = rp ? c.rec3b : c.rec3;
-    const uint64_t par = gie_ld(&rec0[e]);
-    if (par == GIE_NOPROP) return;
-    const unsigned mask = (unsigned)gie_ld(&rec3[e]);
-    if (!mask) return;
-    int g[3], cc[3];
-    gie_unpack_crd(gie_ld(&c.qb[cur][e]), &g[0], &g[1], &g[2]);
-    gie_unpack_crd(gie_ld(&rec1[e]), &cc[0], &cc[1], &cc[2]);
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    uint64_t key[6], old[6];
-    int nid[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        key[k] = 0; old[k] = GIE_NOPROP; nid[k] = 0;
-        if (!((mask >> k) & 1u)) continue;
-        const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
-        const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
-        key[k] = gie_pair_make(gie_d2(cc[0], cc[1], cc[2], ng[0], ng[1], ng[2]), par);
-        nid[k] = gie_lid(c, nb[0], nb[1], nb[2]);
-        old[k] = gie_acas64(&c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])], key[k], GIE_NOPROP);
-    }
-    unsigned win = 0;
-    uint32_t w[6];
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        w[k] = 0;
-        if (!((mask >> k) & 1u) || old[k] != key[k]) continue;
-        win |= 1u << k;
-        gie_st(&c.cand[1][nid[k]], key[k]);                /* the reference's plain store (wave_core.cuh:338-341), applied when wave C starts */
-        w[k] = gie_ld(&c.wl[nid[k]]);
-    }
-    GIE_UNROLL6
-    for (int k = 0; k < 6; k++) {
-        const bool push = ((win >> k) & 1u) && !(w[k] == GIE_WL_SEED(c) || w[k] == GIE_WL_PUSHED(c));
-        if (push) gie_st(&c.wl[nid[k]], GIE_WL_PUSHED(c)); /* this thread is the only writer of nid in this phase */
-        gie_push32_wave(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, push, nid[k]);
-    }
 }
 
 /* UpdateHashBatch for one voxel whose final pair is `pr` (type FNT is handled by the callers).

@@ -151,24 +151,19 @@ typedef struct gie_ctx {
     const float *box_ll, *box_ur;
     const uint8_t *box_act;
     /* ---- frontier queues + counters */
-    uint64_t *qa[2], *qb[2];
-    int32_t *qa_a[2], *qb_a[2]; /* address (slot * 512 + in-block index) of every entry of qa / qb */
+    uint64_t *qa, *qb;      /* the seeds of waves A / B: packed global coordinates ... */
+    int32_t *qa_a, *qb_a;   /* ... and addresses (slot * 512 + in-block index) */
     int32_t *qc[2];
     int qcap_ab, qcap_c;
     int32_t *cnt;           /* device counters, see GIE_CNT_* */
     int32_t *lvl_next, *lvl_vis; /* wave C: active tiles / visits per round (GIE_MAX_LEVELS words each) */
     int32_t *wc_list[2];         /* wave C: the active tiles of a round (parity of the round) */
     int32_t *wc_flag[2];         /*         ... and their membership flags, one word per tile */
-    /* per-entry scratch of the wave phases */
-    uint64_t *rec0, *rec1, *rec2;
-    int32_t *rec3;
-    uint64_t *rec0b, *rec1b;     /* second set of wave B's records (level parity) */
-    int32_t *rec3b;
 } gie_ctx;
 
 enum {
     GIE_CNT_A = 0, GIE_CNT_B, GIE_CNT_C,        /* seed counts from obtainFrontiers */
-    GIE_CNT_NEXT, GIE_CNT_NEXT1, GIE_CNT_NEXT2,  /* next-level counts inside a wave (rotating) */
+    GIE_CNT_FREE3, GIE_CNT_FREE4, GIE_CNT_FREE5, /* (unused since the waves run in block / tile rounds) */
     GIE_CNT_LV0, GIE_CNT_LV1, GIE_CNT_LV2,      /* wave C: entries expanded in a level (rotating) */
     GIE_CNT_ERR,                                /* sticky error flags */
     GIE_CNT_NEWBLK,                             /* blocks allocated this frame */
@@ -176,15 +171,15 @@ enum {
     GIE_CNT_LVL_A, GIE_CNT_LVL_B, GIE_CNT_LVL_C,
     GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
-    GIE_CNT_SPARE0,                             /* wave B: entries that were in its seed list twice */
-    GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (n, cur, level) published after a solo episode */
+    GIE_CNT_SPARE0,                             /* (unused) */
+    GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (unused) */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
-    GIE_CNT_BAR_B = 34,                         /* barrier word of wave A's workgroups (first word of the second cleared range) */
+    GIE_CNT_BAR_B = 34,                         /* (unused; first word of the second cleared range) */
     GIE_CNT_BAR_C = 35,                         /* grid-barrier word of the waves launch */
     GIE_CNT_NEWLIST = 36,                       /* entries in the list of blocks to initialise (blk_new) */
     GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
-    GIE_CNT_BAR_AB2 = 39,                       /* barrier word of wave B's workgroups */
+    GIE_CNT_BAR_AB2 = 39,                       /* (unused) */
     GIE_CNT_TL_FUSE = 40,                       /* entries in the fuse tile list (shares the tl_front buffer: consumed before Mark) */
     GIE_CNT_BARFAIL = 42,                       /* a grid barrier of THIS map update timed out (the sticky GIE_ERRF_BARRIER is the host's copy) */
     GIE_CNT_TSKIP = 41,                         /* tiles whose stored records Mark does not read (counted by the test-only emulation) */

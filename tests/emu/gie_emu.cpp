@@ -184,9 +184,9 @@ static void be_wave_a(be_state *, const gie_ctx &c)
     auto colour = [](const int *g) { return ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1; };
     std::vector<ent> pend[2];
     for (int e = 0; e < n0; e++) {
-        ent t; t.a = c.qa_a[0][e];
+        ent t; t.a = c.qa_a[e];
         if (t.a < 0) continue;
-        gie_unpack_crd(c.qa[0][e], &t.g[0], &t.g[1], &t.g[2]);
+        gie_unpack_crd(c.qa[e], &t.g[0], &t.g[1], &t.g[2]);
         pend[colour(t.g)].push_back(t);
     }
     for (int h = 0; !pend[0].empty() || !pend[1].empty(); h++) {
@@ -251,7 +251,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
                     c.g_coc[a] = lw[e].coc; gie_touch(c, a); c.g_wl[a] = 1;
                     if (lw[e].pair != GIE_NOPROP) {
                         c.g_pair[a] = lw[e].pair;
-                        gie_push64a(c, c.qb[0], c.qb_a[0], &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(L[e].g[0], L[e].g[1], L[e].g[2]), a);
+                        gie_push64a(c, c.qb, c.qb_a, &c.cnt[GIE_CNT_B], c.qcap_ab, gie_pack_crd(L[e].g[0], L[e].g[1], L[e].g[2]), a);
                     }
                 }
                 std::vector<ent> Ln;
@@ -290,10 +290,10 @@ static void be_wave_b(be_state *, const gie_ctx &c)
     {
         std::vector<int> seen;
         for (int e = 0; e < n0; e++) {
-            const int a = c.qb_a[0][e];
+            const int a = c.qb_a[e];
             if (a < 0 || std::find(seen.begin(), seen.end(), a) != seen.end()) continue;      /* the frontier is a set */
             seen.push_back(a);
-            ent t; t.a = a; gie_unpack_crd(c.qb[0][e], &t.g[0], &t.g[1], &t.g[2]);
+            ent t; t.a = a; gie_unpack_crd(c.qb[e], &t.g[0], &t.g[1], &t.g[2]);
             cur.push_back(t);
         }
     }

@@ -339,7 +339,7 @@ class _RankView:
     class ReduceOp:
         SUM = "sum"
 
-    def all_reduce(self, t, op=None):
+    def all_reduce(self, t, op=None, group=None):
         """sum of a one-element tensor over the two ranks (host-synchronous, like the caller's use)"""
         n = self.seq[("ar",)] = self.seq.get(("ar",), 0) + 1
         with self.s.cv:
@@ -351,7 +351,7 @@ class _RankView:
         self.s, self.rank, self.seq = shared, rank, {}
 
     class P2POp:
-        def __init__(self, op, tensor, peer):
+        def __init__(self, op, tensor, peer, group=None):
             self.op, self.tensor, self.peer = op, tensor, peer
 
     def batch_isend_irecv(self, ops):

@@ -20,8 +20,8 @@ feed = bench.make_feed(wl, torch, scenes, dev, 0.05, size, (0, 0, 0), 64)
 NF = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 verbose = len(sys.argv) > 4
 feed.prepare(0, NF)
-names = {0: "start", 1: "A level start", 2: "A phase 1 + barrier", 3: "A phase 2 + barrier", 4: "B start", 5: "B phase 1 (first) + barrier", 6: "B phase 2 + barrier",
-         7: "B phase 3 + next phase 1 + barrier", 8: "A done + grid barrier", 9: "B done + grid barrier", 10: "C done", 11: "C round (n = active tiles) + barrier",
+names = {0: "start", 1: "A seeds -> blocks + barrier", 3: "A round (n = active blocks) + barrier", 4: "B seeds -> blocks + barrier", 6: "B round (n = active blocks) + barrier",
+         8: "A done + grid barrier", 9: "B stores into the volume + grid barrier", 10: "C done", 11: "C round (n = active tiles) + barrier",
          12: "C seeds -> tiles + barrier"}
 for i in range(NF):
     feed.step_input(m, i); m.step(); m.sync()
