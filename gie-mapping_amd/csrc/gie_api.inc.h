@@ -85,6 +85,7 @@ static void gie_scratch_trim(gie_mapper *m)
 
 static int gie_pow2_ge(long long v) { int p = 1; while ((long long)p < v) p <<= 1; return p; }
 
+#define GIE_MAX_POOL_BLOCKS 4000000            /* slot * 512 must stay below 2^31 */
 extern "C" gie_mapper *gie_create(const gie_config *cfg)
 {
     if (!cfg || cfg->voxel_width <= 0.f || cfg->local_size[0] < 1 || cfg->local_size[1] < 1 || cfg->local_size[2] < 1) {
@@ -95,6 +96,11 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     const int L = X > Z ? X : Z;
     if (X > 1024 || Y > 1024 || Z > 1024 || M + 1 + (long long)L * L >= (1ll << 22) || (long long)X * Y * Z > 0x7fffffffll) {
         gie_set_err("gie_create: local volume too large (side <= 1024 and X²+Y²+Z²+max(X,Z)² < 2^22)"); return nullptr;
+    }
+    if (cfg->max_blocks > GIE_MAX_POOL_BLOCKS) {         /* a voxel address is slot * 512 + in-block index in 32 bits */
+        gie_set_err("gie_create: max_blocks above 4 000 000 (2 G voxels, 61 GB of pool) is not supported: voxel addresses are 32 bits; "
+                    "bound the map with retain_radius_blocks instead");
+        return nullptr;
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
@@ -155,7 +161,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.blk_new = gie_dalloc<int32_t>(m, (size_t)m->ncell);
     m->d_rank = gie_dalloc<int32_t>(m, (size_t)m->ncell);
     long long mb = cfg->max_blocks > 0 ? cfg->max_blocks : 3ll * m->ncell + 4096;
-    if (mb > 4000000) mb = 4000000;            /* slot*512 must stay below 2^31 */
+    if (mb > GIE_MAX_POOL_BLOCKS) mb = GIE_MAX_POOL_BLOCKS;   /* (the default of a very large volume; an explicit request above the limit was refused) */
     c.max_blocks = (int)mb;
     const int hcap = gie_pow2_ge(4 * mb);              /* load factor <= 1/4: probe chains stay short (16 bytes per slot) */
     c.hmask = (uint32_t)(hcap - 1);
