@@ -978,9 +978,9 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     /* persistent workgroup: tiles t, t+G, t+2G, …; the NEXT tile is fetched into registers while
      * the envelopes of the current one are computed out of LDS */
     uint32_t pre[NLD];
-    unsigned zmask = 0;                                   /* this thread's z rows that lie in a plane with obstacles */
+    unsigned zmask = 0, zin = 0;                          /* this thread's z rows that lie in a plane with obstacles / inside the volume */
 #pragma unroll
-    for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && c.zocc[z]) zmask |= 1u << j; }
+    for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z) { zin |= 1u << j; if (c.zocc[z]) zmask |= 1u << j; } }
     /* the real sites of EVERY column are the planes with obstacles (a plane that holds one gives
      * every voxel of the plane a closest obstacle): one list for the whole launch (k_edt_prep) */
     const int K = *c.zcount;
@@ -995,22 +995,44 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     int it = 0;
 #define GIE_ZTILE(i) ((((i) >> 1) * (int)gridDim.x + (int)blockIdx.x) * 2 + ((i) & 1))
     int t = GIE_ZTILE(0);
-    const size_t zstride = plane * ZSTEP;                 /* elements between a thread's consecutive rows */
+    /* rows are addressed as buffer offsets: a 32-bit byte offset per thread and tile + a scalar row stride (N * 4 bytes < 2^32 for
+     * every volume gie_create accepts).  With 64-bit pointers the compiler kept sixteen row addresses per thread alive across the
+     * column work and spilled them — and a reload from scratch waits for ALL of the wave's outstanding memory operations
+     * (vmcnt counts in order): the prefetch below was waited for at once, the write-out went store by store. */
+    /* A row a thread has no business with gets an offset beyond the buffer: the hardware's range check drops the access (a load
+     * returns 0 — such rows are never staged — a store goes nowhere), so the sixteen loads and the sixteen stores of a thread are
+     * straight-line code, and the compiler can wait for "all but the last sixteen" — the loads — instead of for everything. */
+#define GIE_BUF_OOB 0xfffffff0u
+    /* every way into the head of the tile loop reads "sixteen loads, then sixteen stores" (dropped ones where there is nothing to
+     * write), so that the wait for the loads there is "all but the last sixteen" on every path */
+#define GIE_Z_DROPPED_STORES() do { _Pragma("unroll") for (int j_ = 0; j_ < NLD; j_++) __builtin_amdgcn_raw_buffer_store_b32(0u, rs_out, GIE_BUF_OOB, 0, 0); } while (0)
+    const unsigned nbytes = (unsigned)((size_t)X * Y * Z * 4u);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(c.cxy2), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(c.bcoc, 0, nbytes, 0x00020000);
+    const unsigned zstride_b = (unsigned)(plane * ZSTEP * 4u);   /* bytes between a thread's consecutive rows */
+    const unsigned tzoff_b = (unsigned)((size_t)tz * plane * 4u);
     /* reader masks of the two 8-wide tile columns a workgroup tile spans (workgroup-uniform) */
     uint64_t nd0, nd1, ndn0 = 0, ndn1 = 0;               /* bit tz: tile (tx, ty, tz) has a reader */
+    /* (read through the scalar cache: a vector load here would sit behind the previous tile's stores in the wave's in-order memory
+     * counter, and waiting for it would wait for them) */
 #define GIE_LOAD_NEED(tt, o0, o1) do { \
         const int txc_ = (((tt) % ntiles_x) * TX) >> 3, tyc_ = ((tt) / ntiles_x) >> 3; \
         const uint64_t *p_ = c.zneed + ((size_t)tyc_ * c.tfd[0] + txc_); \
-        o0 = full ? ~0ull : p_[0]; \
-        o1 = full ? ~0ull : ((txc_ + 1 < c.tfd[0]) ? p_[1] : 0ull); } while (0)
+        o0 = ~0ull; o1 = ~0ull; \
+        if (!full) { \
+            uint64_t a_, b_ = 0ull; \
+            asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_) : "s"(p_) : "memory"); \
+            if (txc_ + 1 < c.tfd[0]) asm volatile("s_load_dwordx2 %0, %1, 0x8\n\ts_waitcnt lgkmcnt(0)" : "=s"(b_) : "s"(p_) : "memory"); \
+            o0 = a_; o1 = b_; } } while (0)
     if (t < ntiles) {
         GIE_LOAD_NEED(t, ndn0, ndn1);
         const int x = (t % ntiles_x) * TX + tx, y = t / ntiles_x;
-        const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)y * X + x;   /* one 64-bit product per tile, then adds */
+        const unsigned voff = tzoff_b + (unsigned)(y * X + x) * 4u;
         if ((ndn0 | ndn1) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && x < X) ? *src : 0xffffffffu; src += zstride; }
+            for (int j = 0; j < NLD; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, (((zmask >> j) & 1u) && x < X) ? voff : GIE_BUF_OOB, j * zstride_b, 0);
         }
+        GIE_Z_DROPPED_STORES();
     }
 #if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 4
 #define GIE_Z_NOMEM 1
@@ -1030,17 +1052,16 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             GIE_LOAD_NEED(tn, ndn0, ndn1);
             if ((ndn0 | ndn1) != 0ull) {
                 const int xn = (tn % ntiles_x) * TX + tx, yn = tn / ntiles_x;
-                const uint32_t *src = c.cxy2 + (size_t)tz * plane + (size_t)yn * X + xn;
+                const unsigned voff = tzoff_b + (unsigned)(yn * X + xn) * 4u;
 #if !defined(GIE_Z_NOMEM)
 #pragma unroll
-                for (int j = 0; j < NLD; j++) { pre[j] = (((zmask >> j) & 1u) && xn < X) ? *src : 0xffffffffu; src += zstride; }
+                for (int j = 0; j < NLD; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, (((zmask >> j) & 1u) && xn < X) ? voff : GIE_BUF_OOB, j * zstride_b, 0);
 #else
-#pragma unroll
-                for (int j = 0; j < NLD; j++) pre[j] = (pre[j] * 1664525u + 1013904223u) & 0x01ff01ffu;      /* measurement only: no loads */
+                asm volatile("" ::: "memory");                   /* measurement only: no loads, the first tile's values again */
 #endif
             }
         }
-        if (!work) continue;                              /* nobody reads this tile: nothing loaded, nothing stored */
+        if (!work) { GIE_Z_DROPPED_STORES(); continue; } /* nobody reads this tile: nothing loaded, nothing stored */
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             const int col = wave + 8 * half;
@@ -1140,13 +1161,35 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
         __syncthreads();
         {
             const int x = x0 + tx;
-            if (x < X) {
-                uint32_t *dst = c.bcoc + (size_t)tz * plane + (size_t)y * X + x;
+            {
+                const unsigned voff = tzoff_b + (unsigned)(y * X + x) * 4u;
+                /* which of this thread's rows have a reader: one mask up front, then the row's LDS reads and stores go out back to
+                 * back (with the 64-bit reader masks looked at inside the loop the compiler spilled them, and every reload waits for
+                 * ALL outstanding memory operations — the stores went out one at a time) */
+                static_assert(ZSTEP % 8 == 0, "a thread's rows are whole z tiles apart");
+                const uint64_t nds = ((tx >> 3) ? nd1 : nd0) >> (tz >> 3);      /* bit (ZSTEP / 8) j: row j's z tile has a reader */
+                unsigned wm = 0;
+#pragma unroll
+                for (int j = 0; j < NLD; j++) if (full || (j * (ZSTEP / 8) < 64 && ((nds >> (j * (ZSTEP / 8))) & 1ull))) wm |= 1u << j;
+                {
+                    unsigned zl = zin;
+                    asm volatile("" : "+v"(zl));          /* (keeps the compiler from hoisting sixteen single-bit masks out of the tile loop — and spilling them) */
+                    wm &= zl;
+                    if (x >= X) wm = 0;                   /* (a column beyond the volume: all of its stores are dropped) */
+                }
 #if defined(GIE_Z_NOMEM)
                 if (tile[tz * TS + tx] == 0x12345678u)          /* measurement only: no write-out */
 #endif
+                {
 #pragma unroll
-                for (int j = 0; j < NLD; j++) { const int z = tz + j * ZSTEP; if (z < Z && (full || ((((tx >> 3) ? nd1 : nd0) >> ((z >> 3) & 63)) & 1ull))) *dst = tile[z * TS + tx]; dst += zstride; }
+                    for (int j0 = 0; j0 < NLD; j0 += 4) {
+                        uint32_t ov[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) ov[u] = (j0 + u < NLD) ? tile[(tz + (j0 + u) * ZSTEP) * TS + tx] : 0u;   /* (a row beyond Z reads the site lists behind the tile: masked below) */
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (j0 + u < NLD) __builtin_amdgcn_raw_buffer_store_b32(ov[u], rs_out, ((wm >> (j0 + u)) & 1u) ? voff : GIE_BUF_OOB, (j0 + u) * zstride_b, 0);
+                    }
+                }
             }
         }
         __syncthreads();                                  /* tile is overwritten by the next trip */
