@@ -2023,6 +2023,19 @@ static __device__ unsigned int g_wprof[256 * 16][16];          /* one row per (w
 #define GIE_WPROF_DUMP() do { } while (0)
 #endif
 
+/* append `value` to a list for every lane with `first`: one counter update per wave (hundreds of single appends to one word
+ * serialise at its L2 slice, ≈ 6 ns each).  Only executing lanes are looked at. */
+__device__ __forceinline__ void gie_list_append_wave(int32_t *list, int32_t *counter, const bool first, const int32_t value)
+{
+    const unsigned long long m = __ballot(first);
+    if (!m) return;
+    const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = gie_aadd32(counter, __popcll(m));
+    base = __shfl(base, leader);
+    if (first) gie_st(&list[base + __popcll(m & ((1ull << lane) - 1ull))], value);
+}
+
 /* ------------------------------------------------------------------ wave A: checkerboard block rounds */
 /* raise_outside (wave_core.cuh:103-224) in the canonical CHECKERBOARD BLOCK-ROUND schedule (oracle/gie_oracle.c wave_a):
  * the hashed 8x8x8 blocks are coloured by the parity of bx + by + bz and the rounds alternate between the colours, so the blocks
@@ -2263,8 +2276,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
         for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
         if (lane < 6 && ((any6 >> lane) & 1u)) {
             const int ns = L.nslot[lane];
-            if (gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0)
-                gie_st(&c.wb_list[(round + 1) & 1][gie_aadd32(&c.lvla_next[round + 1], 1)], (int32_t)ns);
+            gie_list_append_wave(c.wb_list[(round + 1) & 1], &c.lvla_next[round + 1], gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0, ns);
         }
     }
     {
@@ -2289,12 +2301,16 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
         const int a = gie_ld(&c.qa_a[e]);
-        if (a < 0) continue;
         int g[3];
         gie_unpack_crd(gie_ld(&c.qa[e]), &g[0], &g[1], &g[2]);
         const int col = ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1;
-        gie_st(col ? &c.g_prop2[a] : &c.g_prop[a], (uint64_t)0);
-        if (gie_axchg32(&c.wb_flag[col][a >> 9], (int32_t)1) == 0) gie_st(&c.wb_list[col][gie_aadd32(&c.lvla_next[col], 1)], (int32_t)(a >> 9));
+        bool first = false;
+        if (a >= 0) {
+            gie_st(col ? &c.g_prop2[a] : &c.g_prop[a], (uint64_t)0);
+            first = gie_axchg32(&c.wb_flag[col][a >> 9], (int32_t)1) == 0;
+        }
+        gie_list_append_wave(c.wb_list[0], &c.lvla_next[0], first && col == 0, a >> 9);
+        gie_list_append_wave(c.wb_list[1], &c.lvla_next[1], first && col == 1, a >> 9);
     }
     gie_grid_sync(gb, c);
     GIE_TS2(1, n);
@@ -2528,8 +2544,7 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
         for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
         if (lane < 6 && ((any6 >> lane) & 1u)) {
             const int ns = L.nslot[lane];
-            if (gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0)
-                gie_st(&c.wb_list[(round + 1) & 1][gie_aadd32(&c.lvlb_next[round + 1], 1)], (int32_t)ns);
+            gie_list_append_wave(c.wb_list[(round + 1) & 1], &c.lvlb_next[round + 1], gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0, ns);
         }
     }
     /* ---- what the block-run proposes to voxels inside the volume: the face table takes the minimum of the whole wave; whoever
@@ -2596,9 +2611,12 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
      * marks itself twice: the frontier is a set) */
     for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
         const int a = gie_ld(&c.qb_a[e]);
-        if (a < 0) continue;
-        gie_st(&c.g_prop[a], (uint64_t)0);
-        if (gie_axchg32(&c.wb_flag[0][a >> 9], (int32_t)1) == 0) gie_st(&c.wb_list[0][gie_aadd32(&c.lvlb_next[0], 1)], (int32_t)(a >> 9));
+        bool first = false;
+        if (a >= 0) {
+            gie_st(&c.g_prop[a], (uint64_t)0);
+            first = gie_axchg32(&c.wb_flag[0][a >> 9], (int32_t)1) == 0;
+        }
+        gie_list_append_wave(c.wb_list[0], &c.lvlb_next[0], first, a >> 9);
     }
     gie_grid_sync(gb, c);
     GIE_TS2(4, n);
@@ -2806,10 +2824,7 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
             const int dt = (lane == 0) ? -1 : (lane == 1) ? 1 : (lane == 2) ? -c.tfd[0] : (lane == 3) ? c.tfd[0]
                          : (lane == 4) ? -c.tfd[0] * c.tfd[1] : c.tfd[0] * c.tfd[1];
             const int nt = t + dt;
-            if (gie_axchg32(&c.wc_flag[(round + 1) & 1][nt], (int32_t)1) == 0) {
-                const int slot = gie_aadd32(&c.lvl_next[round + 1], 1);
-                gie_st(&c.wc_list[(round + 1) & 1][slot], (int32_t)nt);
-            }
+            gie_list_append_wave(c.wc_list[(round + 1) & 1], &c.lvl_next[round + 1], gie_axchg32(&c.wc_flag[(round + 1) & 1][nt], (int32_t)1) == 0, nt);
         }
     }
     {   /* visits of the tile (one atomic per wave) */
@@ -2837,7 +2852,7 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
         const int id = gie_ld(&c.qc[0][e]);
         const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
         const int t = gie_tile_index(c, x, y, z);
-        if (gie_axchg32(&c.wc_flag[0][t], (int32_t)1) == 0) gie_st(&c.wc_list[0][gie_aadd32(&c.lvl_next[0], 1)], (int32_t)t);
+        gie_list_append_wave(c.wc_list[0], &c.lvl_next[0], gie_axchg32(&c.wc_flag[0][t], (int32_t)1) == 0, t);
     }
     gie_grid_sync(gb, c);
     GIE_TS2(12, n);
