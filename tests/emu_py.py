@@ -18,9 +18,14 @@ def load():
     if _fns is None:
         srcs = [os.path.join(EMU_DIR, "gie_emu.cpp"), os.path.join(EMU_DIR, "gie_emu_ops.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
         newest = max(os.path.getmtime(s) for s in srcs)
-        if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < newest:
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", EMU_SO,
-                                   os.path.join(EMU_DIR, "gie_emu.cpp")])
+        import fcntl
+        with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:       # pytest-xdist workers: one builds, the others wait
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < newest:
+                tmp = EMU_SO + ".%d.tmp" % os.getpid()
+                subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", tmp,
+                                       os.path.join(EMU_DIR, "gie_emu.cpp")])
+                os.replace(tmp, EMU_SO)
         lib = C.CDLL(EMU_SO)
         _fns = _capi.bind(lib, "gie_", {"last_error": (C.c_char_p, []), "sync": (C.c_int, [C.c_void_p])})
     return _fns

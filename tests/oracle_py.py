@@ -20,8 +20,11 @@ def load():
     global _fns, _lib
     if _fns is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("gie_oracle.c", "edt_mt.c")]
-        if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        import fcntl
+        with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:    # pytest-xdist workers: one builds, the others wait
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(s) for s in srcs):
+                subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
         _lib = C.CDLL(ORACLE_SO)
         _fns = _capi.bind(_lib, "go_")
         _lib.go_brute_force_edt.restype = C.c_int
