@@ -320,3 +320,147 @@ def test_depth_ogm_against_float64_restatement_of_the_reference(oracle_lib):
         assert seen[0] > 1000 and seen[1] > 50            # the scenes exercise both labels
     finally:
         o.close()
+
+
+# ------------------------------------------------------------------ ray-casting OGM + fusion: a second statement
+# Written from pntcld_raycast.cu:11-117, ray_cast.h:57-144, local_batch.h:114-126,250-258,303-350 and unify_helper.cuh:34-118 /
+# voxmap_utils.cuh:182-200, not from the oracle: plain Python loops, every float operation an np.float32 operation in the order
+# the reference writes them (no fused multiply-add: DESIGN.md deviation 4).  The pose has no rotation, so the sensor-to-map
+# transform is a single float addition per coordinate and does not go through anybody's SE3 code.
+_F = np.float32
+
+
+def _pos2coord(p, w):
+    return [int(np.floor(_F(_F(p[i]) / w) + _F(0.5))) for i in range(3)]          # floorf(p / w + 0.5f)
+
+
+def _raycast_second_statement(origin, pts, pvt, size, w, min_h, max_h):
+    X, Y, Z = size
+    count = np.zeros((Z, Y, X), np.int32)
+    occ = np.zeros((Z, Y, X), bool)
+    inside = lambda c: 0 <= c[0] < X and 0 <= c[1] < Y and 0 <= c[2] < Z
+    glb = [[_F(_F(p[i]) + _F(origin[i])) for i in range(3)] for p in pts]
+    for g in glb:                                                                   # registerLocObs
+        if g[2] >= min_h and g[2] <= max_h:
+            c = [a - b for a, b in zip(_pos2coord(g, w), pvt)]
+            if inside(c):
+                occ[c[2], c[1], c[0]] = True
+                count[c[2], c[1], c[0]] += 1
+
+    def clear(cg):                                                                  # clearRayLoc on a global coordinate
+        c = [a - b for a, b in zip(cg, pvt)]
+        if inside(c):
+            if occ[c[2], c[1], c[0]]:
+                return False
+            count[c[2], c[1], c[0]] -= 1
+        return True                                                                 # (outside: type UNKNOWN, the add is dropped)
+
+    max_length = _F(_F(_F(0.707) * _F(X)) * w)
+    FLT_MAX = np.finfo(np.float32).max
+    p0 = [_F(v) for v in origin]
+    i0 = _pos2coord(p0, w)
+    for p1 in glb:                                                                  # freeLocObs -> rayCastLoc
+        i1 = _pos2coord(p1, w)
+        clear(i0)
+        if i0 == i1:
+            continue
+        d = [_F(p1[i] - p0[i]) for i in range(3)]
+        ln = _F(np.sqrt(_F(_F(_F(d[0] * d[0]) + _F(d[1] * d[1])) + _F(d[2] * d[2]))))
+        d = [_F(v / ln) for v in d]
+        step, tmax, tdelta = [0] * 3, [FLT_MAX] * 3, [FLT_MAX] * 3
+        cur = list(i0)
+        for i in range(3):
+            step[i] = 1 if d[i] > 0 else (-1 if d[i] < 0 else 0)
+            if step[i]:
+                border = _F(_F(_F(cur[i]) * w) + _F(_F(_F(step[i]) * w) * _F(0.5)))
+                tmax[i] = _F(_F(border - p0[i]) / d[i])
+                tdelta[i] = _F(w / _F(abs(d[i])))
+        while True:
+            if tmax[0] < tmax[1]:
+                dim = 0 if tmax[0] < tmax[2] else 2
+            else:
+                dim = 1 if tmax[1] < tmax[2] else 2
+            cur[dim] += step[dim]
+            tmax[dim] = _F(tmax[dim] + tdelta[dim])
+            if not clear(cur):
+                break
+            if cur == i1:
+                break
+            far = min(min(tmax[0], tmax[1]), tmax[2])
+            if far > max_length or far > ln:
+                break
+    lab = np.where(count > 0, 2, np.where(count < 0, 1, 0)).astype(np.int8)        # getAllocKeys: OCCUPIED / FREE / untouched
+    return count, lab
+
+
+def _fuse_second_statement(occ_val, vox_type, count, thresh):
+    """updateHashOGMWithPntCld on one voxel -> (occ_val, vox_type); types: 0 unknown, 1 free, 2 occupied."""
+    if count == 0:
+        return occ_val, vox_type
+    val, a = (_F(250.0), _F(1.0)) if count > 0 else (_F(0.0), min(_F(1.0), _F(_F(-count) / _F(10.0))))
+    prev = _F(occ_val) if vox_type != 0 else _F(0.0)
+    v = _F(_F(a * val) + _F(_F(_F(1.0) - a) * prev))
+    v = min(v, _F(254.0)); v = max(v, _F(1.0))
+    o = int(v)
+    return o, (2 if o > thresh else 1)
+
+
+def _raycast_scene(k, rng):
+    w = _F(0.1)
+    origin = np.array([0.23 + 0.4 * k, -0.11 + 0.1 * k, 0.31], np.float32)
+    n = 160
+    az, el, r = rng.uniform(-np.pi, np.pi, n), rng.uniform(-0.5, 0.5, n), rng.uniform(0.15, 2.6, n)
+    pts = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], -1).astype(np.float32)
+    pts[:8] = pts[8:16]                                  # several points in one cell: counts above one
+    pts[16] = [0.01, 0.0, 0.0]                           # a point in the sensor's own cell: the ray ends where it starts
+    return w, origin, pts
+
+
+def _check_raycast_and_fusion(make):
+    size = (24, 20, 12)
+    rng = np.random.default_rng(11)
+    cfg = gie.make_config(0.1, size, cutoff_dist=1.0, ogm_min_h=-0.45, ogm_max_h=0.5)
+    m = make(cfg)
+    occ_val = np.zeros(size[::-1], np.int32)
+    vtype = np.zeros(size[::-1], np.int8)
+    known_block = {}
+    try:
+        for k in range(4):
+            w, origin, pts = _raycast_scene(k, rng)
+            m.set_pose(origin, (1.0, 0.0, 0.0, 0.0))
+            pvt = list(m.pivot())
+            assert pvt == [c - s // 2 for c, s in zip(_pos2coord(origin, w), size)]       # calculate_pivot_origin, local_batch.h:129-142
+            m.ogm_pointcloud(pts)
+            got = m.read_ogm()
+            count, lab = _raycast_second_statement(origin, pts, pvt, size, w, _F(-0.45), _F(0.5))
+            assert np.array_equal(got["ray_count"], count), "frame %d: %d cells differ in their ray count" % (k, int((got["ray_count"] != count).sum()))
+            assert np.array_equal(got["inst_type"], lab), "frame %d: labels differ" % k
+            assert (count > 1).any() and (count < -1).any() and (lab == 2).sum() > 50
+            m.fuse()
+            # the world the second statement keeps: voxels by GLOBAL coordinate (the volume moves 4 voxels per frame); a block exists
+            # once a cell of it was touched (getAllocKeys keys every touched cell's block)
+            zz, yy, xx = np.nonzero(count != 0)
+            for x, y, z in zip(xx, yy, zz):
+                g = (x + pvt[0], y + pvt[1], z + pvt[2])
+                o, t = known_block.get(g, (0, 0))
+                known_block[g] = _fuse_second_statement(o, t, int(count[z, y, x]), 180)
+            g = np.array(sorted(known_block), np.int32)
+            gv = m.query_global(g)
+            want = np.array([known_block[tuple(v)] for v in g])
+            assert np.array_equal(gv["occ_val"], want[:, 0]), "frame %d: fused occupancy values differ in %d voxels" % (k, int((gv["occ_val"] != want[:, 0]).sum()))
+            got_t = np.where(gv["vox_type"] == 3, 1, gv["vox_type"])       # a frontier voxel (the merge of an earlier frame) is a free voxel
+            assert np.array_equal(got_t, want[:, 1]), "frame %d: fused types differ" % k
+            m.batch_edt(); m.merge()
+        vals = np.array([v[0] for v in known_block.values()])
+        assert len(np.unique(vals)) > 6                       # the low-pass filter was exercised: values between the extremes
+    finally:
+        m.close()
+
+
+def test_raycast_ogm_and_fusion_against_a_second_statement(oracle_lib):
+    _check_raycast_and_fusion(OracleMapper)
+
+
+@pytest.mark.gpu
+def test_raycast_ogm_and_fusion_against_a_second_statement_hip():
+    _check_raycast_and_fusion(gie.Mapper)
