@@ -2073,16 +2073,12 @@ __device__ __forceinline__ int gie_wa_vanish_lid(const gie_ctx &c, const uint64_
 
 __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &L, const int slot, const int round, const int lane)
 {
-    int bk[3];
-    gie_unpack_crd(gie_ld(&c.g_key[slot]), &bk[0], &bk[1], &bk[2]);
-    const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };
+    /* the chain of dependent round trips of a block-run: [block key + the block's records] -> [the six neighbour lookups + the
+     * vanished-obstacle look-ups of the block's voxels] -> [halo records] -> [their vanished-obstacle look-ups] */
     uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
     const int base = slot * GIE_VBSZ;
-    if (lane < 6) {
-        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
-        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
-    }
     GIE_WPROF_DECL;
+    const uint64_t bkey = gie_ld(&c.g_key[slot]);
     uint64_t cv[8], cc8[8];
     int8_t ty8[8];
     int32_t wl8[8];
@@ -2092,11 +2088,18 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
         cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]) & ~GIE_COC_STALEPAIR; ty8[j] = gie_ld(&c.g_type[a]); wl8[j] = gie_ld(&c.g_wl[a]);
     }
     if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);
+    int bk[3];
+    gie_unpack_crd(bkey, &bk[0], &bk[1], &bk[2]);
+    const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };
     int vl8[8]; int8_t vt8[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) vl8[j] = gie_wa_vanish_lid(c, cc8[j]);
 #pragma unroll
     for (int j = 0; j < 8; j++) vt8[j] = c.glb_type[vl8[j] < 0 ? 0 : vl8[j]];              /* one batch, in flight with the neighbour lookups */
+    if (lane < 6) {
+        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
+        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
+    }
     gie_wave_sync();
     GIE_WPROF_MARK(0);                                                   /* 0: neighbour lookups (own loads in flight) */
     {
@@ -2366,11 +2369,6 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
     const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };              /* global coordinate of the block's first voxel */
     uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
     const int base = slot * GIE_VBSZ;
-    /* ---- the six neighbour blocks (lane k < 6 probes for block k), then one batch of loads */
-    if (lane < 6) {
-        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
-        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
-    }
     GIE_WPROF_DECL;
     uint64_t pv[8], cv[8], cc8[8];
     int8_t ty8[8];
@@ -2386,6 +2384,11 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
         ty8[j] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[a]);
     }
     if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);     /* may be activated again (for round + 2) from now on */
+    /* ---- the six neighbour blocks (lane k < 6 probes for block k) with the block's own records in flight */
+    if (lane < 6) {
+        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
+        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
+    }
     gie_wave_sync();                                                    /* the neighbour slots */
     GIE_WPROF_MARK(8);
     {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the lane's position (a, b) on it -> in-block index of the voxel across the face */

@@ -253,7 +253,8 @@ GIE_HD int gie_hash_find(const gie_ctx &c, int bx, int by, int bz)
     uint32_t h = gie_hash_key(bx, by, bz) & c.hmask;
     for (;;) {
         const uint64_t k = c.hkeys[h];
-        if (k == key) return c.hvals[h];
+        const int v = c.hvals[h];                 /* fetched WITH the key (same index): a hit costs one round trip, not two */
+        if (k == key) return v;
         if (k == GIE_KEY_EMPTY) return -1;
         h = (h + 1) & c.hmask;
     }
