@@ -2,7 +2,7 @@
 thread writes them into the middle row of the edt plane).   python tools/wave_timing.py build | run [workload]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "tools", "ablate", "libgie_hip_wt.so")
+LIB = os.environ.get("GIE_WT_LIB") or os.path.join(ROOT, "tools", "ablate", "libgie_hip_wt.so")
 if sys.argv[1] == "build":
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
