@@ -78,7 +78,11 @@ def pmc(fetch_db, write_db):
         total = (2.0 * fk + wk) * 1024.0
         js[k] = round(total)
         out.append("%-16s %8d %16.0f %18.1f %16.0f %18.1f" % (k, n, fk, 2.0 * fk * 1024 / 1e6, wk, total / 1e6))
-    steps = f.get("edt_pass_y", (0, 0))[1] or w.get("edt_pass_y", (0, 0))[1]        # one launch per map update
+    # one launch of pass Y per map update; the two passes are separate runs of a command whose number of timed regions depends on
+    # the clock, so each pass is normalised by its OWN number of map updates
+    steps_f = f.get("edt_pass_y", (0, 0))[1] or w.get("edt_pass_y", (0, 0))[1]
+    steps_w = w.get("edt_pass_y", (0, 0))[1] or steps_f
+    steps = steps_f
     if steps:
         # bytes per MAP UPDATE under the names gie_profile_read / bench.py use (a stage may be several kernels)
         per_step = defaultdict(float)
@@ -86,7 +90,7 @@ def pmc(fetch_db, write_db):
             if k.startswith("__") or k.startswith("void "):
                 continue
             fk, n = f.get(k, (0.0, 0)); wk, n2 = w.get(k, (0.0, 0))
-            per_step[k.split(".")[0]] += (2.0 * fk * n + wk * n2) * 1024.0 / steps
+            per_step[k.split(".")[0]] += (2.0 * fk * n / steps_f + wk * n2 / steps_w) * 1024.0
         js["_per_step_by_stage"] = {k: round(v) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         js["_map_updates"] = steps
         out.append("")
@@ -97,10 +101,10 @@ def pmc(fetch_db, write_db):
             if k.startswith("__"):
                 continue
             fk, n = f.get(k, (0.0, 0)); wk, n2 = w.get(k, (0.0, 0))
-            tot += (2.0 * fk * n + wk * n2) * 1024.0
-        js["_per_step_total_bytes"] = round(tot / steps)
+            tot += (2.0 * fk * n / steps_f + wk * n2 / steps_w) * 1024.0
+        js["_per_step_total_bytes"] = round(tot)
         out.append("")
-        out.append("all kernels of one map update together: %.1f MB (%d map updates in the run)" % (tot / steps / 1e6, steps))
+        out.append("all kernels of one map update together: %.1f MB (%d / %d map updates in the FETCH / WRITE pass)" % (tot / 1e6, steps_f, steps_w))
     out.append("")
     out.append("per launch = mean over the launches of the run; fetch_corrected = 2 x FETCH_SIZE (gfx950 wide-stream correction,")
     out.append("MI355X_MICROARCH.md §HBM; uncalibrated for scattered 4/8-byte accesses); hbm_bytes = fetch_corrected + WRITE_SIZE.")
