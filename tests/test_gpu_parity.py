@@ -412,6 +412,38 @@ def test_full_size_512_cube_ray_casting(oracle_lib):
 
 
 @pytest.mark.gpu
+def test_full_size_512_cube_c5_headline(oracle_lib):
+    """The bench's headline workload ITSELF at full size: BASELINE config 5's hash world on one 512^3 tile @ 0.05 m, every voxel
+    observed, a quarter of the obstacles toggling, the robot moving 8 voxels per update — three map updates against the oracle,
+    every array bit for bit and every wave statistic (waves A / B / C visit 24 k / 36 k / 20 k voxels per update here; the small
+    scenarios above have a few hundred).  tools/soak_fullsize.py --c5 is the longer form (profiles/r03_soak_fullsize_c5_6_updates.log)."""
+    import bench
+    from gie import scenes
+    size = (512, 512, 512)
+    cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    try:
+        for k in range(3):
+            pos, q = bench.c5_pose(scenes, k, 0.05)
+            lab = np.ascontiguousarray(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, size), size, k, seed=bench.C5["seed"],
+                                                                p_occ=bench.C5["p_occ"], toggle_frac=bench.C5["toggle_frac"]).astype(np.int8))
+            for m in (a, b):
+                m.update(pos, q, "labels", lab)
+            ra, rb = a.read_local(), b.read_local()
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[key], rb[key]), (k, key)
+            assert np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0)
+            sa, sb = a.stats(), b.stats()
+            for key in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_b", "visits_c", "levels_a", "levels_b", "levels_c", "blocks_total"):
+                assert sa[key] == sb[key], (k, key, sa[key], sb[key])
+            if k > 0:
+                assert sb["visits_a"] > 10000 and sb["visits_b"] > 10000 and sb["visits_c"] > 10000
+            del ra, rb, lab
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_partial_pass_z_covers_every_reader(oracle_lib, monkeypatch):
     """The map update only produces the batch EDT where Mark reads it (tiles with a known voxel; wave B
     computes the distance of an unknown face voxel on demand).  Exported without completion, it

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--delta", type=int, default=8)
     ap.add_argument("--ray-sensor", default="vlp16", help="bench.SENSORS preset used for the ray-casting updates (vlp16 | lidar64)")
+    ap.add_argument("--c5", action="store_true", help="BASELINE config 5's hash world under full observation instead of the lidar patterns: "
+                                                      "every update seeds waves A, B and C (24 k / 36 k / 20 k visits at 512^3)")
     args = ap.parse_args()
     import bench
     import gie
@@ -30,19 +32,26 @@ def main():
 
     size = tuple(args.size)
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
-    fr = {"r": bench.make_frames(scenes, 0.05, args.frames, 5, args.ray_sensor),
-          "p": bench.make_frames(scenes, 0.05, args.frames, 5, "vlp16_projective")}
+    fr = {} if args.c5 else {"r": bench.make_frames(scenes, 0.05, args.frames, 5, args.ray_sensor),
+                             "p": bench.make_frames(scenes, 0.05, args.frames, 5, "vlp16_projective")}
     rings, az, phi_min, phi_inc, bins = bench.SENSORS["vlp16_projective"]
     kw = dict(theta_inc=2.0 * np.pi / bins, theta_min=-np.pi, phi_inc=np.radians(phi_inc), phi_min=np.radians(phi_min))
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
     bad = 0
     t_cpu = t_gpu = 0.0
     for k in range(args.frames):
-        s = args.pattern[k % len(args.pattern)]
-        pos, q, data, _ = fr[s][k]
+        s = "c" if args.c5 else args.pattern[k % len(args.pattern)]
+        if s == "c":
+            pos, q = bench.c5_pose(scenes, k, 0.05)
+            data = np.ascontiguousarray(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, size), size, k, seed=bench.C5["seed"], p_occ=bench.C5["p_occ"],
+                                                                 toggle_frac=bench.C5["toggle_frac"]).astype(np.int8))
+        else:
+            pos, q, data, _ = fr[s][k]
         for m in (a, b):
             t0 = time.perf_counter()
-            if s == "r":
+            if s == "c":
+                m.update(pos, q, "labels", data)
+            elif s == "r":
                 m.update(pos, q, "pointcloud", data)
             else:
                 m.update(pos, q, "multiscan", data, **kw)
@@ -55,7 +64,7 @@ def main():
         diff = [key for key in ("type", "dist_sq", "coc") if not np.array_equal(ra[key], rb[key])]
         if not np.allclose(ra["edt"], rb["edt"], rtol=1e-6, atol=0):
             diff.append("edt")
-        diff += [key for key in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_b", "visits_c", "levels_c", "blocks_total")
+        diff += [key for key in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_b", "visits_c", "levels_a", "levels_b", "levels_c", "blocks_total")
                  if sa[key] != sb[key]]
         bad += bool(diff)
         print("update %3d %s known %.4f seeds %d/%d/%d visits %d/%d/%d levels_c %d blocks %d %s" % (
