@@ -383,7 +383,7 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 8, 1);
 
 }
-/* waves A, B and C in one launch; workgroups are co-resident by construction (1024 threads each,
+/* waves A, B and C in one launch; workgroups are co-resident by construction (512 threads and ≈ 151 KB of LDS each:
  * at most one per compute unit).  The frame clear has zeroed the barrier word and the per-level
  * arrays; a second launch inside the same map update (gie_refine) clears them itself. */
 /* The waves kernel synchronises its workgroups with a grid barrier, so ALL of them have to be
