@@ -30,6 +30,7 @@ struct gie_mapper {
     int ncell;
     int has_pose, has_ogm, merge_open;
     int fuse_fresh;                       /* gie_fuse has run and no merge has consumed it yet (a merge needs the frame clear of its own map update) */
+    int pool_base;                        /* GIE_DEBUG_POOL_BASE (tests): the slots below it are never handed out */
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
     int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
     int commit_pvt[3], commit_upvt[3], commit_tb0[3];   /* pivots / block-table origin of that merge */
@@ -85,7 +86,8 @@ static void gie_scratch_trim(gie_mapper *m)
 
 static int gie_pow2_ge(long long v) { int p = 1; while ((long long)p < v) p <<= 1; return p; }
 
-#define GIE_MAX_POOL_BLOCKS 4000000            /* slot * 512 must stay below 2^31 */
+#define GIE_MAX_POOL_BLOCKS (1 << 26)          /* slots are 32-bit, voxel addresses (slot * 512 + index) 64-bit: what bounds a pool is the device's memory
+                                                * (38 B per voxel: 15 M blocks in 288 GB); this is where the hash table's 32-bit index arithmetic ends */
 extern "C" gie_mapper *gie_create(const gie_config *cfg)
 {
     if (!cfg || cfg->voxel_width <= 0.f || cfg->local_size[0] < 1 || cfg->local_size[1] < 1 || cfg->local_size[2] < 1) {
@@ -98,7 +100,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
         gie_set_err("gie_create: local volume too large (side <= 1024 and X²+Y²+Z²+max(X,Z)² < 2^22)"); return nullptr;
     }
     if (cfg->max_blocks > GIE_MAX_POOL_BLOCKS) {         /* a voxel address is slot * 512 + in-block index in 32 bits */
-        gie_set_err("gie_create: max_blocks above 4 000 000 (2 G voxels, 61 GB of pool) is not supported: voxel addresses are 32 bits; "
+        gie_set_err("gie_create: max_blocks above 67 108 864 is not supported (and would not fit the device: 19.5 KB per block); "
                     "bound the map with retain_radius_blocks instead");
         return nullptr;
     }
@@ -168,6 +170,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.hkeys = gie_dalloc<uint64_t>(m, (size_t)hcap, false);
     c.hvals = gie_dalloc<int32_t>(m, (size_t)hcap, false);
     c.pool_count = gie_dalloc<int32_t>(m, 4);
+    m->pool_base = 0;
     c.retain = cfg->retain_radius_blocks > 0 ? cfg->retain_radius_blocks : 0;
     c.free_list = gie_dalloc<int32_t>(m, c.retain > 0 ? (size_t)mb : 1, false);
     const size_t GV = (size_t)mb * GIE_VBSZ;
@@ -189,8 +192,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.qcap_ab = (int)qab; c.qcap_c = (int)qc;
     c.qa = gie_dalloc<uint64_t>(m, (size_t)qab, false);
     c.qb = gie_dalloc<uint64_t>(m, (size_t)qab, false);
-    c.qa_a = gie_dalloc<int32_t>(m, (size_t)qab, false);
-    c.qb_a = gie_dalloc<int32_t>(m, (size_t)qab, false);
+    c.qa_a = gie_dalloc<gie_vaddr>(m, (size_t)qab, false);
+    c.qb_a = gie_dalloc<gie_vaddr>(m, (size_t)qab, false);
     for (int i = 0; i < 2; i++) c.qc[i] = gie_dalloc<int32_t>(m, (size_t)qc, false);
     c.cnt = gie_dalloc<int32_t>(m, GIE_CNT_NUM);
     for (int i = 0; i < 2; i++) c.wc_list[i] = gie_dalloc<int32_t>(m, ntile, false);
@@ -203,6 +206,10 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     bool ok = c.cnt != nullptr;
     for (void *p : m->allocs) ok = ok && p != nullptr;
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
+    if (const char *e = getenv("GIE_DEBUG_POOL_BASE")) {   /* tests: hand out slots from here on (voxel addresses beyond 2^31 without filling a pool) */
+        const long long b = atoll(e);
+        if (b > 0 && b < mb) { const int32_t v = (int32_t)b; be_h2d(&m->be, c.pool_count, &v, sizeof(v)); m->pool_base = (int)b; }
+    }
     be_memset(&m->be, c.hkeys, 0xff, (size_t)hcap * sizeof(uint64_t));
     be_memset(&m->be, c.lprop, 0xff, (size_t)bdr * sizeof(uint64_t));
     be_memset(&m->be, c.cand[0], 0xff, N * sizeof(uint64_t));
@@ -714,7 +721,7 @@ extern "C" int gie_get_stats(gie_mapper *m, gie_frame_stats *s)
     int rc = gie_sync(m);
     int32_t pcs[2] = { 0, 0 };
     be_d2h(&m->be, pcs, m->c.pool_count, 8);
-    const int32_t pc = pcs[0] - pcs[1];                   /* live blocks: handed out minus the ones on the free list */
+    const int32_t pc = pcs[0] - pcs[1] - m->pool_base;    /* live blocks: handed out minus the ones on the free list */
     const int32_t *h = m->h_cnt;
     memset(s, 0, sizeof(*s));
     s->frame = m->c.map_ct; s->blocks_total = pc; s->blocks_new = h[GIE_CNT_NEWBLK];

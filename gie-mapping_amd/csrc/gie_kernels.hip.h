@@ -1322,13 +1322,13 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
     const int slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
     const int skipold = c.tskip[t];
-    int a[8]; int dold[8]; uint64_t oc[8];
+    gie_vaddr a[8]; int dold[8]; uint64_t oc[8];
     unsigned want = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int gz = gz0 + k;
         const int slot = ((gz >> 3) == (gz0 >> 3)) ? slot_lo : slot_hi;
-        a[k] = slot < 0 ? -1 : slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+        a[k] = slot < 0 ? (gie_vaddr)-1 : (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
         if (k < nz && ty[k] != GIE_VOX_UNKNOWN) want |= 1u << k;
         dold[k] = GIE_TMAX_INF; oc[k] = 0;
     }
@@ -1552,14 +1552,14 @@ __global__ __launch_bounds__(64 * GIE_FR_WAVES) void k_frontier_tiles(const gie_
 #define GIE_FR_ABIT ((uint64_t)1 << 63)
 #define GIE_FF_WAVES 4
 #define GIE_FF_AB (64 * GIE_FF_WAVES * 3)                     /* three outside neighbours per voxel: a corner of the volume */
-struct gie_ff_wg { uint64_t ab_crd[GIE_FF_AB]; int32_t ab_addr[GIE_FF_AB]; int32_t cq[64 * GIE_FF_WAVES]; int32_t nab, ncq, base[3], pad_; };   /* 10.3 KB */
+struct gie_ff_wg { uint64_t ab_crd[GIE_FF_AB]; gie_vaddr ab_addr[GIE_FF_AB]; int32_t cq[64 * GIE_FF_WAVES]; int32_t nab, ncq, base[3], pad_; };   /* 10.3 KB */
 struct gie_absink_lds {
     static constexpr bool outside = true;
     gie_ff_wg *L;
-    __device__ __forceinline__ void ab(const gie_ctx &c, int push, uint64_t crd, int a) const {
+    __device__ __forceinline__ void ab(const gie_ctx &c, int push, uint64_t crd, gie_vaddr a) const {
         if (!push) return;
         const int i = __hip_atomic_fetch_add(&L->nab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (i < GIE_FF_AB) { L->ab_crd[i] = crd | (push == 2 ? GIE_FR_ABIT : (uint64_t)0); L->ab_addr[i] = (int32_t)a; }
+        if (i < GIE_FF_AB) { L->ab_crd[i] = crd | (push == 2 ? GIE_FR_ABIT : (uint64_t)0); L->ab_addr[i] = (gie_vaddr)a; }
         else if (push == 2) gie_push64a(c, c.qa, c.qa_a, &c.cnt[GIE_CNT_A], c.qcap_ab, crd, a);    /* (volumes one or two voxels thick: more than three outside neighbours per voxel) */
         else gie_push64a(c, c.qb, c.qb_a, &c.cnt[GIE_CNT_B], c.qcap_ab, crd, a);
     }
@@ -1757,7 +1757,8 @@ __device__ __forceinline__ void gie_row_ld32(const uint32_t *p, const long long 
  * decisions are gie_fuse_finish's (shared gie_fuse_logic), the per-tile known / unknown summaries and
  * the plane flags come out the same */
 /* (few tiles to look at: the list form — a wave per listed tile, the staged per-voxel functor as in k_voxa — in the same launch) */
-__global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c, const op_fuse f, const int32_t *list)
+/* (four workgroups per compute unit: with 64-bit block addresses the kernel wanted 130 registers and lost a quarter of its waves) */
+__global__ __launch_bounds__(256, 4) void k_fuse_rows(const gie_ctx c, const op_fuse f, const int32_t *list)
 {
     {
         const int n = c.cnt[GIE_CNT_TL_FUSE];
@@ -1791,6 +1792,9 @@ __global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c, const op_fus
         unsigned kn = 0u, un = 0u;                                /* bit = quadrant */
         const long long plane = (long long)c.X * c.Y;
         const long long id0 = ((long long)w.lz0 * c.Y + w.ly) * c.X + w.x0;
+        /* the row's place in its block's planes: one 64-bit address per row, 32-bit offsets per layer */
+        uint8_t *const p_occ = c.g_occ + (w.slot < 0 ? 0 : (gie_vaddr)w.slot * GIE_VBSZ + w.arow);
+        int8_t *const p_typ = c.g_type + (w.slot < 0 ? 0 : (gie_vaddr)w.slot * GIE_VBSZ + w.arow);
 #pragma unroll 2
         for (int k = 0; k < 8; k++) {
             const int lz = w.lz0 + k;
@@ -1802,9 +1806,9 @@ __global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c, const op_fus
                 const uint64_t gt8 = gie_row_ld8(c.glb_type, id, w);
                 uint32_t rc[8];
                 if (c.pntcld_mode) gie_row_ld32(reinterpret_cast<const uint32_t *>(c.ray_count), id, w, rc);
-                const int a = w.slot * GIE_VBSZ + (k << 6) + w.arow;
+                const int a = k << 6;
                 uint64_t go8 = 0, gy8 = 0;
-                if (w.slot >= 0) { go8 = *reinterpret_cast<const uint64_t *>(c.g_occ + a); gy8 = *reinterpret_cast<const uint64_t *>(c.g_type + a); }
+                if (w.slot >= 0) { go8 = *reinterpret_cast<const uint64_t *>(p_occ + a); gy8 = *reinterpret_cast<const uint64_t *>(p_typ + a); }
                 uint64_t no8 = go8, ny8 = gy8, ng8 = gt8;
                 bool rc_any = false;
                 const int qz = (k >= q.kz) ? 2 : 0;
@@ -1836,8 +1840,8 @@ __global__ __launch_bounds__(256) void k_fuse_rows(const gie_ctx c, const op_fus
                 if (it8 != 0ull) gie_row_st8(c.inst_type, id, w, 0ull);
                 if (ng8 != gt8) gie_row_st8(c.glb_type, id, w, ng8);
                 if (w.slot >= 0) {
-                    if (no8 != go8) *reinterpret_cast<uint64_t *>(c.g_occ + a) = no8;      /* bytes of voxels outside the volume keep their value */
-                    if (ny8 != gy8) { *reinterpret_cast<uint64_t *>(c.g_type + a) = ny8; if (c.track) c.g_dirty[w.slot] = 1; }
+                    if (no8 != go8) *reinterpret_cast<uint64_t *>(p_occ + a) = no8;        /* bytes of voxels outside the volume keep their value */
+                    if (ny8 != gy8) { *reinterpret_cast<uint64_t *>(p_typ + a) = ny8; if (c.track) c.g_dirty[w.slot] = 1; }
                 }
             }
             if (__ballot(occ_here) != 0ull && lane == __ffsll((long long)__ballot(occ_here)) - 1) c.zocc[lz] = 1;
@@ -2076,7 +2080,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
     /* the chain of dependent round trips of a block-run: [block key + the block's records] -> [the six neighbour lookups + the
      * vanished-obstacle look-ups of the block's voxels] -> [halo records] -> [their vanished-obstacle look-ups] */
     uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
-    const int base = slot * GIE_VBSZ;
+    const gie_vaddr base = (gie_vaddr)slot * GIE_VBSZ;
     GIE_WPROF_DECL;
     const uint64_t bkey = gie_ld(&c.g_key[slot]);
     uint64_t cv[8], cc8[8];
@@ -2084,7 +2088,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
     int32_t wl8[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {                                       /* voxel lane + 64 j = (x, y) = lane, z = j */
-        const int a = base + lane + 64 * j;
+        const gie_vaddr a = base + lane + 64 * j;
         cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]) & ~GIE_COC_STALEPAIR; ty8[j] = gie_ld(&c.g_type[a]); wl8[j] = gie_ld(&c.g_wl[a]);
     }
     if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);
@@ -2110,7 +2114,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const int ns = L.nslot[f];
-            const int an = (ns < 0 ? base : ns * GIE_VBSZ) + hidx[f];
+            const gie_vaddr an = (ns < 0 ? base : (gie_vaddr)ns * GIE_VBSZ) + hidx[f];
             hc[f] = gie_ld(&c.g_coc[an]) & ~GIE_COC_STALEPAIR; ht[f] = gie_ld(&c.g_type[an]); hw[f] = gie_ld(&c.g_wl[an]);
         }
         int hl[6]; int8_t hv[6];
@@ -2200,7 +2204,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
                 if (inside) {
                     if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
                         L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
-                } else { gie_amin64(&wr[L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
+                } else { gie_amin64(&wr[(gie_vaddr)L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
             } else {
                 /* the entry's own lowering: the nearest of the obstacles its neighbours hold, the first direction among equals
                  * (the reference walks the directions in order and replaces on a strict improvement).  Nobody proposes to an
@@ -2267,7 +2271,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
             const unsigned long long m = __ballot((f & GIE_WA_PUSHB) != 0u);
             if (f & GIE_WA_PUSHB) {
                 const int i = qbase + before + __popcll(m & lt);
-                if (i < c.qcap_ab) { gie_st(&c.qb[i], gie_pack_crd(g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j)); gie_st(&c.qb_a[i], (int32_t)(base + v)); }
+                if (i < c.qcap_ab) { gie_st(&c.qb[i], gie_pack_crd(g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j)); gie_st(&c.qb_a[i], (gie_vaddr)(base + v)); }
                 else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
             }
             before += __popcll(m);
@@ -2303,17 +2307,17 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     if (n == 0 || gb.failed) return;               /* same n everywhere */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
-        const int a = gie_ld(&c.qa_a[e]);
+        const gie_vaddr a = gie_ld(&c.qa_a[e]);
         int g[3];
         gie_unpack_crd(gie_ld(&c.qa[e]), &g[0], &g[1], &g[2]);
         const int col = ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1;
         bool first = false;
         if (a >= 0) {
             gie_st(col ? &c.g_prop2[a] : &c.g_prop[a], (uint64_t)0);
-            first = gie_axchg32(&c.wb_flag[col][a >> 9], (int32_t)1) == 0;
+            first = gie_axchg32(&c.wb_flag[col][(int)(a >> 9)], (int32_t)1) == 0;
         }
-        gie_list_append_wave(c.wb_list[0], &c.lvla_next[0], first && col == 0, a >> 9);
-        gie_list_append_wave(c.wb_list[1], &c.lvla_next[1], first && col == 1, a >> 9);
+        gie_list_append_wave(c.wb_list[0], &c.lvla_next[0], first && col == 0, (int32_t)(a >> 9));
+        gie_list_append_wave(c.wb_list[1], &c.lvla_next[1], first && col == 1, (int32_t)(a >> 9));
     }
     gie_grid_sync(gb, c);
     GIE_TS2(1, n);
@@ -2368,14 +2372,14 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
     gie_unpack_crd(gie_ld(&c.g_key[slot]), &bk[0], &bk[1], &bk[2]);
     const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };              /* global coordinate of the block's first voxel */
     uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
-    const int base = slot * GIE_VBSZ;
+    const gie_vaddr base = (gie_vaddr)slot * GIE_VBSZ;
     GIE_WPROF_DECL;
     uint64_t pv[8], cv[8], cc8[8];
     int8_t ty8[8];
     unsigned inv8 = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {                                       /* voxel lane + 64 j = (x, y) = lane, z = j */
-        const int a = base + lane + 64 * j;
+        const gie_vaddr a = base + lane + 64 * j;
         const int nb[3] = { g0[0] + (lane & 7) - c.pvt[0], g0[1] + (lane >> 3) - c.pvt[1], g0[2] + j - c.pvt[2] };
         const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
         const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
@@ -2400,7 +2404,7 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const int ns = L.nslot[f];
-            const int an = (ns < 0 ? base : ns * GIE_VBSZ) + hidx[f];
+            const gie_vaddr an = (ns < 0 ? base : (gie_vaddr)ns * GIE_VBSZ) + hidx[f];
             const int nb[3] = { g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2] };
             const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
             const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
@@ -2520,7 +2524,7 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
             if (inside) {
                 if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
                     L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
-            } else { gie_amin64(&wr[L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
+            } else { gie_amin64(&wr[(gie_vaddr)L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
         }
         gie_wave_sync();
         np = L.npend[pi ^ 1];
@@ -2613,13 +2617,13 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     /* the seeds mark themselves in the plane round 0 reads, their blocks are its active blocks (a voxel that was appended twice
      * marks itself twice: the frontier is a set) */
     for (int e = blockIdx.x * GIE_WAVE_THREADS + threadIdx.x; e < n; e += gridDim.x * GIE_WAVE_THREADS) {
-        const int a = gie_ld(&c.qb_a[e]);
+        const gie_vaddr a = gie_ld(&c.qb_a[e]);
         bool first = false;
         if (a >= 0) {
             gie_st(&c.g_prop[a], (uint64_t)0);
-            first = gie_axchg32(&c.wb_flag[0][a >> 9], (int32_t)1) == 0;
+            first = gie_axchg32(&c.wb_flag[0][(int)(a >> 9)], (int32_t)1) == 0;
         }
-        gie_list_append_wave(c.wb_list[0], &c.lvlb_next[0], first, a >> 9);
+        gie_list_append_wave(c.wb_list[0], &c.lvlb_next[0], first, (int32_t)(a >> 9));
     }
     gie_grid_sync(gb, c);
     GIE_TS2(4, n);

@@ -54,15 +54,15 @@ GIE_DEV void gie_push64(const gie_ctx &c, uint64_t *q, int32_t *counter, int cap
 }
 /* frontiers A / B carry the voxel's address (slot * 512 + in-block index) next to its coordinate: whoever
  * appends an entry has just touched that voxel, and the phases that expand it need no hash probe for it */
-GIE_DEV void gie_push64a(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, int cap, uint64_t v, int a)
+GIE_DEV void gie_push64a(const gie_ctx &c, uint64_t *q, gie_vaddr *qaddr, int32_t *counter, int cap, uint64_t v, gie_vaddr a)
 {
     const int i = gie_aadd32(counter, 1);
-    if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], (int32_t)a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+    if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
 }
 /* the same append for every lane of the wave that has `push` set, with ONE atomic on the counter per wave (tens of
  * thousands of per-lane atomics on one word were most of obtainFrontiers' time when a whole face of the volume seeds waves
  * A / B).  Only executing lanes are looked at, so it is safe in divergent code. */
-GIE_DEV void gie_push64a_wave(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int32_t *counter, int cap, bool push, uint64_t v, int a)
+GIE_DEV void gie_push64a_wave(const gie_ctx &c, uint64_t *q, gie_vaddr *qaddr, int32_t *counter, int cap, bool push, uint64_t v, gie_vaddr a)
 {
 #if defined(GIE_HOST_EMU)
     if (push) gie_push64a(c, q, qaddr, counter, cap, v, a);
@@ -75,7 +75,7 @@ GIE_DEV void gie_push64a_wave(const gie_ctx &c, uint64_t *q, int32_t *qaddr, int
     base = __shfl(base, leader);
     if (push) {
         const int i = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], (int32_t)a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+        if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
     }
 #endif
 }
@@ -145,18 +145,18 @@ GIE_DEV void gie_ray_touch(const gie_ctx &c, int lx, int ly, int lz, gie_ray_mar
 }
 
 /* global voxel address: block slot through the frame's block table (volume +-1 voxel) */
-GIE_DEV int gie_gvox_tab(const gie_ctx &c, int gx, int gy, int gz)
+GIE_DEV gie_vaddr gie_gvox_tab(const gie_ctx &c, int gx, int gy, int gz)
 {
     const int s = c.blk_tab[gie_tab_index(c, gx, gy, gz)];
-    return s < 0 ? -1 : s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+    return s < 0 ? (gie_vaddr)-1 : (gie_vaddr)s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
 }
 /* stream_VB_keys_D bookkeeping as one flag per block (all writers store 1) */
-GIE_DEV void gie_touch(const gie_ctx &c, int a) { if (c.track) gie_st(&c.g_dirty[a >> 9], (int32_t)1); }
+GIE_DEV void gie_touch(const gie_ctx &c, gie_vaddr a) { if (c.track) gie_st(&c.g_dirty[a >> 9], (int32_t)1); }
 /* … or through the hash (anywhere) */
-GIE_DEV int gie_gvox_hash(const gie_ctx &c, int gx, int gy, int gz)
+GIE_DEV gie_vaddr gie_gvox_hash(const gie_ctx &c, int gx, int gy, int gz)
 {
     const int s = gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3);
-    return s < 0 ? -1 : s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+    return s < 0 ? (gie_vaddr)-1 : (gie_vaddr)s * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
 }
 
 /* The stored squared distance of a global voxel is not a plane of its own: every writer of the reference stores dist_sq and
@@ -412,7 +412,7 @@ GIE_DEV void gie_rehash_slot(const gie_ctx &c, int slot)
 /* GlbVoxel defaults (voxmap_utils.cuh:30-43) for voxel i of a fresh block */
 GIE_DEV void gie_init_voxel(const gie_ctx &c, int slot, int i)
 {
-    const int a = slot * GIE_VBSZ + i;
+    const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + i;
     c.g_occ[a] = 0; c.g_type[a] = GIE_VOX_UNKNOWN;
     c.g_coc[a] = gie_pack_crd(GIE_EMPTY_VALUE, GIE_EMPTY_VALUE, GIE_EMPTY_VALUE);
     c.g_pair[a] = 0; c.g_prop[a] = GIE_NOPROP; c.g_prop2[a] = GIE_NOPROP; c.g_wl[a] = -1;
@@ -458,7 +458,7 @@ GIE_DEV void gie_set_occ(uint8_t *occ, int8_t *type, float val, float a, int thr
 }
 
 
-struct gie_fuse_st { int count; int8_t nt, gt0; int a; uint8_t occ; int8_t ty; };
+struct gie_fuse_st { int count; int8_t nt, gt0; gie_vaddr a; uint8_t occ; int8_t ty; };
 
 GIE_DEV void gie_fuse_load1(const gie_ctx &c, int id, int x, int y, int z, gie_fuse_st &s)
 {
@@ -504,7 +504,7 @@ GIE_DEV int gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const
     const int8_t nt = s.nt;
     if (nt != GIE_VOX_UNKNOWN) c.inst_type[id] = GIE_VOX_UNKNOWN;
     const int8_t gt0 = s.gt0;
-    const int a = s.a;
+    const gie_vaddr a = s.a;
     if (a < 0) { if (gt0 != GIE_VOX_UNKNOWN) c.glb_type[id] = GIE_VOX_UNKNOWN; return 0; }
     const int occ_flag = gie_fuse_occ_flag(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     uint8_t occ = s.occ;
@@ -552,7 +552,7 @@ GIE_DEV int gie_fuse_voxel(const gie_ctx &c, int x, int y, int z)
 /* Split in stages so that a thread can keep the loads of several voxels in flight (the sweep is
  * latency-bound): load1 = independent reads, load2 = reads that need load1's block slot,
  * finish = arithmetic + writes.  gie_mark_voxel chains them for one voxel. */
-struct gie_mark_st { uint32_t bc; uint64_t pr; int a; uint64_t ococ; };
+struct gie_mark_st { uint32_t bc; uint64_t pr; gie_vaddr a; uint64_t ococ; };
 
 GIE_DEV void gie_mark_load1(const gie_ctx &c, int id, int x, int y, int z, gie_mark_st &s)
 {
@@ -618,12 +618,12 @@ GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
  * Returns bit0 = the voxel became a C seed (*seed set), bit1 = the neighbour is unknown. */
 /* *push = 1: the neighbour joins frontier B, 2: frontier A (appended by the caller, wave-aggregated), *pa = its address */
 GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int nx, int ny, int nz,
-                                      const int cl[3], const int cw[3], int cd, uint64_t *seed, int *push, int *pa)
+                                      const int cl[3], const int cw[3], int cd, uint64_t *seed, int *push, gie_vaddr *pa)
 {
     *push = 0; *pa = -1;
     int cur_in_q = 0;
     const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
-    const int a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
+    const gie_vaddr a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
     if (a < 0) return 2;
     /* the neighbour's record in one batch of loads (a face voxel is a chain of dependent round trips) */
     const int8_t nty = c.g_type[a];
@@ -707,7 +707,7 @@ struct gie_nbpair_mem { const uint64_t *pair; GIE_DEV_MEMBER uint64_t operator()
  * wave and call (gie_absink_queues), or collected per tile in LDS (k_frontier_tiles) */
 struct gie_absink_queues {
     static constexpr bool outside = true;                  /* false: the caller only hands over voxels off the faces (no outside neighbour: that branch is not compiled) */
-    GIE_DEV_MEMBER void ab(const gie_ctx &c, int push, uint64_t crd, int a) const {
+    GIE_DEV_MEMBER void ab(const gie_ctx &c, int push, uint64_t crd, gie_vaddr a) const {
         gie_push64a_wave(c, c.qb, c.qb_a, &c.cnt[GIE_CNT_B], c.qcap_ab, push == 1, crd, a);
         gie_push64a_wave(c, c.qa, c.qa_a, &c.cnt[GIE_CNT_A], c.qcap_ab, push == 2, crd, a);
     } };
@@ -724,7 +724,6 @@ GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z
     if (!gie_in_loc(c, cl[0], cl[1], cl[2])) return 0;
     int cur_in_q = 0, has_unknown = 0;
     uint64_t seed = 0;
-    int opush[6] = { 0, 0, 0, 0, 0, 0 }, oaddr[6] = { -1, -1, -1, -1, -1, -1 };
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
@@ -749,22 +748,19 @@ GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z
         } else if (SINK::outside) {
             /* a neighbour outside the volume (only voxels on the six faces get here): kept out of
              * line so that the hot interior path stays small */
-            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed, &opush[k], &oaddr[k]);
+            int opush = 0;
+            gie_vaddr oaddr = -1;
+            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed, &opush, &oaddr);
             cur_in_q |= r & 1; has_unknown |= (r >> 1) & 1;
-        }
-    }
-    if (SINK::outside && !c.fast_mode && (x == 0 || y == 0 || z == 0 || x == c.X - 1 || y == c.Y - 1 || z == c.Z - 1)) {
-        GIE_UNROLL6
-        for (int k = 0; k < 6; k++) {                     /* neighbours outside the volume that seed wave B / wave A */
-            const uint64_t crd = gie_pack_crd(x + dx[k] + c.pvt[0], y + dy[k] + c.pvt[1], z + dz[k] + c.pvt[2]);
-            sink.ab(c, opush[k], crd, oaddr[k]);
+            /* a neighbour outside the volume that seeds wave B / wave A (the sinks only look at executing lanes) */
+            sink.ab(c, opush, gie_pack_crd(nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]), oaddr);
         }
     }
     if (cur_in_q) { c.wl[id] = GIE_WL_SEED(c); c.cand[1][id] = seed; }   /* the pair the seed enters wave C with */
     if (ty == GIE_VOX_FREE && has_unknown) {
         c.glb_type[id] = GIE_VOX_FNT;
         if (c.fused && cd != c.empty_value) {       /* UpdateHashBatch's FNT store (unify_helper.cuh:448-523); a pair wave C lowers from EMPTY brings its own */
-            const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+            const gie_vaddr a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
             if (a >= 0) c.g_type[a] = GIE_VOX_FNT;
         }
     }
@@ -823,7 +819,7 @@ GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
  * local plane cannot — a voxel whose pair was EMPTY (not committed) when it left: flag set = its last commit happened
  * during this stay in the volume and the pair of that commit is (stored distance, stored closest obstacle). */
 template <bool AGENT>
-GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, int a, uint64_t pr)
+GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, gie_vaddr a, uint64_t pr)
 {
     const int d = gie_pair_dist(pr);
     if (d == c.empty_value) {
@@ -864,7 +860,7 @@ GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, in
     const int cell = (((gz >> 3) - b.otb0[2]) * c.tdim[1] + ((gy >> 3) - b.otb0[1])) * c.tdim[0] + ((gx >> 3) - b.otb0[0]);
     const int slot = c.blk_tab[cell];
     if (slot < 0) return;
-    const int a = slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+    const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
     const uint64_t pr = c.pair[id];
     if (gie_pair_dist(pr) != c.empty_value) {         /* committed by that update: the pair it would have stored */
         int cw[3];
@@ -886,7 +882,7 @@ GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, in
 GIE_DEV void gie_commit_merged(const gie_ctx &c, int id, int8_t ty, int slot, int x, int y, int z, uint64_t pr)
 {
     if (ty == GIE_VOX_UNKNOWN) return;       /* lower_inside has no type test (wave_core.cuh:353-393), UpdateHashBatch has (unify_helper.cuh:459) */
-    const int a = slot < 0 ? -1 : slot * GIE_VBSZ + gie_vox_in_blk(x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    const gie_vaddr a = slot < 0 ? (gie_vaddr)-1 : (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     gie_commit_pair<true>(c, id, a, pr);
     if (a >= 0 && gie_pair_dist(pr) != c.empty_value && ty == GIE_VOX_FNT) gie_st(&c.g_type[a], (int8_t)GIE_VOX_FNT);
 }
@@ -898,7 +894,7 @@ GIE_DEV void gie_commit_merged(const gie_ctx &c, int id, int8_t ty, int slot, in
 
 /* ================================================================== commit */
 /* UpdateHashBatch, unify_helper.cuh:448-523 */
-struct gie_commit_st { int8_t ty; uint64_t pr; int a; };
+struct gie_commit_st { int8_t ty; uint64_t pr; gie_vaddr a; };
 
 GIE_DEV void gie_commit_load1(const gie_ctx &c, int id, int x, int y, int z, gie_commit_st &s)
 {
@@ -916,7 +912,7 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
         if (gie_pair_par(pr) == GIE_PAR_NONE) c.edt[id] = (float)c.max_loc_dist_sq;
         return;
     }
-    const int a = s.a;
+    const gie_vaddr a = s.a;
     if (a < 0) return;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
@@ -946,7 +942,7 @@ GIE_DEV void gie_commit_voxel(const gie_ctx &c, int x, int y, int z)
  * block-table lookup per voxel, and the previous frame's pair is read only in the one branch that
  * needs it.  Not used while the changed-block flags are on (gie_stream_enable): a pair that is
  * committed twice could flag a block the reference's single commit would not. */
-struct gie_markc_st { uint32_t bc; int a; int dold; uint64_t ococ; int skipold; int g[3]; };
+struct gie_markc_st { uint32_t bc; gie_vaddr a; int dold; uint64_t ococ; int skipold; int g[3]; };
 
 /* ---- which stored global records Mark has to read at all.  MarkLimitedObserve compares the batch distance with the voxel's
  * stored (distance, closest obstacle) and keeps the stored one when it is smaller AND its obstacle lies outside the (whole)
@@ -1101,7 +1097,7 @@ GIE_DEV void gie_halo_export_voxel(const gie_ctx &c, int face, int i, gie_halo_v
     gie_face_coord(c, face, i, 0, &x, &y, &z);
     gie_halo_voxel h;
     h.pad[0] = h.pad[1] = 0; h.occ_val = 0;
-    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    const gie_vaddr a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     if (a < 0 || c.g_type[a] == GIE_VOX_UNKNOWN) {
         h.vox_type = GIE_VOX_UNKNOWN; h.dist_sq = c.empty_value; h.coc[0] = h.coc[1] = h.coc[2] = GIE_EMPTY_VALUE;
     } else {
@@ -1125,7 +1121,7 @@ GIE_DEV void gie_halo_import_voxel(const gie_ctx &c, int face, int i, const gie_
     if (in[i].vox_type == GIE_VOX_UNKNOWN) return;
     int x, y, z;
     gie_face_coord(c, face, i, 1, &x, &y, &z);
-    const int a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+    const gie_vaddr a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     if (a < 0) return;
     c.g_type[a] = in[i].vox_type;
     c.g_occ[a] = in[i].occ_val;
@@ -1147,7 +1143,7 @@ GIE_DEV int gie_refine_voxel(const gie_ctx &c, int id)
     for (int k = 0; k < 6; k++) {
         const int nx = x + dx[k], ny = y + dy[k], nz = z + dz[k];
         if (gie_in_loc(c, nx, ny, nz)) continue;
-        const int a = gie_gvox_tab(c, nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]);
+        const gie_vaddr a = gie_gvox_tab(c, nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]);
         if (a < 0 || c.g_type[a] == GIE_VOX_UNKNOWN) continue;
         if (gie_invalid_dist(c, gie_gdist(c, c.g_coc[a], nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]))) continue;
         int ncx, ncy, ncz;
@@ -1215,13 +1211,13 @@ GIE_DEV void gie_stream_list(const gie_ctx &c, const int32_t *rank, int32_t *lis
 GIE_DEV void gie_stream_gather(const gie_ctx &c, const int32_t *list, int first, int32_t *keys, gie_voxel *out, int i)
 {
     const int slot = list[first + (i >> 9)], j = i & 511;
-    const int a = slot * GIE_VBSZ + ((j >> 6) | (((j >> 3) & 7) << 3) | ((j & 7) << 6));
+    const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + ((j >> 6) | (((j >> 3) & 7) << 3) | ((j & 7) << 6));
     gie_voxel v;
     v.occ_val = c.g_occ[a]; v.vox_type = c.g_type[a]; v.pad = 0;
     {   /* the voxel's global coordinate: block key * 8 + in-block position */
         int k[3];
         gie_unpack_crd(c.g_key[slot], &k[0], &k[1], &k[2]);
-        const int ib = a & (GIE_VBSZ - 1);
+        const int ib = (int)(a & (GIE_VBSZ - 1));
         v.dist_sq = gie_gdist(c, c.g_coc[a], k[0] * 8 + (ib & 7), k[1] * 8 + ((ib >> 3) & 7), k[2] * 8 + (ib >> 6));
     }
     gie_unpack_crd(c.g_coc[a], &v.coc[0], &v.coc[1], &v.coc[2]);
@@ -1236,7 +1232,7 @@ GIE_DEV void gie_stream_clear(const gie_ctx &c, const int32_t *list, int first, 
 
 GIE_DEV void gie_query_voxel(const gie_ctx &c, const int32_t *xyz, int i, gie_voxel *out)
 {
-    const int a = gie_gvox_hash(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    const gie_vaddr a = gie_gvox_hash(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     out[i].pad = 0;
     if (a < 0) {
         out[i].occ_val = 0; out[i].vox_type = GIE_VOX_UNKNOWN; out[i].dist_sq = c.empty_value;

@@ -19,6 +19,9 @@
 
 #define GIE_VB 8
 #define GIE_VBSZ 512
+/* address of a voxel of the global map: slot * 512 + in-block index.  64 bits: a pool beyond 2^31 / 512 = 4.19 M blocks (288 GB hold
+ * about 15 M) is addressed like a small one */
+typedef long long gie_vaddr;
 
 /* ---- 64-bit (dist, parent) pair: [63:42] dist (22 bit) | [41] new-in-this-level | [40:0] parent
  * parent = closest obstacle in wave-range coordinates, x | y<<14 | z<<28 (x,y < 16384, z < 8192).
@@ -152,7 +155,7 @@ typedef struct gie_ctx {
     const uint8_t *box_act;
     /* ---- frontier queues + counters */
     uint64_t *qa, *qb;      /* the seeds of waves A / B: packed global coordinates ... */
-    int32_t *qa_a, *qb_a;   /* ... and addresses (slot * 512 + in-block index) */
+    gie_vaddr *qa_a, *qb_a; /* ... and addresses (slot * 512 + in-block index) */
     int32_t *qc[2];
     int qcap_ab, qcap_c;
     int32_t *cnt;           /* device counters, see GIE_CNT_* */

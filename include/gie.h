@@ -56,7 +56,7 @@ typedef struct gie_config {
     int32_t fast_mode;            /* wave/fast_mode (code default true, parameters.h:93)       */
     int32_t for_motion_planner;   /* robot sphere forced FREE in the OGM kernels               */
     int32_t robot_r2_grids;       /* ceil(robot_r/voxel_width)^2                               */
-    int32_t max_blocks;           /* block pool capacity (hash/block_max); 0 = size from volume; at most 4 000 000 (gie_create fails above) */
+    int32_t max_blocks;           /* block pool capacity (hash/block_max); 0 = size from volume.  19.5 KB of device memory per block; voxel addresses are 64-bit, so the device's memory is the limit */
     int32_t device_id;            /* HIP device ordinal                                         */
     int32_t retain_radius_blocks; /* block-pool lifecycle.  0 = the reference's rule: blocks are never freed and the pool only
                                      shrinks (BlockAllocBase::allocate_n throws when it is empty, blockalloc.h:50-67; its free

@@ -180,7 +180,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
     const int n0 = c.cnt[GIE_CNT_A] < c.qcap_ab ? c.cnt[GIE_CNT_A] : c.qcap_ab;
     c.cnt[GIE_CNT_SEED_A] = n0; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B];
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    struct ent { int a; int g[3]; };
+    struct ent { gie_vaddr a; int g[3]; };
     auto colour = [](const int *g) { return ((g[0] >> 3) + (g[1] >> 3) + (g[2] >> 3)) & 1; };
     std::vector<ent> pend[2];
     for (int e = 0; e < n0; e++) {
@@ -197,7 +197,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
         std::stable_sort(cur.begin(), cur.end(), [](const ent &p, const ent &q) { return (p.a >> 9) < (q.a >> 9); });
         std::vector<std::pair<ent, uint64_t>> xprops;               /* raises proposed into neighbouring blocks (min per voxel) */
         for (size_t b0 = 0; b0 < cur.size();) {
-            const int slot = cur[b0].a >> 9;
+            const int slot = (int)(cur[b0].a >> 9);
             std::vector<ent> L;
             while (b0 < cur.size() && (cur[b0].a >> 9) == slot) L.push_back(cur[b0++]);
             while (!L.empty()) {                                    /* one level inside the block */
@@ -206,7 +206,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
                 std::vector<low> lw(L.size());
                 std::vector<std::pair<ent, uint64_t>> props;
                 for (size_t e = 0; e < L.size(); e++) {             /* phase 1: reads of the level-start state, proposals */
-                    const int a = L[e].a; const int *g = L[e].g;
+                    const gie_vaddr a = L[e].a; const int *g = L[e].g;
                     lw[e].lowered = false; lw[e].pair = GIE_NOPROP;
                     const uint64_t lcoc = c.g_coc[a] & ~GIE_COC_STALEPAIR;
                     int cd = gie_gdist(c, lcoc, g[0], g[1], g[2]);
@@ -218,7 +218,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
                         const int ng[3] = { g[0] + dx[k], g[1] + dy[k], g[2] + dz[k] };
                         const int nb[3] = { ng[0] - c.pvt[0], ng[1] - c.pvt[1], ng[2] - c.pvt[2] };
                         if (gie_in_loc(c, nb[0], nb[1], nb[2]) || gie_in_whole(c, nb[0], nb[1], nb[2])) continue;
-                        const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+                        const gie_vaddr na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
                         if (na < 0 || c.g_type[na] == GIE_VOX_UNKNOWN) continue;
                         const uint64_t ncoc = c.g_coc[na] & ~GIE_COC_STALEPAIR;
                         int nc[3];
@@ -247,7 +247,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
                 }
                 for (size_t e = 0; e < L.size(); e++) {             /* phase 2: apply */
                     if (!lw[e].lowered) continue;
-                    const int a = L[e].a;
+                    const gie_vaddr a = L[e].a;
                     c.g_coc[a] = lw[e].coc; gie_touch(c, a); c.g_wl[a] = 1;
                     if (lw[e].pair != GIE_NOPROP) {
                         c.g_pair[a] = lw[e].pair;
@@ -256,7 +256,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
                 }
                 std::vector<ent> Ln;
                 for (auto &x : props) {
-                    const int na = x.first.a;
+                    const gie_vaddr na = x.first.a;
                     int lw3[3];
                     gie_unpack_wr(gie_pair_par(x.second), &lw3[0], &lw3[1], &lw3[2]);
                     c.g_coc[na] = gie_pack_crd(lw3[0] + c.upvt[0], lw3[1] + c.upvt[1], lw3[2] + c.upvt[2]);
@@ -267,7 +267,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
             }
         }
         for (auto &x : xprops) {                                    /* end of the round */
-            const int na = x.first.a;
+            const gie_vaddr na = x.first.a;
             int lw3[3];
             gie_unpack_wr(gie_pair_par(x.second), &lw3[0], &lw3[1], &lw3[2]);
             c.g_coc[na] = gie_pack_crd(lw3[0] + c.upvt[0], lw3[1] + c.upvt[1], lw3[2] + c.upvt[2]);
@@ -285,12 +285,12 @@ static void be_wave_b(be_state *, const gie_ctx &c)
     const int n0 = c.cnt[GIE_CNT_B] < c.qcap_ab ? c.cnt[GIE_CNT_B] : c.qcap_ab;
     c.cnt[GIE_CNT_FRONT_B] = n0; c.cnt[GIE_CNT_SEED_C] = c.cnt[GIE_CNT_C];
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-    struct ent { int a; int g[3]; };
+    struct ent { gie_vaddr a; int g[3]; };
     std::vector<ent> cur;
     {
-        std::vector<int> seen;
+        std::vector<gie_vaddr> seen;
         for (int e = 0; e < n0; e++) {
-            const int a = c.qb_a[e];
+            const gie_vaddr a = c.qb_a[e];
             if (a < 0 || std::find(seen.begin(), seen.end(), a) != seen.end()) continue;      /* the frontier is a set */
             seen.push_back(a);
             ent t; t.a = a; gie_unpack_crd(c.qb[e], &t.g[0], &t.g[1], &t.g[2]);
@@ -303,9 +303,9 @@ static void be_wave_b(be_state *, const gie_ctx &c)
         c.cnt[GIE_CNT_LVL_B] += 1;
         std::stable_sort(cur.begin(), cur.end(), [](const ent &p, const ent &q) { return (p.a >> 9) < (q.a >> 9); });
         std::vector<std::pair<ent, uint64_t>> xprops;               /* proposals across block borders of the running round (min per voxel) */
-        auto xfind = [&](int a) { for (auto &x : xprops) if (x.first.a == a) return &x; return (std::pair<ent, uint64_t> *)nullptr; };
+        auto xfind = [&](gie_vaddr a) { for (auto &x : xprops) if (x.first.a == a) return &x; return (std::pair<ent, uint64_t> *)nullptr; };
         for (size_t b0 = 0; b0 < cur.size();) {
-            const int slot = cur[b0].a >> 9;
+            const int slot = (int)(cur[b0].a >> 9);
             std::vector<ent> L;
             while (b0 < cur.size() && (cur[b0].a >> 9) == slot) L.push_back(cur[b0++]);
             while (!L.empty()) {                                    /* one level inside the block */
@@ -313,7 +313,7 @@ static void be_wave_b(be_state *, const gie_ctx &c)
                 struct snap { bool active; uint64_t par; int cc[3]; };
                 std::vector<snap> sn(L.size());
                 for (size_t e = 0; e < L.size(); e++) {
-                    const int a = L[e].a;
+                    const gie_vaddr a = L[e].a;
                     sn[e].active = false;
                     if (gie_gdist(c, c.g_coc[a], L[e].g[0], L[e].g[1], L[e].g[2]) > c.cutoff_sq) continue;     /* (the distance stored BEFORE the commit) */
                     const uint64_t pr = c.g_pair[a] & ~GIE_PAIR_NEW;
@@ -334,7 +334,7 @@ static void be_wave_b(be_state *, const gie_ctx &c)
                         const int cand = gie_d2(sn[e].cc[0], sn[e].cc[1], sn[e].cc[2], ng[0], ng[1], ng[2]);
                         if (!gie_in_loc(c, nb[0], nb[1], nb[2])) {
                             if (gie_in_whole(c, nb[0], nb[1], nb[2])) continue;
-                            const int na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
+                            const gie_vaddr na = gie_gvox_hash(c, ng[0], ng[1], ng[2]);
                             if (na < 0 || c.g_type[na] == GIE_VOX_UNKNOWN) continue;
                             int nc[3];
                             gie_unpack_crd(c.g_coc[na], &nc[0], &nc[1], &nc[2]);

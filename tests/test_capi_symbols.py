@@ -57,8 +57,8 @@ def test_bad_config_is_rejected_by_the_checker_too(oracle_lib):
     cfg = gie.make_config(0.05, (1024, 1024, 1024))
     assert lib.gie_create(C.byref(cfg)) is None
     assert b"too large" in lib.gie_last_error()
-    # ... and a block pool beyond what 32-bit voxel addresses reach: refused, not silently clamped
+    # ... and a block pool beyond the hash table's index arithmetic: refused, not silently clamped
     cfg = gie.make_config(0.05, (64, 64, 64))
-    cfg.max_blocks = 5000000
+    cfg.max_blocks = (1 << 26) + 1
     assert lib.gie_create(C.byref(cfg)) is None
     assert b"max_blocks" in lib.gie_last_error()

@@ -64,6 +64,24 @@ def test_hip_matches_oracle(oracle_lib, sc):
     parity.run_and_compare(sc, OracleMapper, gie.Mapper)
 
 
+def test_voxel_addresses_beyond_2_to_31(oracle_lib, monkeypatch):
+    """voxel addresses (slot * 512 + index) are 64-bit.  A pool of 4.3 M blocks (84 GB of planes on the device) whose
+    slots are handed out from 4.25 M on (GIE_DEBUG_POOL_BASE): every address of the run lies beyond 2^31.  Slot numbers are not
+    observable, so the run has to equal the oracle's like any other — the hash world with waves A / B / C (every kernel that
+    forms an address: allocation, block initialisation, fuse, Mark + commit, obtainFrontiers, the block rounds, the pair flush,
+    global queries) and a lidar scene through ray casting and the projective OGM."""
+    monkeypatch.setenv("GIE_DEBUG_POOL_BASE", "4250000")
+
+    def big_pool(cfg):
+        big = type(cfg).from_buffer_copy(cfg)
+        big.max_blocks = 4300000
+        return gie.Mapper(big)
+
+    for name in ("c5_hash_world", "mixed", "raycast"):
+        sc = [x for x in SCENARIOS if x.name == name][0]
+        parity.run_and_compare(sc, OracleMapper, big_pool)
+
+
 def test_long_drive_on_a_fixed_pool(oracle_lib):
     """a 2 000-update C5 drive in a straight line at 64^3 on a FIXED pool (retain_radius_blocks = 2: the pool holds
     the retention zone, 13^3 blocks, and nothing more — without recycling the drive would need 130 000 blocks).  HIP == oracle:
