@@ -695,7 +695,7 @@ def run_bench():
                                "kernels_ms_per_step and the roofline objects: the first region replayed on a fresh mapper with start / stop events "
                                "on every kernel's dispatch (costs ms_per_step_instrumented - ms_per_step)")
         line["error_bar"] = ("the duration of the Mark + commit sweep belongs to the MAPPER INSTANCE (where its planes lie in physical memory), not to "
-                             "the build: the same binary measures 0.85-0.93 ms there, i.e. ms_per_step 2.58-2.69 from run to run (about +-2 %; "
+                             "the build: the same binary measures 0.85-0.93 ms there, i.e. ms_per_step 2.6-2.75 from run to run (about +-3 %; "
                              "round 2: +-5 %); the instrumented replay runs on a second mapper and can sit in the other band (DESIGN.md 4)")
         if world == 1 and not args.no_extras:
             extras = {}
