@@ -274,7 +274,7 @@ class Runner:
         if self.exchange:
             t, d = self.tiling, self.dist
             if self.backend != "nccl":
-                self.rounds_total += t.exchange_until_stable(m, d, self.rank, self.world)
+                self.rounds_total += t.exchange_until_stable(m, d, self.rank, self.world, sparse=os.environ.get("GIE_HALO_SPARSE", "0") == "1")
             elif self.halo_mode == "stream":
                 # one exchange round per map update, enqueued on the mapper's own stream (RCCL included): the host never waits
                 try:
@@ -284,9 +284,9 @@ class Runner:
                     sys.stderr.write("bench: %s\n" % self.fallback_note)
                     self.halo_mode = "stable"
                     self.halo_bufs = {}
-                    self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, group=self.group)
+                    self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, group=self.group, sparse=os.environ.get("GIE_HALO_SPARSE", "0") == "1")
             else:
-                self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, group=self.group)
+                self.rounds_total += t.exchange_until_stable_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, group=self.group, sparse=os.environ.get("GIE_HALO_SPARSE", "0") == "1")
 
     def barrier(self):
         self.torch.cuda.synchronize()

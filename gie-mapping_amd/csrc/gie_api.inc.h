@@ -871,6 +871,56 @@ extern "C" int gie_halo_import(gie_mapper *m, int face, const gie_halo_voxel *in
     be_sync(&m->be);
     return rc;
 }
+/* sparse face layers (include/gie.h) */
+extern "C" int gie_halo_export_sparse_dev(gie_mapper *m, int face, gie_halo_entry *d_out, int32_t *d_count)
+{
+    int rc = gie_need_pose(m, "gie_halo_export_sparse"); if (rc) return rc;
+    if (face < 0 || face > 5 || !d_out || !d_count) { gie_set_err("gie_halo_export_sparse: bad arguments"); return GIE_ERR_INVALID; }
+    be_memset(&m->be, d_count, 0, sizeof(int32_t));
+    op_halo_export_sparse op; op.face = face; op.out = d_out; op.count = d_count;
+    be_lin(&m->be, m->c, op, gie_face_count(m->c, face));
+    return GIE_OK;
+}
+extern "C" int gie_halo_import_sparse_dev(gie_mapper *m, int face, const gie_halo_entry *d_in, const int32_t *d_count)
+{
+    int rc = gie_need_pose(m, "gie_halo_import_sparse"); if (rc) return rc;
+    if (face < 0 || face > 5 || !d_in || !d_count) { gie_set_err("gie_halo_import_sparse: bad arguments"); return GIE_ERR_INVALID; }
+    const int n = gie_face_count(m->c, face);
+    op_halo_need_sparse nd; nd.face = face; nd.nface = n; nd.in = d_in; nd.count = d_count;
+    be_lin(&m->be, m->c, nd, n);
+    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 1);
+    op_halo_import_sparse im; im.face = face; im.nface = n; im.in = d_in; im.count = d_count;
+    be_lin(&m->be, m->c, im, n);
+    return GIE_OK;
+}
+extern "C" int gie_halo_export_sparse(gie_mapper *m, int face, gie_halo_entry *out, int32_t *count)
+{
+    int rc = gie_need_pose(m, "gie_halo_export_sparse"); if (rc) return rc;
+    if (face < 0 || face > 5 || !out || !count) { gie_set_err("gie_halo_export_sparse: bad arguments"); return GIE_ERR_INVALID; }
+    const int n = gie_face_count(m->c, face);
+    char *d = (char *)gie_scratch(m, 1, (size_t)n * sizeof(gie_halo_entry) + 16, "gie_halo_export_sparse");
+    if (!d) return GIE_ERR_DEVICE;
+    int32_t *d_count = (int32_t *)d;
+    gie_halo_entry *d_out = (gie_halo_entry *)(d + 16);
+    rc = gie_halo_export_sparse_dev(m, face, d_out, d_count);
+    be_d2h(&m->be, count, d_count, sizeof(int32_t));
+    if (*count > 0) be_d2h(&m->be, out, d_out, (size_t)*count * sizeof(gie_halo_entry));
+    return rc;
+}
+extern "C" int gie_halo_import_sparse(gie_mapper *m, int face, const gie_halo_entry *in, int32_t count)
+{
+    int rc = gie_need_pose(m, "gie_halo_import_sparse"); if (rc) return rc;
+    const int n = (face < 0 || face > 5) ? -1 : gie_face_count(m->c, face);
+    if (n < 0 || count < 0 || count > n || (count > 0 && !in)) { gie_set_err("gie_halo_import_sparse: bad arguments"); return GIE_ERR_INVALID; }
+    if (count == 0) return GIE_OK;
+    char *d = (char *)gie_scratch(m, 1, (size_t)count * sizeof(gie_halo_entry) + 16, "gie_halo_import_sparse");
+    if (!d) return GIE_ERR_DEVICE;
+    be_h2d(&m->be, d, &count, sizeof(int32_t));
+    be_h2d(&m->be, d + 16, in, (size_t)count * sizeof(gie_halo_entry));
+    rc = gie_halo_import_sparse_dev(m, face, (const gie_halo_entry *)(d + 16), (const int32_t *)d);
+    be_sync(&m->be);
+    return rc;
+}
 /* several faces per call: one launch per step instead of one per face and step, and ONE block
  * allocation for all ghost layers (a 2x2x2 tile has three shared faces; the exchange is bound by
  * the number of small launches) */

@@ -214,6 +214,9 @@ struct op_tile_summary {
 struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
 struct op_halo_need { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_need_voxel(c, face, i, in); } };
 struct op_halo_import { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_import_voxel(c, face, i, in); } };
+struct op_halo_export_sparse { int face; gie_halo_entry *out; int32_t *count; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_sparse_voxel(c, face, i, out, count); } };
+struct op_halo_need_sparse { int face, nface; const gie_halo_entry *in; const int32_t *count; GIE_DEVM void operator()(const gie_ctx &c, int j) const { gie_halo_need_entry(c, face, j, in, count, nface); } };
+struct op_halo_import_sparse { int face, nface; const gie_halo_entry *in; const int32_t *count; GIE_DEVM void operator()(const gie_ctx &c, int j) const { gie_halo_import_entry(c, face, j, in, count, nface); } };
 /* the same three operations for several faces in one launch: item i belongs to the face whose
  * [off[f], off[f+1]) range holds it (faces without a buffer have an empty range) */
 struct gie_face_set { int off[7]; GIE_DEVM int face_of(int i) const { int f = 0; while (f < 5 && i >= off[f + 1]) f++; return f; } };

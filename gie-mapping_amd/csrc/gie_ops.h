@@ -1091,7 +1091,7 @@ GIE_HD int gie_face_count(const gie_ctx &c, int face)
 { const int axis = face >> 1; return axis == 0 ? c.Y * c.Z : (axis == 1 ? c.X * c.Z : c.X * c.Y); }
 
 /* committed state of the voxels on one face of the local volume */
-GIE_DEV void gie_halo_export_voxel(const gie_ctx &c, int face, int i, gie_halo_voxel *out)
+GIE_DEV gie_halo_voxel gie_halo_record(const gie_ctx &c, int face, int i)
 {
     int x, y, z;
     gie_face_coord(c, face, i, 0, &x, &y, &z);
@@ -1105,28 +1105,62 @@ GIE_DEV void gie_halo_export_voxel(const gie_ctx &c, int face, int i, gie_halo_v
         h.dist_sq = gie_gdist(c, c.g_coc[a], x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
         gie_unpack_crd(c.g_coc[a], &h.coc[0], &h.coc[1], &h.coc[2]);
     }
-    out[i] = h;
+    return h;
+}
+GIE_DEV void gie_halo_export_voxel(const gie_ctx &c, int face, int i, gie_halo_voxel *out) { out[i] = gie_halo_record(c, face, i); }
+/* the sparse form of a layer: the KNOWN voxels only, as (index in the layer, record), in no particular order (one counter update
+ * per wave).  An unknown ghost changes nothing on import, so the two forms are interchangeable. */
+GIE_DEV void gie_halo_export_sparse_voxel(const gie_ctx &c, int face, int i, gie_halo_entry *out, int32_t *count)
+{
+    const gie_halo_voxel h = gie_halo_record(c, face, i);
+    const bool known = h.vox_type != GIE_VOX_UNKNOWN;
+#if defined(GIE_HOST_EMU)
+    if (known) { const int s = gie_aadd32(count, 1); out[s].index = i; out[s].v = h; }
+#else
+    const unsigned long long m = __ballot(known);
+    if (!m) return;
+    const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = gie_aadd32(count, __popcll(m));
+    base = __shfl(base, leader);
+    if (known) { const int s = base + __popcll(m & ((1ull << lane) - 1ull)); out[s].index = i; out[s].v = h; }
+#endif
 }
 /* ghost voxels just outside `face`: mark the blocks they need … */
-GIE_DEV void gie_halo_need_voxel(const gie_ctx &c, int face, int i, const gie_halo_voxel *in)
+GIE_DEV void gie_halo_need_rec(const gie_ctx &c, int face, int i, const gie_halo_voxel &v)
 {
-    if (in[i].vox_type == GIE_VOX_UNKNOWN) return;
+    if (v.vox_type == GIE_VOX_UNKNOWN) return;
     int x, y, z;
     gie_face_coord(c, face, i, 1, &x, &y, &z);
     c.blk_need[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])] = 1;
 }
+GIE_DEV void gie_halo_need_voxel(const gie_ctx &c, int face, int i, const gie_halo_voxel *in) { gie_halo_need_rec(c, face, i, in[i]); }
 /* … and store them (type / dist² / coc of the owning tile) */
-GIE_DEV void gie_halo_import_voxel(const gie_ctx &c, int face, int i, const gie_halo_voxel *in)
+GIE_DEV void gie_halo_import_rec(const gie_ctx &c, int face, int i, const gie_halo_voxel &v)
 {
-    if (in[i].vox_type == GIE_VOX_UNKNOWN) return;
+    if (v.vox_type == GIE_VOX_UNKNOWN) return;
     int x, y, z;
     gie_face_coord(c, face, i, 1, &x, &y, &z);
     const gie_vaddr a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
     if (a < 0) return;
-    c.g_type[a] = in[i].vox_type;
-    c.g_occ[a] = in[i].occ_val;
-    c.g_coc[a] = gie_pack_crd(in[i].coc[0], in[i].coc[1], in[i].coc[2]);      /* (in[i].dist_sq is this obstacle's distance: the owner's record is a witness) */
+    c.g_type[a] = v.vox_type;
+    c.g_occ[a] = v.occ_val;
+    c.g_coc[a] = gie_pack_crd(v.coc[0], v.coc[1], v.coc[2]);      /* (v.dist_sq is this obstacle's distance: the owner's record is a witness) */
     gie_touch(c, a);
+}
+GIE_DEV void gie_halo_import_voxel(const gie_ctx &c, int face, int i, const gie_halo_voxel *in) { gie_halo_import_rec(c, face, i, in[i]); }
+/* the sparse form: entry j of `*count` (an index outside the layer is ignored) */
+GIE_DEV void gie_halo_need_entry(const gie_ctx &c, int face, int j, const gie_halo_entry *in, const int32_t *count, int nface)
+{
+    if (j >= *count) return;
+    const gie_halo_entry e = in[j];
+    if ((unsigned)e.index < (unsigned)nface) gie_halo_need_rec(c, face, e.index, e.v);
+}
+GIE_DEV void gie_halo_import_entry(const gie_ctx &c, int face, int j, const gie_halo_entry *in, const int32_t *count, int nface)
+{
+    if (j >= *count) return;
+    const gie_halo_entry e = in[j];
+    if ((unsigned)e.index < (unsigned)nface) gie_halo_import_rec(c, face, e.index, e.v);
 }
 /* obtainFrontiers' C-seed rule (unify_helper.cuh:365-399) for a face voxel against its ghost
  * neighbours, on the committed state: a ghost whose closest obstacle lies outside this tile and

@@ -123,6 +123,10 @@ DEVICE_ONLY = {
     "halo_export_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "halo_import_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "halo_import_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
+    "halo_export_sparse": (C.c_int, [_H, C.c_int, C.c_void_p, c_i32p]),
+    "halo_import_sparse": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int32]),
+    "halo_export_sparse_dev": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
+    "halo_import_sparse_dev": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "ogm_multiscan_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(MultiScanParam)]),
     "ogm_depth_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(CamParam)]),
     "ogm_labels_dev": (C.c_int, [_H, C.c_void_p]),

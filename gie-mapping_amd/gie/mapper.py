@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_PKG, "csrc", "libgie_hip.so")
 
 SEENDIST_DTYPE = np.dtype([("d", "<f4"), ("s", "u1"), ("o", "u1"), ("pad", "u1", (2,))])
 HALO_DTYPE = np.dtype([("dist_sq", "<i4"), ("coc", "<i4", (3,)), ("vox_type", "i1"), ("occ_val", "u1"), ("pad", "i1", (2,))])
+HALO_ENTRY_DTYPE = np.dtype([("index", "<i4"), ("v", HALO_DTYPE)])          # gie_halo_entry: a known voxel of a sparse face layer
 VOXEL_DTYPE = np.dtype([("occ_val", "u1"), ("vox_type", "i1"), ("pad", "<i2"), ("dist_sq", "<i4"),
                         ("coc", "<i4", (3,))])
 
@@ -218,6 +219,18 @@ class MapperBase:
         assert layer.shape[0] == self._f["halo_count"](self._h, face)
         self._chk(self._f["halo_import"](self._h, face, _ptr(layer)))
 
+    def halo_export_sparse(self, face):
+        """The layer's known voxels only: array of HALO_ENTRY_DTYPE (index in the layer, record), in no particular order."""
+        n = self._f["halo_count"](self._h, face)
+        out = np.empty(n, HALO_ENTRY_DTYPE)
+        cnt = C.c_int32(0)
+        self._chk(self._f["halo_export_sparse"](self._h, face, _ptr(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def halo_import_sparse(self, face, entries):
+        entries = np.ascontiguousarray(entries, dtype=HALO_ENTRY_DTYPE)
+        self._chk(self._f["halo_import_sparse"](self._h, face, _ptr(entries), int(entries.shape[0])))
+
     def refine(self):
         n = C.c_int32(0)
         self._chk(self._f["refine"](self._h, C.byref(n)))
@@ -331,6 +344,12 @@ class Mapper(MapperBase):
 
     def halo_count(self, face):
         return self._f["halo_count"](self._h, face)
+
+    def halo_export_sparse_dev(self, face, dptr, dcount):
+        self._chk(self._f["halo_export_sparse_dev"](self._h, face, C.c_void_p(dptr), C.c_void_p(dcount)))
+
+    def halo_import_sparse_dev(self, face, dptr, dcount):
+        self._chk(self._f["halo_import_sparse_dev"](self._h, face, C.c_void_p(dptr), C.c_void_p(dcount)))
 
     def halo_export_dev(self, face, dptr):
         self._chk(self._f["halo_export_dev"](self._h, face, C.c_void_p(dptr)))

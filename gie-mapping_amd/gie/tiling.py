@@ -83,10 +83,11 @@ def neighbours(rank, world_size):
 # Mark-time state.  Round 0 exports / imports them and finishes the merge (gie_merge_end: obtainFrontiers + waves with fresh
 # ghosts); the rounds after it are export / import / gie_refine.
 
-def exchange_until_stable_local(mappers, grid, max_rounds=64):
+def exchange_until_stable_local(mappers, grid, max_rounds=64, sparse=False, sent=None):
     """All tiles live in this process (tests, single-GPU checks): export every shared face, hand
     it to the neighbour, finish the merge (round 0) or refine, repeat until no tile seeded anything.
-    Returns the refinement rounds run."""
+    Returns the refinement rounds run.  sparse=True: the layers travel in their sparse form (known voxels only,
+    gie_halo_export_sparse / gie_halo_import_sparse); `sent` (a list) collects the bytes of every layer handed over."""
     world = grid[0] * grid[1] * grid[2]
     assert world == len(mappers)
     rounds = 0
@@ -94,9 +95,14 @@ def exchange_until_stable_local(mappers, grid, max_rounds=64):
         layers = {}
         for r, m in enumerate(mappers):
             for face, nb in neighbours(r, world).items():
-                layers[(nb, face ^ 1)] = m.halo_export(face)
+                layers[(nb, face ^ 1)] = m.halo_export_sparse(face) if sparse else m.halo_export(face)
+                if sent is not None:
+                    sent.append(layers[(nb, face ^ 1)].nbytes)
         for (r, face), layer in layers.items():
-            mappers[r].halo_import(face, layer)
+            if sparse:
+                mappers[r].halo_import_sparse(face, layer)
+            else:
+                mappers[r].halo_import(face, layer)
         if k == 0:
             for m in mappers:
                 m.merge_end()
@@ -147,33 +153,60 @@ def exchange_until_stable_local_device(mappers, grid, device, max_rounds=64, buf
     return rounds
 
 
-def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=None, max_rounds=64, group=None):
+def exchange_until_stable_device(mapper, dist, rank, world_size, device, bufs=None, max_rounds=64, group=None, sparse=False):
     """Device-resident form of exchange_until_stable for backend "nccl" (RCCL over xGMI): the
     face layers are written by the export kernel straight into the send tensors and read by the
-    import kernel from the receive tensors; nothing crosses PCIe except the seed count."""
+    import kernel from the receive tensors; nothing crosses PCIe except the seed count.
+    sparse=True: gie_halo_export_sparse_dev compacts the known voxels of a layer; the neighbours exchange the entry counts
+    (one more small batch and one host read per round — this form waits for the host anyway), then only that many entries."""
     import torch
     nbs = neighbours(rank, world_size)
     if bufs is None:
         bufs = {}
+    esz = 24 if sparse else 20
     for face in nbs:
         if face not in bufs:
-            n = mapper.halo_count(face) * 20
+            n = mapper.halo_count(face) * esz
             bufs[face] = (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
+            if sparse:
+                bufs[("count", face)] = (torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device))
     rounds = 0
     for k in range(max_rounds + 1):
         ops = []
-        for face, nb in sorted(nbs.items()):
-            snd, rcv = bufs[face]
-            mapper.halo_export_dev(face, snd.data_ptr())
-            ops.append(dist.P2POp(dist.isend, snd, nb, group=group))
-            ops.append(dist.P2POp(dist.irecv, rcv, nb, group=group))
-        mapper.sync()                                   # export kernels ran on the mapper's own stream
+        if sparse:
+            cops = []
+            for face, nb in sorted(nbs.items()):
+                cs, cr = bufs[("count", face)]
+                mapper.halo_export_sparse_dev(face, bufs[face][0].data_ptr(), cs.data_ptr())
+                cops.append(dist.P2POp(dist.isend, cs, nb, group=group))
+                cops.append(dist.P2POp(dist.irecv, cr, nb, group=group))
+            mapper.sync()
+            if cops:
+                for w in dist.batch_isend_irecv(cops):
+                    w.wait()
+                torch.cuda.synchronize(device)
+            for face, nb in sorted(nbs.items()):
+                ns, nr = int(bufs[("count", face)][0].item()), int(bufs[("count", face)][1].item())
+                if ns:
+                    ops.append(dist.P2POp(dist.isend, bufs[face][0][:ns * esz], nb, group=group))
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, bufs[face][1][:nr * esz], nb, group=group))
+        else:
+            for face, nb in sorted(nbs.items()):
+                snd, rcv = bufs[face]
+                mapper.halo_export_dev(face, snd.data_ptr())
+                ops.append(dist.P2POp(dist.isend, snd, nb, group=group))
+                ops.append(dist.P2POp(dist.irecv, rcv, nb, group=group))
+            mapper.sync()                               # export kernels ran on the mapper's own stream
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             torch.cuda.synchronize(device)
         for face in sorted(nbs):
-            mapper.halo_import_dev(face, bufs[face][1].data_ptr())
+            if sparse:
+                mapper.halo_import_sparse_dev(face, bufs[face][1].data_ptr(), bufs[("count", face)][1].data_ptr())
+            else:
+                mapper.halo_import_dev(face, bufs[face][1].data_ptr())
         if k == 0:
             mapper.merge_end()
             continue
@@ -262,30 +295,53 @@ def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
     return rounds
 
 
-def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64, group=None):
+def exchange_until_stable(mapper, dist, rank, world_size, device=None, max_rounds=64, group=None, sparse=False):
     """One tile per rank: face layers travel with torch.distributed point-to-point ops (RCCL over
     xGMI with backend "nccl", gloo on CPU); a 1-int all-reduce(sum) of the seed counts is the
-    convergence test.  Returns the refinement rounds run."""
+    convergence test.  Returns the refinement rounds run.  sparse=True: only the known voxels of a layer travel
+    (gie_halo_export_sparse); the neighbours tell each other the entry counts first, so a round is two batches."""
     import torch
-    from .mapper import HALO_DTYPE
+    from .mapper import HALO_DTYPE, HALO_ENTRY_DTYPE
     nbs = neighbours(rank, world_size)
     rounds = 0
     for k in range(max_rounds + 1):
         sends, recvs, ops = {}, {}, []
+        if sparse:
+            lays = {face: mapper.halo_export_sparse(face) for face in sorted(nbs)}
+            cs = {face: torch.tensor([lays[face].shape[0]], dtype=torch.int64) for face in lays}
+            cr = {face: torch.zeros(1, dtype=torch.int64) for face in lays}
+            if device is not None:
+                cs = {f: t.to(device) for f, t in cs.items()}; cr = {f: t.to(device) for f, t in cr.items()}
+            cops = []
+            for face, nb in sorted(nbs.items()):
+                cops.append(dist.P2POp(dist.isend, cs[face], nb, group=group))
+                cops.append(dist.P2POp(dist.irecv, cr[face], nb, group=group))
+            if cops:
+                for w in dist.batch_isend_irecv(cops):
+                    w.wait()
         for face, nb in sorted(nbs.items()):
-            lay = mapper.halo_export(face)
-            t = torch.from_numpy(lay.view(np.uint8).copy())
-            r = torch.empty_like(t)
+            if sparse:
+                t = torch.from_numpy(lays[face].view(np.uint8).copy())
+                r = torch.empty(int(cr[face].item()) * HALO_ENTRY_DTYPE.itemsize, dtype=torch.uint8)
+            else:
+                lay = mapper.halo_export(face)
+                t = torch.from_numpy(lay.view(np.uint8).copy())
+                r = torch.empty_like(t)
             if device is not None:
                 t, r = t.to(device), r.to(device)
             sends[face], recvs[face] = t, r
-            ops.append(dist.P2POp(dist.isend, t, nb, group=group))
-            ops.append(dist.P2POp(dist.irecv, r, nb, group=group))
+            if t.numel():
+                ops.append(dist.P2POp(dist.isend, t, nb, group=group))
+            if r.numel():
+                ops.append(dist.P2POp(dist.irecv, r, nb, group=group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         for face in sorted(nbs):
-            mapper.halo_import(face, recvs[face].cpu().numpy().view(HALO_DTYPE))
+            if sparse:
+                mapper.halo_import_sparse(face, recvs[face].cpu().numpy().view(HALO_ENTRY_DTYPE))
+            else:
+                mapper.halo_import(face, recvs[face].cpu().numpy().view(HALO_DTYPE))
         if k == 0:
             mapper.merge_end()
             continue

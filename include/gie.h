@@ -261,6 +261,16 @@ int gie_halo_import(gie_mapper *h, int face, const gie_halo_voxel *in);
 /* same with DEVICE buffers (RCCL send/recv tensors), asynchronous on the mapper's stream */
 int gie_halo_export_dev(gie_mapper *h, int face, gie_halo_voxel *d_out);
 int gie_halo_import_dev(gie_mapper *h, int face, const gie_halo_voxel *d_in);
+/* SPARSE face layers: only the KNOWN voxels of a layer, as (index in the layer, record) in no particular order.  An unknown ghost
+ * changes nothing on import, so the two forms are interchangeable and may be mixed from round to round; a layer of a sparsely
+ * observed face (a lidar's) is a few per cent of the dense one, a fully observed face (BASELINE config 5) gains nothing.  `out`
+ * holds gie_halo_count(face) entries at most; the count travels with the payload (the _dev forms keep it on the device: the
+ * import launches over the whole layer and looks at the first *d_count entries, so nothing waits for the host). */
+typedef struct gie_halo_entry { int32_t index; gie_halo_voxel v; } gie_halo_entry;
+int gie_halo_export_sparse(gie_mapper *h, int face, gie_halo_entry *out, int32_t *count);
+int gie_halo_import_sparse(gie_mapper *h, int face, const gie_halo_entry *in, int32_t count);
+int gie_halo_export_sparse_dev(gie_mapper *h, int face, gie_halo_entry *d_out, int32_t *d_count);
+int gie_halo_import_sparse_dev(gie_mapper *h, int face, const gie_halo_entry *d_in, const int32_t *d_count);
 /* returns the number of voxels seeded from ghost neighbours in *seeded (0 = nothing changed) */
 /* Several faces in one call (NULL entry = face not exchanged): one launch per step for all of
  * them and one block allocation for all ghost layers. */

@@ -74,7 +74,7 @@ def test_two_ranks_gloo():
     assert p1[0] - p0[0] == 32 and p1[1] == p0[1] and p1[2] == p0[2]   # adjacent, non-overlapping local volumes
 
 
-def _worker_halo(rank, world, port, out):
+def _worker_halo(rank, world, port, out, sparse=False):
     sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -91,7 +91,7 @@ def _worker_halo(rank, world, port, out):
     res = []
     for pos, q, img in T._sensor_frames(4):
         m.update(pos, q, "multiscan", img, tiled=True, **T.KW)
-        rounds = tiling.exchange_until_stable(m, dist, rank, world)
+        rounds = tiling.exchange_until_stable(m, dist, rank, world, sparse=sparse)
         r = m.read_local()
         res.append((rounds, r["type"].copy(), r["dist_sq"].copy(), r["coc"].copy()))
     m.close()
@@ -99,15 +99,17 @@ def _worker_halo(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_halo_exchange_matches_in_process_exchange(oracle_lib):
+@pytest.mark.parametrize("sparse", [False, True], ids=["dense_layers", "sparse_layers"])
+def test_two_ranks_halo_exchange_matches_in_process_exchange(oracle_lib, sparse):
     """The torch.distributed exchange (isend/irecv + all-reduce of the seed count) must give each
-    rank exactly what the in-process exchange of the oracle gives the corresponding tile."""
+    rank exactly what the in-process exchange of the oracle gives the corresponding tile — with dense face layers and
+    with sparse ones (entry counts first, then the known voxels only)."""
     import test_tiling_halo as T
     from oracle_py import OracleMapper
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_halo, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_halo, args=(r, 2, port, q, sparse)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=600) for _ in procs)
