@@ -2243,7 +2243,9 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
         np = L.npend[pi ^ 1];
     }
     GIE_WPROF_MARK(0);                                                   /* 2: levels inside the block */
-    /* ---- write back what changed; the voxels that were lowered with a pair join wave B's seeds (one counter update per block) */
+    /* ---- write back what changed; the voxels that were lowered with a pair join wave B's seeds (one counter update per block);
+     * neighbour blocks that received a proposal take part in the next round.  The counter update and the six flag exchanges are in
+     * flight together, the append to the block list follows (two dependent round trips, not three). */
     {
         int npush = 0;
         unsigned f8[8];
@@ -2252,10 +2254,20 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
             f8[j] = L.flag[lane + 64 * j];
             npush += __popcll(__ballot((f8[j] & GIE_WA_PUSHB) != 0u));
         }
-        int qbase = 0;
-        if (npush > 0) {
-            if (lane == 0) qbase = gie_aadd32(&c.cnt[GIE_CNT_B], npush);
-            qbase = __shfl(qbase, 0);
+        unsigned any6 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
+        const bool act = lane < 6 && ((any6 >> lane) & 1u);
+        const int ns = act ? L.nslot[lane] : 0;
+        int32_t r1 = 1;
+        if (act) r1 = gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1);
+        if (lane == 63 && npush > 0) r1 = gie_aadd32(&c.cnt[GIE_CNT_B], npush);
+        const int qbase = __shfl(r1, 63);
+        const bool first = act && r1 == 0;
+        const unsigned long long fm = __ballot(first);
+        int ab0 = 0;
+        if (fm != 0ull) {
+            if (lane == 0) ab0 = gie_aadd32(&c.lvla_next[round + 1], __popcll(fm));
         }
         int before = 0;
 #pragma unroll
@@ -2276,14 +2288,9 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
             }
             before += __popcll(m);
         }
-    }
-    {
-        unsigned any6 = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
-        if (lane < 6 && ((any6 >> lane) & 1u)) {
-            const int ns = L.nslot[lane];
-            gie_list_append_wave(c.wb_list[(round + 1) & 1], &c.lvla_next[round + 1], gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0, ns);
+        if (fm != 0ull) {
+            ab0 = __shfl(ab0, 0);
+            if (first) gie_st(&c.wb_list[(round + 1) & 1][ab0 + __popcll(fm & ((1ull << lane) - 1ull))], (int32_t)ns);
         }
     }
     {
@@ -2544,19 +2551,16 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
             gie_touch(c, base + v);
         }
     }
-    /* ---- neighbour blocks that received a proposal take part in the next round */
+    /* ---- (i) neighbour blocks that received a proposal take part in the next round; (ii) what the block-run proposes to voxels
+     * inside the volume goes to the face table, which takes the minimum of the whole wave — whoever finds a voxel's slot empty
+     * lists the voxel.  Two stages of returning atomics, each stage of BOTH in flight together (a block-run is a chain of dependent
+     * round trips: four here would be a fifth of it): flag exchanges + table minima, then the two list appends. */
     {
         unsigned any6 = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
-        if (lane < 6 && ((any6 >> lane) & 1u)) {
-            const int ns = L.nslot[lane];
-            gie_list_append_wave(c.wb_list[(round + 1) & 1], &c.lvlb_next[round + 1], gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1) == 0, ns);
-        }
-    }
-    /* ---- what the block-run proposes to voxels inside the volume: the face table takes the minimum of the whole wave; whoever
-     * finds a voxel's slot empty lists the voxel (all of the block-run's minima in flight together, one list append per block-run) */
-    {
+        const bool act = lane < 6 && ((any6 >> lane) & 1u);
+        const int ns = act ? L.nslot[lane] : 0;
         const int p = lane & 7, q = lane >> 3;
         const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
         uint64_t key[14], old[14];
@@ -2572,25 +2576,37 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
             nid[t] = gie_lid(c, x, y, z); bi[t] = gie_bdr_index(c, x, y, z);
             hitm |= 1u << t;
         }
-        if (__ballot(hitm != 0u) != 0ull) {
+        const bool anyhit = __ballot(hitm != 0u) != 0ull;
+        /* stage 1 */
+        int32_t fx = 1;
+        if (act) fx = gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1);
+        if (anyhit) {
 #pragma unroll
             for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) old[t] = gie_amin64(&c.lprop[bi[t]], key[t]);
-            int mine = 0;
+        }
+        const bool first = act && fx == 0;
+        const unsigned long long fm = __ballot(first);
+        int mine = 0;
 #pragma unroll
-            for (int t = 0; t < 14; t++) if (((hitm >> t) & 1u) && old[t] == GIE_NOPROP) mine++; else hitm &= ~(1u << t);
-            int incl = mine;                                /* inclusive prefix sum over the lanes */
+        for (int t = 0; t < 14; t++) if (((hitm >> t) & 1u) && old[t] == GIE_NOPROP) mine++; else hitm &= ~(1u << t);
+        int incl = mine;                                    /* inclusive prefix sum over the lanes */
+        if (anyhit) {
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
-            const int total = __shfl(incl, 63);
-            if (total > 0) {
-                int qb = 0;
-                if (lane == 0) qb = gie_aadd32(&c.cnt[GIE_CNT_INL], total);
-                qb = __shfl(qb, 0) + incl - mine;
+        }
+        const int total = anyhit ? __shfl(incl, 63) : 0;
+        /* stage 2: lane 0 appends to the list of voxels, lane 1 to the list of blocks */
+        int base = 0;
+        if (lane == 0 && total > 0) base = gie_aadd32(&c.cnt[GIE_CNT_INL], total);
+        if (lane == 1 && fm != 0ull) base = gie_aadd32(&c.lvlb_next[round + 1], __popcll(fm));
+        const int qb0 = __shfl(base, 0), ab0 = __shfl(base, 1);
+        if (first) gie_st(&c.wb_list[(round + 1) & 1][ab0 + __popcll(fm & ((1ull << lane) - 1ull))], (int32_t)ns);
+        if (total > 0) {
+            int qb = qb0 + incl - mine;
 #pragma unroll
-                for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) {
-                    if (qb < c.qcap_c) gie_st(&c.qc[1][qb], (int32_t)nid[t]); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
-                    qb++;
-                }
+            for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) {
+                if (qb < c.qcap_c) gie_st(&c.qc[1][qb], (int32_t)nid[t]); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+                qb++;
             }
         }
     }
