@@ -265,7 +265,6 @@ template <int CP, int TX, int WAVES> static void gie_launch_edt_z(be_state *b, c
 template <int CP> static void gie_launch_edt_xz(be_state *b, const gie_ctx &c, bool zpass, int full)
 {
     if (!zpass) {
-        const int rows = c.Y * c.Z;
         GIE_LAUNCH(b, k_edt_x<CP>, dim3((c.Y + GIE_EDTX_WAVES - 1) / GIE_EDTX_WAVES, c.Z), dim3(64 * GIE_EDTX_WAVES), 0, c);
     } else {
         gie_launch_edt_z<CP, 16, 8>(b, c, full);      /* 2 workgroups per CU overlap load / envelope / store phases */
@@ -309,8 +308,6 @@ static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
     else if (lx == 64) GIE_LAUNCH(b, k_markc<64>, g, t, 0, c, list);
     else GIE_LAUNCH(b, k_markc<32>, g, t, 0, c, list);
 }
-/* lanes of a wave along x in the sweep form of the kernels that touch the global block planes */
-static int be_sweep_lx(const char *env, int dflt) { const char *e = getenv(env); const int v = e ? atoi(e) : dflt; return (v == 8 || v == 16 || v == 32) ? v : 64; }
 /* dense (block-row) form of fuse; GIE_ROWS=0 keeps the thread-per-z-column sweep */
 static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(getenv("GIE_ROWS")) : 1; return v ? 2 : 0; }
 /* fuse: one launch — the kernel walks its tile list (a wave per tile) or sweeps the volume by block rows, whichever the list's

@@ -2154,7 +2154,6 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
     GIE_WPROF_MARK(0);                                                   /* 1: halo + own records into LDS */
     unsigned xmask = 0;
     int nvis = 0;
-    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     for (int sub = 0; np > 0; sub++) {
         GIE_WPROF_ADD(6, 1);
         const int pi = sub & 1;

@@ -469,6 +469,7 @@ GIE_DEV void gie_fuse_load1(const gie_ctx &c, int id, int x, int y, int z, gie_f
 }
 GIE_DEV void gie_fuse_load2(const gie_ctx &c, gie_fuse_st &s)
 {
+    s.occ = 0; s.ty = GIE_VOX_UNKNOWN;
     if (s.a < 0) return;
     s.occ = c.g_occ[s.a];
     s.ty = c.g_type[s.a];

@@ -82,8 +82,6 @@ static void be_vox_list_col(const gie_ctx &c, const op_markc &f, int x, int y, i
     for (int z = z0; z < z0 + 8 && z < c.Z; z++) { valid |= 1u << (z - z0); if (f.skip(c, gie_lid(c, x, y, z), x, y, z)) continue; const int r = f(c, x, y, z); if (r) known |= 1u << (z - z0); if (r > vmax) vmax = r; }
     f.column_max(c, x, y, z0, known, valid, vmax);
 }
-static int be_sweep_lx(const char *, int dflt) { return dflt; }
-static int be_rows_mode() { return 0; }
                        /* the block-row kernels are device-only forms of the same functors */
 
 template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, int always_list, int = 64)
