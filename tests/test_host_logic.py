@@ -185,3 +185,24 @@ def test_rejected_pose_leaves_the_mapper_untouched_and_fuse_needs_a_scan():
             m.fuse()                                  # the scan was consumed
     finally:
         m.close()
+
+
+def test_random_scenarios_emulation_matches_oracle(oracle_lib):
+    """tools/fuzz_parity.py's generator (random volume shapes, sensors, drives, cut-offs, modes, block retention) on the emulated device
+    logic: a fixed seed's first scenarios (the GPU form ran 4 185 of them: profiles/r03_fuzz_parity_seed11_summary.txt)."""
+    import importlib.util
+    import numpy as np
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from emu_py import EmuMapper
+    rng = np.random.default_rng(7)
+    ran = 0
+    for i in range(40):
+        sc = fz.random_scenario(rng, i)
+        if sc.size[0] * sc.size[1] * sc.size[2] > 64 * 64 * 40:
+            continue                                   # (keeps the CPU suite short; the generator's stream stays the same)
+        parity.run_and_compare(sc, OracleMapper, EmuMapper, production=bool(i % 2))
+        ran += 1
+    assert ran >= 15
