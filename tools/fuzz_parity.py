@@ -33,8 +33,55 @@ def random_scenario(rng, i):
     return parity.Scenario("fuzz%d" % i, size, **kw)
 
 
+def run_tiled(rng, i, Under, OracleMapper):
+    """A random TILED hash world: 2 / 4 / 8 block-aligned tiles of one volume, face layers exchanged in process until no tile
+    changes (dense or sparse layers), the oracle's tiles against the tiles of the mapper under test, bit for bit."""
+    import gie
+    from gie import scenes, tiling
+    world = int(rng.choice([2, 4, 8]))
+    grid = tiling.tile_grid(world)
+    tile = tuple(int(rng.choice([8, 16, 24, 32, 40])) for _ in range(3))
+    whole = tuple(grid[a] * tile[a] for a in range(3))
+    voxel = float(rng.choice([0.05, 0.1]))
+    cut = float(rng.choice([0.3, 0.5, 1.0, 100.0])) * (voxel / 0.05)
+    frames, delta, seed = int(rng.integers(3, 8)), int(rng.integers(0, 10)), int(rng.integers(1, 1000))
+    p_occ, toggle, sparse = float(rng.choice([0.003, 0.01, 0.03])), float(rng.choice([0.0, 0.25, 0.5])), bool(rng.random() < 0.5)
+    desc = "tiled%d %d tiles of %s voxel %.2f frames %d delta %d cutoff %.1f p_occ %.3f toggle %.2f %s" % (
+        i, world, tile, voxel, frames, delta, cut, p_occ, toggle, "sparse layers" if sparse else "dense layers")
+    cfg = gie.make_config(voxel, tile, cutoff_dist=cut)
+
+    def run(make, sp):
+        ms, out = [], []
+        for r in range(world):
+            m = make(cfg); m.set_tile(tiling.tile_offset_voxels(r, world, tile), whole); ms.append(m)
+        try:
+            for k in range(frames):
+                pos, q = scenes.pose(k, voxel, delta_vox=delta, yaw_deg=2.0)
+                for r, m in enumerate(ms):
+                    pvt = scenes.local_pivot(pos, voxel, tile, tiling.tile_offset_voxels(r, world, tile))
+                    m.set_pose(pos, q)
+                    m.ogm_labels(scenes.hash_world_labels(pvt, tile, k, seed=seed, p_occ=p_occ, toggle_frac=toggle).astype(np.int8))
+                    m.fuse(); m.batch_edt(); m.merge_begin_tiled()
+                rounds = tiling.exchange_until_stable_local(ms, grid, sparse=sp)
+                out.append((rounds, [m.read_local() for m in ms], [m.stats() for m in ms]))
+        finally:
+            for m in ms:
+                m.close()
+        return out
+    want, got = run(OracleMapper, False), run(Under, sparse)
+    for k, ((ra, la, sa), (rb, lb, sb)) in enumerate(zip(want, got)):
+        assert ra == rb, "%s frame %d: %d vs %d refinement rounds" % (desc, k, ra, rb)
+        for t in range(world):
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(la[t][key], lb[t][key]), "%s frame %d tile %d: %s differs" % (desc, k, t, key)
+            for key in ("visits_a", "visits_b", "blocks_total"):       # (wave C runs once per refinement round: its counters are per launch)
+                assert sa[t][key] == sb[t][key], "%s frame %d tile %d: stat %s %d != %d" % (desc, k, t, key, sa[t][key], sb[t][key])
+    return desc, [sum(s[t][key] for _, _, s in want for t in range(world)) for key in ("visits_a", "visits_b", "visits_c")]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tiled", action="store_true", help="random tiled hash worlds (2 / 4 / 8 tiles, in-process exchange) instead of single volumes")
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--emu", action="store_true")
@@ -49,7 +96,15 @@ def main():
         Under = gie.Mapper
     rng = np.random.default_rng(args.seed)
     t0, i, ok = time.time(), 0, 0
-    while time.time() - t0 < 60.0 * args.minutes:
+    while args.tiled and time.time() - t0 < 60.0 * args.minutes:
+        try:
+            desc, v = run_tiled(rng, i, Under, OracleMapper)
+        except AssertionError as e:
+            print("MISMATCH seed %d #%d: %s" % (args.seed, i, str(e).splitlines()[0]), flush=True)
+            sys.exit(1)
+        i += 1; ok += 1
+        print("ok %s | visits %d/%d/%d" % (desc, v[0], v[1], v[2]), flush=True)
+    while not args.tiled and time.time() - t0 < 60.0 * args.minutes:
         sc = random_scenario(rng, i)
         i += 1
         if args.only >= 0 and i - 1 != args.only:
