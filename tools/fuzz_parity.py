@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd"), os.path.join(ROOT, "tests")]
 
 
-def random_scenario(rng, i):
+def random_scenario(rng, i, big=False):
     import parity
-    dims = [8, 16, 24, 29, 32, 37, 40, 48, 56, 64, 72, 96]
+    dims = [96, 120, 128, 152, 160, 192] if big else [8, 16, 24, 29, 32, 37, 40, 48, 56, 64, 72, 96]
     size = tuple(int(rng.choice(dims)) for _ in range(3))
     if rng.random() < 0.15:
         size = (size[0], size[1], int(rng.choice([1, 8, 11, 16])))
@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--emu", action="store_true")
+    ap.add_argument("--big", action="store_true", help="volume sides of 96 ... 192 voxels (thousands of active blocks per wave round)")
     ap.add_argument("--only", type=int, default=-1, help="run scenario number N of the seed only")
     args = ap.parse_args()
     import gie
@@ -105,7 +106,7 @@ def main():
         i += 1; ok += 1
         print("ok %s | visits %d/%d/%d" % (desc, v[0], v[1], v[2]), flush=True)
     while not args.tiled and time.time() - t0 < 60.0 * args.minutes:
-        sc = random_scenario(rng, i)
+        sc = random_scenario(rng, i, args.big)
         i += 1
         if args.only >= 0 and i - 1 != args.only:
             continue
