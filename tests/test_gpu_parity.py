@@ -75,7 +75,12 @@ def test_voxel_addresses_beyond_2_to_31(oracle_lib, monkeypatch):
     def big_pool(cfg):
         big = type(cfg).from_buffer_copy(cfg)
         big.max_blocks = 4300000
-        return gie.Mapper(big)
+        try:
+            return gie.Mapper(big)
+        except RuntimeError as e:
+            if "allocation failed" in str(e):
+                pytest.skip("the device cannot hold an 84 GB block pool right now")
+            raise
 
     for name in ("c5_hash_world", "mixed", "raycast"):
         sc = [x for x in SCENARIOS if x.name == name][0]
