@@ -105,7 +105,9 @@ typedef struct gie_costmap_hdr {
     uint8_t pad[3];
 } gie_costmap_hdr;
 
-/* SeenDist payload element, local_batch.h:19-24 (8 bytes). */
+/* SeenDist payload element, local_batch.h:19-24 (8 bytes: float d; bool s; bool o; 2 bytes of tail padding).
+ * d = _edt_D in VOXEL units; o = `bool` converted from the voxel's type (local_batch.h:389): 1 for FREE /
+ * OCCUPIED / FNT, 0 for UNKNOWN; s is never written by the reference (here: 0, padding 0). */
 typedef struct gie_seendist {
     float d;
     uint8_t s;

@@ -1326,10 +1326,11 @@ int go_read_batch_edt(gie_oracle *o, int32_t *dist_sq, int32_t *coc)
     }
     return 0;
 }
-/* LocMap::convertCostMap (local_batch.h:382-391): d = edt, o = type, s untouched (App. B #9) */
+/* LocMap::convertCostMap (local_batch.h:382-391): d = edt, o = (bool)type -- SeenDist.o is a `bool` assigned from a
+ * `char` (local_batch.h:19-24,389), so it is 1 for every known type and 0 for UNKNOWN --, s untouched (App. B #9) */
 int go_read_costmap(gie_oracle *o, gie_seendist *payload, gie_costmap_hdr *hdr)
 {
-    if (payload) for (int i = 0; i < o->N; i++) { payload[i].d = o->edt[i]; payload[i].s = 0; payload[i].o = (uint8_t)o->glb_type[i]; payload[i].pad[0] = payload[i].pad[1] = 0; }
+    if (payload) for (int i = 0; i < o->N; i++) { payload[i].d = o->edt[i]; payload[i].s = 0; payload[i].o = (uint8_t)(o->glb_type[i] != 0); payload[i].pad[0] = payload[i].pad[1] = 0; }
     if (hdr) {
         hdr->x_size = o->X; hdr->y_size = o->Y; hdr->z_size = o->Z;
         hdr->x_origin = o->msg_origin[0]; hdr->y_origin = o->msg_origin[1]; hdr->z_origin = o->msg_origin[2];
