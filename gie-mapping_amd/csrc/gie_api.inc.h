@@ -33,6 +33,7 @@ struct gie_mapper {
     int pool_base;                        /* GIE_DEBUG_POOL_BASE (tests): the slots below it are never handed out */
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
     int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
+    int flush_tab_ok;                     /* ... and _glb_type / the block table are still that update's (no gie_fuse since) */
     int commit_pvt[3], commit_upvt[3], commit_tb0[3];   /* pivots / block-table origin of that merge */
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
     int ogm_unlabelled;                   /* ray-cast scan whose _inst_type labels have not been written (gie_read_ogm does it) */
@@ -106,7 +107,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0; m->fuse_fresh = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -440,17 +441,24 @@ extern "C" int gie_fuse(gie_mapper *m)
     if (!m->has_ogm) { gie_set_err("gie_fuse: no scan has been fed since the last fuse (call gie_ogm_* first)"); return GIE_ERR_INVALID; }
     m->has_ogm = 0;
     m->ogm_unlabelled = 0;                /* fuse consumes the scan */
+    const int unmerged = m->deferred && !m->flush_tab_ok;   /* types and block table are no longer those of the last fused merge: a gie_fuse
+                                                              without a merge came in between (the staged ABI allows it) */
     m->fuse_fresh = 1;
     be_time(&m->be, 2);
     /* allocHashTB (glb_hash_map.cu:58-113): flag missing blocks, rank them with an exclusive
      * scan, insert + initialise, then resolve the frame's block table */
     be_prof(&m->be, GIE_K_ALLOC, 0);
-    const int was_fused = m->deferred;    /* the map update before this one ran fused (and nothing has been merged since) */
+    const int was_fused = m->deferred && !unmerged;    /* the map update before this one ran fused, and it was the one before */
     if (m->deferred) {
         /* the stored pairs the last (fused) merge left out, for the voxels that are not in this volume any more; before
-         * anything of that update — types, pairs, block table — is overwritten, and before blocks are erased */
+         * anything of that update — types, pairs, block table — is overwritten, and before blocks are erased.
+         * `deferred` stays set until the next merge: when fuses follow each other without one, every one of them
+         * flushes what has left the volume of that LAST MERGE by now — the local pair plane is still that merge's — finding
+         * the blocks through the hash (types and block table are the un-merged fuse's by then); a record flushed before has
+         * lost its mark and is left alone. */
         const gie_ctx &c = m->c;
         op_pair_flush op;
+        op.b.rehash = unmerged;
         const int sz[3] = { c.X, c.Y, c.Z };
         int w[3];
         for (int i = 0; i < 3; i++) {
@@ -464,7 +472,6 @@ extern "C" int gie_fuse(gie_mapper *m)
         if (w[0] == 0 || w[1] == 0 || w[2] == 0) { for (int i = 0; i < 3; i++) { op.b.lo[i] = op.b.hi[i] = 0; w[i] = 0; } }   /* nothing stays */
         op.b.n0 = (c.X - w[0]) * c.Y * c.Z; op.b.n1 = w[0] * (c.Y - w[1]) * c.Z; op.b.n2 = w[0] * w[1] * (c.Z - w[2]);
         be_lin(&m->be, c, op, op.b.n0 + op.b.n1 + op.b.n2);
-        m->deferred = 0;
     }
     if (m->c.retain > 0) {
         /* block-pool lifecycle (gie_config.retain_radius_blocks): erase what lies too far behind, before anything is allocated;
@@ -511,6 +518,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_fuse(&m->be, m->c, m->c.tl_front);
     be_prof(&m->be, GIE_K_FUSE, 1);
     be_time(&m->be, 3);
+    m->flush_tab_ok = 0;
     return GIE_OK;
 }
 
@@ -555,7 +563,8 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
     m->merge_open = 1;
-    if (m->c.fused) { m->deferred = 1; for (int i = 0; i < 3; i++) { m->commit_pvt[i] = m->c.pvt[i]; m->commit_upvt[i] = m->c.upvt[i]; m->commit_tb0[i] = m->c.tb0[i]; } }
+    if (m->c.fused) { m->deferred = 1; m->flush_tab_ok = 1; for (int i = 0; i < 3; i++) { m->commit_pvt[i] = m->c.pvt[i]; m->commit_upvt[i] = m->c.upvt[i]; m->commit_tb0[i] = m->c.tb0[i]; } }
+    else m->deferred = 0;     /* the reference's order: its commit sweep stores every pair, also the ones an earlier fused update left out (gie_commit_finish) */
     return GIE_OK;
 }
 /* second half: obtainFrontiers, waves A / B / C, commit */

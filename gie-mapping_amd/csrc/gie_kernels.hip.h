@@ -2216,27 +2216,73 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
         }
         gie_wave_sync();
         /* ---- the lowerings (the neighbour an entry takes its obstacle from is not an entry: it is not raised) */
+        bool deferred = false;
         for (int e = lane; e < nent; e += 64) {
             const int v = L.list[e];
             const uint64_t t = L.prop[v];
             if (t == GIE_NOPROP) continue;
-            L.prop[v] = GIE_NOPROP;
             const int k = (int)(t & 7u), ax = k >> 1, sg = (k & 1) ? 1 : -1;
             const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
             const int ux = ex + (ax == 0 ? sg : 0), uy = ey + (ax == 1 ? sg : 0), uz = ez + (ax == 2 ? sg : 0);
             const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
             const int hp = (ax == 0) ? (ey + 8 * ez) : ((ax == 1) ? (ex + 8 * ez) : (ex + 8 * ey));
             const uint64_t ncoc = inside ? L.coc[(ux & 7) + 8 * (uy & 7) + 64 * (uz & 7)] : L.halo[k][hp];
-            L.coc[v] = ncoc;
-            unsigned f = (L.flag[v] & ~(GIE_WA_RAISED | GIE_WA_VANISHED)) | GIE_WA_DIRTY;
             int ncx, ncy, ncz;
             gie_unpack_crd(ncoc, &ncx, &ncy, &ncz);
             const int nw[3] = { ncx - c.upvt[0], ncy - c.upvt[1], ncz - c.upvt[2] };
-            if (gie_in_wr(c, nw[0], nw[1], nw[2])) {
-                L.pair[v] = gie_pair_make((int)(t >> 3), gie_pack_wr(nw[0], nw[1], nw[2]));
-                f |= GIE_WA_PAIR | GIE_WA_PUSHB;
+            if (!gie_in_wr(c, nw[0], nw[1], nw[2])) { deferred = true; continue; }      /* the rare corner below; L.prop[v] keeps the minimum */
+            L.prop[v] = GIE_NOPROP;
+            L.coc[v] = ncoc;
+            L.pair[v] = gie_pair_make((int)(t >> 3), gie_pack_wr(nw[0], nw[1], nw[2]));
+            L.flag[v] = (uint8_t)((L.flag[v] & ~(GIE_WA_RAISED | GIE_WA_VANISHED)) | GIE_WA_DIRTY | GIE_WA_PAIR | GIE_WA_PUSHB);
+        }
+        if (__ballot(deferred) != 0ull) {
+            /* An entry whose nearest offered obstacle lies OUTSIDE the wave range (it cannot be packed into a pair).  The reference
+             * walks the directions in order (wave_core.cuh:199-221): every strict improvement overwrites distance and obstacle, and
+             * only then an un-encodable obstacle `continue`s -- so the voxel ends up with the nearest obstacle, but its PAIR (and its
+             * place in frontier B) is that of the LAST improvement whose obstacle was inside the wave range, if there was one.
+             * Replayed here by the entry's own lane from the level-start state: a neighbour that was an entry of this level was
+             * raised when the level began (it may have been lowered a moment ago by another lane: then it is in L.list). */
+            gie_wave_sync();
+            for (int e = lane; e < nent; e += 64) {
+                const int v = L.list[e];
+                const uint64_t t = L.prop[v];
+                if (t == GIE_NOPROP) continue;
+                const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
+                const int g[3] = { g0[0] + ex, g0[1] + ey, g0[2] + ez };
+                const uint64_t lcoc = L.coc[v];
+                int cd = gie_gdist(c, lcoc, g[0], g[1], g[2]);
+                uint64_t fin = lcoc, spair = GIE_NOPROP;
+                for (int k = 0; k < 6; k++) {
+                    const int ax = k >> 1, sg = (k & 1) ? 1 : -1;
+                    const int ux = ex + (ax == 0 ? sg : 0), uy = ey + (ax == 1 ? sg : 0), uz = ez + (ax == 2 ? sg : 0);
+                    const int nb[3] = { g0[0] + ux - c.pvt[0], g0[1] + uy - c.pvt[1], g0[2] + uz - c.pvt[2] };
+                    if (gie_in_loc(c, nb[0], nb[1], nb[2]) || gie_in_whole(c, nb[0], nb[1], nb[2])) continue;
+                    const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+                    const int hp = (ax == 0) ? (ey + 8 * ez) : ((ax == 1) ? (ex + 8 * ez) : (ex + 8 * ey));
+                    const int nv = (ux & 7) + 8 * (uy & 7) + 64 * (uz & 7);
+                    const uint64_t ncoc = inside ? L.coc[nv] : L.halo[k][hp];
+                    const unsigned nf = inside ? L.flag[nv] : L.hflag[k][hp];
+                    if (!(nf & GIE_WA_OK) || (nf & (GIE_WA_RAISED | GIE_WA_VANISHED)) || ncoc == lcoc) continue;
+                    if (inside && (nf & GIE_WA_DIRTY)) {
+                        bool was_entry = false;
+                        for (int i = 0; i < nent; i++) was_entry |= (L.list[i] == (uint16_t)nv);
+                        if (was_entry) continue;
+                    }
+                    int nc[3];
+                    gie_unpack_crd(ncoc, &nc[0], &nc[1], &nc[2]);
+                    const int d = gie_d2(nc[0], nc[1], nc[2], g[0], g[1], g[2]);
+                    if (d >= cd) continue;
+                    cd = d; fin = ncoc;
+                    const int nw[3] = { nc[0] - c.upvt[0], nc[1] - c.upvt[1], nc[2] - c.upvt[2] };
+                    if (gie_in_wr(c, nw[0], nw[1], nw[2])) spair = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
+                }
+                L.prop[v] = GIE_NOPROP;
+                L.coc[v] = fin;
+                unsigned f = (L.flag[v] & ~(GIE_WA_RAISED | GIE_WA_VANISHED)) | GIE_WA_DIRTY;
+                if (spair != GIE_NOPROP) { L.pair[v] = spair; f |= GIE_WA_PAIR | GIE_WA_PUSHB; }
+                L.flag[v] = (uint8_t)f;
             }
-            L.flag[v] = (uint8_t)f;
         }
         gie_wave_sync();
         np = L.npend[pi ^ 1];

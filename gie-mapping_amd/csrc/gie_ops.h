@@ -839,7 +839,7 @@ GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, gie_vaddr a, uint64_t pr)
 }
 /* The voxels of the LAST fused map update's volume (pivot opvt, wave-range pivot oupvt, block table still that update's)
  * that the next volume (pivot c.pvt) no longer holds, enumerated as three slabs: item i -> old local coordinate. */
-struct gie_flush_boxes { int opvt[3], oupvt[3], otb0[3]; int lo[3], hi[3]; int n0, n1, n2; };   /* [lo, hi) = old local range that stays, per axis */
+struct gie_flush_boxes { int opvt[3], oupvt[3], otb0[3]; int lo[3], hi[3]; int n0, n1, n2; int rehash; };   /* rehash: types and block table are no longer that update's (a fuse without a merge came in between): find the block through the hash */   /* [lo, hi) = old local range that stays, per axis */
 GIE_DEV int gie_flush_skipax(int i, int lo, int hi) { return i < lo ? i : i + (hi - lo); }        /* i-th coordinate outside [lo, hi) */
 GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, int i)
 {
@@ -856,12 +856,16 @@ GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, in
         x = b.lo[0] + j % w0; y = b.lo[1] + (j / w0) % w1; z = gie_flush_skipax(j / (w0 * w1), b.lo[2], b.hi[2]);
     }
     const int id = gie_lid(c, x, y, z);
-    if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;    /* (still the last update's types: fuse has not run yet) */
     const int gx = x + b.opvt[0], gy = y + b.opvt[1], gz = z + b.opvt[2];
-    const int cell = (((gz >> 3) - b.otb0[2]) * c.tdim[1] + ((gy >> 3) - b.otb0[1])) * c.tdim[0] + ((gx >> 3) - b.otb0[0]);
-    const int slot = c.blk_tab[cell];
+    int slot;
+    if (!b.rehash) {
+        if (c.glb_type[id] == GIE_VOX_UNKNOWN) return;    /* (still the last update's types: fuse has not run yet) */
+        const int cell = (((gz >> 3) - b.otb0[2]) * c.tdim[1] + ((gy >> 3) - b.otb0[1])) * c.tdim[0] + ((gx >> 3) - b.otb0[0]);
+        slot = c.blk_tab[cell];
+    } else slot = gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3);
     if (slot < 0) return;
     const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+    if (b.rehash && !(c.g_coc[a] & GIE_COC_STALEPAIR)) return;    /* never committed in this stay, or flushed by an earlier fuse (and waves A / B may have rewritten it since) */
     const uint64_t pr = c.pair[id];
     if (gie_pair_dist(pr) != c.empty_value) {         /* committed by that update: the pair it would have stored */
         int cw[3];
@@ -909,11 +913,24 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
     if (ty == GIE_VOX_UNKNOWN) return;
     const uint64_t pr = s.pr;
     const int d = gie_pair_dist(pr);
+    const gie_vaddr a = s.a;
     if (d == c.empty_value) {
         if (gie_pair_par(pr) == GIE_PAR_NONE) c.edt[id] = (float)c.max_loc_dist_sq;
+        if (a >= 0) {
+            /* nothing to commit -- but a FUSED update before this one may have left this record's stored pair out (bit 63 of the
+             * stored obstacle, gie_commit_pair): the mapper changed to the reference's order in between (gie_stream_enable), and
+             * nobody will flush it later */
+            const uint64_t cc = c.g_coc[a];
+            if (cc & GIE_COC_STALEPAIR) {
+                int ox, oy, oz;
+                gie_unpack_crd(cc, &ox, &oy, &oz);
+                const int gx = id % c.X + c.pvt[0], gy = (id / c.X) % c.Y + c.pvt[1], gz = id / (c.X * c.Y) + c.pvt[2];
+                c.g_pair[a] = gie_pair_make(gie_gdist(c, cc, gx, gy, gz), gie_pack_wr((ox - c.upvt[0]) & 0x3fff, (oy - c.upvt[1]) & 0x3fff, (oz - c.upvt[2]) & 0x1fff));
+                c.g_coc[a] = cc & ~GIE_COC_STALEPAIR;
+            }
+        }
         return;
     }
-    const gie_vaddr a = s.a;
     if (a < 0) return;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);

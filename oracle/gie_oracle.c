@@ -794,6 +794,9 @@ static int cmp_i3_block(const void *a, const void *b)
 static int same_block(const i3 *p, int x, int y, int z) { return fdiv8(p->x) == fdiv8(x) && fdiv8(p->y) == fdiv8(y) && fdiv8(p->z) == fdiv8(z); }
 static int block_colour(int x, int y, int z) { return (fdiv8(x) + fdiv8(y) + fdiv8(z)) & 1; }
 
+/* test instrumentation: how often raise_outside's stale-pair corner (below) was taken since the library was loaded */
+int go_debug_stale_pairs = 0;
+int go_debug_stale_last[3] = { 0, 0, 0 };                      /* ... and the voxel it was taken for last */
 static void wave_a(gie_oracle *o, queue *front, queue *fb)
 {
     const int ct = o->map_ct;
@@ -855,8 +858,11 @@ static void wave_a(gie_oracle *o, queue *front, queue *fb)
                                 cd = d;
                                 lr->lowered = 1; lr->dist = d; lr->coc[0] = nv->coc[0]; lr->coc[1] = nv->coc[1]; lr->coc[2] = nv->coc[2];
                                 const int nw[3] = { nv->coc[0] - o->upvt[0], nv->coc[1] - o->upvt[1], nv->coc[2] - o->upvt[2] };
-                                lr->pair_set = 0;
-                                if (!in_wr(o, nw[0], nw[1], nw[2])) continue;
+                                /* wave_core.cuh:199-221: distance and obstacle are overwritten first; an obstacle outside the
+                                 * wave range then `continue`s -- the pair of an EARLIER direction's lowering (inside the wave
+                                 * range) stays, and the voxel stays in frontier B with it ("stale pair": wave B will commit
+                                 * that pair over the nearer, un-encodable obstacle) */
+                                if (!in_wr(o, nw[0], nw[1], nw[2])) { if (lr->pair_set) { go_debug_stale_pairs++; go_debug_stale_last[0] = g[0]; go_debug_stale_last[1] = g[1]; go_debug_stale_last[2] = g[2]; } continue; }
                                 lr->pair_set = 1; lr->pair_dist = d; lr->pair_par = pack_wr(nw[0], nw[1], nw[2]);
                             }
                         }

@@ -236,7 +236,7 @@ static void be_wave_a(be_state *, const gie_ctx &c)
                             const int d = gie_d2(nc[0], nc[1], nc[2], g[0], g[1], g[2]);
                             if (cd > d) {
                                 cd = d;
-                                lw[e].lowered = true; lw[e].coc = ncoc; lw[e].pair = GIE_NOPROP;
+                                lw[e].lowered = true; lw[e].coc = ncoc;        /* the pair of an earlier in-range lowering stays (wave_core.cuh:199-221) */
                                 const int nw[3] = { nc[0] - c.upvt[0], nc[1] - c.upvt[1], nc[2] - c.upvt[2] };
                                 if (gie_in_wr(c, nw[0], nw[1], nw[2])) lw[e].pair = gie_pair_make(d, gie_pack_wr(nw[0], nw[1], nw[2]));
                             }

@@ -175,3 +175,41 @@ def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False, product
         a.close()
         b.close()
     return out
+
+
+def run_irregular(sc, make_a, make_b, fuse_only=(), stream_on=(), compare_margin=None):
+    """The staged ABI driven off the beaten path: map updates that stop after gie_fuse (`fuse_only`: frame numbers
+    without batch EDT and merge -- a node that skips the EDT of a frame, or an update that failed half way) and updates that run
+    with the changed-block flags on (`stream_on`: frame numbers; the mapper then uses the reference's order Mark ... commit instead
+    of the fused sweep, so the run changes between the two forms).  After every COMPLETE update everything is compared as in
+    run_and_compare; after a fuse-only update the fused types and the stored occupancy."""
+    cfg = sc.config()
+    a, b = make_a(cfg), make_b(cfg)
+    rng = np.random.default_rng(sc.seed + 78)
+    margin = sc.probe_margin if compare_margin is None else compare_margin
+    try:
+        for k, (pos, q, kind, data, kw) in enumerate(sc.frames_iter()):
+            on = k in stream_on
+            for m in (a, b):
+                m.stream_enable(on)
+                m.set_pose(pos, q)
+                _feed(m, kind, data, kw)
+                m.fuse()
+            if k in fuse_only:
+                ta, tb = a.read_local(edt=False, dist_sq=False, coc=False)["type"], b.read_local(edt=False, dist_sq=False, coc=False)["type"]
+                assert np.array_equal(ta, tb), "%s frame %d (fuse only): fused types differ" % (sc.name, k)
+                xyz = probe_coords(a.pivot(), sc.size, rng, margin=margin)
+                ga, gb = a.query_global(xyz), b.query_global(xyz)
+                for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+                    assert np.array_equal(ga[key], gb[key]), "%s frame %d (fuse only): global %s differs in %d probes" % (
+                        sc.name, k, key, int((ga[key] != gb[key]).reshape(len(xyz), -1).any(-1).sum()))
+                continue
+            for m in (a, b):
+                m.batch_edt(); m.merge()
+            if on:
+                for m in (a, b):
+                    m.stream_changed()                       # drain the flags
+            _compare_after_merge(sc, k, a, b, rng, True)
+    finally:
+        a.close()
+        b.close()

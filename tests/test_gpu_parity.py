@@ -36,6 +36,9 @@ SCENARIOS = [
                     extent=(3.0, 3.0, 1.2), img=(240, 320, 260.0)),
     parity.Scenario("c4_slab", (320, 320, 40), voxel=0.05, sensor="lidar_points", frames=5, delta_vox=4, yaw_deg=2.0,
                     extent=(8.0, 8.0, 1.0), n_boxes=60, cutoff_dist=5.0, lidar_az=900),
+    # BASELINE C4 as SURVEY §8(d) states it: the same volume with fast_mode = true (cfg/uav_laser3D_params.yaml:27)
+    parity.Scenario("c4_slab_fast", (320, 320, 40), voxel=0.05, sensor="lidar_points", frames=5, delta_vox=4, yaw_deg=2.0,
+                    extent=(8.0, 8.0, 1.0), n_boxes=60, cutoff_dist=5.0, lidar_az=900, fast_mode=True),
     # BASELINE C5's sensor-less world through gie_ogm_labels (vector kernel: X % 16 == 0; functor path: odd sizes / robot sphere)
     parity.Scenario("c5_hash_world", (48, 48, 32), voxel=0.05, sensor="labels", frames=8, delta_vox=8, yaw_deg=2.0, seed=5,
                     cutoff_dist=2.0, p_occ=0.01),
@@ -621,3 +624,16 @@ def test_waves_wait_out_a_kernel_that_holds_every_compute_unit(oracle_lib):
         assert visits > 0
     finally:
         a.close(); b.close()
+
+
+IRREGULAR = [("mixed", (3, 6), ()), ("blink_empty_scans", (3, 6, 7, 11), ()), ("c5_hash_world", (2, 3, 5), ()), ("retain_odd_r1", (2, 5, 6), ()),
+             ("mixed", (), (3, 4, 8)), ("blink_empty_scans", (5, 12), (3, 4, 9, 10, 13)), ("c5_128cube", (1, 3), ())]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,fuse_only,stream_on", IRREGULAR, ids=["%s-f%s-s%s" % (n, "_".join(map(str, f)), "_".join(map(str, s))) for n, f, s in IRREGULAR])
+def test_irregular_call_orders(oracle_lib, name, fuse_only, stream_on):
+    """gie_fuse without a merge behind it, and runs that change between the fused sweep and the reference's order (see
+    tests/test_host_logic.py::test_irregular_call_orders_emulation; ADVICE r3)."""
+    sc = [s for s in SCENARIOS if s.name == name][0]
+    parity.run_irregular(sc, OracleMapper, gie.Mapper, fuse_only=set(fuse_only), stream_on=set(stream_on))

@@ -206,3 +206,19 @@ def test_random_scenarios_emulation_matches_oracle(oracle_lib):
         parity.run_and_compare(sc, OracleMapper, EmuMapper, production=bool(i % 2))
         ran += 1
     assert ran >= 15
+
+
+IRREGULAR = [
+    # (scenario name, fuse-only frames, frames with the changed-block flags on)
+    ("mixed", (3, 6), ()), ("blink_empty_scans", (3, 6, 7, 11), ()), ("c5_hash_world", (2, 3, 5), ()),
+    ("retain_odd_r1", (2, 5, 6), ()),
+    ("mixed", (), (3, 4, 8)), ("blink_empty_scans", (), (2, 3, 4, 9, 10, 14)), ("blink_empty_scans", (5, 12), (3, 4, 9, 10, 13)),
+]
+
+
+@pytest.mark.parametrize("name,fuse_only,stream_on", IRREGULAR, ids=["%s-f%s-s%s" % (n, "_".join(map(str, f)), "_".join(map(str, s))) for n, f, s in IRREGULAR])
+def test_irregular_call_orders_emulation(oracle_lib, name, fuse_only, stream_on):
+    """gie_fuse without a merge behind it, and runs that change between the fused sweep and the reference's order: the stored
+    pairs a fused update leaves out must still reach the map (they did not when a fuse was not followed by a merge)."""
+    sc = [s for s in SCENARIOS if s.name == name][0]
+    parity.run_irregular(sc, OracleMapper, EmuMapper, fuse_only=set(fuse_only), stream_on=set(stream_on))
