@@ -32,6 +32,8 @@ struct gie_mapper {
     int fuse_fresh;                       /* gie_fuse has run and no merge has consumed it yet (a merge needs the frame clear of its own map update) */
     int pool_base;                        /* GIE_DEBUG_POOL_BASE (tests): the slots below it are never handed out */
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
+    long long tomb_bound;                 /* upper bound of the tombstones those erasures left in the table */
+    int retain_box_valid, retain_box_lo[3], retain_box_hi[3];   /* block box +- retain of the last update that erased */
     int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
     int flush_tab_ok;                     /* ... and _glb_type / the block table are still that update's (no gie_fuse since) */
     int commit_pvt[3], commit_upvt[3], commit_tb0[3];   /* pivots / block-table origin of that merge */
@@ -107,7 +109,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -209,7 +211,10 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
     if (const char *e = getenv("GIE_DEBUG_POOL_BASE")) {   /* tests: hand out slots from here on (voxel addresses beyond 2^31 without filling a pool) */
         const long long b = atoll(e);
-        if (b > 0 && b < mb) { const int32_t v = (int32_t)b; be_h2d(&m->be, c.pool_count, &v, sizeof(v)); m->pool_base = (int)b; }
+        if (b > 0 && b < mb) {
+            const int32_t v = (int32_t)b; be_h2d(&m->be, c.pool_count, &v, sizeof(v)); m->pool_base = (int)b;
+            be_memset(&m->be, c.g_key, 0xff, (size_t)b * sizeof(uint64_t));    /* the slots below the base were never handed out: erasure and re-hash walk every slot below the pool top and must find them empty */
+        }
     }
     be_memset(&m->be, c.hkeys, 0xff, (size_t)hcap * sizeof(uint64_t));
     be_memset(&m->be, c.lprop, 0xff, (size_t)bdr * sizeof(uint64_t));
@@ -477,8 +482,28 @@ extern "C" int gie_fuse(gie_mapper *m)
         /* block-pool lifecycle (gie_config.retain_radius_blocks): erase what lies too far behind, before anything is allocated;
          * every GIE_REHASH_PERIOD-th map update the hash table is rebuilt from the live slots, which drops the tombstones */
         be_lin(&m->be, m->c, op_evict(), m->c.max_blocks);
-        if (++m->evictions >= GIE_REHASH_PERIOD) {
-            m->evictions = 0;
+        {   /* how many hash cells this erasure can have turned into tombstones: every live block lay inside the retention box of
+             * the update before (what was farther was erased then, and blocks are only allocated inside the volume's box), so at
+             * most the block coordinates of that box that are not in this update's.  The host never reads the device's count;
+             * the bound decides when the table is rebuilt — a robot that jumps to new ground every update would otherwise use
+             * up the table's EMPTY cells (lookups end at one) long before the period is over */
+            long long vol_prev = m->retain_box_valid ? 1 : 0, vol_both = m->retain_box_valid ? 1 : 0;
+            for (int i = 0; i < 3; i++) {
+                const long long lo = (long long)m->c.vb_lo[i] - m->c.retain, hi = (long long)m->c.vb_hi[i] + m->c.retain;
+                if (m->retain_box_valid) {
+                    vol_prev *= (long long)m->retain_box_hi[i] - m->retain_box_lo[i] + 1;
+                    const long long a = lo > m->retain_box_lo[i] ? lo : m->retain_box_lo[i], b = hi < m->retain_box_hi[i] ? hi : m->retain_box_hi[i];
+                    vol_both *= b >= a ? b - a + 1 : 0;
+                }
+                m->retain_box_lo[i] = (int)lo; m->retain_box_hi[i] = (int)hi;
+            }
+            m->retain_box_valid = 1;
+            long long gone = vol_prev - vol_both;
+            if (gone > m->c.max_blocks) gone = m->c.max_blocks;
+            m->tomb_bound += gone;
+        }
+        if (++m->evictions >= GIE_REHASH_PERIOD || m->tomb_bound > ((long long)m->c.hmask + 1) / 4) {
+            m->evictions = 0; m->tomb_bound = 0;
             be_memset(&m->be, m->c.hkeys, 0xff, ((size_t)m->c.hmask + 1) * sizeof(uint64_t));
             be_lin(&m->be, m->c, op_rehash(), m->c.max_blocks);
         }

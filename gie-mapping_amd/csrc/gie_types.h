@@ -254,13 +254,14 @@ GIE_HD int gie_hash_find(const gie_ctx &c, int bx, int by, int bz)
 {
     const uint64_t key = gie_pack_crd(bx, by, bz);
     uint32_t h = gie_hash_key(bx, by, bz) & c.hmask;
-    for (;;) {
+    for (uint32_t probes = 0; probes <= c.hmask; probes++) {     /* bounded like gie_key_insert: a table without an EMPTY cell left must not hang the device */
         const uint64_t k = c.hkeys[h];
         const int v = c.hvals[h];                 /* fetched WITH the key (same index): a hit costs one round trip, not two */
         if (k == key) return v;
         if (k == GIE_KEY_EMPTY) return -1;
         h = (h + 1) & c.hmask;
     }
+    return -1;
 }
 
 /* first face of the volume a boundary voxel lies on → slot in the 2(XY+YZ+XZ) proposal table */

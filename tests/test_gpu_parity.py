@@ -637,3 +637,9 @@ def test_irregular_call_orders(oracle_lib, name, fuse_only, stream_on):
     tests/test_host_logic.py::test_irregular_call_orders_emulation; ADVICE r3)."""
     sc = [s for s in SCENARIOS if s.name == name][0]
     parity.run_irregular(sc, OracleMapper, gie.Mapper, fuse_only=set(fuse_only), stream_on=set(stream_on))
+
+
+@pytest.mark.gpu
+def test_jumping_robot_keeps_the_hash_table_alive(oracle_lib):
+    from test_host_logic import _jumping_robot
+    _jumping_robot(gie.Mapper, updates=300)

@@ -222,3 +222,34 @@ def test_irregular_call_orders_emulation(oracle_lib, name, fuse_only, stream_on)
     pairs a fused update leaves out must still reach the map (they did not when a fuse was not followed by a merge)."""
     sc = [s for s in SCENARIOS if s.name == name][0]
     parity.run_irregular(sc, OracleMapper, EmuMapper, fuse_only=set(fuse_only), stream_on=set(stream_on))
+
+
+def _jumping_robot(make_b, updates=150):
+    """A robot that lands on new ground in every update (jumps of 100 voxels) with block retention on: every update erases all it
+    held.  The tombstones of the erased blocks use up the hash table's EMPTY cells — 125 per update against a table of 512
+    cells here — long before the 64-update rebuild period is over; lookups must stay finite and the map right."""
+    import numpy as np
+    import gie as _gie
+    from gie import scenes
+    size, voxel = (16, 16, 16), 0.05
+    cfg = _gie.make_config(voxel, size, cutoff_dist=0.5, retain_radius_blocks=1, max_blocks=120)
+    a, b = OracleMapper(cfg), make_b(cfg)
+    rng = np.random.default_rng(5)
+    try:
+        for i in range(updates):
+            pos, q = scenes.pose(i, voxel, delta_vox=100, yaw_deg=1.0)
+            lab = scenes.hash_world_labels(scenes.local_pivot(pos, voxel, size), size, i, seed=5, p_occ=0.02, toggle_frac=0.25).astype(np.int8)
+            for m in (a, b):
+                m.update(pos, q, "labels", lab)
+            if i % 13 == 0 or i == updates - 1:
+                xyz = parity.probe_coords(a.pivot(), size, rng, n=2000, margin=24)
+                ga, gb = a.query_global(xyz), b.query_global(xyz)
+                for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+                    assert np.array_equal(ga[key], gb[key]), (i, key)
+                assert a.stats()["blocks_total"] == b.stats()["blocks_total"]
+    finally:
+        a.close(); b.close()
+
+
+def test_jumping_robot_keeps_the_hash_table_alive_emulation(oracle_lib):
+    _jumping_robot(EmuMapper)

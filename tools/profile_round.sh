@@ -24,12 +24,16 @@ cd $ROOT
 T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | head -1); W=$(find $OUT/write -name "*.db" | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (MI355X)"; python tools/rocpd_summary.py stats "$T"; echo; echo "# bench.py line of the same (profiled) run:"; cat $OUT/bench_trace.json; } > $OUT/kernel_stats.txt
 { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes) -- python bench.py $ARGS"; python tools/rocpd_summary.py pmc "$F" "$W" $OUT/traffic.json; } > $OUT/hbm_traffic.txt
-# the entry bench.py's roofline.traffic reads (profiles/traffic_r02.json: merge it in by hand under the workload's key)
+# the entry bench.py's roofline.traffic reads: stamped with the content hash of the kernel sources (bench.csrc_hash) so that it is
+# only ever priced against durations of the same kernels; merge it into profiles/traffic_r04.json with tools/merge_traffic.py
 python - "$OUT/traffic.json" "$TAG" "$ARGS" > $OUT/traffic_entry.json <<'PY'
 import json, sys
+sys.path.insert(0, ".")
+import bench
 t = json.load(open(sys.argv[1]))
 print(json.dumps({"source": "profiles/%s_hbm_traffic.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py %s`, "
                             "%d map updates, fetch x2 (gfx950 wide-stream correction), bytes per map update" % (sys.argv[2], sys.argv[3], t.get("_map_updates", 0)),
+                  "csrc_hash": bench.csrc_hash(),
                   "kernels": t.get("_per_step_by_stage", {})}, indent=1))
 PY
 rm -rf $OUT/trace $OUT/fetch $OUT/write      # the databases are large; the summaries are what travels back
