@@ -148,6 +148,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tmax = gie_dalloc<int32_t>(m, 2 * ntile);
     c.tmax_prev = c.tmax ? c.tmax + ntile : nullptr;
     c.tskip = gie_dalloc<uint8_t>(m, ntile);
+    c.ucol = gie_dalloc<uint8_t>(m, (((size_t)X * Y * ((Z + 7) / 8)) + 3) & ~(size_t)3);
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
     c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
@@ -675,7 +676,13 @@ extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *
 {
     if (!m) { gie_set_err("gie_read_local: null handle"); return GIE_ERR_INVALID; }
     const size_t N = (size_t)m->c.N;
-    if (edt) be_d2h(&m->be, edt, m->c.edt, N * sizeof(float));
+    if (edt) {           /* `_edt_D` is derived from the pairs where the reference would have written it (gie_ops.h gie_edt_value) */
+        float *de = (float *)gie_scratch(m, 0, N * 4, "gie_read_local");
+        if (!de) return GIE_ERR_DEVICE;
+        op_export_edt op; op.out = de;
+        be_lin(&m->be, m->c, op, m->c.N);
+        be_d2h(&m->be, edt, de, N * sizeof(float));
+    }
     if (type) be_d2h(&m->be, type, m->c.glb_type, N);
     if (dist_sq || coc_xyz) {
         int32_t *dd = dist_sq ? (int32_t *)gie_scratch(m, 0, N * 4, "gie_read_local") : nullptr;

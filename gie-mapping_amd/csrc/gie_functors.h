@@ -253,8 +253,9 @@ struct op_stream_clear { const int32_t *list; int first; GIE_DEVM void operator(
 struct op_export_pair { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_pair(c, i, d, coc); } };
 struct op_export_bcoc { int32_t *d; int32_t *coc; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_export_bcoc(c, i, d, coc); } };
 /* `bool o = char` (local_batch.h:19-24,389): 1 for FREE / OCCUPIED / FNT, 0 for UNKNOWN -- not the raw type */
+struct op_export_edt { float *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { out[i] = gie_edt_value(c, i); } };
 struct op_costmap { gie_seendist *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const {
-        gie_seendist s; s.d = c.edt[i]; s.s = 0; s.o = (uint8_t)(c.glb_type[i] != 0); s.pad[0] = s.pad[1] = 0; out[i] = s; } };
+        gie_seendist s; s.d = gie_edt_value(c, i); s.s = 0; s.o = (uint8_t)(c.glb_type[i] != 0); s.pad[0] = s.pad[1] = 0; out[i] = s; } };
 
 
 

@@ -26,6 +26,7 @@ struct be_state {
     hipEvent_t ev[GIE_NEV];
     int ev_set[GIE_NEV];
     void *scan_tmp; size_t scan_bytes;
+    void *arena;                        /* GIE_ARENA_MB (placement experiments): be_arena */
     hipEvent_t copy_ev[2];              /* completion of the async D2H copies (changed-block streaming) */
     /* per-kernel event profiling */
     int prof_on;
@@ -37,6 +38,7 @@ struct be_state {
 };
 #include <vector>
 
+struct be_arena { char *base; size_t size, top; int k; std::vector<long long> skew; };
 static void gie_set_err(const std::string &s);
 #include <string>
 
@@ -71,7 +73,7 @@ static int be_init(be_state *b, int device)
     }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
-    b->scan_tmp = nullptr; b->scan_bytes = 0;
+    b->scan_tmp = nullptr; b->scan_bytes = 0; b->arena = nullptr;
     for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
     b->prof_on = 0; b->cur_id = -1; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
     for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; }
@@ -90,16 +92,45 @@ static void be_fini(be_state *b)
     for (int i = 0; i < GIE_NEV; i++) (void)hipEventDestroy(b->ev[i]);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(b->copy_ev[i]);
     (void)hipStreamDestroy(b->stream);
+    if (b->arena) { be_arena *a = (be_arena *)b->arena; if (a->base) (void)hipFree(a->base); delete a; b->arena = nullptr; }
+}
+/* Placement experiments ("placement bands"): GIE_ARENA_MB=<MiB> takes ONE allocation of that size per mapper and
+ * carves every plane of 64 MiB and more out of it, the k-th such plane GIE_ARENA_SKEW[k] MiB (comma list, default 0) behind the
+ * 2 MiB-rounded end of the one before; smaller buffers and whatever does not fit go through hipMalloc as usual. */
+static be_arena *be_arena_of(be_state *b)
+{
+    static const char *e = getenv("GIE_ARENA_MB");
+    if (!e || atoll(e) <= 0) return nullptr;
+    if (!b->arena) {
+        be_arena *a = new be_arena();
+        a->size = (size_t)atoll(e) << 20; a->top = 0; a->k = 0; a->base = nullptr;
+        if (const char *sk = getenv("GIE_ARENA_SKEW")) { std::string t(sk); size_t i = 0; while (i < t.size()) { size_t j = t.find(',', i); if (j == std::string::npos) j = t.size(); a->skew.push_back(atoll(t.substr(i, j - i).c_str())); i = j + 1; } }
+        if (hipMalloc((void **)&a->base, a->size) != hipSuccess) { a->base = nullptr; a->size = 0; }
+        b->arena = a;
+    }
+    return (be_arena *)b->arena;
 }
 static void *be_alloc(be_state *b, size_t bytes, bool zero)
 {
     void *p = nullptr;
     (void)hipSetDevice(b->device);
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    be_arena *a = bytes >= ((size_t)64 << 20) ? be_arena_of(b) : nullptr;
+    if (a && a->base) {
+        const size_t sk = (size_t)((a->k < (int)a->skew.size() ? a->skew[a->k] : 0) << 20);
+        const size_t at = ((a->top + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1)) + sk;
+        if (at + bytes <= a->size) { p = a->base + at; a->top = at + bytes; a->k++; }
+    }
+    if (!p && hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
     if (zero) GIE_HIP_OK(hipMemsetAsync(p, 0, bytes, b->stream));
     return p;
 }
-static void be_free(be_state *b, void *p) { (void)hipStreamSynchronize(b->stream); (void)hipFree(p); }
+static void be_free(be_state *b, void *p)
+{
+    (void)hipStreamSynchronize(b->stream);
+    be_arena *a = (be_arena *)b->arena;
+    if (a && a->base && (char *)p >= a->base && (char *)p < a->base + a->size) return;      /* goes with the arena (be_fini) */
+    (void)hipFree(p);
+}
 static void be_memset(be_state *b, void *p, int v, size_t bytes) { GIE_HIP_OK(hipMemsetAsync(p, v, bytes, b->stream)); }
 static void be_h2d(be_state *b, void *d, const void *h, size_t bytes)
 {   /* blocking like the reference's GPU_MEMCPY_H2D (cuda_macro.h:33): the caller may reuse h */

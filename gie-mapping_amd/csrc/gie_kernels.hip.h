@@ -1322,6 +1322,8 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
     const int slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
     const int skipold = c.tskip[t];
+    const size_t ui = gie_ucol_index(c, x, y, z0);
+    const unsigned ub = c.ucol[ui];                     /* indices that have just turned known: their old pair says nothing about `_edt_D` */
     gie_vaddr a[8]; int dold[8]; uint64_t oc[8];
     unsigned want = 0;
 #pragma unroll
@@ -1351,6 +1353,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
             int ft;
             const uint64_t pr = gie_mark_logic(c, x, y, z0 + k, bc[k], dold[k], oc[k], &c.pair[id], &ft);
             flag |= ft;
+            gie_edt_before_keep(c, (int)id, pr, (ub >> k) & 1u);
             c.pair[id] = pr;
             gie_commit_pair<false>(c, (int)id, a[k], pr);
             const int d = gie_pair_dist(pr);
@@ -1359,6 +1362,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
         known |= 1u << k; vmax = r > vmax ? r : vmax;
     }
     if (flag) c.tflag[t] = 1;
+    if (ub & known) c.ucol[ui] = (uint8_t)(ub & ~known);           /* (the byte is this thread's) */
     gie_markc_column(c, x, y, z0, known, valid, vmax);
 }
 template <int LX>
@@ -2762,7 +2766,7 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
         const size_t id = in ? (size_t)(z0 + j) * plane + col : 0;
         pv[j] = gie_ld(&c.pair[id]);
         cv[j] = gie_ld(&rd[id]);
-        if (c.fused) tys |= (uint64_t)(uint8_t)c.glb_type[id] << (8 * j);
+        tys |= (uint64_t)(uint8_t)c.glb_type[id] << (8 * j);
         if (!in) { pv[j] = 0ull; cv[j] = GIE_NOPROP; }                    /* a voxel outside the volume: distance 0, never improved */
     }
     if (c.fused && colin) {
@@ -2877,6 +2881,7 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
         const int z = z0 + j;
         const size_t id = (size_t)z * plane + col;
         const uint64_t pr = L.pair[lane + 64 * j];
+        if ((int8_t)(tys >> (8 * j)) == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, (int)id, x, y, z, pv[j]);     /* (`_edt_D` is derived from the pairs: gie_ops.h) */
         gie_st(&c.pair[id], pr);
         if (c.fused) {
             const int slot = (((z + c.pvt[2]) >> 3) == ((z0 + c.pvt[2]) >> 3)) ? slot_lo : slot_hi;

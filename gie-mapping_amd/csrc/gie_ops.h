@@ -474,6 +474,47 @@ GIE_DEV void gie_fuse_load2(const gie_ctx &c, gie_fuse_st &s)
     s.occ = c.g_occ[s.a];
     s.ty = c.g_type[s.a];
 }
+/* ---- `_edt_D` (the float distance plane of the CostMap) is DERIVED, not stored (round 4).  UpdateHashBatch writes it for every
+ * known voxel from the voxel's final pair — sqrtf(dist), or X^2+Y^2+Z^2 for "see nothing" (EMPTY, 0xffffffff) — except where the
+ * pair is (EMPTY, some parent): obstacle outside the wave range, "don't update" (unify_helper.cuh:467-475); UNKNOWN voxels keep
+ * theirs, by LOCAL index, and so does `_dist_id_pair`.  Hence the plane is a function of the pair plane wherever the pair at an
+ * index is the one its last commit saw and is not of the keeping kind, and the 4-byte store per voxel (0.54 GB of the 2.7 GB the
+ * C5 sweep wrote, ~0.1 ms) is left out; readers (gie_read_local, gie_read_costmap) evaluate gie_edt_value.  The plane `edt`
+ * holds the value only where that does not work, written at the moment it stops working:
+ *   - Mark turns a known voxel's pair into (EMPTY, parent): edt <- value of the pair it overwrites (gie_edt_before_keep);
+ *   - a wave changes the pair of an UNKNOWN voxel (lower_inside and lower_outside's stores have no type test, wave_core.cuh:
+ *     336-346, 353-393; UpdateHashBatch skips the voxel): edt <- value of the pair before the change, and the index is marked
+ *     (gie_edt_unknown_touch) — one bit per index (`ucol`: a byte per z-column of eight voxels, bit = z & 7), cleared when Mark
+ *     next writes the index's pair.
+ * An index that merely changes between known and unknown (the volume moves) needs nothing: neither plane is touched. */
+GIE_DEV bool gie_pair_keeps_edt(const gie_ctx &c, uint64_t pr) { return gie_pair_dist(pr) == c.empty_value && gie_pair_par(pr) != GIE_PAR_NONE; }
+GIE_DEV float gie_edt_of_pair(const gie_ctx &c, uint64_t pr) { const int d = gie_pair_dist(pr); return d == c.empty_value ? (float)c.max_loc_dist_sq : sqrtf((float)d); }
+GIE_DEV size_t gie_ucol_index(const gie_ctx &c, int x, int y, int z) { return ((size_t)(z >> 3) * c.Y + y) * c.X + x; }
+GIE_DEV float gie_edt_value(const gie_ctx &c, int id)
+{
+    const int plane = c.X * c.Y, z = id / plane, r = id - z * plane;
+    const uint64_t pr = c.pair[id];
+    const bool marked = (c.ucol[(size_t)(z >> 3) * plane + r] >> (z & 7)) & 1u;
+    return (!marked && !gie_pair_keeps_edt(c, pr)) ? gie_edt_of_pair(c, pr) : c.edt[id];
+}
+/* Mark is about to store `pr_new` for the known voxel `id`; `marked` = the index's ucol bit */
+GIE_DEV void gie_edt_before_keep(const gie_ctx &c, int id, uint64_t pr_new, bool marked)
+{
+    if (marked || !gie_pair_keeps_edt(c, pr_new)) return;
+    const uint64_t old = c.pair[id];
+    if (!gie_pair_keeps_edt(c, old)) c.edt[id] = gie_edt_of_pair(c, old);
+}
+/* a wave is about to change the pair of the UNKNOWN voxel (x, y, z) from `old`; the caller owns the voxel's z-column (a lane of
+ * wave C's tile routine), other wavefronts read the byte in later rounds: agent-scope accesses */
+GIE_DEV void gie_edt_unknown_touch(const gie_ctx &c, int id, int x, int y, int z, uint64_t old)
+{
+    uint8_t *const u = &c.ucol[gie_ucol_index(c, x, y, z)];
+    const uint8_t ub = gie_ld(u);
+    if ((ub >> (z & 7)) & 1u) return;
+    if (!gie_pair_keeps_edt(c, old)) gie_st(&c.edt[id], gie_edt_of_pair(c, old));
+    gie_st(u, (uint8_t)(ub | (1u << (z & 7))));
+}
+
 /* external obstacle boxes (unify_helper.cuh:60-78, voxmap_utils.cuh:203-207): box 0 is a fence ("outside => occupied"),
  * boxes >= 1 are obstacles ("inside => occupied"), each only while activated */
 GIE_DEV int gie_fuse_occ_flag(const gie_ctx &c, int gx, int gy, int gz)
@@ -600,6 +641,12 @@ GIE_DEV void gie_mark_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         flag_tile = !gie_in_loc(c, cn[0], cn[1], cn[2]);
     }
     if (flag_tile) c.tflag[gie_tile_index(c, x, y, z)] = 1;         /* all writers store 1 */
+    {
+        uint8_t *const u = &c.ucol[gie_ucol_index(c, x, y, z)];
+        const uint8_t ub = *u;
+        gie_edt_before_keep(c, id, pr, (ub >> (z & 7)) & 1u);
+        if ((ub >> (z & 7)) & 1u) *u = (uint8_t)(ub & ~(1u << (z & 7)));     /* (a column's eight voxels belong to one thread) */
+    }
     c.pair[id] = pr;
 }
 GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
@@ -823,19 +870,12 @@ template <bool AGENT>
 GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, gie_vaddr a, uint64_t pr)
 {
     const int d = gie_pair_dist(pr);
-    if (d == c.empty_value) {
-        if (gie_pair_par(pr) == GIE_PAR_NONE) { if (AGENT) gie_st(&c.edt[id], (float)c.max_loc_dist_sq); else c.edt[id] = (float)c.max_loc_dist_sq; }
-        return;
-    }
+    if (d == c.empty_value) return;
     if (a < 0) return;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
     const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]) | GIE_COC_STALEPAIR;
-    if (AGENT) {
-        gie_st(&c.g_coc[a], ncoc); gie_st(&c.edt[id], sqrtf((float)d));
-    } else {
-        c.g_coc[a] = ncoc; c.edt[id] = sqrtf((float)d);     /* (nontemporal stores: no gain measured) */
-    }
+    if (AGENT) gie_st(&c.g_coc[a], ncoc); else c.g_coc[a] = ncoc;     /* (nontemporal stores: no gain measured) */
 }
 /* The voxels of the LAST fused map update's volume (pivot opvt, wave-range pivot oupvt, block table still that update's)
  * that the next volume (pivot c.pvt) no longer holds, enumerated as three slabs: item i -> old local coordinate. */
@@ -915,7 +955,6 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
     const int d = gie_pair_dist(pr);
     const gie_vaddr a = s.a;
     if (d == c.empty_value) {
-        if (gie_pair_par(pr) == GIE_PAR_NONE) c.edt[id] = (float)c.max_loc_dist_sq;
         if (a >= 0) {
             /* nothing to commit -- but a FUSED update before this one may have left this record's stored pair out (bit 63 of the
              * stored obstacle, gie_commit_pair): the mapper changed to the reference's order in between (gie_stream_enable), and
@@ -937,7 +976,6 @@ GIE_DEV void gie_commit_finish(const gie_ctx &c, int id, const gie_commit_st &s)
     const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]);
     if (c.track && ((c.g_coc[a] & ~GIE_COC_STALEPAIR) != ncoc || (ty == GIE_VOX_FNT && c.g_type[a] != GIE_VOX_FNT))) gie_touch(c, a);   /* (same obstacle: same distance) */
     c.g_coc[a] = ncoc;
-    c.edt[id] = sqrtf((float)d);
     c.g_pair[a] = pr;
     if (ty == GIE_VOX_FNT) c.g_type[a] = GIE_VOX_FNT;
 }
@@ -1080,6 +1118,12 @@ GIE_DEV int gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, cons
     int flag_tile;
     const uint64_t pr = gie_mark_logic(c, x, y, z, s.bc, s.dold, s.ococ, &c.pair[id], &flag_tile);
     if (flag_tile) c.tflag[gie_tile_index(c, x, y, z)] = 1;
+    {
+        uint8_t *const u = &c.ucol[gie_ucol_index(c, x, y, z)];
+        const uint8_t ub = *u;
+        gie_edt_before_keep(c, id, pr, (ub >> (z & 7)) & 1u);
+        if ((ub >> (z & 7)) & 1u) *u = (uint8_t)(ub & ~(1u << (z & 7)));
+    }
     c.pair[id] = pr;
     gie_commit_pair<false>(c, id, s.a, pr);
     const int d = gie_pair_dist(pr);

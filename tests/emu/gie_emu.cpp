@@ -392,6 +392,7 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     auto tile = [&](int id) { const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y); return gie_tile_index(c, x, y, z); };
     auto set_pair = [&](int id, uint64_t pr) {
+        if (c.glb_type[id] == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, id, id % c.X, (id / c.X) % c.Y, id / (c.X * c.Y), c.pair[id]);
         c.pair[id] = pr;
         if (c.fused) {
             const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
