@@ -346,7 +346,10 @@ static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(geten
 static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list)
 {
     static const int mult = getenv("GIE_ROWS_MULT") ? atoi(getenv("GIE_ROWS_MULT")) : 16;
-    if (be_rows_mode()) GIE_LAUNCH(b, k_fuse_rows, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
+    if (be_rows_mode()) {
+        if (c.pntcld_mode) GIE_LAUNCH(b, k_fuse_rows<true>, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
+        else GIE_LAUNCH(b, k_fuse_rows<false>, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
+    }
     else be_vox_list<true>(b, c, op_fuse(), list, GIE_CNT_TL_FUSE, 0);
 }
 /* obtainFrontiers: the voxels on the six faces of the volume one per lane (an 8x8 patch per wave) with the tile summary + tile

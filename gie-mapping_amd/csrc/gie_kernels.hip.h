@@ -1762,7 +1762,9 @@ __device__ __forceinline__ void gie_row_ld32(const uint32_t *p, const long long 
  * the plane flags come out the same */
 /* (few tiles to look at: the list form — a wave per listed tile, the staged per-voxel functor as in k_voxa — in the same launch) */
 /* (four workgroups per compute unit: with 64-bit block addresses the kernel wanted 130 registers and lost a quarter of its waves) */
-__global__ __launch_bounds__(256, 4) void k_fuse_rows(const gie_ctx c, const op_fuse f, const int32_t *list)
+/* (PNT: the scan is a ray-cast one — hit / miss counters instead of labels; a template parameter so that the label form does not carry the eight counters of a row in registers) */
+template <bool PNT>
+__global__ __launch_bounds__(256, PNT ? 3 : 4) void k_fuse_rows(const gie_ctx c, const op_fuse f, const int32_t *list)
 {
     {
         const int n = c.cnt[GIE_CNT_TL_FUSE];
@@ -1809,17 +1811,33 @@ __global__ __launch_bounds__(256, 4) void k_fuse_rows(const gie_ctx c, const op_
                 const uint64_t it8 = gie_row_ld8(c.inst_type, id, w);
                 const uint64_t gt8 = gie_row_ld8(c.glb_type, id, w);
                 uint32_t rc[8];
-                if (c.pntcld_mode) gie_row_ld32(reinterpret_cast<const uint32_t *>(c.ray_count), id, w, rc);
+                if (PNT) gie_row_ld32(reinterpret_cast<const uint32_t *>(c.ray_count), id, w, rc);
                 const int a = k << 6;
                 uint64_t go8 = 0, gy8 = 0;
                 if (w.slot >= 0) { go8 = *reinterpret_cast<const uint64_t *>(p_occ + a); gy8 = *reinterpret_cast<const uint64_t *>(p_typ + a); }
                 uint64_t no8 = go8, ny8 = gy8, ng8 = gt8;
                 bool rc_any = false;
                 const int qz = (k >= q.kz) ? 2 : 0;
+                /* Labelled scans (the projective sensors, gie_ogm_labels): the eight voxels of the row as ONE 64-bit word, byte-parallel
+                 * (gie_fuse_row8_labels, gie_ops.h).  The per-voxel loop below costs ~55 vector instructions per voxel and a wave runs
+                 * it whenever any of its 512 voxels needs it. */
+                const uint64_t ONES = 0x0101010101010101ull, L7 = 0x7f7f7f7f7f7f7f7full, H8 = 0x8080808080808080ull;
+                if (!PNT && w.full && w.slot >= 0 && c.nbox <= 0 && c.occ_thresh >= 127) {
+                    gie_fuse_row8_labels(c.occ_thresh, it8, go8, gy8, &no8, &ny8);
+                    ng8 = ny8;
+                    const uint32_t km = (uint32_t)((((ny8 | (ny8 >> 1)) & ONES) * 0x0102040810204080ull) >> 56);      /* bit i: voxel i is known */
+                    const uint32_t lo = (1u << q.ix) - 1u;                                                           /* (ix = 8: the whole row) */
+                    if (km & lo) kn |= 1u << qz;
+                    if (~km & lo & 0xffu) un |= 1u << qz;
+                    if (km & ~lo & 0xffu) kn |= 1u << (qz + 1);
+                    if (~km & ~lo & 0xffu) un |= 1u << (qz + 1);
+                    const uint64_t t2 = ny8 ^ (2ull * ONES);                                                          /* a byte of t2 is zero where the type is OCCUPIED */
+                    occ_here = ((((t2 & L7) + L7) | t2) & H8) != H8;
+                } else
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     if (i < w.xlo || i >= w.xhi) continue;
-                    const int count = c.pntcld_mode ? (int)rc[i] : 0;
+                    const int count = PNT ? (int)rc[i] : 0;
                     rc_any |= count != 0;
                     const int8_t nt = (int8_t)(it8 >> (8 * i));
                     int8_t ty = GIE_VOX_UNKNOWN;

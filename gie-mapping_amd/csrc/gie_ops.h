@@ -458,6 +458,44 @@ GIE_DEV void gie_set_occ(uint8_t *occ, int8_t *type, float val, float a, int thr
 }
 
 
+/* The occupancy filter of a labelled scan for EIGHT voxels at once: bytes i of `it8` / `go8` / `gy8` = scan label / stored occupancy /
+ * stored type of voxel i of a row, results in *no8 / *ny8.  Nearly all voxels are free space seen free, or not seen at all, and for
+ * those set_hashvoxel_occ_val (voxmap_utils.cuh:181-200) is integer arithmetic on bytes:
+ *   label FREE: val = 0.5 * occ (occ = 0 for an UNKNOWN voxel), clamped up to 1, truncated = max(1, occ >> 1); the type becomes FREE
+ *     because occ >> 1 <= 127 <= the occupancy threshold (the caller checks thresh >= 127);
+ *   no label (or any other value): nothing changes;
+ *   label OCCUPIED (1 % of the voxels): the fp32 filter, voxel by voxel — a wavefront pays for the largest number of such voxels
+ *     one of its rows holds (one or two), not for eight.
+ * Equal to gie_fuse_logic byte by byte (tests/test_host_logic.py::test_byte_parallel_occupancy_filter, exhaustive). */
+GIE_DEV void gie_fuse_row8_labels(int thresh, uint64_t it8, uint64_t go8, uint64_t gy8, uint64_t *no8, uint64_t *ny8)
+{
+    const uint64_t ONES = 0x0101010101010101ull, L7 = 0x7f7f7f7f7f7f7f7full, H8 = 0x8080808080808080ull;
+    const uint64_t tf = it8 ^ ONES, to = it8 ^ (2ull * ONES);
+    const uint64_t mF = (((((tf & L7) + L7) | tf) & H8) ^ H8) >> 7;           /* 1 in the bytes whose label is FREE */
+    const uint64_t mO = (((((to & L7) + L7) | to) & H8) ^ H8) >> 7;           /* ... OCCUPIED */
+    const uint64_t fF = mF * 0xffull;
+    const uint64_t mK = ((gy8 | (gy8 >> 1)) & ONES) * 0xffull;                /* 0xff in the bytes whose stored type is known (types are 0..3) */
+    uint64_t half = (go8 >> 1) & L7 & mK;
+    half += ONES ^ (((half + L7) & H8) >> 7);                                 /* 0 -> 1 */
+    uint64_t o8 = (go8 & ~fF) | (half & fF), y8 = (gy8 & ~fF) | (ONES & fF);
+    uint32_t ob = (uint32_t)((mO * 0x0102040810204080ull) >> 56);             /* bit i: voxel i carries an OCCUPIED label */
+    while (ob) {
+#if defined(GIE_HOST_EMU)
+        int i = 0;
+        while (!((ob >> i) & 1u)) i++;
+#else
+        const int i = __ffs((int)ob) - 1;
+#endif
+        ob &= ob - 1u;
+        uint8_t occ = (uint8_t)(go8 >> (8 * i));
+        int8_t ty = (int8_t)(gy8 >> (8 * i));
+        gie_set_occ(&occ, &ty, 250.f, 0.8f, thresh);
+        o8 = (o8 & ~(0xffull << (8 * i))) | ((uint64_t)occ << (8 * i));
+        y8 = (y8 & ~(0xffull << (8 * i))) | ((uint64_t)(uint8_t)ty << (8 * i));
+    }
+    *no8 = o8; *ny8 = y8;
+}
+
 struct gie_fuse_st { int count; int8_t nt, gt0; gie_vaddr a; uint8_t occ; int8_t ty; };
 
 GIE_DEV void gie_fuse_load1(const gie_ctx &c, int id, int x, int y, int z, gie_fuse_st &s)

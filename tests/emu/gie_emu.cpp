@@ -464,3 +464,13 @@ static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seed
 }
 
 #include "../../gie-mapping_amd/csrc/gie_api.inc.h"
+
+/* test hooks: the byte-parallel occupancy filter of the block-row fuse kernel (gie_ops.h) and the per-voxel one it must equal */
+extern "C" void gie_emu_fuse_row8(int thresh, uint64_t it8, uint64_t go8, uint64_t gy8, uint64_t *no8, uint64_t *ny8) { gie_fuse_row8_labels(thresh, it8, go8, gy8, no8, ny8); }
+extern "C" void gie_emu_fuse_voxel(int thresh, int label, int occ_in, int ty_in, int *occ_out, int *ty_out)
+{
+    gie_ctx c; memset(&c, 0, sizeof(c)); c.pntcld_mode = 0; c.occ_thresh = thresh;
+    uint8_t occ = (uint8_t)occ_in; int8_t ty = (int8_t)ty_in;
+    gie_fuse_logic(c, 0, (int8_t)label, 0, &occ, &ty);
+    *occ_out = occ; *ty_out = ty;
+}

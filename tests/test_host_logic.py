@@ -253,3 +253,39 @@ def _jumping_robot(make_b, updates=150):
 
 def test_jumping_robot_keeps_the_hash_table_alive_emulation(oracle_lib):
     _jumping_robot(EmuMapper)
+
+
+def test_byte_parallel_occupancy_filter():
+    """gie_fuse_row8_labels (the block-row fuse kernel's byte-parallel form of set_hashvoxel_occ_val for labelled scans) against the
+    per-voxel filter: every (label 0..3, stored type 0..3, stored occupancy 0..255) in every byte position, thresholds 127..255,
+    and random rows."""
+    import ctypes as C
+    import numpy as np
+    import emu_py
+    emu_py.load()
+    lib = C.CDLL(emu_py.EMU_SO)
+    lib.gie_emu_fuse_row8.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.gie_emu_fuse_voxel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def one(thresh, label, occ, ty):
+        o, t = C.c_int(), C.c_int()
+        lib.gie_emu_fuse_voxel(thresh, label, occ, ty, C.byref(o), C.byref(t))
+        return o.value, t.value
+    def row(thresh, labels, occs, tys):
+        pack = lambda v: sum((int(b) & 0xff) << (8 * i) for i, b in enumerate(v))
+        no, ny = C.c_uint64(), C.c_uint64()
+        lib.gie_emu_fuse_row8(thresh, pack(labels), pack(occs), pack(tys), C.byref(no), C.byref(ny))
+        return [(no.value >> (8 * i)) & 0xff for i in range(8)], [(ny.value >> (8 * i)) & 0xff for i in range(8)]
+    rng = np.random.default_rng(3)
+    for thresh in (127, 180, 200, 254, 255):
+        table = {(l, t, o): one(thresh, l, o, t) for l in range(4) for t in range(4) for o in range(256)}
+        # every combination in byte 0..7, the other bytes random
+        for pos in range(8):
+            for l in range(4):
+                for t in range(4):
+                    for o in range(0, 256, 1 if pos in (0, 7) else 17):
+                        labels, occs, tys = rng.integers(0, 4, 8), rng.integers(0, 256, 8), rng.integers(0, 4, 8)
+                        labels[pos], occs[pos], tys[pos] = l, o, t
+                        no, ny = row(thresh, labels, occs, tys)
+                        for i in range(8):
+                            assert (no[i], ny[i]) == table[(int(labels[i]), int(tys[i]), int(occs[i]))], (thresh, pos, i, labels, occs, tys, no, ny)
