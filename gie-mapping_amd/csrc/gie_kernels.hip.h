@@ -990,10 +990,15 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
     for (int m = 0; m < CP; m++) { const int z = 64 * m + lane; if (z < Z && c.zocc[z]) zvalid |= 1u << m; }
     __syncthreads();
 
-    /* a workgroup takes x-adjacent tiles in PAIRS, one after the other: a 16-column row segment is half
-     * a 128-byte line, and the other half is then still in this XCD's L2 */
+    /* A 16-column row segment is half a 128-byte line.  x-adjacent tiles — the two halves of the same lines — go to two workgroups
+     * of the SAME XCD (workgroup ids are dealt round-robin over the eight XCDs: b and b ^ 8 share one) in the same iteration, so
+     * that the second half is still in that XCD's L2 when it is asked for (round 4; before, one workgroup took the two tiles one
+     * after the other — a whole tile's column work apart — and the pass fetched 1.46x its bytes).  A grid that is not a multiple
+     * of 16 workgroups keeps the old order. */
     int it = 0;
-#define GIE_ZTILE(i) ((((i) >> 1) * (int)gridDim.x + (int)blockIdx.x) * 2 + ((i) & 1))
+    const bool xpair = (gridDim.x & 15u) == 0u;
+    const int pq = ((int)blockIdx.x & 7) | (((int)blockIdx.x >> 4) << 3), ph = ((int)blockIdx.x >> 3) & 1, phalf = (int)gridDim.x >> 1;
+#define GIE_ZTILE(i) (xpair ? (((i) * phalf + pq) * 2 + ph) : ((((i) >> 1) * (int)gridDim.x + (int)blockIdx.x) * 2 + ((i) & 1)))
     int t = GIE_ZTILE(0);
     /* rows are addressed as buffer offsets: a 32-bit byte offset per thread and tile + a scalar row stride (N * 4 bytes < 2^32 for
      * every volume gie_create accepts).  With 64-bit pointers the compiler kept sixteen row addresses per thread alive across the
