@@ -322,6 +322,75 @@ def test_depth_ogm_against_float64_restatement_of_the_reference(oracle_lib):
         o.close()
 
 
+def _scan2d_f64(pos, q, size, w, rng, theta_inc, theta_min, min_h, max_h, eps_m=1e-4):
+    """HOKUYO_FAST::setLocalOccupancy (hokuyo_fast.cu:9-81) + SCAN_HELPER::G2L (hokuyo_helper.h:17-33) in float64: the voxel centre
+    in the sensor frame; theta = atan2(y, x) -> bin floor((theta - theta_min) / theta_inc + 0.5) modulo scan_num; the voxel is looked
+    at only when |z| < voxel width (depth = horizontal range, else -1); range NaN or <= 0.3 -> nothing; ideal < real - 0.3 -> FREE;
+    ideal > real + 0.3 -> nothing; else OCCUPIED inside the height gate."""
+    g = _voxel_positions(pos, size, w)
+    rt, t = _g2l(pos, q)
+    l = g @ rt.T + t
+    n = rng.shape[0]
+    theta = np.arctan2(l[..., 1], l[..., 0])
+    tt = (theta - theta_min) / theta_inc + 0.5
+    ti = np.floor(tt).astype(np.int64) % n
+    wv = float(np.float32(w))
+    inplane = np.abs(l[..., 2]) < wv
+    ideal = np.sqrt(l[..., 0] ** 2 + l[..., 1] ** 2)
+    real = rng.astype(np.float64)[ti]
+    ok = inplane & ~np.isnan(real) & (real > 0.3)
+    free = ok & (ideal < real - 0.3)
+    beyond = ok & (ideal > real + 0.3)
+    band = ok & ~free & ~beyond
+    occ = band & (g[..., 2] >= min_h) & (g[..., 2] <= max_h)
+    lab = np.zeros(g.shape[:-1], np.int8)
+    lab[free] = 1
+    lab[occ] = 2
+    with np.errstate(invalid="ignore"):
+        m_bin = np.minimum(tt % 1.0, 1 - tt % 1.0)
+        m_z = np.abs(np.abs(l[..., 2]) - wv)
+        m_rng = np.minimum(np.abs(ideal - (real - 0.3)), np.abs(ideal - (real + 0.3)))
+        m_h = np.minimum(np.abs(g[..., 2] - min_h), np.abs(g[..., 2] - max_h))
+    sure = (m_z > 1e-5) & (~inplane | ((m_bin > 2e-3) & (ideal > 1e-3))) & (~ok | (m_rng > eps_m)) & (~band | (m_h > 1e-5)) \
+        & (~inplane | np.isnan(real) | (np.abs(real - 0.3) > 1e-5))
+    return lab, sure
+
+
+def test_scan2d_ogm_against_float64_restatement_of_the_reference(oracle_lib):
+    """The hokuyo path had no check outside the oracle's own arithmetic: a tilted sensor (roll and pitch, so that the
+    |z| < voxel-width slab cuts through the volume obliquely), a NaN stretch and a too-short stretch in the scan."""
+    size, w = (48, 48, 12), 0.1
+    world = scenes.BoxWorld(6, extent=(4.0, 4.0, 1.0), n_boxes=30, toggle_frac=0.0)
+    cfg = gie.make_config(w, size, cutoff_dist=1.0, ogm_min_h=-0.25, ogm_max_h=0.3)
+    o = OracleMapper(cfg)
+    seen = [0, 0]
+    try:
+        for k, tilt in ((0, 0.0), (3, 0.06), (6, -0.04)):
+            pos, qy = scenes.pose(k, w, delta_vox=4, yaw_deg=31.0)
+            # yaw * roll(tilt) * pitch(tilt / 2), Hamilton product, (w, x, y, z)
+            def qmul(a, b):
+                return (a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0])
+            q = qmul(qmul(qy, (math.cos(tilt / 2), math.sin(tilt / 2), 0.0, 0.0)), (math.cos(tilt / 4), 0.0, math.sin(tilt / 4), 0.0))
+            q = tuple(float(np.float32(v)) for v in q)
+            _, rg = scenes.lidar_frame(world, k, pos, q, rings=1, az=360, phi_min_deg=0.0, max_range=30.0)
+            r = np.where(np.isfinite(rg[0]), rg[0], np.nan).astype(np.float32)
+            r[40:55] = np.nan
+            r[200:210] = 0.25
+            kw = dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi + np.pi / 360)
+            o.set_pose(pos, q)
+            o.ogm_scan2d(r, **kw)
+            lab = o.read_ogm()["inst_type"]
+            f32 = lambda v: float(np.float32(v))
+            want, sure = _scan2d_f64(pos, q, size, w, r, f32(kw["theta_inc"]), f32(kw["theta_min"]), f32(-0.25), f32(0.3))
+            nf, no = _compare(lab, want, sure, "scan2d frame %d" % k)
+            seen[0] += nf; seen[1] += no
+            o.fuse(); o.batch_edt(); o.merge()
+        assert seen[0] > 1000 and seen[1] > 30            # the scenes exercise both labels
+    finally:
+        o.close()
+
+
 # ------------------------------------------------------------------ ray-casting OGM + fusion: a second statement
 # Written from pntcld_raycast.cu:11-117, ray_cast.h:57-144, local_batch.h:114-126,250-258,303-350 and unify_helper.cuh:34-118 /
 # voxmap_utils.cuh:182-200, not from the oracle: plain Python loops, every float operation an np.float32 operation in the order
