@@ -744,9 +744,9 @@ def run_bench():
         line["timing_note"] = ("value / ms_per_step: median of the timed regions, each EXACTLY K steps between barrier + synchronize, MAX over ranks; "
                                "kernels_ms_per_step and the roofline objects: the first region replayed on a fresh mapper with start / stop events "
                                "on every kernel's dispatch (costs ms_per_step_instrumented - ms_per_step)")
-        line["error_bar"] = ("the duration of the Mark + commit sweep belongs to the MAPPER INSTANCE (where its planes lie in physical memory), not to "
-                             "the build: the same binary measures 0.85-0.93 ms there, i.e. ms_per_step 2.6-2.75 from run to run (about +-3 %; "
-                             "round 2: +-5 %); the instrumented replay runs on a second mapper and can sit in the other band (DESIGN.md 4)")
+        line["error_bar"] = ("the duration of the Mark + commit sweep depends on where the mapper's planes lie in physical memory (two write streams "
+                             "that overlap or take turns): 0.80 or 0.89 ms for the same kernel.  Since round 4 gie_create re-draws the four planes "
+                             "against a probe of the sweep's memory pattern (GIE_PLACE_TRIES, DESIGN.md 4): 12 of 12 fresh mappers at 0.80 +- 0.02 ms")
         if world == 1 and not args.no_extras:
             extras = {}
             for wl in ("vlp16_projective", "vlp16"):

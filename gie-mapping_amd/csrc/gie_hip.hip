@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -338,6 +339,28 @@ static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
     if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list);
     else if (lx == 64) GIE_LAUNCH(b, k_markc<64>, g, t, 0, c, list);
     else GIE_LAUNCH(b, k_markc<32>, g, t, 0, c, list);
+}
+/* placement probe (k_place_probe): median of `reps` timed launches, ms */
+static float be_place_probe(be_state *b, const gie_ctx &c, int reps, int streams = 15)
+{
+    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
+    const long long ntile = (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
+    const int nslot = (int)(ntile < c.max_blocks ? ntile : c.max_blocks);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    std::vector<float> ms;
+    hipLaunchKernelGGL(k_place_probe, dim3(b->cu_total * mult), dim3(256), 0, b->stream, c, nslot, streams);      /* warm-up: page tables, clocks */
+    for (int r = 0; r < reps; r++) {
+        (void)hipEventRecord(e0, b->stream);
+        hipLaunchKernelGGL(k_place_probe, dim3(b->cu_total * mult), dim3(256), 0, b->stream, c, nslot, streams);
+        (void)hipEventRecord(e1, b->stream);
+        (void)hipEventSynchronize(e1);
+        float t = 0.f; (void)hipEventElapsedTime(&t, e0, e1); ms.push_back(t);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::sort(ms.begin(), ms.end());
+    GIE_HIP_OK(hipMemsetAsync(c.pair, 0, (size_t)c.N * sizeof(uint64_t), b->stream));
+    return ms.empty() ? -1.f : ms[ms.size() / 2];
 }
 /* dense (block-row) form of fuse; GIE_ROWS=0 keeps the thread-per-z-column sweep */
 static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(getenv("GIE_ROWS")) : 1; return v ? 2 : 0; }

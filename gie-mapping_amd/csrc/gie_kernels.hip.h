@@ -1393,6 +1393,43 @@ __global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *l
     }
 }
 
+/* ------------------------------------------------------------------ placement probe */
+/* The memory pattern of the dense Mark + commit sweep on a mapper's own planes, without its arithmetic: a z-column of eight voxels
+ * per thread, 32 lanes along x by 2 along y; reads the type and the batch obstacle, writes the pair and — at the address the voxel
+ * would have in a pool filled in tile order — the stored obstacle.  How long it takes depends on where the planes lie in physical
+ * memory (DESIGN.md 4 "placement"), which is what gie_create uses it for; it leaves garbage in `pair` and `g_coc` (the caller clears
+ * the former, the latter is initialised when a block is handed out). */
+__global__ __launch_bounds__(256) void k_place_probe(const gie_ctx c, const int nslot, const int streams)
+{
+    constexpr int LX = 32, LY = 2, WY = 4 * LY;
+    const int lane = threadIdx.x & 63;
+    const int gx = (c.X + LX - 1) / LX, gy = (c.Y + WY - 1) / WY, gz = (c.Z + 7) / 8;
+    const int nv = gx * gy * gz;
+    const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
+    const size_t plane = (size_t)c.X * c.Y;
+    for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++) {
+        const int xg = v % gx;
+        const int x = xg * LX + lx, y = ((v / gx) % gy) * WY + ly, z0 = (v / (gx * gy)) * 8;
+        if (x >= c.X || y >= c.Y) continue;
+        const size_t id0 = ((size_t)z0 * c.Y + y) * c.X + x;
+        const int nz = min(8, c.Z - z0);
+        int8_t ty[8]; uint32_t bc[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const size_t id = id0 + (size_t)(k < nz ? k : 0) * plane; ty[k] = (streams & 1) ? c.glb_type[id] : (int8_t)k; bc[k] = (streams & 2) ? c.bcoc[id] : (uint32_t)x; }
+        const int t = gie_tile_index(c, x, y, z0);
+        const gie_vaddr base = (gie_vaddr)(t % nslot) * GIE_VBSZ + ((x & 7) | ((y & 7) << 3));
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k >= nz) break;
+            const uint64_t pr = ((uint64_t)bc[k] << 20) | (uint64_t)(uint8_t)ty[k];
+            if (streams & 4) c.pair[id0 + (size_t)k * plane] = pr;
+            if (streams & 8) c.g_coc[base + (k << 6)] = pr ^ 0x5555ull;
+            if (!(streams & 12) && pr == 0x123456789abcull) c.pair[id0] = pr;       /* (keeps the loads alive) */
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ obtainFrontiers: tiles out of LDS, faces one voxel per lane */
 /* obtainFrontiers (unify_helper.cuh:275-446).  The per-voxel decisions are gie_frontier_finish_nb's (gie_ops.h); what the two
  * kernels here change is where their inputs come from and who looks at which voxel (the thread-per-column form walked a

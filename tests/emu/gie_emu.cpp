@@ -26,6 +26,7 @@ static void be_memset(be_state *, void *p, int v, size_t n) { memset(p, v, n); }
 static void be_h2d(be_state *, void *d, const void *h, size_t n) { memcpy(d, h, n); }
 static void be_d2h(be_state *, void *h, const void *d, size_t n) { memcpy(h, d, n); }
 static int be_sync(be_state *) { return 0; }
+static float be_place_probe(be_state *, const gie_ctx &, int, int = 15) { return 0.f; }      /* (a device measurement: nothing to emulate) */
 static void *be_stream_handle(be_state *) { return nullptr; }
 static void *be_host_alloc(be_state *, size_t bytes) { return malloc(bytes ? bytes : 1); }
 static void be_host_free(be_state *, void *p) { free(p); }

@@ -13,6 +13,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False, max_blocks=bench.pool_blocks("c5", size, 40))
     for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
         m = gie.Mapper(cfg)
+        probe_ms = -1.0
+        if os.environ.get("PROBE_PLACE"):
+            import ctypes as C
+            f = gie.mapper._lib.gie_debug_place_probe; f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+            v = C.c_float(0); f(m._h, 5, C.byref(v)); probe_ms = v.value
         feed = bench.make_feed("c5", torch, scenes, dev, 0.05, size, (0, 0, 0), 10)
         feed.prepare(0, 8)
         for i in range(3):
@@ -22,8 +27,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
             feed.step_input(m, i); m.step()
         m.sync()
         pr = m.profile_read()
-        print("RESULT size=%s skew=%s rep=%d mark_commit/Gvox=%.4f mark_commit=%.4f fuse=%.4f z=%.4f x=%.4f total=%.4f" % (
-            "x".join(map(str, size)), os.environ.get("GIE_ARENA_SKEW", "-"), rep, pr["mark_commit"][0] / max(1, pr["mark_commit"][1]) / (size[0] * size[1] * size[2] / 134217728.0),
+        print("RESULT probe=%.4f size=%s skew=%s rep=%d mark_commit/Gvox=%.4f mark_commit=%.4f fuse=%.4f z=%.4f x=%.4f total=%.4f" % (
+            probe_ms, "x".join(map(str, size)), os.environ.get("GIE_ARENA_SKEW", "-"), rep, pr["mark_commit"][0] / max(1, pr["mark_commit"][1]) / (size[0] * size[1] * size[2] / 134217728.0),
             *[pr[k][0] / max(1, pr[k][1]) for k in ("mark_commit", "fuse", "edt_pass_z", "edt_pass_x")],
             sum(v[0] for v in pr.values()) / 5.0), flush=True)
         m.close()
