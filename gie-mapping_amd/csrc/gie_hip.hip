@@ -240,6 +240,10 @@ template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f,
     if (n <= 0) return;
     GIE_LAUNCH(b, k_lin<F>, dim3((n + 255) / 256), dim3(256), 0, c, f, n);
 }
+static void be_flush_clear(be_state *b, const gie_ctx &c, const op_pair_flush &f, int n, const gie_clear_list &l)
+{
+    GIE_LAUNCH(b, k_flush_clear, dim3(32 * l.n + (n + 255) / 256), dim3(256), 0, c, f, n, l);
+}
 static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels)
 {
     if ((c.X & 15) == 0 && !c.for_motion_planner && ((uintptr_t)labels & 15) == 0) {

@@ -330,6 +330,24 @@ __global__ __launch_bounds__(256) void k_clear(const gie_clear_list l)
     for (uint32_t i = tail0 + tid; i < bytes; i += nth) p[i] = 0;
 }
 
+/* the frame clear and the flush of the stored pairs a fused update left out (gie_pair_flush_voxel) in one launch: the first
+ * 32 * l.n workgroups clear, the others flush — they touch different arrays */
+__global__ __launch_bounds__(256) void k_flush_clear(const gie_ctx c, const op_pair_flush f, const int n, const gie_clear_list l)
+{
+    const int nclr = 32 * l.n;
+    if ((int)blockIdx.x >= nclr) { const int i = ((int)blockIdx.x - nclr) * 256 + (int)threadIdx.x; if (i < n) f(c, i); return; }
+    const int r = blockIdx.x >> 5, bx = blockIdx.x & 31;
+    unsigned char *p = (unsigned char *)l.p[r];
+    const uint32_t bytes = l.bytes[r];
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) < bytes ? (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) : bytes;
+    const uint32_t nvec = (bytes - head) / 16u, tail0 = head + nvec * 16u;
+    const uint32_t tid = bx * 256 + threadIdx.x, nth = 32 * 256;
+    for (uint32_t i = tid; i < head; i += nth) p[i] = 0;
+    uint4 *v = (uint4 *)(p + head);
+    for (uint32_t i = tid; i < nvec; i += nth) v[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tail0 + tid; i < bytes; i += nth) p[i] = 0;
+}
+
 /* ------------------------------------------------------------------ block allocation */
 /* allocHashTB (glb_hash_map.cu:58-113) + the frame's block table in one sweep over the table
  * cells: look the block up; a cell the scan observed without a block gets a slot (one atomic per
@@ -1230,6 +1248,7 @@ __global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx 
     /* the same tiles as a list (mark / commit / pass Z visit only these when they are few): one atomic per workgroup */
     const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_KNOWN], k);
     if (slot >= 0) c.tl_known[slot] = t;
+    if (c.oldskip && colok && tz < c.tfd[2]) gie_tile_oldskip(c, t);     /* (tskip is zero otherwise: the frame clear) */
 }
 
 /* ------------------------------------------------------------------ adaptive sweeps */

@@ -108,6 +108,7 @@ typedef struct gie_ctx {
     int32_t *tmax, *tmax_prev; /* per tile: 1 + the largest distance this / the previous (fused) map update committed in it; 0x7fffffff: a voxel of
                                 * the tile was not committed; 0: the tile was not looked at */
     uint8_t *ucol;          /* per z-column of eight voxels (index ((z >> 3) * Y + y) * X + x), bit z & 7: the local index has turned from unknown to known and Mark has not written its pair since (gie_ops.h "`_edt_D` is derived") */
+    int oldskip;            /* this update's batch EDT flags the tiles whose stored records Mark need not read (gie_tile_oldskip) */
     uint8_t *tskip;         /* per tile: Mark need not read the stored global records of this tile (gie_tile_oldskip) */
     int prev_valid;         /* tmax_prev describes the map update right before this one */
     int prev_shift[3];      /* previous local coordinate = local coordinate + prev_shift */

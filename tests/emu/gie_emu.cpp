@@ -109,6 +109,7 @@ static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels) { op_
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 template <class F> static void be_range(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
+static void be_flush_clear(be_state *b, const gie_ctx &c, const op_pair_flush &f, int n, const gie_clear_list &l) { be_lin(b, c, f, n); be_clear(b, l); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell);
 /* sequential allocHashTB: flag → rank → insert → initialise → table */
@@ -145,6 +146,7 @@ static void be_edt_prep(be_state *, const gie_ctx &c)
 {
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     for (int t = 0; t < ntile; t++) if (c.tknown[t]) c.tl_known[c.cnt[GIE_CNT_TL_KNOWN]++] = t;
+    if (c.oldskip) for (int t = 0; t < ntile; t++) gie_tile_oldskip(c, t);
 }
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
 static void be_edt(be_state *, const gie_ctx &c, int)

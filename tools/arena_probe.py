@@ -31,6 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
             probe_ms, "x".join(map(str, size)), os.environ.get("GIE_ARENA_SKEW", "-"), rep, pr["mark_commit"][0] / max(1, pr["mark_commit"][1]) / (size[0] * size[1] * size[2] / 134217728.0),
             *[pr[k][0] / max(1, pr[k][1]) for k in ("mark_commit", "fuse", "edt_pass_z", "edt_pass_x")],
             sum(v[0] for v in pr.values()) / 5.0), flush=True)
+        print("KERNELS rep=%d " % rep + " ".join("%s=%.4f" % (k, v[0] / max(1, v[1])) for k, v in sorted(pr.items())), flush=True)
         m.close()
     sys.exit(0)
 random.seed(int(os.environ.get("PROBE_SEED", "1")))
@@ -46,6 +47,8 @@ for c in configs:
         env["GIE_ARENA_MB"] = os.environ.get("ARENA_MB", "40000"); env["GIE_ARENA_SKEW"] = c
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
     for ln in r.stdout.splitlines():
+        if ln.startswith("KERNELS"):
+            print(ln, flush=True)
         if ln.startswith("RESULT"):
             print(("separate " if c is None else "arena    ") + ln, flush=True)
     if r.returncode != 0:
