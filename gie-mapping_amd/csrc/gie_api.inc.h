@@ -734,7 +734,9 @@ extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *
 {
     if (!m) { gie_set_err("gie_read_local: null handle"); return GIE_ERR_INVALID; }
     const size_t N = (size_t)m->c.N;
-    if (edt) {           /* `_edt_D` is derived from the pairs where the reference would have written it (gie_ops.h gie_edt_value) */
+    static const int edt_raw = getenv("GIE_EDT_RAW") ? atoi(getenv("GIE_EDT_RAW")) : 0;     /* measurement builds keep time stamps in the plane (tools/wave_timing.py) */
+    if (edt && edt_raw) be_d2h(&m->be, edt, m->c.edt, N * sizeof(float));
+    else if (edt) {      /* `_edt_D` is derived from the pairs where the reference would have written it (gie_ops.h gie_edt_value) */
         float *de = (float *)gie_scratch(m, 0, N * 4, "gie_read_local");
         if (!de) return GIE_ERR_DEVICE;
         op_export_edt op; op.out = de;
