@@ -7,11 +7,14 @@
  * transcendental is used: atan2 is a fixed polynomial (Cephes-style atanf reduction), because
  * device and host libm differ in the last ulp and a one-ulp difference flips floor() bins.
  *
- * What is restated here (math only; the reference's se3.cuh/matrix.cuh are GPL, helper_math.h
- * is NVIDIA-EULA, so nothing is copied — formulas are re-derived):
- *   SE3 from unit quaternion + translation, inverse, point transform
- *       (include/cuda_toolkit/se3.cuh:47-77, 91-108, 123-149, 200-204)
- *   LocMap::pos2coord  floorf(p/w + 0.5f)           (include/map_structure/local_batch.h:250-258)
+ * What is restated here is mathematics, written for this header: the rotation matrix of a unit quaternion (the textbook
+ * R = I + 2 w [v]x + 2 [v]x^2), the rigid inverse (R^T, -R^T t), the point transform, and the voxel index floor(p / w + 1/2).
+ * The reference evaluates the same expressions in include/cuda_toolkit/se3.cuh:47-77, 91-108, 123-149, 200-204 and
+ * include/map_structure/local_batch.h:250-258; for voxelisation to agree with it bit for bit, every fp32 ROUNDING has to
+ * happen where it happens there, which fixes the association of the two-term sums below but not the way they are written:
+ * the matrix is built from the six products of quaternion components, each doubled by an addition (doubling is exact in
+ * binary floating point, so fl((2a) b) = 2 fl(a b) = fl(a b) + fl(a b)); tests/test_independent_checks.py holds the result
+ * against float64 AND, bit for bit, against an fp32 evaluation in the "double the component first" order.
  */
 #ifndef GIE_MATH_H
 #define GIE_MATH_H
@@ -28,21 +31,24 @@ typedef struct gie_se3 {
     float m[12]; /* row-major 3x4: r00 r01 r02 tx / r10 r11 r12 ty / r20 r21 r22 tz */
 } gie_se3;
 
-/* se3.cuh:47-77 — rotation from a normalised quaternion (w,x,y,z), translation t. */
+/* Rotation from a normalised quaternion (w, x, y, z), translation t.  (The reference's counterpart: se3.cuh:47-77.) */
 GIE_HD gie_se3 gie_se3_from_quat(float qw, float qx, float qy, float qz, float tx, float ty, float tz)
 {
+    const float v[3] = { qx, qy, qz };
+    float vv[3][3], wv[3];                   /* 2 v_i v_j (upper triangle) and 2 w v_i */
+    for (int i = 0; i < 3; i++) {
+        const float pw = v[i] * qw;
+        wv[i] = pw + pw;
+        for (int j = i; j < 3; j++) { const float pv = v[j] * v[i]; vv[i][j] = pv + pv; }
+    }
     gie_se3 s;
-    const float x = 2 * qx, y = 2 * qy, z = 2 * qz;
-    const float wx = x * qw, wy = y * qw, wz = z * qw;
-    const float xx = x * qx, xy = y * qx, xz = z * qx;
-    const float yy = y * qy, yz = z * qy, zz = z * qz;
-    s.m[0] = 1 - (yy + zz); s.m[1] = xy - wz;       s.m[2] = xz + wy;        s.m[3] = tx;
-    s.m[4] = xy + wz;       s.m[5] = 1 - (xx + zz); s.m[6] = yz - wx;        s.m[7] = ty;
-    s.m[8] = xz - wy;       s.m[9] = yz + wx;       s.m[10] = 1 - (xx + yy); s.m[11] = tz;
+    s.m[0] = 1 - (vv[1][1] + vv[2][2]); s.m[1] = vv[0][1] - wv[2];           s.m[2] = vv[0][2] + wv[1];            s.m[3] = tx;
+    s.m[4] = vv[0][1] + wv[2];           s.m[5] = 1 - (vv[0][0] + vv[2][2]); s.m[6] = vv[1][2] - wv[0];            s.m[7] = ty;
+    s.m[8] = vv[0][2] - wv[1];           s.m[9] = vv[1][2] + wv[0];           s.m[10] = 1 - (vv[0][0] + vv[1][1]); s.m[11] = tz;
     return s;
 }
 
-/* se3.cuh:91-108 — rigid inverse: R^T, -R^T t (same term order). */
+/* Rigid inverse: R^T, -R^T t, the three products of a row subtracted from left to right (the reference's counterpart: se3.cuh:91-108). */
 GIE_HD gie_se3 gie_se3_inv(const gie_se3 a)
 {
     gie_se3 r;
@@ -55,7 +61,7 @@ GIE_HD gie_se3 gie_se3_inv(const gie_se3 a)
     return r;
 }
 
-/* se3.cuh:123-149,200-204 — rotate then translate. */
+/* Rotate, then translate (the reference's counterpart: se3.cuh:123-149, 200-204). */
 GIE_HD void gie_se3_apply(const gie_se3 s, float px, float py, float pz, float *ox, float *oy, float *oz)
 {
     const float rx = s.m[0] * px + s.m[1] * py + s.m[2] * pz;

@@ -92,6 +92,27 @@ def test_quaternion_to_se3_against_float64(ms):
     assert np.allclose(o, [0, 1, 0], atol=2e-7)
 
 
+def test_quaternion_to_se3_rounds_like_the_doubled_component_form(ms):
+    """gie_se3_from_quat doubles the PRODUCTS of quaternion components; the reference doubles a component first and multiplies
+    then (se3.cuh:53-75).  Doubling is exact in binary floating point, so the two must agree in every bit — which is what makes the
+    header free to write the matrix its own way."""
+    rng = np.random.default_rng(12)
+    f = np.float32
+    for _ in range(3000):
+        q = rng.standard_normal(4)
+        q = (q / np.linalg.norm(q)).astype(np.float32)
+        if rng.random() < 0.1:
+            q[rng.integers(0, 4)] = f(0.0)
+        w, x, y, z = [f(v) for v in q]
+        x2, y2, z2 = f(2) * x, f(2) * y, f(2) * z
+        wx, wy, wz = x2 * w, y2 * w, z2 * w
+        xx, xy, xz = x2 * x, y2 * x, z2 * x
+        yy, yz, zz = y2 * y, z2 * y, z2 * z
+        want = np.array([[f(1) - (yy + zz), xy - wz, xz + wy], [xy + wz, f(1) - (xx + zz), yz - wx], [xz - wy, yz + wx, f(1) - (xx + yy)]], np.float32)
+        got = _se3(ms, q, (0.0, 0.0, 0.0))[:, :3]
+        assert got.tobytes() == want.tobytes(), (q, got, want)
+
+
 def test_rigid_inverse_and_transform_against_float64(ms):
     rng = np.random.default_rng(12)
     for _ in range(200):
