@@ -215,13 +215,15 @@ GIE_DEV int gie_classify_multiscan(const gie_ctx &c, const float *ranges, const 
     const float gx = (float)(x + c.pvt[0]) * w, gy = (float)(y + c.pvt[1]) * w, gz = (float)(z + c.pvt[2]) * w;
     float lx, ly, lz;
     gie_se3_apply(c.G2L, gx, gy, gz, &lx, &ly, &lz);
-    const float theta = gie_atan2f(ly, lx);
-    int theta_idx = (int)floorf((theta - p.theta_min) / p.theta_inc + 0.5f);
-    theta_idx = gie_pos_mod(theta_idx, p.scan_num);
+    /* (the ring first: two thirds of a cubic volume lie above or below a 16-ring lidar's field of view, whole wavefronts of 64
+     * x-adjacent voxels at a time, and leave before the azimuth's atan2 and division; the values are the same in either order) */
     const float range_hor = sqrtf(ly * ly + lx * lx);
     const float phi = gie_atan2f(lz, range_hor);
     const int phi_idx = (int)floorf((phi - p.phi_min) / p.phi_inc + 0.5f);
     if (phi_idx < 0 || phi_idx >= p.ring_num) return GIE_VOX_UNKNOWN;
+    const float theta = gie_atan2f(ly, lx);
+    int theta_idx = (int)floorf((theta - p.theta_min) / p.theta_inc + 0.5f);
+    theta_idx = gie_pos_mod(theta_idx, p.scan_num);
     const float ideal = sqrtf(lx * lx + ly * ly);
     if (ideal < 0 || theta_idx < 0 || theta_idx >= p.scan_num) return GIE_VOX_UNKNOWN;
     const float real = ranges[phi_idx * p.scan_num + theta_idx];
@@ -240,10 +242,10 @@ GIE_DEV int gie_classify_scan2d(const gie_ctx &c, const float *ranges, const gie
     const float gx = (float)(x + c.pvt[0]) * w, gy = (float)(y + c.pvt[1]) * w, gz = (float)(z + c.pvt[2]) * w;
     float lx, ly, lz;
     gie_se3_apply(c.G2L, gx, gy, gz, &lx, &ly, &lz);
+    if (!(fabsf(lz) < w)) return GIE_VOX_UNKNOWN;        /* (the slab test first: nearly every voxel leaves here, before the atan2) */
     const float theta = gie_atan2f(ly, lx);
     int theta_idx = (int)floorf((theta - p.theta_min) / p.theta_inc + 0.5f);
     theta_idx = gie_pos_mod(theta_idx, p.scan_num);
-    if (!(fabsf(lz) < w)) return GIE_VOX_UNKNOWN;
     const float ideal = sqrtf(lx * lx + ly * ly);
     const float real = ranges[theta_idx];
     if (real != real || real <= 0.3f) return GIE_VOX_UNKNOWN;
