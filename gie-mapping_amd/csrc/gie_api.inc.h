@@ -35,6 +35,7 @@ struct gie_mapper {
     long long tomb_bound;                 /* upper bound of the tombstones those erasures left in the table */
     int retain_box_valid, retain_box_lo[3], retain_box_hi[3];   /* block box +- retain of the last update that erased */
     int deferred;                         /* the last merge ran fused: the stored pairs of its volume's voxels are still to be written when they leave (gie_commit_pair) */
+    int32_t *blk_tab2; int tab_valid, tab_tb0[3];   /* the other block table (the tables of consecutive fuses alternate) and where the current one was built */
     int flush_tab_ok;                     /* ... and _glb_type / the block table are still that update's (no gie_fuse since) */
     int commit_pvt[3], commit_upvt[3], commit_tb0[3];   /* pivots / block-table origin of that merge */
     int edt_partial;                      /* the last batch EDT skipped tiles nobody reads (gie_read_batch_edt completes it) */
@@ -209,6 +210,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     for (int i = 0; i < 3; i++) c.tdim[i] = cfg->local_size[i] / 8 + 3;
     m->ncell = c.tdim[0] * c.tdim[1] * c.tdim[2];
     c.blk_tab = gie_dalloc<int32_t>(m, (size_t)m->ncell, false);
+    m->blk_tab2 = gie_dalloc<int32_t>(m, (size_t)m->ncell, false);
+    c.tab_prev = nullptr; m->tab_valid = 0;
     c.blk_need = gie_dalloc<uint8_t>(m, (size_t)m->ncell);
     c.blk_new = gie_dalloc<int32_t>(m, (size_t)m->ncell);
     m->d_rank = gie_dalloc<int32_t>(m, (size_t)m->ncell);
@@ -313,6 +316,7 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
         c.tb0[i] = (c.pvt[i] - 1) >> 3;
         c.vb_lo[i] = (c.pvt[i] - 1) >> 3; c.vb_hi[i] = (c.pvt[i] + sz[i]) >> 3;
     }
+    c.tab_prev = nullptr;                                 /* the block table belongs to the pose before: the next gie_fuse builds this one's (from it) */
     const uint32_t f = (uint32_t)c.map_ct & 0x3ffffu;
     if (f == 0) {                                         /* stamp wrap: clear the stamp planes once */
         be_memset(&m->be, c.wl, 0, (size_t)c.N * sizeof(uint32_t));
@@ -590,7 +594,18 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* + the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
      * earlier frames), listed in the block-initialisation launch; fuse, Mark, commit and pass Z walk their list or
      * sweep the volume — each kernel decides from the length of its list (gie_use_lists) */
+    {   /* the table of the fuse before answers for the blocks it knew (k_cell_alloc); the two tables alternate */
+        gie_ctx &c = m->c;
+        if (m->tab_valid) {
+            c.tab_prev = c.blk_tab;
+            for (int i = 0; i < 3; i++) c.tab_prev_d[i] = c.tb0[i] - m->tab_tb0[i];
+            int32_t *t = c.blk_tab; c.blk_tab = m->blk_tab2; m->blk_tab2 = t;
+        } else c.tab_prev = nullptr;
+        for (int i = 0; i < 3; i++) m->tab_tb0[i] = c.tb0[i];
+        m->tab_valid = 1;
+    }
     be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0, (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
+    m->c.tab_prev = m->c.blk_tab; m->c.tab_prev_d[0] = m->c.tab_prev_d[1] = m->c.tab_prev_d[2] = 0;     /* (a second allocation pass of this update — ghost layers — looks into this table first) */
     be_prof(&m->be, GIE_K_ALLOC, 1);
     be_prof(&m->be, GIE_K_FUSE, 0);
     be_fuse(&m->be, m->c, m->c.tl_front);

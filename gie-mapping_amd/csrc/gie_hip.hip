@@ -261,7 +261,8 @@ static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, 
 {
     if (clear_list) GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_NEWLIST], 0, sizeof(int32_t), b->stream));
     GIE_LAUNCH(b, k_cell_alloc, dim3((ncell + 255) / 256), dim3(256), 0, c, ncell);
-    const int ninit = b->cu_total * 4;
+    static const int imult = getenv("GIE_INIT_MULT") ? atoi(getenv("GIE_INIT_MULT")) : 4;
+    const int ninit = b->cu_total * imult;
     int nfl = (fuse_list_ntile + 255) / 256; if (nfl > 2 * b->cu_total) nfl = 2 * b->cu_total;
     GIE_LAUNCH(b, k_block_init_list, dim3(ninit + nfl), dim3(256), 0, c, ninit, fuse_list_ntile);
 }

@@ -125,6 +125,9 @@ typedef struct gie_ctx {
     int tb0[3];             /* block coordinate of table cell 0 */
     int tdim[3];
     int32_t *blk_tab;       /* slot or -1 */
+    const int32_t *tab_prev; /* the block table of the fuse before (or this one again, for a second allocation pass of the same update), or null: a
+                              * cell it holds a slot for needs no hash lookup (blocks inside the volume's box are never erased or moved) */
+    int tab_prev_d[3];      /* cell (bx, by, bz) of this table = cell (bx, by, bz) + tab_prev_d of that one */
     uint8_t *blk_need;      /* observed-this-scan flag per table cell */
     int32_t *blk_new;       /* scratch: new-block flag / rank */
     /* ---- global map: hash + SoA block pool */
