@@ -2060,17 +2060,30 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
 #define GIE_WAVE_SLOTS(want) ((want) < GIE_WAVE_THREADS / 64 ? (want) : GIE_WAVE_THREADS / 64)
 #define GIE_BAR_SPIN_LIMIT (1 << 22)
 
-struct gie_gridbar { int32_t *word; int epoch; int failed; int nwg; int *s_fail; };   /* nwg = workgroups that meet at this barrier */
+/* The visit count of a round is a word every block-run of the round would add to: a thousand wavefronts within the same few
+ * microseconds, and same-address atomics serialise at their L2 slice (~6-10 ns each; round 4: 15 us of a 278 us launch, found by
+ * leaving them out).  They are summed per WORKGROUP in LDS (GIE_VIS_ADD) and handed to the round's word by one lane at the grid
+ * barrier.  (The lengths of the next round's lists are such words too.  Tried: per-wavefront chunks of 16 list entries with the
+ * unused ones filled with -1 — the holes outnumbered the entries ten to one and the next round read them one dependent load at a
+ * time, 0.28 -> 0.39 ms; a per-workgroup LDS queue copied out at the barrier — no holes, but the reservation's round trip sits on
+ * every round's critical path and gives back what it saves, 0.270 against 0.263 ms with the visit counts alone.) */
+#define GIE_VIS_ADD(p, v) __hip_atomic_fetch_add(gb.s_vis, (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+struct gie_gridbar { int32_t *word; int epoch; int failed; int nwg; int *s_fail; int *s_vis; };   /* nwg = workgroups that meet at this barrier */
 
 /* Everything the wave kernels share between workgroups is read and written with agent-scope
  * (write-through, L1-bypassing) accesses — gie_ld / gie_st / atomics — so the barrier needs no
  * cache write-back or invalidate (each costs microseconds per level): every wave drains its own
  * stores, the workgroup meets, one lane arrives on the counter and polls it. */
-__device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c)
+/* vis_word: where the visits of the round that ends here go */
+__device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c, int32_t *const vis_word = nullptr)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (gb.nwg <= 1) return;             /* one workgroup: its waves share the CU's L2 path */
+    if (threadIdx.x == 0 && vis_word) {                   /* the workgroup's visits of the round: one update of the round's word, performed before the arrival below */
+        const int v = *gb.s_vis;
+        if (v) { gie_aadd32(vis_word, v); *gb.s_vis = 0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
+    if (gb.nwg <= 1) { __syncthreads(); return; }             /* one workgroup: its waves share the CU's L2 path */
     gb.epoch += 1;
     if (threadIdx.x == 0 && !gb.failed) {
         const int target = gb.epoch * gb.nwg;
@@ -2174,7 +2187,7 @@ __device__ __forceinline__ int gie_wa_vanish_lid(const gie_ctx &c, const uint64_
     return gie_in_loc(c, x, y, z) ? gie_lid(c, x, y, z) : -1;
 }
 
-__device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &L, const int slot, const int round, const int lane)
+__device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_gridbar &gb, gie_wa_tile &L, const int slot, const int round, const int lane)
 {
     /* the chain of dependent round trips of a block-run: [block key + the block's records] -> [the six neighbour lookups + the
      * vanished-obstacle look-ups of the block's voxels] -> [halo records] -> [their vanished-obstacle look-ups] */
@@ -2441,7 +2454,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_wa_tile &
         int sv = nvis;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sv += __shfl_xor(sv, o);
-        if (lane == 0 && sv > 0) gie_aadd32(&c.lvla_vis[round], sv);
+        if (lane == 0 && sv > 0) GIE_VIS_ADD(&c.lvla_vis[round], sv);
     }
     GIE_WPROF_DRAIN();
     GIE_WPROF_MARK(0);                                                   /* 3: write-back, activation (drained) */
@@ -2479,9 +2492,9 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
         if (wave < GIE_WA_WAVES) {
             const int32_t *list = c.wb_list[round & 1];
             for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WA_WAVES)      /* (spread over the workgroups first) */
-                gie_wave_a_block(c, tiles[wave], gie_ld(&list[i]), round, lane);
+                gie_wave_a_block(c, gb, tiles[wave], gie_ld(&list[i]), round, lane);
         }
-        gie_grid_sync(gb, c);
+        gie_grid_sync(gb, c, &c.lvla_vis[round]);
         GIE_TS2(3, nt);
         round++;
     }
@@ -2517,7 +2530,7 @@ struct gie_wb_tile { uint64_t pair[512], prop[512], halo[6][64]; uint32_t sdist[
 #define GIE_WB_INVOL 4u                                   /* the position lies inside the volume: its slot holds the distance a proposal has to beat
                                                            * (`_aux[n]`, wave_core.cuh:334: the Mark-time pair's distance of an observed voxel, the batch
                                                            * distance of an unknown one), fetched with the block — the levels never wait for memory */
-__device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &L, const int slot, const int round, const int lane)
+__device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &gb, gie_wb_tile &L, const int slot, const int round, const int lane)
 {
     int bk[3];
     gie_unpack_crd(gie_ld(&c.g_key[slot]), &bk[0], &bk[1], &bk[2]);
@@ -2758,7 +2771,7 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_wb_tile &
         int sv = nvis;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sv += __shfl_xor(sv, o);
-        if (lane == 0 && sv > 0) gie_aadd32(&c.lvlb_vis[round], sv);
+        if (lane == 0 && sv > 0) GIE_VIS_ADD(&c.lvlb_vis[round], sv);
     }
     GIE_WPROF_DRAIN();
     GIE_WPROF_MARK(8);
@@ -2794,9 +2807,9 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
         if (wave < GIE_WB_WAVES) {
             const int32_t *list = c.wb_list[round & 1];
             for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WB_WAVES)      /* (spread over the workgroups first) */
-                gie_wave_b_block(c, tiles[wave], gie_ld(&list[i]), round, lane);
+                gie_wave_b_block(c, gb, tiles[wave], gie_ld(&list[i]), round, lane);
         }
-        gie_grid_sync(gb, c);
+        gie_grid_sync(gb, c, &c.lvlb_vis[round]);
         GIE_TS2(6, nt);
         round++;
     }
@@ -2841,7 +2854,7 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
 #define GIE_WC_WAVES GIE_WAVE_SLOTS(10)                                   /* waves of a workgroup that take tiles: 14.6 KB of LDS each */
 struct gie_wc_tile { uint64_t pair[512], prop[512], halo[6][64]; uint16_t list[512], pend[2][512]; int32_t npend[2]; };   /* 14.6 KB */
 
-__device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L, const int t, const int round, const int lane)
+__device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &gb, gie_wc_tile &L, const int t, const int round, const int lane)
 {
     const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
     const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
@@ -2999,7 +3012,7 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_wc_tile &L
         int s = nvis;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0 && s > 0) gie_aadd32(&c.lvl_vis[round], s);
+        if (lane == 0 && s > 0) GIE_VIS_ADD(&c.lvl_vis[round], s);
     }
     gie_wave_sync();                                       /* the LDS block is reused for the wave's next tile */
 }
@@ -3031,9 +3044,9 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
         if (wave < GIE_WC_WAVES) {
             const int32_t *list = c.wc_list[round & 1];
             for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WC_WAVES)      /* (spread over the workgroups first) */
-                gie_wave_c_tile(c, tiles[wave], gie_ld(&list[i]), round, lane);
+                gie_wave_c_tile(c, gb, tiles[wave], gie_ld(&list[i]), round, lane);
         }
-        gie_grid_sync(gb, c);
+        gie_grid_sync(gb, c, &c.lvl_vis[round]);
         GIE_TS2(11, nt);
         round++;
     }
@@ -3055,9 +3068,9 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     gie_wa_tile *const s_ablocks = reinterpret_cast<gie_wa_tile *>(s_lds);    /* wave A: one 8x8x8 block of the global map (+ halo) per wave */
     gie_wc_tile *const s_tiles = reinterpret_cast<gie_wc_tile *>(s_lds);      /* wave C: one 8x8x8 tile (+ halo) per wave */
     gie_wb_tile *const s_blocks = reinterpret_cast<gie_wb_tile *>(s_lds);     /* wave B: one 8x8x8 block of the global map (+ halo) per wave */
-    __shared__ int s_fail;
-    if (threadIdx.x == 0) s_fail = 0;
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail };
+    __shared__ int s_fail, s_vis;
+    if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail, &s_vis };
     {   /* nothing seeded anywhere (the usual case of a sparse scan over a settled map): nothing can be
          * produced either, so the launch ends here — same counters for every workgroup, no barrier */
         const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);
