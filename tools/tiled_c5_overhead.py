@@ -58,6 +58,9 @@ def run(tiled):
         m.sync()
     dt = 1e3 * (time.perf_counter() - t0) / K
     stats = [m.stats() for m in ms]
+    for st in stats:
+        st["visits_c_per_update"] = st["total_visits_c"] / float(3 + K)
+        st["visits_ab_per_update"] = (st["total_visits_a"] + st["total_visits_b"]) / float(3 + K)
     for m in ms:
         m.close()
     return dt, stats
@@ -66,4 +69,7 @@ def run(tiled):
 a, sa = run(False)
 b, sb = run(True)
 print("tiles of %d^3, %d refinement round(s): 8 independent tiles %.3f ms per update of all eight; tiled %.3f ms; ratio %.3f" % (T, rounds, a, b, b / a))
+print("wave C visits per tile and map update (all wavefront launches of an update, mean over the run): independent %s | tiled %s" % (
+    [int(s_["visits_c_per_update"]) for s_ in sa], [int(s_["visits_c_per_update"]) for s_ in sb]))
+print("wave A + B visits per tile and map update: independent %s | tiled %s" % ([int(s_["visits_ab_per_update"]) for s_ in sa], [int(s_["visits_ab_per_update"]) for s_ in sb]))
 print("wave C visits per tile and update, last update: independent %s | tiled %s" % ([s["visits_c"] for s in sa], [s["visits_c"] for s in sb]))
