@@ -60,7 +60,7 @@ static int be_init(be_state *b, int device)
     if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
     { hipDeviceProp_t pr; b->num_cu = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 64; }
     b->cu_total = b->num_cu;
-    b->num_cu = b->num_cu >= 64 ? b->num_cu / 2 : b->num_cu;   /* wave grids: 128 workgroups measured best (64: 20.6, 128: 17.7, 256: 20.0 us per BFS level — a compute unit's request queue vs barrier fan-in) */
+    b->num_cu = b->num_cu >= 64 ? (b->num_cu * 5) / 8 : b->num_cu;   /* wave grids: 160 of 256 workgroups measured best with the block rounds of rounds 3-4 (C5 waves 128: 0.270, 160: 0.261, 192: 0.266, 256: 0.271 ms; with the level-synchronous waves of round 2 it was 128: 64: 20.6, 128: 17.7, 256: 20.0 us per BFS level — a compute unit's request queue vs barrier fan-in) */
     { const char *e = getenv("GIE_WAVE_WGS"); if (e && atoi(e) > 0 && atoi(e) <= 256) b->num_cu = atoi(e); }
     {   /* the waves kernel meets at a hand-rolled grid barrier: its grid must fit the device at once.  Checked here, once,
          * against the runtime's own occupancy answer (what hipLaunchCooperativeKernel would check at every launch, at
@@ -338,7 +338,7 @@ static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
 {
     static const int generic = getenv("GIE_MARKC_GENERIC") ? atoi(getenv("GIE_MARKC_GENERIC")) : 0;
     static const int lx = getenv("GIE_MARKC_LX") ? atoi(getenv("GIE_MARKC_LX")) : 32;
-    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
+    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 64;     /* workgroups per compute unit of the dense sweep: 16 / 32 / 48 / 64 / 96 / 128 measured 1.00 / 0.80 / 0.78 / 0.76 / 0.78 / 0.79 ms at 512^3 (round 4; 64 = exactly four virtual workgroups each) */
     if (generic) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0, lx == 16 || lx == 8 || lx == 32 ? lx : 64); return; }
     const dim3 g(b->cu_total * mult), t(256);
     if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list);
@@ -348,7 +348,7 @@ static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
 /* placement probe (k_place_probe): median of `reps` timed launches, ms */
 static float be_place_probe(be_state *b, const gie_ctx &c, int reps, int streams = 15)
 {
-    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
+    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 64;     /* (the sweep's own grid: be_markc) */
     const long long ntile = (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
     const int nslot = (int)(ntile < c.max_blocks ? ntile : c.max_blocks);
     hipEvent_t e0, e1;
@@ -373,7 +373,7 @@ static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(geten
  * length calls for; GIE_ROWS=0: the thread-per-z-column sweep of k_voxa instead of the block rows */
 static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list)
 {
-    static const int mult = getenv("GIE_ROWS_MULT") ? atoi(getenv("GIE_ROWS_MULT")) : 16;
+    static const int mult = getenv("GIE_ROWS_MULT") ? atoi(getenv("GIE_ROWS_MULT")) : 32;     /* 8 / 16 / 32 / 48 workgroups per compute unit: 0.225 / 0.215 / 0.195 / 0.19 ms at 512^3 (round 4: with the byte-parallel filter the kernel is short enough for the tail of its last workgroups to show; 32 = one virtual wavefront per wavefront) */
     if (be_rows_mode()) {
         if (c.pntcld_mode) GIE_LAUNCH(b, k_fuse_rows<true>, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
         else GIE_LAUNCH(b, k_fuse_rows<false>, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);

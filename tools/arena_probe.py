@@ -36,6 +36,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     sys.exit(0)
 random.seed(int(os.environ.get("PROBE_SEED", "1")))
 configs = [None, ""]                       # None: separate allocations (the library's default); "": arena, no skew
+if int(os.environ.get("PROBE_CONFIGS", "16")) == -2:
+    configs = [None]
 n = int(os.environ.get("PROBE_CONFIGS", "16"))
 for _ in range(n):
     configs.append(",".join(str(random.choice([0, 2, 6, 14, 30, 62, 126, 254, 510])) for _ in range(14)))
