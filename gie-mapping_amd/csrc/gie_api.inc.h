@@ -29,6 +29,7 @@ struct gie_mapper {
     be_state be;
     int ncell;
     int has_pose, has_ogm, merge_open;
+    int bar_fault_left;     /* map updates whose wavefront launch gets the barrier fault (gie_debug_fault_barrier) */
     int fuse_fresh;                       /* gie_fuse has run and no merge has consumed it yet (a merge needs the frame clear of its own map update) */
     int pool_base;                        /* GIE_DEBUG_POOL_BASE (tests): the slots below it are never handed out */
     int evictions;                        /* map updates with block erasure since the hash table was last rebuilt */
@@ -156,7 +157,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -678,7 +679,10 @@ extern "C" int gie_merge_end(gie_mapper *m)
      * per tile out of LDS (k_frontier_faces / k_frontier_tiles; 0.32 -> 0.15 ms on the C5 workload) */
     be_frontier_tiles(&m->be, m->c, m->c.tl_known, GIE_CNT_TL_KNOWN, m->c.tl_front, GIE_CNT_TL_FRONT);
     be_prof(&m->be, GIE_K_FRONTIER, 1);
+    m->c.bar_fault = m->bar_fault_left > 0 ? 1 : 0;
+    if (m->bar_fault_left > 0) m->bar_fault_left--;
     be_prof(&m->be, GIE_K_WAVE_C, 0); be_waves(&m->be, m->c, m->c.fast_mode ? 0 : 1, m->c.fast_mode ? 1 : 0, 0); be_prof(&m->be, GIE_K_WAVE_C, 1);
+    m->c.bar_fault = 0;
     if (!m->c.fused) {
         be_prof(&m->be, GIE_K_COMMIT, 0);
         be_vox_list<true>(&m->be, m->c, op_commit(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
@@ -1106,6 +1110,14 @@ extern "C" int gie_debug_place_probe(gie_mapper *m, int reps, float *ms)
     if (!m || !ms || m->has_pose) { gie_set_err("gie_debug_place_probe: only on a fresh mapper"); return GIE_ERR_INVALID; }
     *ms = be_place_probe(&m->be, m->c, reps > 0 ? (reps & 0xffff) : 3, (reps >> 16) ? (reps >> 16) : 15);      /* (streams to exercise in the upper half of `reps`: 1 type, 2 batch obstacle, 4 pair, 8 stored obstacle) */
     return gie_sync(m);
+}
+/* test hook (not in gie.h): the wavefront launches of the next `updates` map updates meet at a barrier that cannot complete — the
+ * GIE_ERR_TIMEOUT path of include/gie.h without a second process holding the device (tests/test_gpu_parity.py) */
+extern "C" int gie_debug_fault_barrier(gie_mapper *m, int updates)
+{
+    if (!m || updates < 0) { gie_set_err("gie_debug_fault_barrier: bad arguments"); return GIE_ERR_INVALID; }
+    m->bar_fault_left = updates;
+    return GIE_OK;
 }
 extern "C" int gie_profile_enable(gie_mapper *m, int on)
 {

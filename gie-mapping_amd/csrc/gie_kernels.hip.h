@@ -817,8 +817,9 @@ __device__ __forceinline__ void gie_row_argmin_banded_lin(const int2 *mb, const 
 template <int CP>
 __device__ __forceinline__ bool gie_row_window(const uint32_t *sk, const int L, const int lane, uint32_t (&best)[CP], const unsigned bandneed = ~0u)
 {
+    /* (a position beyond the row starts at 0 and stays there: the finish test below is one comparison per band, without a mask) */
 #pragma unroll
-    for (int m = 0; m < CP; m++) best[m] = sk[64 * m + lane];
+    for (int m = 0; m < CP; m++) best[m] = (64 * m + lane < L) ? sk[64 * m + lane] : 0u;
     unsigned active = 0;                                  /* bands (64 positions each) that still have a position without its bound */
 #pragma unroll
     for (int m = 0; m < CP; m++) if (64 * m < L && ((bandneed >> m) & 1u)) active |= 1u << m;
@@ -832,8 +833,7 @@ __device__ __forceinline__ bool gie_row_window(const uint32_t *sk, const int L, 
 #pragma unroll
         for (int m = 0; m < CP; m++) {
             if (!((active >> m) & 1u)) continue;          /* wave-uniform */
-            const uint32_t bm = (64 * m + lane < L) ? (best[m] >> 10) : 0u;
-            if (!__any(w1 <= bm)) active &= ~(1u << m);
+            if (!__any(best[m] >= (w1 << 10))) active &= ~(1u << m);      /* w1 <= value of the key: the low ten bits are the site */
         }
         if (!active) return true;
         if (W >= GIE_WIN_MAX) return false;
@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(256) void k_edt_z_direct(const gie_ctx c)
  * time, 0.28 -> 0.39 ms; a per-workgroup LDS queue copied out at the barrier — no holes, but the reservation's round trip sits on
  * every round's critical path and gives back what it saves, 0.270 against 0.263 ms with the visit counts alone.) */
 #define GIE_VIS_ADD(p, v) __hip_atomic_fetch_add(gb.s_vis, (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-struct gie_gridbar { int32_t *word; int epoch; int failed; int nwg; int *s_fail; int *s_vis; };   /* nwg = workgroups that meet at this barrier */
+struct gie_gridbar { int32_t *word; int epoch; int failed; int nwg; int *s_fail; int *s_vis; int spin_limit; };   /* nwg = workgroups that meet at this barrier */
 
 /* Everything the wave kernels share between workgroups is read and written with agent-scope
  * (write-through, L1-bypassing) accesses — gie_ld / gie_st / atomics — so the barrier needs no
@@ -2093,11 +2093,11 @@ __device__ __forceinline__ void gie_grid_sync(gie_gridbar &gb, const gie_ctx &c,
         int spins = 0;
         while (__hip_atomic_load(gb.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > GIE_BAR_SPIN_LIMIT) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); gie_st(&c.cnt[GIE_CNT_BARFAIL], (int32_t)1); break; }
+            if (++spins > gb.spin_limit) { gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_BARRIER); gie_st(&c.cnt[GIE_CNT_BARFAIL], (int32_t)1); break; }
         }
         /* a timed-out barrier poisons the launch: this block leaves; the others time out at their
          * next barrier (bounded spin), so nobody hangs */
-        if (spins > GIE_BAR_SPIN_LIMIT) *gb.s_fail = 1;
+        if (spins > gb.spin_limit) *gb.s_fail = 1;
     }
     __syncthreads();
     if (*gb.s_fail) gb.failed = 1;
@@ -3072,7 +3072,8 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     gie_wb_tile *const s_blocks = reinterpret_cast<gie_wb_tile *>(s_lds);     /* wave B: one 8x8x8 block of the global map (+ halo) per wave */
     __shared__ int s_fail, s_vis;
     if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x, &s_fail, &s_vis };
+    /* (c.bar_fault: the timeout path on purpose — a barrier that waits for one workgroup more than there are, with a short limit) */
+    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x + (c.bar_fault ? 1 : 0), &s_fail, &s_vis, c.bar_fault ? (1 << 10) : GIE_BAR_SPIN_LIMIT };
     {   /* nothing seeded anywhere (the usual case of a sparse scan over a settled map): nothing can be
          * produced either, so the launch ends here — same counters for every workgroup, no barrier */
         const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);

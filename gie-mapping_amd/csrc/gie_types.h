@@ -75,6 +75,7 @@ typedef struct gie_ctx {
     float min_h, max_h;
     int cutoff_sq;
     int fast_mode, for_motion_planner, robot_r2;
+    int bar_fault;          /* test hook (gie_debug_fault_barrier): the wavefront kernel's grid barrier waits for a workgroup that does not exist, with a short spin limit */
     int max_width, max_loc_dist_sq;
     int wr[3];              /* _wave_range */
     int empty_value;        /* EMPTY_VALUE or the wide sentinel */

@@ -598,6 +598,7 @@ def test_waves_wait_out_a_kernel_that_holds_every_compute_unit(oracle_lib):
     so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_helpers", "libspin.so")
     if not os.path.exists(so):
         pytest.skip("tests/gpu_helpers/libspin.so not built (__graft_entry__.build())")
+    gie.load_library()                                                   # first: one HIP runtime per process (gie/mapper.py load_library) — the helper must bind to the one the mapper uses
     spin = C.CDLL(so)
     spin.spin_start.argtypes = [C.c_int, C.c_double]
     sc = parity.Scenario("vlp16", (48, 48, 16), sensor="multiscan", frames=10, delta_vox=5, yaw_deg=10.0)
@@ -643,3 +644,77 @@ def test_irregular_call_orders(oracle_lib, name, fuse_only, stream_on):
 def test_jumping_robot_keeps_the_hash_table_alive(oracle_lib):
     from test_host_logic import _jumping_robot
     _jumping_robot(gie.Mapper, updates=300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stream", [False, True], ids=["fused", "changed_block_flags"])
+def test_barrier_timeout_leaves_what_gie_h_says(oracle_lib, stream):
+    """GIE_ERR_TIMEOUT (include/gie.h:28-35), forced: `gie_debug_fault_barrier` makes the wavefront launch of one map update
+    meet at a barrier that waits for a workgroup that does not exist (short spin limit), the path a second process
+    holding the compute units would take.  What the header promises, checked on a drive with seeds of all three
+    waves: the condition is reported once; Mark's own distances are committed when Mark and commit are one sweep
+    (the state of the oracle after Mark + UpdateHashBatch without the waves: go_merge_begin_tiled), nothing of the
+    update is committed when the changed-block flags are on (the stored records of the voxels known before are the
+    ones from before the update); the next updates run normally — no error, waves with visits again."""
+    import ctypes as C
+    sc = parity.Scenario("c3_no_cutoff", (56, 56, 20), voxel=0.1, sensor="multiscan", frames=10, delta_vox=6, yaw_deg=12.0,
+                         cutoff_dist=100.0, extent=(5.0, 5.0, 1.5))
+    cfg = sc.config()
+    a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    fault = gie.mapper._lib.gie_debug_fault_barrier
+    fault.argtypes = [C.c_void_p, C.c_int]
+    try:
+        if stream:
+            a.stream_enable(True); b.stream_enable(True)
+        faulted = -1
+        visits_after = 0
+        for k, (pos, q, kind, data, kw) in enumerate(sc.frames_iter()):
+            for m in (a, b):
+                m.set_pose(pos, q)
+                parity._feed(m, kind, data, kw)
+            if faulted < 0 and k >= 6:                     # (frame 6 of this drive seeds all three waves: 141 / 226 / 40)
+                # the oracle one stage at a time: does this update seed the waves?  (decided after Mark: look at a copy's statistics)
+                a.fuse(); a.batch_edt()
+                X, Y, Z = sc.size
+                pv = np.array(a.pivot())
+                zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+                xyz = (np.stack([xx, yy, zz], -1).reshape(-1, 3) + pv).astype(np.int32)
+                before = b.query_global(xyz)
+                a.merge_begin_tiled()                      # Mark + UpdateHashBatch, no obtainFrontiers, no waves
+                assert fault(b._h, 1) == 0
+                b.step()
+                with pytest.raises(RuntimeError, match=r"\(4\)"):      # GIE_ERR_TIMEOUT
+                    b.sync()
+                b.sync()                                   # reported once
+                sb = b.stats()
+                assert sb["seeds_a"] + sb["seeds_b"] + sb["seeds_c"] > 0, "the faulted update has to have seeds (choose another frame)"
+                after = b.query_global(xyz)
+                known_before = before["vox_type"] != 0
+                if stream:
+                    for key in ("dist_sq", "coc"):
+                        assert np.array_equal(before[key][known_before], after[key][known_before]), key
+                else:
+                    ra, rb = a.read_local(edt=False), b.read_local(edt=False)
+                    known = ra["type"] != 0
+                    assert np.array_equal(ra["type"] != 0, rb["type"] != 0)
+                    for key in ("dist_sq", "coc"):
+                        assert np.array_equal(ra[key][known], rb[key][known]), "local " + key
+                    ga = a.query_global(xyz)
+                    kn = ga["vox_type"] != 0
+                    for key in ("dist_sq", "coc"):
+                        assert np.array_equal(ga[key][kn], after[key][kn]), "stored " + key
+                faulted = k
+                a.merge_end()                              # (the oracle goes on as if nothing had happened: only the types are compared below)
+                continue
+            a.step()
+            b.step()
+            b.sync()                                       # no error left over
+            ta, tb = a.read_local(edt=False, dist_sq=False, coc=False)["type"], b.read_local(edt=False, dist_sq=False, coc=False)["type"]
+            assert np.array_equal(ta != 0, tb != 0), k     # (known / unknown does not depend on the waves)
+            if faulted >= 0:
+                s = b.stats()
+                visits_after += s["visits_a"] + s["visits_b"] + s["visits_c"]
+        assert faulted >= 0 and visits_after > 0
+    finally:
+        a.close()
+        b.close()
