@@ -597,7 +597,8 @@ extern "C" int gie_fuse(gie_mapper *m)
      * sweep the volume — each kernel decides from the length of its list (gie_use_lists) */
     {   /* the table of the fuse before answers for the blocks it knew (k_cell_alloc); the two tables alternate */
         gie_ctx &c = m->c;
-        if (m->tab_valid) {
+        static const int no_prev = getenv("GIE_NO_TAB_PREV") ? atoi(getenv("GIE_NO_TAB_PREV")) : 0;      /* (debugging: every block through the hash) */
+        if (m->tab_valid && !no_prev) {
             c.tab_prev = c.blk_tab;
             for (int i = 0; i < 3; i++) c.tab_prev_d[i] = c.tb0[i] - m->tab_tb0[i];
             int32_t *t = c.blk_tab; c.blk_tab = m->blk_tab2; m->blk_tab2 = t;

@@ -915,6 +915,8 @@ GIE_DEV void gie_commit_pair(const gie_ctx &c, int id, gie_vaddr a, uint64_t pr)
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
     const uint64_t ncoc = gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]) | GIE_COC_STALEPAIR;
+    /* (tried in round 4: leaving the store out when the record read before already holds this value — a settled scene would write
+     * nothing — makes the dense sweep 12 % SLOWER on the C5 workload, 0.82 -> 0.93 ms: the test splits every wavefront's stores) */
     if (AGENT) gie_st(&c.g_coc[a], ncoc); else c.g_coc[a] = ncoc;     /* (nontemporal stores: no gain measured) */
 }
 /* The voxels of the LAST fused map update's volume (pivot opvt, wave-range pivot oupvt, block table still that update's)

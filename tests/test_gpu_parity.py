@@ -58,6 +58,12 @@ SCENARIOS = [
     parity.Scenario("blink_empty_scans", (32, 28, 12), voxel=0.05, sensor="labels_blink", frames=18, delta_vox=5, yaw_deg=2.0, seed=9,
                     cutoff_dist=1.0, p_occ=0.004, toggle=0.3, probe_margin=30),
     parity.Scenario("retain_lidar", (48, 48, 16), sensor="multiscan", frames=16, delta_vox=7, yaw_deg=10.0, retain=1, probe_margin=40),
+    # a robot that turns round and meets the blocks it has erased again (round-4 fuzz, seed 51 #30 and seed 53 #57: the table of the
+    # fuse before reaches a cell beyond the retention box and used to hand an erased block on from update to update)
+    parity.Scenario("retain_turn_back", (72, 64, 96), voxel=0.1, sensor="mixed", frames=10, delta_vox=8, yaw_deg=28.425771268056188, seed=870,
+                    cutoff_dist=0.5, extent=(6.76, 6.76, 4.34), toggle=0.25, lidar_az=180, p_occ=0.003, retain=1, turn=3),
+    parity.Scenario("retain_turn_back_lidar", (152, 96, 160), voxel=0.1, sensor="lidar_points", frames=10, delta_vox=5, yaw_deg=7.861227329719755, seed=841,
+                    cutoff_dist=0.5, extent=(10.6, 10.6, 6.9), toggle=0.5, lidar_az=720, p_occ=0.003, retain=1, turn=3, probe_margin=40),
     parity.Scenario("retain_odd_r1", (37, 29, 11), sensor="mixed", frames=12, delta_vox=5, yaw_deg=33.0, retain=1, turn=5, probe_margin=40),
 ]
 
