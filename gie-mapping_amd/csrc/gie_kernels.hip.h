@@ -361,17 +361,7 @@ __global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int n
     bool isnew = false;
     if (i < ncell) {
         const int bx = i % c.tdim[0], by = (i / c.tdim[0]) % c.tdim[1], bz = i / (c.tdim[0] * c.tdim[1]);
-        if (c.tab_prev) {                    /* one coalesced read instead of a chain of hash probes for every block the table before knew */
-            const int px = bx + c.tab_prev_d[0], py = by + c.tab_prev_d[1], pz = bz + c.tab_prev_d[2];
-            if ((unsigned)px < (unsigned)c.tdim[0] && (unsigned)py < (unsigned)c.tdim[1] && (unsigned)pz < (unsigned)c.tdim[2])
-                found = c.tab_prev[(pz * c.tdim[1] + py) * c.tdim[0] + px];
-            /* With block erasure (retain_radius_blocks) the table before may name a block that this update's erasure — it runs
-             * before the allocation — has just taken away: the table reaches a cell or two beyond the retention box, and an
-             * entry there would be handed from table to table for as long as the cell stays in range (found by the round-4 fuzz,
-             * seeds 51 / 53: a robot that turns round met its erased blocks again, with their old contents).  The slot's own key
-             * says whether it still holds this block. */
-            if (found >= 0 && c.retain > 0 && c.g_key[found] != gie_pack_crd(bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2])) found = -1;
-        }
+        found = gie_cell_prev_slot(c, bx, by, bz);   /* one coalesced read instead of a chain of hash probes for every block the table before knew */
         if (found < 0) found = gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]);
         isnew = found < 0 && c.blk_need[i];
         c.blk_need[i] = 0;

@@ -373,6 +373,25 @@ GIE_DEV void gie_cell_insert(const gie_ctx &c, int cell, int slot)
     gie_key_insert(c, gie_pack_crd(bx, by, bz), bx, by, bz, slot);
 }
 
+/* The slot the block table of the fuse before (c.tab_prev, shifted by c.tab_prev_d cells) holds for table cell (bx, by, bz) of this
+ * update, -1: none / not in that table — then the hash answers.  INVARIANT: a slot returned here is the one the hash would find.
+ * With block erasure (retain_radius_blocks) the table before may name a block that this update's erasure — it runs before the
+ * allocation — has just taken away: the table reaches a cell or two beyond the retention box, and an entry there would be handed
+ * from table to table for as long as the cell stays in range (found by the round-4 fuzz, seeds 51 / 53: a robot that turns round
+ * met its erased blocks again, with their old contents).  The slot's own key says whether it still holds this block.  (The
+ * emulation's allocation never looks at the table; it checks the invariant for every cell: tests/emu/gie_emu.cpp.) */
+GIE_DEV int gie_cell_prev_slot(const gie_ctx &c, int bx, int by, int bz)
+{
+    if (!c.tab_prev) return -1;
+    const int px = bx + c.tab_prev_d[0], py = by + c.tab_prev_d[1], pz = bz + c.tab_prev_d[2];
+    if (!((unsigned)px < (unsigned)c.tdim[0] && (unsigned)py < (unsigned)c.tdim[1] && (unsigned)pz < (unsigned)c.tdim[2])) return -1;
+    const int found = c.tab_prev[(pz * c.tdim[1] + py) * c.tdim[0] + px];
+#if !defined(GIE_EMU_BREAK_PREV_CHECK)
+    if (found >= 0 && c.retain > 0 && c.g_key[found] != gie_pack_crd(bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2])) return -1;
+#endif
+    return found;
+}
+
 /* ---- block-pool lifecycle (gie_config.retain_radius_blocks > 0; the reference never erases: blockalloc.h:50-67) */
 /* Slot `r` of `cnt` blocks a caller allocates at once: the first `nf` come from the top of the free list (entries
  * [ftop - nf, ftop)), the rest from the bump allocator starting at `base`. */

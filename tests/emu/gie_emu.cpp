@@ -115,6 +115,17 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
 /* sequential allocHashTB: flag → rank → insert → initialise → table */
 static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *rank, int, int fuse_list_ntile = 0)
 {
+    /* the device's allocation (k_cell_alloc) asks the block table of the fuse before first: whatever that names has to be what the
+     * hash finds (gie_cell_prev_slot) */
+    for (int cell = 0; cell < ncell; cell++) {
+        const int bx = cell % c.tdim[0], by = (cell / c.tdim[0]) % c.tdim[1], bz = cell / (c.tdim[0] * c.tdim[1]);
+        const int prev = gie_cell_prev_slot(c, bx, by, bz);
+        if (prev >= 0 && prev != gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2])) {
+            fprintf(stderr, "gie_emu: the block table of the fuse before names slot %d for block (%d, %d, %d), the hash %d\n", prev, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2],
+                    gie_hash_find(c, bx + c.tb0[0], by + c.tb0[1], bz + c.tb0[2]));
+            abort();
+        }
+    }
     be_lin(b, c, op_cell_flag(), ncell);
     be_exclusive_scan(b, c.blk_new, rank, ncell);
     op_cell_insert ins; ins.flag = c.blk_new; ins.rank = rank;

@@ -44,6 +44,11 @@ SCENARIOS = [
                     cutoff_dist=1.0, p_occ=0.004, toggle=0.3, probe_margin=30),
     parity.Scenario("retain_lidar", (48, 48, 16), sensor="multiscan", frames=16, delta_vox=7, yaw_deg=10.0, retain=1, probe_margin=40),
     parity.Scenario("retain_odd_r1", (37, 29, 11), sensor="mixed", frames=12, delta_vox=5, yaw_deg=33.0, retain=1, turn=5, probe_margin=40),
+    # a robot that turns round and meets the blocks it has erased again, in a volume whose block table reaches a cell beyond the
+    # retention box (round-4 fuzz on the GPU, seed 51 #30).  The device's allocation asks the table of the fuse before first; the
+    # emulation does not, but checks for every cell that the table names what the hash finds (gie_cell_prev_slot, gie_emu.cpp)
+    parity.Scenario("retain_turn_back", (72, 64, 96), voxel=0.1, sensor="mixed", frames=10, delta_vox=8, yaw_deg=28.425771268056188, seed=870,
+                    cutoff_dist=0.5, extent=(6.76, 6.76, 4.34), toggle=0.25, lidar_az=180, p_occ=0.003, retain=1, turn=3),
 ]
 
 
