@@ -2962,8 +2962,13 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &g
             }
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                /* (the pre-read only drops proposals that cannot improve: values only decrease; a halo pair is the neighbour's at the start of the round) */
-                if (!((okm >> k) & 1u) || !(d[k] < gie_pair_dist(seen[k]))) continue;
+                /* (the pre-read only drops proposals that cannot improve: values only decrease; a halo pair is the neighbour's at the start of the round.
+                 * NOT in round 0 across a tile border: the neighbour may be a seed its own tile is about to ASSIGN, and the seed wave B leaves
+                 * on an unknown face voxel — accepted against the batch distance, wave_core.cuh:334 — can lie ABOVE the stale pair the plane
+                 * still holds for it: a proposal between the two was dropped here and the voxel kept the seed's distance (round-4 fuzz,
+                 * seed 83 #63).  Sent on, it meets the assigned pair in round 1 — what the sequential schedule does.) */
+                if (!((okm >> k) & 1u)) continue;
+                if (!(d[k] < gie_pair_dist(seen[k])) && (((inm >> k) & 1u) || round != 0)) continue;
                 const uint64_t key = gie_pair_make(d[k], par);
                 const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
                 if ((inm >> k) & 1u) {

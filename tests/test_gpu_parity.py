@@ -65,6 +65,11 @@ SCENARIOS = [
     parity.Scenario("retain_turn_back_lidar", (152, 96, 160), voxel=0.1, sensor="lidar_points", frames=10, delta_vox=5, yaw_deg=7.861227329719755, seed=841,
                     cutoff_dist=0.5, extent=(10.6, 10.6, 6.9), toggle=0.5, lidar_az=720, p_occ=0.003, retain=1, turn=3, probe_margin=40),
     parity.Scenario("retain_odd_r1", (37, 29, 11), sensor="mixed", frames=12, delta_vox=5, yaw_deg=33.0, retain=1, turn=5, probe_margin=40),
+    # wave C, round 0, across a tile border: the neighbour is a seed that wave B left on an UNKNOWN face voxel — accepted against the
+    # batch distance (wave_core.cuh:334), above the stale pair the plane still holds for it — and a proposal between the two used to
+    # be dropped by the pre-read of the halo (round-4 fuzz, --focus retain --big, seed 83 #63: one voxel, 182 instead of 179)
+    parity.Scenario("wave_c_seed_above_stale_pair", (96, 120, 160), voxel=0.2, sensor="mixed", frames=11, delta_vox=10, yaw_deg=30.029303880177924,
+                    seed=742, cutoff_dist=100.0, extent=(20.2, 20.2, 13.3), toggle=0.5, lidar_az=360, p_occ=0.01, retain=2, turn=5, probe_margin=40),
 ]
 
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd"), os.path.join(ROOT, "tests")]
 
 
-def random_scenario(rng, i, big=False):
+def random_scenario(rng, i, big=False, focus=None):
     import parity
     dims = [96, 120, 128, 152, 160, 192] if big else [8, 16, 24, 29, 32, 37, 40, 48, 56, 64, 72, 96]
     size = tuple(int(rng.choice(dims)) for _ in range(3))
@@ -27,6 +27,9 @@ def random_scenario(rng, i, big=False):
               p_occ=float(rng.choice([0.003, 0.01, 0.03])), toggle=float(rng.choice([0.0, 0.25, 0.5])),
               retain=int(rng.choice([0, 0, 0, 1, 2])), turn=int(rng.choice([0, 0, 3, 5])), probe_margin=int(rng.choice([12, 40])),
               lidar_az=int(rng.choice([180, 360, 720])))
+    if focus == "retain":          # block erasure on a robot that turns round: long drives, small radii, frequent turns
+        kw.update(retain=int(rng.choice([1, 1, 2, 3])), turn=int(rng.choice([2, 3, 4, 5, 7])), frames=int(rng.integers(8, 17)),
+                  delta_vox=int(rng.integers(3, 17)), probe_margin=40)
     if sensor in ("depth", "mixed", "multiscan", "lidar_points", "scan2d"):
         ext = max(size) * voxel
         kw["extent"] = (0.6 * ext + 1.0, 0.6 * ext + 1.0, 0.4 * size[2] * voxel + 0.5)
@@ -87,6 +90,7 @@ def main():
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("--big", action="store_true", help="volume sides of 96 ... 192 voxels (thousands of active blocks per wave round)")
     ap.add_argument("--only", type=int, default=-1, help="run scenario number N of the seed only")
+    ap.add_argument("--focus", default=None, choices=[None, "retain"], help="retain: every scenario erases blocks (retain_radius_blocks 1-3) on a drive that turns round")
     args = ap.parse_args()
     import gie
     import parity
@@ -106,7 +110,7 @@ def main():
         i += 1; ok += 1
         print("ok %s | visits %d/%d/%d" % (desc, v[0], v[1], v[2]), flush=True)
     while not args.tiled and time.time() - t0 < 60.0 * args.minutes:
-        sc = random_scenario(rng, i, args.big)
+        sc = random_scenario(rng, i, args.big, args.focus)
         i += 1
         if args.only >= 0 and i - 1 != args.only:
             continue
