@@ -58,6 +58,13 @@ int main(int argc, char **argv)
 #else
         if (transport == "rccl") throw std::runtime_error("built without RCCL (compile with -DGIE_WITH_RCCL and link rccl + amdhip64)");
 #endif
+        {   /* Ranks that share a device (the socket transport puts every rank on device 0 unless told otherwise, and is what a single-device check uses): the persistent
+             * grids of their wavefront kernels have to be resident side by side, or the grid barriers of two half-resident grids
+             * wait for each other until they time out (GIE_ERR_TIMEOUT).  The library reads GIE_WAVE_WGS at
+             * gie_create; a value the caller has set stands. */
+            const int sharing = transport == "rccl" ? 1 : world;      /* (host-staged sockets: ranks of one host, as a rule of one device — also with an explicit --device) */
+            if (sharing > 1) { const std::string v = std::to_string(std::max(8, 192 / sharing)); setenv("GIE_WAVE_WGS", v.c_str(), 0); }
+        }
         TiledMapper node(p, layout, *tr, transport == "rccl" ? (device >= 0 ? device : rank) : (device >= 0 ? device : 0), rounds);
         const size_t N = (size_t)tile[0] * tile[1] * tile[2];
 
