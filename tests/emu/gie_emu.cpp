@@ -471,10 +471,119 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
         round++;
     }
 }
+/* which statement of wave C the emulation runs (environment at load, or gie_emu_wave_c_model at any time) */
+static int g_emu_wave_c_device = (getenv("GIE_EMU_WAVE_C") && !strcmp(getenv("GIE_EMU_WAVE_C"), "device")) ? 1 : 0;
+static int g_emu_wave_c_r0filter = getenv("GIE_EMU_WAVE_C_R0FILTER") ? atoi(getenv("GIE_EMU_WAVE_C_R0FILTER")) : 0;
+extern "C" void gie_emu_wave_c_model(int device, int r0filter) { g_emu_wave_c_device = device; g_emu_wave_c_r0filter = r0filter; }
+/* Wave C the way the DEVICE schedules it (gie_wave_c_tile / gie_wave_c_run in gie_kernels.hip.h), stated sequentially: a second model
+ * beside the canonical one above, selected with GIE_EMU_WAVE_C=device or gie_emu_wave_c_model(1, 0).  What it keeps of the kernel and the canonical statement does
+ * not have: the seeds are assigned INSIDE round 0 (first sub-level of their tile), a tile's halo is what the pair plane held when the
+ * round started, an expansion drops a proposal that does not beat the pair it sees for the neighbour (tile: live, halo: the
+ * snapshot) — except across a tile border in round 0, where the neighbour may be a seed about to be assigned above its stale pair
+ * (the fault the round-4 fuzz found on the GPU; GIE_EMU_WAVE_C_R0FILTER=1 / gie_emu_wave_c_model(1, 1) puts the old filter back: tests/test_host_logic.py shows
+ * that this model then differs from the oracle on that scenario) —, proposals across borders wait in the candidate plane of the
+ * round's parity and are merged by the neighbour's tile in the next round.  Tiles of a round are taken one after the other here; on
+ * the device they run side by side and a halo read may also see a neighbour's write-back of the same round — a lower value, which
+ * only drops proposals that could not have won either. */
+static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int)
+{
+    const int r0filter = g_emu_wave_c_r0filter;
+    const int n0 = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c;
+    c.cnt[GIE_CNT_FRONT_C] = n0;
+    if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = n0; c.cnt[GIE_CNT_SEED_A] = c.cnt[GIE_CNT_A]; c.cnt[GIE_CNT_SEED_B] = c.cnt[GIE_CNT_B]; }
+    if (n0 == 0) return;
+    const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    std::vector<char> flag[2] = { std::vector<char>((size_t)ntile, 0), std::vector<char>((size_t)ntile, 0) };
+    std::vector<int> list[2];
+    for (int e = 0; e < n0; e++) {
+        const int id = c.qc[0][e];
+        const int t = gie_tile_index(c, id % c.X, (id / c.X) % c.Y, id / (c.X * c.Y));
+        if (!flag[0][(size_t)t]) { flag[0][(size_t)t] = 1; list[0].push_back(t); }
+    }
+    int round = 0;
+    while (!list[round & 1].empty()) {
+        uint64_t *rd = c.cand[(round + 1) & 1], *wr = c.cand[round & 1];
+        const std::vector<uint64_t> snap(c.pair, c.pair + c.N);       /* the halos of the round */
+        list[(round + 1) & 1].clear();
+        long long vis = 0;
+        for (const int t : list[round & 1]) {
+            flag[round & 1][(size_t)t] = 0;
+            const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+            const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
+            uint64_t pair[512], prop[512], loaded[512];
+            bool in[512];
+            std::vector<int> pend;
+            for (int v = 0; v < 512; v++) {
+                const int x = x0 + (v & 7), y = y0 + ((v >> 3) & 7), z = z0 + (v >> 6);
+                in[v] = gie_in_loc(c, x, y, z);
+                pair[v] = 0; prop[v] = GIE_NOPROP;                   /* a position outside the volume: distance 0, never improved */
+                if (in[v]) {
+                    const int id = gie_lid(c, x, y, z);
+                    pair[v] = c.pair[id]; prop[v] = rd[id];
+                    if (prop[v] != GIE_NOPROP) { rd[id] = GIE_NOPROP; pend.push_back(v); }
+                }
+                loaded[v] = pair[v];
+            }
+            unsigned xmask = 0;
+            for (int sub = 0;; sub++) {
+                std::vector<int> ent, pend_next;
+                for (const int v : pend) {
+                    const uint64_t cd = prop[v];
+                    prop[v] = GIE_NOPROP;
+                    if ((round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(pair[v])) { pair[v] = cd & ~GIE_PAIR_NEW; vis++; ent.push_back(v); }
+                }
+                if (ent.empty()) break;
+                for (const int v : ent) {
+                    const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
+                    const uint64_t par = gie_pair_par(pair[v]);
+                    int cw[3];
+                    gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
+                    const int cl[3] = { cw[0] + c.upvt[0] - c.pvt[0], cw[1] + c.upvt[1] - c.pvt[1], cw[2] + c.upvt[2] - c.pvt[2] };
+                    for (int k = 0; k < 6; k++) {
+                        const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
+                        const int nx = x0 + ux, ny = y0 + uy, nz = z0 + uz;
+                        if (!gie_in_loc(c, nx, ny, nz)) continue;
+                        const int d = gie_d2(cl[0], cl[1], cl[2], nx, ny, nz);
+                        if (d >= c.empty_value) continue;
+                        const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
+                        const int nid = gie_lid(c, nx, ny, nz);
+                        const uint64_t seen = inside ? pair[ux + 8 * uy + 64 * uz] : snap[(size_t)nid];
+                        if (!(d < gie_pair_dist(seen)) && (inside || round != 0 || r0filter)) continue;
+                        const uint64_t key = gie_pair_make(d, par);
+                        if (inside) {
+                            const int nv = ux + 8 * uy + 64 * uz;
+                            if (prop[nv] == GIE_NOPROP) pend_next.push_back(nv);
+                            if (key < prop[nv]) prop[nv] = key;
+                        } else { if (key < wr[nid]) wr[nid] = key; xmask |= 1u << k; }
+                    }
+                }
+                pend.swap(pend_next);
+            }
+            for (int v = 0; v < 512; v++) {
+                if (!in[v] || pair[v] == loaded[v]) continue;
+                const int x = x0 + (v & 7), y = y0 + ((v >> 3) & 7), z = z0 + (v >> 6);
+                const int id = gie_lid(c, x, y, z);
+                if (c.glb_type[id] == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, id, x, y, z, loaded[v]);
+                c.pair[id] = pair[v];
+                if (c.fused) gie_commit_merged(c, id, c.glb_type[id], c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])], x, y, z, pair[v]);
+            }
+            const int dt[6] = { -1, 1, -c.tfd[0], c.tfd[0], -c.tfd[0] * c.tfd[1], c.tfd[0] * c.tfd[1] };
+            for (int k = 0; k < 6; k++) if ((xmask >> k) & 1u) {
+                const int nt = t + dt[k];
+                if (!flag[(round + 1) & 1][(size_t)nt]) { flag[(round + 1) & 1][(size_t)nt] = 1; list[(round + 1) & 1].push_back(nt); }
+            }
+        }
+        if (vis > 0) { c.cnt[GIE_CNT_LVL_C] += 1; c.cnt[GIE_CNT_VIS_C] += (int)vis; *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += vis; }
+        round++;
+    }
+}
 static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
+    const int device_c = g_emu_wave_c_device;
     if (with_ab) { be_wave_a(b, c); be_wave_b(b, c); }
-    be_wave_c(b, c, record_seeds, clear_first);
+    if (device_c) be_wave_c_device(b, c, record_seeds, clear_first);
+    else be_wave_c(b, c, record_seeds, clear_first);
 }
 
 #include "../../gie-mapping_amd/csrc/gie_api.inc.h"

@@ -11,6 +11,7 @@ EMU_DIR = os.path.join(HERE, "emu")
 EMU_SO = os.path.join(EMU_DIR, "libgie_emu.so")
 CSRC = os.path.join(os.path.dirname(HERE), "gie-mapping_amd", "csrc")
 _fns = None
+_lib = None
 
 
 def load():
@@ -26,11 +27,19 @@ def load():
                 subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", tmp,
                                        os.path.join(EMU_DIR, "gie_emu.cpp")])
                 os.replace(tmp, EMU_SO)
-        lib = C.CDLL(EMU_SO)
+        global _lib
+        lib = _lib = C.CDLL(EMU_SO)
         _fns = _capi.bind(lib, "gie_", {"last_error": (C.c_char_p, []), "sync": (C.c_int, [C.c_void_p]),
                                         "halo_export_sparse": _capi.DEVICE_ONLY["halo_export_sparse"],
                                         "halo_import_sparse": _capi.DEVICE_ONLY["halo_import_sparse"]})
     return _fns
+
+
+def wave_c_model(device, r0filter=False):
+    """Which statement of wave C the emulation runs from now on: the canonical one (device=False) or the sequential model of the
+    DEVICE's tile rounds (gie_emu.cpp be_wave_c_device); r0filter=True puts the round-0 halo filter back that round 4 removed."""
+    load()
+    _lib.gie_emu_wave_c_model(int(bool(device)), int(bool(r0filter)))
 
 
 class EmuMapper(MapperBase):

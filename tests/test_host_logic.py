@@ -294,3 +294,37 @@ def test_byte_parallel_occupancy_filter():
                         no, ny = row(thresh, labels, occs, tys)
                         for i in range(8):
                             assert (no[i], ny[i]) == table[(int(labels[i]), int(tys[i]), int(occs[i]))], (thresh, pos, i, labels, occs, tys, no, ny)
+
+
+WAVE_C_MODEL = ["depth", "mixed", "c3_no_cutoff", "c5_hash_world", "c5_dense_odd", "retain_lidar", "retain_turn_back", "odd_dims", "planner_boxes"]
+
+
+@pytest.mark.parametrize("name", WAVE_C_MODEL)
+def test_device_schedule_of_wave_c_matches_oracle(oracle_lib, name):
+    """The emulation's SECOND statement of wave C: the tile rounds as the device runs them (seeds assigned inside round 0, halos as of
+    the start of the round, proposals that do not beat the pair in sight dropped, proposals across tile borders merged a round
+    later) against the oracle's sequential schedule — every stage, every frame, and the wave statistics."""
+    import emu_py
+    sc = [s for s in SCENARIOS if s.name == name][0]
+    emu_py.wave_c_model(True)
+    try:
+        parity.run_and_compare(sc, OracleMapper, EmuMapper)
+    finally:
+        emu_py.wave_c_model(False)
+
+
+def test_device_schedule_of_wave_c_needs_the_unfiltered_round_0(oracle_lib):
+    """What the retain-focused fuzz of round 4 found on the GPU (seed 83 #63), on the CPU: with the halo filter also applied
+    across tile borders in round 0 — the kernel before the fix — the device schedule leaves ONE voxel at the distance of the seed
+    wave B put on it (182) where the oracle reaches 179 through the neighbour across the tile border; without it they agree."""
+    import emu_py
+    sc = parity.Scenario("wave_c_seed_above_stale_pair", (96, 120, 160), voxel=0.2, sensor="mixed", frames=9, delta_vox=10, yaw_deg=30.029303880177924,
+                         seed=742, cutoff_dist=100.0, extent=(20.2, 20.2, 13.3), toggle=0.5, lidar_az=360, p_occ=0.01, retain=2, turn=5, probe_margin=40)
+    emu_py.wave_c_model(True, r0filter=True)
+    try:
+        with pytest.raises(AssertionError, match="frame 8: post-merge dist_sq differs in 1 voxels"):
+            parity.run_and_compare(sc, OracleMapper, EmuMapper)
+        emu_py.wave_c_model(True, r0filter=False)
+        parity.run_and_compare(sc, OracleMapper, EmuMapper)
+    finally:
+        emu_py.wave_c_model(False)

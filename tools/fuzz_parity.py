@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("--big", action="store_true", help="volume sides of 96 ... 192 voxels (thousands of active blocks per wave round)")
     ap.add_argument("--only", type=int, default=-1, help="run scenario number N of the seed only")
+    ap.add_argument("--device-wave-c", action="store_true", help="with --emu: the emulation runs its model of the DEVICE's wave C tile rounds (gie_emu.cpp be_wave_c_device) instead of the canonical statement")
     ap.add_argument("--focus", default=None, choices=[None, "retain"], help="retain: every scenario erases blocks (retain_radius_blocks 1-3) on a drive that turns round")
     args = ap.parse_args()
     import gie
@@ -97,6 +98,9 @@ def main():
     from oracle_py import OracleMapper
     if args.emu:
         from emu_py import EmuMapper as Under
+        if args.device_wave_c:
+            import emu_py
+            emu_py.wave_c_model(True)
     else:
         Under = gie.Mapper
     rng = np.random.default_rng(args.seed)
