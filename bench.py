@@ -746,7 +746,9 @@ def run_bench():
                                "on every kernel's dispatch (costs ms_per_step_instrumented - ms_per_step)")
         line["error_bar"] = ("the duration of the Mark + commit sweep depends on where the mapper's planes lie in physical memory (two write streams "
                              "that overlap or take turns): 0.80 or 0.89 ms for the same kernel.  Since round 4 gie_create re-draws the four planes "
-                             "against a probe of the sweep's memory pattern (GIE_PLACE_TRIES, DESIGN.md 4): 12 of 12 fresh mappers at 0.80 +- 0.02 ms")
+                             "against a probe of the sweep's memory pattern (GIE_PLACE_TRIES, DESIGN.md 4): mapper to mapper within +- 0.02 ms on one box.  "
+                             "From BOX to box the whole update ranges 2.34 ... 2.45 ms (nine fresh boxes at the end of round 4: six at 2.34 - 2.38, three at "
+                             "2.44 - 2.45 whose probe is slower for every placement drawn, 0.59 against 0.51 - 0.52 ms; Mark + commit 0.76 against 0.84 ms)")
         if world == 1 and not args.no_extras:
             extras = {}
             for wl in ("vlp16_projective", "vlp16"):
