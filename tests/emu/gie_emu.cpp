@@ -472,7 +472,7 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
     }
 }
 /* which statement of wave C the emulation runs (environment at load, or gie_emu_wave_c_model at any time) */
-static int g_emu_wave_c_device = (getenv("GIE_EMU_WAVE_C") && !strcmp(getenv("GIE_EMU_WAVE_C"), "device")) ? 1 : 0;
+static int g_emu_wave_c_device = (getenv("GIE_EMU_WAVE_C") && !strcmp(getenv("GIE_EMU_WAVE_C"), "device")) ? 1 : (getenv("GIE_EMU_WAVE_C") && !strcmp(getenv("GIE_EMU_WAVE_C"), "device_live_halo")) ? 2 : 0;
 static int g_emu_wave_c_r0filter = getenv("GIE_EMU_WAVE_C_R0FILTER") ? atoi(getenv("GIE_EMU_WAVE_C_R0FILTER")) : 0;
 extern "C" void gie_emu_wave_c_model(int device, int r0filter) { g_emu_wave_c_device = device; g_emu_wave_c_r0filter = r0filter; }
 /* Wave C the way the DEVICE schedules it (gie_wave_c_tile / gie_wave_c_run in gie_kernels.hip.h), stated sequentially: a second model
@@ -548,7 +548,7 @@ static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int
                         if (d >= c.empty_value) continue;
                         const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
                         const int nid = gie_lid(c, nx, ny, nz);
-                        const uint64_t seen = inside ? pair[ux + 8 * uy + 64 * uz] : snap[(size_t)nid];
+                        const uint64_t seen = inside ? pair[ux + 8 * uy + 64 * uz] : (g_emu_wave_c_device == 2 ? c.pair[nid] : snap[(size_t)nid]);   /* (2: the other end of the device's race — a halo read sees the write-backs of the tiles taken before this one in the same round) */
                         if (!(d < gie_pair_dist(seen)) && (inside || round != 0 || r0filter)) continue;
                         const uint64_t key = gie_pair_make(d, par);
                         if (inside) {

@@ -39,7 +39,7 @@ def wave_c_model(device, r0filter=False):
     """Which statement of wave C the emulation runs from now on: the canonical one (device=False) or the sequential model of the
     DEVICE's tile rounds (gie_emu.cpp be_wave_c_device); r0filter=True puts the round-0 halo filter back that round 4 removed."""
     load()
-    _lib.gie_emu_wave_c_model(int(bool(device)), int(bool(r0filter)))
+    _lib.gie_emu_wave_c_model(int(device), int(bool(r0filter)))       # device = 2: halos read the live plane (the other end of the device's race)
 
 
 class EmuMapper(MapperBase):

@@ -299,14 +299,15 @@ def test_byte_parallel_occupancy_filter():
 WAVE_C_MODEL = ["depth", "mixed", "c3_no_cutoff", "c5_hash_world", "c5_dense_odd", "retain_lidar", "retain_turn_back", "odd_dims", "planner_boxes"]
 
 
+@pytest.mark.parametrize("halo", [1, 2], ids=["halo_as_of_round_start", "halo_live"])
 @pytest.mark.parametrize("name", WAVE_C_MODEL)
-def test_device_schedule_of_wave_c_matches_oracle(oracle_lib, name):
+def test_device_schedule_of_wave_c_matches_oracle(oracle_lib, name, halo):
     """The emulation's SECOND statement of wave C: the tile rounds as the device runs them (seeds assigned inside round 0, halos as of
     the start of the round, proposals that do not beat the pair in sight dropped, proposals across tile borders merged a round
     later) against the oracle's sequential schedule — every stage, every frame, and the wave statistics."""
     import emu_py
     sc = [s for s in SCENARIOS if s.name == name][0]
-    emu_py.wave_c_model(True)
+    emu_py.wave_c_model(halo)          # 1: a tile's halo is the plane as of the start of the round; 2: the live plane — the two ends of what a halo read can see on the device
     try:
         parity.run_and_compare(sc, OracleMapper, EmuMapper)
     finally:

@@ -100,7 +100,7 @@ def main():
         from emu_py import EmuMapper as Under
         if args.device_wave_c:
             import emu_py
-            emu_py.wave_c_model(True)
+            emu_py.wave_c_model(2 if os.environ.get("FUZZ_HALO_LIVE") else 1)
     else:
         Under = gie.Mapper
     rng = np.random.default_rng(args.seed)
