@@ -1,33 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — map-update throughput of the MI355X incremental-EDT path.
 
-One step = one full map update of a 512^3 local volume at 0.05 m voxels (set_pose → OGM → block
-allocation + fuse → batch EDT → Mark / obtainFrontiers / waves A,B,C / commit), i.e. the GPU work
-of VOLMAPNODE::publishMap (src/volumetric_mapper.cpp:138-224).  Inputs are resident in HBM when
-a timed region starts.
+One step = one full map update of a local volume (set_pose → OGM → block allocation + fuse → batch EDT → Mark /
+obtainFrontiers / waves A,B,C / commit), i.e. the GPU work of VOLMAPNODE::publishMap (src/volumetric_mapper.cpp:138-224).
+Inputs are resident in HBM when a timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|vlp16_projective|vlp16|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|c2|c3|c4|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workloads (all synthetic):
-  c5 (default)       BASELINE config 5's sensor-less world: voxel occupied iff hash(x,y,z) < 1 %, FULL
-                     observation, a quarter of the obstacles toggles every frame, the robot moves 8 voxels
-                     per frame.  Every voxel of the volume goes through every stage, so the algorithmic
-                     bytes of a map update are 132 B x N exactly, and the toggling obstacles next to the
-                     faces of the moving volume seed waves A, B and C in every timed step.
-  vlp16_projective   16-ring lidar cloud binned into the 16x440 range image of the reference's laser3D
-                     path (projective OGM): a quarter of the volume becomes known, flood waves.
-  vlp16 / lidar64*   the cloud through parallel ray casting (ugv_dataset / uav_raycast path): < 1 % of the
-                     volume known per frame.
-With N > 1 every rank owns one 512^3 tile of a larger volume around the same robot (2x2x2 tiles =
-1024^3 on 8 GPUs = BASELINE config 5 itself): one-voxel halo exchange + refinement over RCCL after
-every update (gie/tiling.py).  Per-GPU work is fixed: scaling is "weak".  Rank 0 prints ONE JSON line.
+Workloads (all synthetic; PRESETS below holds grid / voxel / cutoff / fast_mode of each):
+  c5 (default, headline)  BASELINE config 5's sensor-less hash world on a 512^3 grid at 0.05 m, cutoff 2 m: FULL observation,
+                     a quarter of the obstacles toggles every frame, the robot moves 8 voxels per frame.
+  c2 / c2_projective BASELINE config 2: 256^3 at 0.05 m, cutoff 2 m, 640x480 depth camera; the 307 200-point cloud through
+                     parallel ray casting (the reference's cow_lady path) / the same image through the projective depth kernel.
+  c3 / c3_projective BASELINE config 3: 512^3 at 0.1 m, cutoff 100 m (= no cutoff), fast_mode off, 16-ring lidar with 100 m
+                     range; ray casting / the 16x440 range image through the projective lidar kernel.
+  c4 / c4_nofast     BASELINE config 4 (uav_raycast): 320x320x40 at 0.05 m, cutoff 5 m, lidar through ray casting,
+                     fast_mode on (cfg/uav_laser3D_params.yaml:27) / off.
+  vlp16* / lidar64*  a lidar in the headline's 512^3 / 0.05 m / 2 m volume (ray casting, or *_projective).
+With N > 1 every rank owns one 512^3 tile of a larger volume around the same robot (2x2x2 tiles = 1024^3 on 8 GPUs =
+BASELINE config 5 itself): one-voxel halo exchange + refinement over RCCL after every update until no tile changed
+(gie/tiling.py exchange_converged_device).  Per-GPU work is fixed: scaling is "weak".
 
-Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
-synchronize on both sides (MAX over ranks); regions repeat until >= 0.5 s has been timed and
-`value` / `ms_per_step` come from the median region.  Per-step latencies (median, p95) come from a
-further pass with one event pair per step on the mapper's stream, kernel durations from a replay of
-the first region on a fresh mapper with HIP events on every kernel's dispatch.
+Rank 0 prints ONE JSON line, kept below 8 KB (build_line): headline keys, ONE roofline object, cpu_baseline, per-workload
+step times.  Everything else (per-kernel roofline trees, notes, regions) goes to profiles/bench_last_full.json.
+
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides (MAX over
+ranks); regions repeat until >= 0.5 s has been timed and `value` / `ms_per_step` come from the median region.  Per-step
+latencies (median, p95) come from a further pass with one event pair per step on the mapper's stream, kernel durations from
+a replay of the first region on a fresh mapper with HIP events on every kernel's dispatch.
 """
 import argparse
 import json
@@ -66,19 +67,48 @@ LIDARS = {
     "lidar64": (64, 1800, -30.0, 60.0 / 64, None),
     "lidar64_projective": (64, 1800, -30.0, 60.0 / 64, 1800),
 }
-WORKLOADS = ["c5"] + sorted(LIDARS)
+# name -> grid, voxel [m], cutoff [m], fast_mode, feed ("hash" | "lidar" | "depth"), lidar/depth model, robot step [voxels/frame],
+# box world (seed, half extent [m], boxes, min / max box size [m]), sensor range [m]
+PRESETS = {
+    "c5": {"size": (512, 512, 512), "voxel": 0.05, "cutoff": 2.0, "fast": False, "feed": "hash", "delta": 8},
+    "c2": {"size": (256, 256, 256), "voxel": 0.05, "cutoff": 2.0, "fast": False, "feed": "depth", "projective": False, "delta": 4,
+           "world": (2, (8.0, 8.0, 3.0), 80, 0.4, 2.5), "range": 8.0},
+    "c2_projective": {"size": (256, 256, 256), "voxel": 0.05, "cutoff": 2.0, "fast": False, "feed": "depth", "projective": True, "delta": 4,
+                      "world": (2, (8.0, 8.0, 3.0), 80, 0.4, 2.5), "range": 8.0},
+    "c3": {"size": (512, 512, 512), "voxel": 0.1, "cutoff": 100.0, "fast": False, "feed": "lidar", "sensor": "vlp16", "delta": 8,
+           "world": (3, (40.0, 40.0, 4.0), 300, 1.0, 6.0), "range": 100.0},
+    "c3_projective": {"size": (512, 512, 512), "voxel": 0.1, "cutoff": 100.0, "fast": False, "feed": "lidar", "sensor": "vlp16_projective",
+                      "delta": 8, "world": (3, (40.0, 40.0, 4.0), 300, 1.0, 6.0), "range": 100.0},
+    "c4": {"size": (320, 320, 40), "voxel": 0.05, "cutoff": 5.0, "fast": True, "feed": "lidar", "sensor": "vlp16", "delta": 4,
+           "world": (4, (12.0, 12.0, 3.0), 200, 0.4, 3.0), "range": 30.0},
+    "c4_nofast": {"size": (320, 320, 40), "voxel": 0.05, "cutoff": 5.0, "fast": False, "feed": "lidar", "sensor": "vlp16", "delta": 4,
+                  "world": (4, (12.0, 12.0, 3.0), 200, 0.4, 3.0), "range": 30.0},
+}
+for _name in LIDARS:     # a lidar in the headline's volume (rounds 1-4's extra runs)
+    PRESETS[_name] = {"size": (512, 512, 512), "voxel": 0.05, "cutoff": 2.0, "fast": False, "feed": "lidar", "sensor": _name, "delta": 8,
+                      "world": (5, (12.0, 12.0, 3.0), 200, 0.4, 3.0), "range": 30.0}
+WORKLOADS = list(PRESETS)
+BASELINE_CONFIG = {"c5": 5, "c2": 2, "c2_projective": 2, "c3": 3, "c3_projective": 3, "c4": 4, "c4_nofast": 4}
+DEFAULT_EXTRAS = ("vlp16_projective", "vlp16", "c2", "c2_projective", "c3", "c3_projective", "c4", "c4_nofast")
+DEPTH_CAM = {"rows": 480, "cols": 640, "fx": 525.0, "fy": 525.0, "cx": 319.5, "cy": 239.5}
 C5 = {"seed": 5, "p_occ": 0.01, "toggle_frac": 0.25, "delta_vox": 8, "yaw_deg": 2.0}
 C5_TURN = 24             # like the lidar robot below, the c5 robot drives 24 frames out (+8 voxels each) and 24 back, so the map it
                          # leaves behind is bounded however many regions a command times (round 2: a straight line forever ran
                          # the default block pool dry after ~157 updates and the driver's --steps 20 --warmup 5 died in it)
 MAX_REGIONS = 12         # timed regions per workload at most
+HALO_MAX_ROUNDS = 4      # N > 1: refinement rounds enqueued per map update at most (the tail rounds exit on the device-side flag)
 
 
 SENSORS = LIDARS
 
 
+def box_world(scenes, spec):
+    seed, extent, n_boxes, lo, hi = spec
+    return scenes.BoxWorld(seed, extent=extent, n_boxes=n_boxes, toggle_frac=0.25, ground_z=-1.5, min_size=lo, max_size=hi)
+
+
 def lidar_world(scenes):
-    return scenes.BoxWorld(5, extent=(12.0, 12.0, 3.0), n_boxes=200, toggle_frac=0.25, ground_z=-1.5, min_size=0.4, max_size=3.0)
+    return box_world(scenes, PRESETS["vlp16"]["world"])
 
 
 LIDAR_TURN = 24          # the robot of the lidar workloads drives 24 frames out and 24 back: it stays inside the 12 m box world
@@ -126,11 +156,11 @@ def pool_blocks(workload, size, updates):
     return int(c5_pool_blocks(size, updates) * 1.05) + 4096
 
 
-def lidar_host_frame(scenes, world, voxel, sensor, i):
+def lidar_host_frame(scenes, world, voxel, sensor, i, delta_vox=8, max_range=30.0, device=None):
     """(pos, quat, cloud or range image, points in the cloud) of frame i of a lidar workload."""
     rings, az, phi_min, phi_inc, bins = LIDARS[sensor]
-    pos, q = scenes.pose(turn_index(i, LIDAR_TURN), voxel, delta_vox=8, yaw_deg=2.0)
-    pts, _ = scenes.lidar_frame(world, i, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc, max_range=30.0)
+    pos, q = scenes.pose(turn_index(i, LIDAR_TURN), voxel, delta_vox=delta_vox, yaw_deg=2.0)
+    pts, _ = scenes.lidar_frame(world, i, pos, q, rings=rings, az=az, phi_min_deg=phi_min, phi_inc_deg=phi_inc, max_range=max_range, device=device)
     npts = pts.shape[0]
     if bins is not None:   # Vlp16MapMaker::convertPyntCld binning (vlp16_map_maker.cpp:73-147)
         pts = scenes.range_image(pts, scan_num=bins, ring_num=rings, phi_min_deg=phi_min, phi_inc_deg=phi_inc)
@@ -186,17 +216,20 @@ class HashWorldFeed:
 class LidarFeed:
     """A 16- or 64-ring lidar in a box world: point clouds (ray casting) or range images (projective OGM)."""
 
-    def __init__(self, torch, scenes, dev, voxel, sensor, nframes):
+    def __init__(self, torch, scenes, dev, voxel, sensor, nframes, preset=None):
         self.torch, self.scenes, self.dev, self.voxel, self.sensor = torch, scenes, dev, voxel, sensor
         self.rings, self.az, self.phi_min, self.phi_inc, self.bins = LIDARS[sensor]
         self.kind = "pointcloud" if self.bins is None else "multiscan"
-        self.world = lidar_world(scenes)
+        p = preset or PRESETS[sensor]
+        self.delta, self.max_range = p["delta"], p["range"]
+        self.world = box_world(scenes, p["world"])
+        self.cast_dev = dev if getattr(dev, "type", "cpu") == "cuda" else None      # ray / box tests of the synthetic scene on the GPU
         self.frames = {}
         self.npts = []
 
     def _frame(self, i):
         if i not in self.frames:
-            pos, q, pts, npts = lidar_host_frame(self.scenes, self.world, self.voxel, self.sensor, i)
+            pos, q, pts, npts = lidar_host_frame(self.scenes, self.world, self.voxel, self.sensor, i, self.delta, self.max_range, self.cast_dev)
             self.npts.append(npts)
             self.frames[i] = (pos, q, pts, self.torch.from_numpy(pts).to(self.dev))
         return self.frames[i]
@@ -204,7 +237,8 @@ class LidarFeed:
     def prepare(self, first, count):
         for i in range(first, first + count):
             self._frame(i)
-        self.torch.cuda.synchronize()
+        if self.cast_dev is not None:
+            self.torch.cuda.synchronize()
 
     def step_input(self, m, i):
         pos, q, _, d = self._frame(i)
@@ -224,15 +258,66 @@ class LidarFeed:
                       phi_inc=math.radians(self.phi_inc), phi_min=math.radians(self.phi_min))
 
     def describe(self):
-        return ("synthetic %d-ring x %d lidar cloud (%d pts/frame) in a box world with 25 %% toggling boxes via %s"
-                % (self.rings, self.az, int(np.mean(self.npts)) if self.npts else 0,
-                   "parallel ray casting" if self.bins is None else "%dx%d range image (projective OGM)" % (self.rings, self.bins)))
+        return ("%d-ring x %d lidar, %d pts/frame, %s" % (self.rings, self.az, int(np.mean(self.npts)) if self.npts else 0,
+                "ray casting" if self.bins is None else "%dx%d range image (projective)" % (self.rings, self.bins)))
+
+
+class DepthFeed:
+    """BASELINE config 2: a 640x480 pinhole depth camera in a box world; the valid pixels as a point cloud through ray casting
+    (PntcldMapMaker, the reference's cow_lady launch) or the image itself through the projective depth kernel (RealsenseMapMaker)."""
+
+    def __init__(self, torch, scenes, dev, voxel, preset):
+        self.torch, self.scenes, self.dev, self.voxel = torch, scenes, dev, voxel
+        self.projective = bool(preset["projective"])
+        self.kind = "depth" if self.projective else "pointcloud"
+        self.delta, self.max_range = preset["delta"], preset["range"]
+        self.world = box_world(scenes, preset["world"])
+        self.cast_dev = dev if getattr(dev, "type", "cpu") == "cuda" else None
+        self.frames = {}
+        self.npts = []
+
+    def _frame(self, i):
+        if i not in self.frames:
+            pos, q = self.scenes.pose(turn_index(i, LIDAR_TURN), self.voxel, delta_vox=self.delta, yaw_deg=2.0)
+            depth = self.scenes.depth_frame(self.world, i, pos, q, max_depth=self.max_range, device=self.cast_dev, **DEPTH_CAM)
+            host = depth if self.projective else self.scenes.depth_to_points(depth, DEPTH_CAM["fx"], DEPTH_CAM["fy"], DEPTH_CAM["cx"], DEPTH_CAM["cy"])
+            self.npts.append(int(np.isfinite(depth).sum()))
+            self.frames[i] = (pos, q, host, self.torch.from_numpy(host).to(self.dev))
+        return self.frames[i]
+
+    def prepare(self, first, count):
+        for i in range(first, first + count):
+            self._frame(i)
+        if self.cast_dev is not None:
+            self.torch.cuda.synchronize()
+
+    def step_input(self, m, i):
+        pos, q, _, d = self._frame(i)
+        m.set_pose(pos, q)
+        if self.projective:
+            m.ogm_depth_dev(d.data_ptr(), DEPTH_CAM["rows"], DEPTH_CAM["cols"], DEPTH_CAM["cx"], DEPTH_CAM["cy"], DEPTH_CAM["fx"], DEPTH_CAM["fy"], valid_nan=True)
+        else:
+            m.ogm_pointcloud_dev(d.data_ptr(), d.shape[0])
+
+    def oracle_update(self, om, i):
+        pos, q, host, _ = self._frame(i)
+        if self.projective:
+            om.update(pos, q, "depth", host, cx=DEPTH_CAM["cx"], cy=DEPTH_CAM["cy"], fx=DEPTH_CAM["fx"], fy=DEPTH_CAM["fy"], valid_nan=True)
+        else:
+            om.update(pos, q, "pointcloud", host)
+
+    def describe(self):
+        return ("%dx%d depth camera, %d valid px/frame, %s" % (DEPTH_CAM["cols"], DEPTH_CAM["rows"], int(np.mean(self.npts)) if self.npts else 0,
+                "projective depth kernel" if self.projective else "cloud through ray casting"))
 
 
 def make_feed(workload, torch, scenes, dev, voxel, size, tile_off, nframes):
-    if workload == "c5":
+    p = PRESETS[workload]
+    if p["feed"] == "hash":
         return HashWorldFeed(torch, scenes, dev, voxel, size, tile_off)
-    return LidarFeed(torch, scenes, dev, voxel, workload, nframes)
+    if p["feed"] == "depth":
+        return DepthFeed(torch, scenes, dev, voxel, p)
+    return LidarFeed(torch, scenes, dev, voxel, p["sensor"], nframes, preset=p)
 
 
 def percentile(xs, p):
@@ -258,9 +343,13 @@ class Runner:
             tgrid = tiling.tile_grid(world)
             self.m.set_tile(tiling.tile_offset_voxels(rank, world, size), tuple(tgrid[i] * size[i] for i in range(3)))
         self.halo_bufs = {}
-        hr = os.environ.get("GIE_HALO_ROUNDS", "1")
-        self.halo_mode = "stable" if hr == "stable" else "stream"
-        self.halo_rounds = 1 if hr == "stable" else max(1, int(hr))
+        # GIE_HALO_ROUNDS: "converged" (default) = stream-ordered rounds gated by a device-side "some tile changed" word that is
+        # all-reduced over RCCL on the mapper's stream, at most HALO_MAX_ROUNDS of them (tiling.exchange_converged_device: what the
+        # parity tests hold against the tiled oracle); "stable" = host-synchronised rounds until no tile changes; an integer = that
+        # many ungated stream-ordered rounds (round 4's default was 1)
+        hr = os.environ.get("GIE_HALO_ROUNDS", "converged")
+        self.halo_mode = hr if hr in ("stable", "converged") else "stream"
+        self.halo_rounds = HALO_MAX_ROUNDS if hr in ("stable", "converged") else max(1, int(hr))
         self.rounds_total = 0
         self.updates = 0
         self.checked_pivot = False
@@ -281,10 +370,13 @@ class Runner:
             t, d = self.tiling, self.dist
             if self.backend != "nccl":
                 self.rounds_total += t.exchange_until_stable(m, d, self.rank, self.world, sparse=os.environ.get("GIE_HALO_SPARSE", "0") == "1")
-            elif self.halo_mode == "stream":
-                # one exchange round per map update, enqueued on the mapper's own stream (RCCL included): the host never waits
+            elif self.halo_mode in ("stream", "converged"):
+                # exchange rounds enqueued on the mapper's own stream (RCCL included): the host never waits
                 try:
-                    self.rounds_total += t.exchange_rounds_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, rounds=self.halo_rounds, group=self.group)
+                    if self.halo_mode == "converged":
+                        t.exchange_converged_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, max_rounds=self.halo_rounds, group=self.group)
+                    else:
+                        self.rounds_total += t.exchange_rounds_device(m, d, self.rank, self.world, self.dev, self.halo_bufs, rounds=self.halo_rounds, group=self.group)
                 except Exception as e:                                  # e.g. no external-stream support: host-synchronised rounds
                     self.fallback_note = "stream-ordered exchange failed (%s: %s): host-synchronised rounds" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
                     sys.stderr.write("bench: %s\n" % self.fallback_note)
@@ -345,11 +437,11 @@ class Runner:
 
 
 def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff_dist, W, K, rank, world, dev, local_rank, backend,
-                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False, group=None, transport_note=None):
+                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False, group=None, transport_note=None, fast_mode=False):
     """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
-    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=local_rank, retain_radius_blocks=DRIVE["retain"],
+    cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=fast_mode, device_id=local_rank, retain_radius_blocks=DRIVE["retain"],
                           max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)))
     feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
     r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, group=group)
@@ -393,13 +485,22 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     blocks = st1["blocks_total"]
     rounds_per_step = r.rounds_total / float(max(1, r.updates))
     halo_mode = r.halo_mode
+    round_stats = None
+    if r.exchange and halo_mode == "converged":      # what the gated rounds did is counted on the device (gie_round_stats)
+        round_stats = r.m.round_stats()
+        rounds_per_step = round_stats["rounds_run"] / float(max(1, round_stats["updates"]))
+        if dist is not None:                          # the worst tile: every rank's count over the control plane
+            t = torch.tensor([float(round_stats["rounds_run"]), float(round_stats["updates_unconverged"])], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            round_stats = dict(round_stats, rounds_run=int(t[0].item()), updates_unconverged=int(t[1].item()))
+            rounds_per_step = round_stats["rounds_run"] / float(max(1, round_stats["updates"]))
     notes = [n for n in (transport_note, r.fallback_note) if n]
     r.close()
     if rank != 0:
         return None
     # kernel durations: the first region replayed on a fresh mapper with start / stop events on every kernel's dispatch
     # (rank 0's tile, no halo exchange: the exchange kernels are not roofline candidates)
-    feed2 = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
+    feed2 = feed            # (same frames: a lidar / depth feed keeps the scans it has generated)
     r2 = Runner(torch, gie, tiling, None, feed2, cfg, rank, world, size, dev, backend, exchange=False)
     r2.warmup(W)
     if feed2.kind == "pointcloud":          # cells one scan's ray casting counts in (hits + cleared cells = the ray kernels' unit)
@@ -427,6 +528,7 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     alg = dict(ALG_BYTES)
     if feed2.kind == "pointcloud":
         alg["fuse"] = 15                     # ray-cast fuse also reads / zeroes _ray_count
+    model_errors = []
 
     def kernel_roof(name):
         tot_ms, n = prof[name]
@@ -453,11 +555,13 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         tb = (traffic or {}).get("kernels", {}).get(name)
         phys = tb if tb else lay
         o = {"kernel": name, "avg_launch_ms": round(avg_ms, 4),
-             "achieved": round(phys / sec / 1e9, 1), "frac": round(min(1.0, phys / sec / 1e9 / HBM_PEAK_GBS), 4),
+             "achieved": round(phys / sec / 1e9, 1), "frac": round(phys / sec / 1e9 / HBM_PEAK_GBS, 4),
              "frac_basis": "pmc" if tb else "layout_lower_bound", "traffic": int(tb) if tb else None,
              "achieved_algorithmic": round(b / sec / 1e9, 1), "frac_algorithmic": round(b / sec / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": int(b),
              "layout_bytes_per_launch": int(lay)}
         o.update(what)
+        if o["frac"] > 1.0:                  # not clamped: a fraction above 1 says the byte model is wrong for this launch
+            model_errors.append(name)
         return o
 
     traffic = load_traffic(workload, size, world)
@@ -492,7 +596,7 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         phys = sum((k["traffic"] if allpmc else k["layout_bytes_per_launch"]) for k in ks)
         ab = sum(k["alg_bytes_per_launch"] for k in ks)
         return {"kernels": [k["kernel"] for k in ks], "ms_per_step": round(total_ms, 4), "achieved": round(phys / sec / 1e9, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(min(1.0, phys / sec / 1e9 / HBM_PEAK_GBS), 4), "frac_basis": "pmc" if allpmc else "layout_lower_bound",
+                "unit": "GB/s", "frac": round(phys / sec / 1e9 / HBM_PEAK_GBS, 4), "frac_basis": "pmc" if allpmc else "layout_lower_bound",
                 "traffic": int(phys) if allpmc else None, "alg_bytes_per_step": int(ab),
                 "achieved_algorithmic": round(ab / sec / 1e9, 1), "frac_algorithmic": round(ab / sec / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -510,25 +614,31 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         "timed_regions": len(regions), "region_ms": [round(1e3 * x, 3) for x in regions], "timed_s": round(sum(regions), 3),
         "step_ms": ({"median": round(percentile(lat, 0.5), 4), "p95": round(percentile(lat, 0.95), 4), "min": round(min(lat), 4),
                      "max": round(max(lat), 4), "n": len(lat), "how": "one event pair per step on the mapper's stream, separate pass"} if lat else None),
-        "config": {"workload": "%dx%dx%d local grid @ %.2f m, %s, OGM + fuse + batch EDT + waves A/B/C + commit, cutoff %.1f m, fast_mode off"
-                               % (size[0], size[1], size[2], voxel, feed2.describe(), cutoff_dist),
-                   "preset": workload,
+        "config": {"workload": "%dx%dx%d @ %.2f m, %s, full map update, cutoff %.0f m, fast_mode %s"
+                               % (size[0], size[1], size[2], voxel, feed2.describe(), cutoff_dist, "on" if fast_mode else "off"),
+                   "preset": workload, "baseline_config": BASELINE_CONFIG.get(workload),
+                   "grid": list(size), "voxel_m": voxel, "cutoff_m": cutoff_dist, "fast_mode": bool(fast_mode),
                    "drive": ({"mode": DRIVE["mode"], "turn_frames": C5_TURN if DRIVE["mode"] == "turn" else None, "delta_vox": C5["delta_vox"],
                               "retain_radius_blocks": DRIVE["retain"]} if workload == "c5" else
-                             {"mode": "turn", "turn_frames": LIDAR_TURN, "delta_vox": 8, "retain_radius_blocks": DRIVE["retain"]}),
-                   "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU, one-voxel halo exchange + refinement over %s (%.1f rounds/step, %s)%s"
-                             % (tgrid + tuple(size) + ("RCCL" if backend == "nccl" else "gloo with host staging", rounds_per_step,
-                                                       "stream-ordered, fixed" if (halo_mode == "stream" and backend == "nccl") else "until no tile changes",
-                                                       ("; " + "; ".join(notes)) if notes else ""))) if world > 1 else "single volume",
+                             {"mode": "turn", "turn_frames": LIDAR_TURN, "delta_vox": PRESETS[workload]["delta"], "retain_radius_blocks": DRIVE["retain"]}),
+                   "tiles": ("%dx%dx%d tiles of %dx%dx%d, one per GPU" % (tgrid + tuple(size))) if world > 1 else "single volume",
                    "known_voxel_fraction": round(res["known"], 4),
                    "wave_visits_per_step": [round(visits[k], 1) for k in "abc"],
                    "wave_levels_last_step": [st1["levels_a"], st1["levels_b"], st1["levels_c"]],
                    "blocks": blocks},
+        "steps": K, "warmup": W,
         "kernels_ms_per_step": {k: round(v[0] / K, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
         "ms_per_step_instrumented": round(1e3 * dt_instr / K, 4),
         "roofline": roofline, "roofline_wavefront_sweep": wavefront, "roofline_update": update,
         "roofline_sweeps": {k: {kk: vv for kk, vv in v.items() if kk != "kernel"} for k, v in sweeps.items()},
     }
+    if world > 1:       # the halo exchange this run timed (VERDICT r4 "next" #3 / #10)
+        out["config"].update({
+            "exchange": "RCCL" if backend == "nccl" else "gloo, host staging", "rccl_ranks": world if backend == "nccl" else 0,
+            "halo_mode": halo_mode, "halo_max_rounds": r.halo_rounds, "rounds_per_update": round(rounds_per_step, 3),
+            "updates_unconverged": (round_stats or {}).get("updates_unconverged"), "exchange_notes": notes})
+    if model_errors:
+        out["roofline_model_errors"] = sorted(model_errors)
     if accuracy is not None:
         out["accuracy"] = accuracy
     return out
@@ -600,7 +710,7 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
     cores = os.cpu_count() or 1
     # the occupancy the EDT works on: frame W of the workload (for the hash world the fused types are the labels: a first
     # observation of an obstacle gives 250 * 0.8 = 200 > 180)
-    if workload == "c5":
+    if PRESETS[workload]["feed"] == "hash":
         pos, _ = c5_pose(scenes, W, voxel)
         pvt = scenes.local_pivot(pos, voxel, size)
         lab = scenes.hash_world_labels(pvt, size, W, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"],
@@ -609,8 +719,8 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
         types = lab.cpu().numpy()
         del lab
     else:
-        feed = LidarFeed(torch, scenes, dev, voxel, workload, W + 1)
-        cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=False, device_id=dev.index or 0)
+        feed = make_feed(workload, torch, scenes, dev, voxel, size, (0, 0, 0), W + 1)
+        cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=PRESETS[workload]["fast"], device_id=dev.index or 0)
         m = gie.Mapper(cfg)
         feed.prepare(0, W + 1)
         for i in range(W + 1):
@@ -628,36 +738,124 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
         oracle_py.edt_mt(types, nthreads=cores)
     dt = (time.perf_counter() - t0) / reps
     out = {"value": round(n / dt / 1e6, 2), "unit": "Mvoxels/s", "cores": cores, "host_cores": cores, "kind": "port",
-           "stage": "batch EDT only (exact separable 3-pass EDT + closest obstacle), %d threads" % cores,
+           "stage": "batch EDT only (exact separable EDT + closest obstacle), %d threads" % cores,
            "ms_per_update": round(1e3 * dt, 2),
-           "sample": "%dx%dx%d grid of frame %d of the same workload (%d obstacles), %d + 1 repetitions, %.1f s of wall time"
+           "sample": "%dx%dx%d grid of frame %d (%d obstacles), %d+1 repetitions, %.1f s"
                      % (size[0], size[1], size[2], W, int((types == 2).sum()), reps, t1 + dt * reps)}
     del types
     # the whole map update, scalar port on one core, bounded sample (128^3 under full observation, 256^3 for the sparse lidar scans)
-    s2 = (128, 128, 128) if workload in ("c5", "vlp16_projective", "lidar64_projective") else (256, 256, 256)
-    cfg = gie.make_config(voxel, s2, cutoff_dist=cutoff_dist, fast_mode=False)
+    hashw = PRESETS[workload]["feed"] == "hash"
+    s2 = (128, 128, 128) if (hashw or workload.endswith("_projective")) else tuple(min(256, e) for e in size)
+    cfg = gie.make_config(voxel, s2, cutoff_dist=min(cutoff_dist, 5.0), fast_mode=PRESETS[workload]["fast"])
     om = oracle_py.OracleMapper(cfg)
-    lf = None if workload == "c5" else LidarFeed(torch, scenes, torch.device("cpu"), voxel, workload, 32)
+    lf = None if hashw else make_feed(workload, torch, scenes, torch.device("cpu"), voxel, s2, (0, 0, 0), 32)
     t0 = time.perf_counter()
     k = 0
     while k < 32 and (k < 3 or time.perf_counter() - t0 < 10.0):
-        if workload == "c5":
+        if hashw:
             pos, q = c5_pose(scenes, k, voxel)
             lab = scenes.hash_world_labels(scenes.local_pivot(pos, voxel, s2), s2, k, seed=C5["seed"], p_occ=C5["p_occ"], toggle_frac=C5["toggle_frac"])
             om.update(pos, q, "labels", lab.astype(np.int8))
         else:
-            pos, q, pts, _ = lf._frame(k)
             lf.oracle_update(om, k)
         k += 1
     dt2 = time.perf_counter() - t0
     om.close()
     out["full_update_1core"] = {"value": round(s2[0] * s2[1] * s2[2] * k / dt2 / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-                                "sample": "%dx%dx%d grid, same generator, %d map updates through the scalar oracle (%.1f s, input generation included)"
-                                          % (s2[0], s2[1], s2[2], k, dt2)}
+                                "stage": "whole map update, scalar restatement (oracle/gie_oracle.c)",
+                                "sample": "%dx%dx%d grid, same generator, %d map updates, %.1f s incl. input generation" % (s2[0], s2[1], s2[2], k, dt2)}
     return out
 
 
 PARTIAL = {}     # per workload: the regions timed so far (printed with an "error" key if the run dies later on)
+FULL_FILE = os.path.join("profiles", "bench_last_full.json")
+LINE_LIMIT = 8000           # bytes of the ONE line on stdout (a 21.8 KB line left the driver's record unparsed)
+
+
+def _short(v, n=120):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+
+
+def compact_roofline(r):
+    """The ONE roofline object of the line: the contract's keys + what prices it."""
+    keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frac_basis", "frac_algorithmic",
+            "achieved_algorithmic", "alg_bytes_per_launch", "layout_bytes_per_launch", "voxels_per_launch", "csrc_hash")
+    return {k: r.get(k) for k in keys if k in r}
+
+
+def build_line(main_res, extras, cpu, n_gpus, metric="edt_map_update_throughput", full_file=FULL_FILE):
+    """(line, full): `line` is what rank 0 prints — headline keys, ONE roofline (dominant kernel), cpu_baseline, per-workload step
+    times and fractions, below LINE_LIMIT bytes, no string above 120 characters; `full` is everything (written to full_file)."""
+    full = {"metric": metric, "value": main_res["value"], "unit": "Mvoxels/s", "n_gpus": n_gpus, "steps": main_res["steps"], "warmup": main_res["warmup"],
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic"}
+    full.update({k: v for k, v in main_res.items() if k not in full})
+    full["extra_runs"] = extras
+    if cpu is not None:
+        full["cpu_baseline"] = cpu
+    full["notes"] = {
+        "timing": "value / ms_per_step: median of the timed regions, each EXACTLY K steps between barrier + synchronize, MAX over ranks; kernels_ms_per_step and "
+                  "the roofline objects: the first region replayed on a fresh mapper with start / stop events on every kernel's dispatch",
+        "roofline": "dominant kernel of the map update.  achieved = traffic / avg_launch_ms, frac = achieved / peak: traffic = HBM bytes per launch from the rocprofv3 "
+                    "PMC passes (separate passes; profiles/) of this workload on THESE kernel sources (csrc_hash; a profile of other sources is withheld and frac "
+                    "falls back to the bytes this build's layout must move at least: frac_basis); avg_launch_ms from HIP events on the kernel's own dispatch in this "
+                    "run.  *_algorithmic = SURVEY 8(d)'s reference-layout bytes x the units of one launch / the same duration; it exceeds 1 when the kernel moves "
+                    "fewer bytes than the reference's layout implies.  Not clamped: a frac above 1 is listed under roofline_model_errors",
+    }
+    cfgm = main_res["config"]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["hz"] = main_res["hz"]
+    line["config"] = {k: _short(v) for k, v in cfgm.items() if k not in ("drive", "exchange_notes", "wave_levels_last_step")}
+    line["roofline"] = compact_roofline(main_res["roofline"])
+    ws, up = main_res.get("roofline_wavefront_sweep") or {}, main_res.get("roofline_update") or {}
+    line["roofline_wavefront_sweep"] = {k: ws.get(k) for k in ("ms_per_step", "frac", "frac_basis", "frac_algorithmic") if k in ws}
+    line["roofline_update"] = {k: up.get(k) for k in ("ms_per_step", "frac", "frac_basis", "frac_algorithmic") if k in up}
+    if main_res.get("step_ms"):
+        line["step_ms"] = {k: main_res["step_ms"][k] for k in ("median", "p95")}
+    line["timed_regions"], line["timed_s"] = main_res["timed_regions"], main_res["timed_s"]
+    line["kernels_ms_per_step"] = main_res["kernels_ms_per_step"]
+    if main_res.get("roofline_model_errors"):
+        line["roofline_model_errors"] = main_res["roofline_model_errors"]
+    if cpu is not None:
+        line["cpu_baseline"] = {k: (_short(v) if not isinstance(v, dict) else {kk: _short(vv) for kk, vv in v.items()}) for k, v in cpu.items()}
+        line["config"]["cpu_baseline_stage"] = _short(cpu.get("stage", ""))
+    if extras:
+        preset = cfgm.get("preset", "main")
+        line["ms_per_step_by_workload"] = {preset: main_res["ms_per_step"], **{wl: e["ms_per_step"] for wl, e in extras.items()}}
+        line["mvoxels_per_s_by_workload"] = {preset: main_res["value"], **{wl: e["value"] for wl, e in extras.items()}}
+        # one fraction each: the dominant kernel of that workload's update (name : frac, physical; frac_basis in the full file)
+        line["frac_by_workload"] = {preset: [main_res["roofline"]["kernel"], main_res["roofline"]["frac"]],
+                                    **{wl: [e["roofline"]["kernel"], e["roofline"]["frac"]] for wl, e in extras.items()}}
+        line["baseline_config_by_workload"] = {wl: BASELINE_CONFIG[wl] for wl in [preset] + list(extras) if wl in BASELINE_CONFIG}
+        ogm = {}
+        for wl, kern in (("vlp16_projective", "ogm_classify"), ("vlp16", "ray_free"), ("c2", "ray_free"), ("c2_projective", "ogm_classify")):
+            rr = (extras.get(wl) or {}).get("roofline_sweeps", {}).get(kern)
+            if rr:
+                ogm["%s:%s" % (wl, kern)] = {k: rr.get(k) for k in ("avg_launch_ms", "frac", "frac_basis")}
+        if ogm:
+            line["roofline_ogm"] = ogm
+    if main_res.get("accuracy") is not None:
+        line["accuracy"] = {k: _short(v) for k, v in main_res["accuracy"].items()}
+    line["detail"] = full_file
+    # the limit holds whatever a run produces: drop the least important blocks first
+    for k in ("roofline_ogm", "kernels_ms_per_step", "mvoxels_per_s_by_workload", "baseline_config_by_workload", "accuracy", "roofline_update", "step_ms"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line, full
+
+
+def write_full(full, path=FULL_FILE):
+    """Everything the line leaves out, beside the committed profiles (and under gpurun_out/ when that exists: it travels back from a GPU box)."""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if d != ROOT and not os.path.isdir(d):
+                continue
+            f = os.path.join(d, path) if d == ROOT else os.path.join(d, os.path.basename(path))
+            os.makedirs(os.path.dirname(f), exist_ok=True)
+            with open(f, "w") as fh:
+                json.dump(full, fh, indent=1)
+        except OSError as e:                 # a read-only checkout must not cost the line
+            sys.stderr.write("bench: could not write %s: %s\n" % (path, e))
 
 
 def main():
@@ -669,13 +867,12 @@ def main():
             raise
         if rank == 0:
             line = {"metric": "edt_map_update_throughput", "value": None, "unit": "Mvoxels/s", "higher_is_better": True,
-                    "error": "%s: %s" % (type(e).__name__, e), "partial": {}}
+                    "error": _short("%s: %s" % (type(e).__name__, e), 400), "partial": {}}
             for wl, p in PARTIAL.items():
                 rs = sorted(p["region_s"])
                 if rs:
                     med = rs[len(rs) // 2]
-                    line["partial"][wl] = {"timed_regions": len(rs), "region_ms": [round(1e3 * x, 3) for x in p["region_s"]],
-                                           "ms_per_step": round(1e3 * med / p["steps"], 4),
+                    line["partial"][wl] = {"timed_regions": len(rs), "ms_per_step": round(1e3 * med / p["steps"], 4),
                                            "value": round(p["n_voxels"] * p["steps"] / med / 1e6, 2)}
             print(json.dumps(line), flush=True)
         raise
@@ -686,8 +883,9 @@ def run_bench():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 512])
-    ap.add_argument("--voxel", type=float, default=0.05)
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="local grid (default: the workload's preset)")
+    ap.add_argument("--voxel", type=float, default=None, help="voxel width in m (default: the preset's)")
+    ap.add_argument("--cutoff", type=float, default=None, help="wave cutoff distance in m (default: the preset's)")
     ap.add_argument("--workload", "--sensor", dest="workload", choices=WORKLOADS, default="c5")
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="repeat the K-step region until this much has been timed")
     ap.add_argument("--drive", choices=["turn", "line"], default="turn", help="c5 robot: 24 frames out and 24 back (default), or a straight line forever")
@@ -697,7 +895,8 @@ def run_bench():
                     help="accuracy profiler (the reference's Gnd_truth_checker, gt_checker.h:30-80): RMSE of the local EDT after the last "
                          "timed update against the exact distance to the nearest occupied voxel of the volume")
     ap.add_argument("--no-extras", "--no-secondary", dest="no_extras", action="store_true",
-                    help="skip the projective-lidar and ray-casting runs reported beside the headline")
+                    help="skip the runs reported beside the headline (lidar workloads, BASELINE configs 2 / 3 / 4)")
+    ap.add_argument("--extras", default=None, help="comma list of workloads to run beside the headline (default: %s)" % ",".join(DEFAULT_EXTRAS))
     args = ap.parse_args()
     DRIVE["mode"], DRIVE["retain"] = args.drive, max(0, args.retain)
 
@@ -730,47 +929,33 @@ def run_bench():
         if transport_note and rank == 0:
             sys.stderr.write("bench: %s\n" % transport_note)
 
-    size = tuple(args.size)
-    cutoff_dist = 2.0
     dev = torch.device("cuda", local_rank)
     W, K = args.warmup, args.steps
-    main_res = run_workload(torch, gie, scenes, tiling, dist, args.workload, size, args.voxel, cutoff_dist, W, K, rank, world, dev,
-                            local_rank, backend, min_timed_s=args.min_timed_s, rms=args.rms, group=group, transport_note=transport_note)
+
+    def run(wl, **kw):
+        p = PRESETS[wl]
+        size = tuple(args.size) if (args.size and wl == args.workload) else p["size"]
+        voxel = args.voxel if (args.voxel and wl == args.workload) else p["voxel"]
+        cutoff = args.cutoff if (args.cutoff and wl == args.workload) else p["cutoff"]
+        return run_workload(torch, gie, scenes, tiling, kw.pop("dist", None), wl, size, voxel, cutoff, kw.pop("W", W), kw.pop("K", K), kw.pop("rank", 0),
+                            kw.pop("world", 1), dev, local_rank, backend, fast_mode=p["fast"], **kw), (size, voxel, cutoff)
+
+    main_res, (size, voxel, cutoff) = run(args.workload, dist=dist, rank=rank, world=world, min_timed_s=args.min_timed_s, rms=args.rms, group=group,
+                                          transport_note=transport_note)
     if rank == 0:
-        line = {"metric": "edt_map_update_throughput", "value": main_res["value"], "unit": "Mvoxels/s", "n_gpus": world, "steps": K, "warmup": W,
-                "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
-                "data": "synthetic"}
-        line.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
-        line["timing_note"] = ("value / ms_per_step: median of the timed regions, each EXACTLY K steps between barrier + synchronize, MAX over ranks; "
-                               "kernels_ms_per_step and the roofline objects: the first region replayed on a fresh mapper with start / stop events "
-                               "on every kernel's dispatch (costs ms_per_step_instrumented - ms_per_step)")
-        line["error_bar"] = ("the duration of the Mark + commit sweep depends on where the mapper's planes lie in physical memory (two write streams "
-                             "that overlap or take turns): 0.80 or 0.89 ms for the same kernel.  Since round 4 gie_create re-draws the four planes "
-                             "against a probe of the sweep's memory pattern (GIE_PLACE_TRIES, DESIGN.md 4): mapper to mapper within +- 0.02 ms on one box.  "
-                             "From BOX to box the whole update ranges 2.34 ... 2.45 ms (nine fresh boxes at the end of round 4: six at 2.34 - 2.38, three at "
-                             "2.44 - 2.45 whose probe is slower for every placement drawn, 0.59 against 0.51 - 0.52 ms; Mark + commit 0.76 against 0.84 ms)")
+        extras = {}
         if world == 1 and not args.no_extras:
-            extras = {}
-            for wl in ("vlp16_projective", "vlp16"):
-                if wl == args.workload:
-                    continue
-                e = run_workload(torch, gie, scenes, tiling, None, wl, size, args.voxel, cutoff_dist, W, K, 0, 1, dev, local_rank, backend,
-                                 min_timed_s=0.1, max_regions=4)
-                extras[wl] = {k: e[k] for k in ("value", "ms_per_step", "hz", "timed_regions", "step_ms", "config", "kernels_ms_per_step", "roofline",
-                                                "roofline_wavefront_sweep", "roofline_update", "roofline_sweeps")}
-            line["extra_runs"] = extras
-            # the two OGM paths north_star names, as top-level keys (the headline's own scan is a label copy: SURVEY 8(d) defines C5 so)
-            line["ms_per_step_by_workload"] = {args.workload: main_res["ms_per_step"], **{wl: e["ms_per_step"] for wl, e in extras.items()}}
-            ogm = {}
-            for wl, kern in (("vlp16_projective", "ogm_classify"), ("vlp16", "ray_free"), ("vlp16", "ray_register")):
-                r = extras.get(wl, {}).get("roofline_sweeps", {}).get(kern)
-                if r:
-                    ogm["%s:%s" % (wl, kern)] = {k: r.get(k) for k in ("avg_launch_ms", "achieved", "frac", "frac_basis", "traffic", "frac_algorithmic")}
-            line["roofline_ogm"] = ogm
+            names = [w for w in (args.extras.split(",") if args.extras else DEFAULT_EXTRAS) if w and w != args.workload]
+            for wl in names:
+                # short runs: W / K bounded (the synthetic scans of a workload are generated once, outside every timed region)
+                e, _ = run(wl, W=min(W, 3), K=min(K, 10), min_timed_s=0.1, max_regions=3, with_latency=False)
+                extras[wl] = e
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scenes, torch, dev, args.voxel, size, cutoff_dist, args.workload, W)
-            line["config"]["cpu_baseline_stage"] = line["cpu_baseline"]["stage"] + " (the whole map update on one core: cpu_baseline.full_update_1core)"
-        print(json.dumps(line))
+            cpu = cpu_baseline(scenes, torch, dev, voxel, size, cutoff, args.workload, W)
+        line, full = build_line(main_res, extras, cpu, world)
+        write_full(full)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()                                    # rank 0's instrumented pass is over
         dist.destroy_process_group()

@@ -54,6 +54,8 @@ struct gie_mapper {
     int32_t h_cnt[GIE_CNT_NUM];
     int32_t next_off[3], next_whole[3];
     float us[4];
+    int flushed_ct;                       /* map tick (c.map_ct) of the pose the owed pairs were last written for ahead of gie_fuse (gie_owed_pairs_before_import) */
+    long long *d_round_stats;             /* exchange rounds without the host: rounds enqueued / run, updates / updates left unconverged (k_round_note) */
 };
 
 template <class T> static T *gie_dalloc(gie_mapper *m, size_t n, bool zero = true)
@@ -157,7 +159,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
@@ -257,6 +259,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.lvl_vis = c.lvl_next + GIE_MAX_LEVELS;
     c.lvlb_next = c.lvl_next + 2 * GIE_MAX_LEVELS; c.lvlb_vis = c.lvl_next + 3 * GIE_MAX_LEVELS;
     c.lvla_next = c.lvl_next + 4 * GIE_MAX_LEVELS; c.lvla_vis = c.lvl_next + 5 * GIE_MAX_LEVELS;
+    m->d_round_stats = gie_dalloc<long long>(m, 4);
+    c.gate = nullptr;
     bool ok = c.cnt != nullptr;
     for (void *p : m->allocs) ok = ok && p != nullptr;
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
@@ -492,6 +496,45 @@ extern "C" int gie_set_ext_boxes(gie_mapper *m, const float *ll, const float *ur
     return GIE_OK;
 }
 
+/* The block table of the current pose is built from the one before: that one answers for the blocks it knew (k_cell_alloc), the
+ * two tables alternate.  Called right before an allocation pass over all cells (be_block_alloc). */
+static void gie_table_roll(gie_mapper *m)
+{
+    gie_ctx &c = m->c;
+    static const int no_prev = getenv("GIE_NO_TAB_PREV") ? atoi(getenv("GIE_NO_TAB_PREV")) : 0;      /* (debugging: every block through the hash) */
+    if (m->tab_valid && !no_prev) {
+        c.tab_prev = c.blk_tab;
+        for (int i = 0; i < 3; i++) c.tab_prev_d[i] = c.tb0[i] - m->tab_tb0[i];
+        int32_t *t = c.blk_tab; c.blk_tab = m->blk_tab2; m->blk_tab2 = t;
+    } else c.tab_prev = nullptr;
+    for (int i = 0; i < 3; i++) m->tab_tb0[i] = c.tb0[i];
+    m->tab_valid = 1;
+}
+
+/* the stored pairs the last (fused) merge left out, for the voxels of ITS volume that the volume of the current pose no longer
+ * holds (gie_pair_flush_voxel): the functor + how many voxels it covers.  rehash: types and block table on the device are no longer
+ * that merge's — blocks are found through the hash and a record that has been flushed before (no mark) is left alone. */
+static int gie_flush_op(gie_mapper *m, op_pair_flush *out, int rehash)
+{
+    const gie_ctx &c = m->c;
+    op_pair_flush op;
+    op.b.rehash = rehash;
+    const int sz[3] = { c.X, c.Y, c.Z };
+    int w[3];
+    for (int i = 0; i < 3; i++) {
+        op.b.opvt[i] = m->commit_pvt[i]; op.b.oupvt[i] = m->commit_upvt[i]; op.b.otb0[i] = m->commit_tb0[i];
+        const long long s = (long long)m->commit_pvt[i] - c.pvt[i];          /* old local + s = new local */
+        long long lo = -s > 0 ? -s : 0, hi = sz[i] - s < sz[i] ? sz[i] - s : sz[i];
+        if (hi < lo) hi = lo;
+        if (lo > sz[i]) { lo = sz[i]; hi = sz[i]; }
+        op.b.lo[i] = (int)lo; op.b.hi[i] = (int)hi; w[i] = (int)(hi - lo);
+    }
+    if (w[0] == 0 || w[1] == 0 || w[2] == 0) { for (int i = 0; i < 3; i++) { op.b.lo[i] = op.b.hi[i] = 0; w[i] = 0; } }   /* nothing stays */
+    op.b.n0 = (c.X - w[0]) * c.Y * c.Z; op.b.n1 = w[0] * (c.Y - w[1]) * c.Z; op.b.n2 = w[0] * w[1] * (c.Z - w[2]);
+    *out = op;
+    return op.b.n0 + op.b.n1 + op.b.n2;
+}
+
 /* ---- stages */
 extern "C" int gie_fuse(gie_mapper *m)
 {
@@ -518,20 +561,7 @@ extern "C" int gie_fuse(gie_mapper *m)
          * lost its mark and is left alone. */
         const gie_ctx &c = m->c;
         op_pair_flush op;
-        op.b.rehash = unmerged;
-        const int sz[3] = { c.X, c.Y, c.Z };
-        int w[3];
-        for (int i = 0; i < 3; i++) {
-            op.b.opvt[i] = m->commit_pvt[i]; op.b.oupvt[i] = m->commit_upvt[i]; op.b.otb0[i] = m->commit_tb0[i];
-            const long long s = (long long)m->commit_pvt[i] - c.pvt[i];          /* old local + s = new local */
-            long long lo = -s > 0 ? -s : 0, hi = sz[i] - s < sz[i] ? sz[i] - s : sz[i];
-            if (hi < lo) hi = lo;
-            if (lo > sz[i]) { lo = sz[i]; hi = sz[i]; }
-            op.b.lo[i] = (int)lo; op.b.hi[i] = (int)hi; w[i] = (int)(hi - lo);
-        }
-        if (w[0] == 0 || w[1] == 0 || w[2] == 0) { for (int i = 0; i < 3; i++) { op.b.lo[i] = op.b.hi[i] = 0; w[i] = 0; } }   /* nothing stays */
-        op.b.n0 = (c.X - w[0]) * c.Y * c.Z; op.b.n1 = w[0] * (c.Y - w[1]) * c.Z; op.b.n2 = w[0] * w[1] * (c.Z - w[2]);
-        nflush = op.b.n0 + op.b.n1 + op.b.n2;
+        nflush = gie_flush_op(m, &op, unmerged);
         flush_op = op;
         if (m->c.retain > 0) { be_lin(&m->be, c, op, nflush); nflush = 0; }      /* before blocks are erased; otherwise it shares the frame clear's launch below */
     }
@@ -595,17 +625,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     /* + the tiles fuse has to look at (an existing block overlaps them, or they still hold types from
      * earlier frames), listed in the block-initialisation launch; fuse, Mark, commit and pass Z walk their list or
      * sweep the volume — each kernel decides from the length of its list (gie_use_lists) */
-    {   /* the table of the fuse before answers for the blocks it knew (k_cell_alloc); the two tables alternate */
-        gie_ctx &c = m->c;
-        static const int no_prev = getenv("GIE_NO_TAB_PREV") ? atoi(getenv("GIE_NO_TAB_PREV")) : 0;      /* (debugging: every block through the hash) */
-        if (m->tab_valid && !no_prev) {
-            c.tab_prev = c.blk_tab;
-            for (int i = 0; i < 3; i++) c.tab_prev_d[i] = c.tb0[i] - m->tab_tb0[i];
-            int32_t *t = c.blk_tab; c.blk_tab = m->blk_tab2; m->blk_tab2 = t;
-        } else c.tab_prev = nullptr;
-        for (int i = 0; i < 3; i++) m->tab_tb0[i] = c.tb0[i];
-        m->tab_valid = 1;
-    }
+    gie_table_roll(m);
     be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 0, (int)((size_t)m->c.tfd[0] * m->c.tfd[1] * m->c.tfd[2]));
     m->c.tab_prev = m->c.blk_tab; m->c.tab_prev_d[0] = m->c.tab_prev_d[1] = m->c.tab_prev_d[2] = 0;     /* (a second allocation pass of this update — ghost layers — looks into this table first) */
     be_prof(&m->be, GIE_K_ALLOC, 1);
@@ -934,6 +954,41 @@ extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])
 }
 
 /* ---- tiling: halo exchange + refinement (include/gie.h) */
+/* The halo entry points read and write the global map through the frame's block table (gie_gvox_tab) and the ABI only asks them
+ * for a pose — so they may run between gie_set_pose and that pose's gie_fuse, when the table on the device is still the previous
+ * pose's (the ghost-block pass then left a table the next gie_fuse misread; and an export read the cells of the new
+ * origin out of the old table).  Before any of them touches the map:
+ *  - the stored pairs the last fused merge still owes to the voxels that have left its volume are written (as gie_fuse would):
+ *    ghosts land just outside the NEW volume, on exactly those voxels, and a flush after the import would overwrite them;
+ *    gie_fuse's own flush then goes by the marks (rehash form);
+ *  - the block table is rebuilt at this pose's origin (the allocation pass of gie_fuse, nothing flagged but what a scan of this
+ *    pose has observed so far). */
+static void gie_owed_pairs_before_import(gie_mapper *m)
+{
+    gie_ctx &c = m->c;
+    if (!m->deferred || m->flushed_ct == c.map_ct) return;
+    if (m->commit_pvt[0] == c.pvt[0] && m->commit_pvt[1] == c.pvt[1] && m->commit_pvt[2] == c.pvt[2]) return;
+    op_pair_flush op;
+    const int n = gie_flush_op(m, &op, m->flush_tab_ok ? 0 : 1);
+    be_lin(&m->be, c, op, n);
+    m->flushed_ct = c.map_ct;
+    m->flush_tab_ok = 0;
+}
+static int gie_table_is_this_poses(const gie_mapper *m)
+{ return m->tab_valid && m->tab_tb0[0] == m->c.tb0[0] && m->tab_tb0[1] == m->c.tb0[1] && m->tab_tb0[2] == m->c.tb0[2]; }
+/* ghost voxels need their blocks: the allocation pass of gie_fuse again, over every cell of the block table */
+static void gie_ghost_block_alloc(gie_mapper *m)
+{
+    gie_ctx &c = m->c;
+    gie_owed_pairs_before_import(m);
+    if (!gie_table_is_this_poses(m)) { gie_table_roll(m); m->flush_tab_ok = 0; }      /* (the table of the last fused merge is the OTHER one now) */
+    be_block_alloc(&m->be, c, m->ncell, m->d_rank, 1);
+    c.tab_prev = c.blk_tab; c.tab_prev_d[0] = c.tab_prev_d[1] = c.tab_prev_d[2] = 0;
+}
+static void gie_table_for_pose(gie_mapper *m)
+{
+    if (!gie_table_is_this_poses(m)) gie_ghost_block_alloc(m);
+}
 extern "C" int gie_set_tile(gie_mapper *m, const int32_t off[3], const int32_t whole[3])
 {
     if (!m || !off || !whole) { gie_set_err("gie_set_tile: bad arguments"); return GIE_ERR_INVALID; }
@@ -952,6 +1007,7 @@ extern "C" int gie_halo_export_dev(gie_mapper *m, int face, gie_halo_voxel *d_ou
 {
     int rc = gie_need_pose(m, "gie_halo_export"); if (rc) return rc;
     if (face < 0 || face > 5 || !d_out) { gie_set_err("gie_halo_export: bad arguments"); return GIE_ERR_INVALID; }
+    gie_table_for_pose(m);
     op_halo_export op; op.face = face; op.out = d_out;
     be_lin(&m->be, m->c, op, gie_face_count(m->c, face));
     return GIE_OK;
@@ -975,7 +1031,7 @@ extern "C" int gie_halo_import_dev(gie_mapper *m, int face, const gie_halo_voxel
     /* ghost voxels need their blocks: same allocation path as gie_fuse */
     op_halo_need nd; nd.face = face; nd.in = d;
     be_lin(&m->be, m->c, nd, n);
-    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 1);
+    gie_ghost_block_alloc(m);
     op_halo_import im; im.face = face; im.in = d;
     be_lin(&m->be, m->c, im, n);
     return GIE_OK;
@@ -997,6 +1053,7 @@ extern "C" int gie_halo_export_sparse_dev(gie_mapper *m, int face, gie_halo_entr
 {
     int rc = gie_need_pose(m, "gie_halo_export_sparse"); if (rc) return rc;
     if (face < 0 || face > 5 || !d_out || !d_count) { gie_set_err("gie_halo_export_sparse: bad arguments"); return GIE_ERR_INVALID; }
+    gie_table_for_pose(m);
     be_memset(&m->be, d_count, 0, sizeof(int32_t));
     op_halo_export_sparse op; op.face = face; op.out = d_out; op.count = d_count;
     be_lin(&m->be, m->c, op, gie_face_count(m->c, face));
@@ -1009,7 +1066,7 @@ extern "C" int gie_halo_import_sparse_dev(gie_mapper *m, int face, const gie_hal
     const int n = gie_face_count(m->c, face);
     op_halo_need_sparse nd; nd.face = face; nd.nface = n; nd.in = d_in; nd.count = d_count;
     be_lin(&m->be, m->c, nd, n);
-    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 1);
+    gie_ghost_block_alloc(m);
     op_halo_import_sparse im; im.face = face; im.nface = n; im.in = d_in; im.count = d_count;
     be_lin(&m->be, m->c, im, n);
     return GIE_OK;
@@ -1056,6 +1113,7 @@ extern "C" int gie_halo_export_all_dev(gie_mapper *m, gie_halo_voxel *const d_ou
 {
     int rc = gie_need_pose(m, "gie_halo_export_all"); if (rc) return rc;
     if (!d_out) { gie_set_err("gie_halo_export_all: bad arguments"); return GIE_ERR_INVALID; }
+    gie_table_for_pose(m);
     op_halo_export_all op;
     const int n = gie_face_set_of(m->c, (const void *const *)d_out, &op.fs);
     for (int f = 0; f < 6; f++) op.out[f] = d_out[f];
@@ -1072,20 +1130,21 @@ extern "C" int gie_halo_import_all_dev(gie_mapper *m, const gie_halo_voxel *cons
     for (int f = 0; f < 6; f++) { nd.in[f] = d_in[f]; im.in[f] = d_in[f]; }
     if (n == 0) return GIE_OK;
     be_lin(&m->be, m->c, nd, n);
-    be_block_alloc(&m->be, m->c, m->ncell, m->d_rank, 1);
+    gie_ghost_block_alloc(m);
     be_lin(&m->be, m->c, im, n);
     return GIE_OK;
 }
 extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
 {
     int rc = gie_need_pose(m, "gie_refine"); if (rc) return rc;
+    gie_table_for_pose(m);
     gie_ctx &c = m->c;
     {   /* what the second waves launch of this map update needs zeroed, in one launch */
         gie_clear_list l; l.n = 0;
         l.p[l.n] = c.cnt + GIE_CNT_C; l.bytes[l.n++] = sizeof(int32_t);
         l.p[l.n] = c.cnt + GIE_CNT_BAR_C; l.bytes[l.n++] = sizeof(int32_t);
         l.p[l.n] = c.lvl_next; l.bytes[l.n++] = 2 * GIE_MAX_LEVELS * sizeof(int32_t);
-        be_clear(&m->be, l);
+        be_clear(&m->be, l, c.gate);
     }
     const int nb = 2 * (c.X * c.Y + c.Y * c.Z + c.X * c.Z);
     be_lin(&m->be, c, op_refine(), nb);
@@ -1096,6 +1155,35 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     rc = gie_sync(m);
     *seeded = m->h_cnt[GIE_CNT_FRONT_C];
     return rc;
+}
+/* exchange rounds until no tile changed, without the host (include/gie.h) */
+extern "C" int gie_round_gate(gie_mapper *m, const int32_t *d_go)
+{
+    if (!m) { gie_set_err("gie_round_gate: null handle"); return GIE_ERR_INVALID; }
+    m->c.gate = d_go;
+    return GIE_OK;
+}
+extern "C" int gie_refine_dev(gie_mapper *m, int32_t *d_changed)
+{
+    if (!d_changed) { gie_set_err("gie_refine_dev: bad arguments"); return GIE_ERR_INVALID; }
+    int rc = gie_refine(m, nullptr); if (rc) return rc;
+    be_round_note(&m->be, m->c, d_changed, m->d_round_stats, nullptr, 0);
+    return GIE_OK;
+}
+extern "C" int gie_round_end(gie_mapper *m, const int32_t *d_go)
+{
+    if (!m) { gie_set_err("gie_round_end: null handle"); return GIE_ERR_INVALID; }
+    m->c.gate = nullptr;
+    be_round_note(&m->be, m->c, nullptr, m->d_round_stats, d_go, 1);
+    return GIE_OK;
+}
+extern "C" int gie_round_stats(gie_mapper *m, int64_t out[4])
+{
+    if (!m || !out) { gie_set_err("gie_round_stats: bad arguments"); return GIE_ERR_INVALID; }
+    long long v[4] = { 0, 0, 0, 0 };
+    be_d2h(&m->be, v, m->d_round_stats, sizeof(v));
+    for (int i = 0; i < 4; i++) out[i] = (int64_t)v[i];
+    return gie_sync(m);
 }
 extern "C" int gie_get_stream(gie_mapper *m, void **stream)
 {

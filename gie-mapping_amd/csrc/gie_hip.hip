@@ -254,9 +254,13 @@ static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels)
         GIE_LAUNCH(b, k_labels16, dim3((nvec + 255) / 256), dim3(256), 0, c, labels, nvec);
     } else { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
 }
-static void be_clear(be_state *b, const gie_clear_list &l)
+static void be_clear(be_state *b, const gie_clear_list &l, const int32_t *gate = nullptr)
 {
-    if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(32, l.n), dim3(256), 0, l);
+    if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(32, l.n), dim3(256), 0, l, gate);
+}
+static void be_round_note(be_state *b, const gie_ctx &c, int32_t *changed, long long *stats, const int32_t *go, int end)
+{
+    GIE_LAUNCH(b, k_round_note, dim3(1), dim3(64), 0, c, changed, stats, go, end);
 }
 /* allocHashTB + block table (see k_cell_alloc) */
 /* fuse_list_ntile > 0: the fuse tile list (op_fuse_list over that many tiles) is built in the block-initialisation launch */

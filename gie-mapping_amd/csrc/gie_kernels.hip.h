@@ -67,6 +67,7 @@ __global__ __launch_bounds__(GIE_VOX_BX *GIE_VOX_BY) void k_voxz(const gie_ctx c
 template <class F>
 __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const int n)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) f(c, i);
 }
@@ -315,8 +316,9 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
 
 /* ------------------------------------------------------------------ frame clear */
 /* every small array that has to be zero when a map update starts, in one launch (blockIdx.y = region) */
-__global__ __launch_bounds__(256) void k_clear(const gie_clear_list l)
+__global__ __launch_bounds__(256) void k_clear(const gie_clear_list l, const int32_t *gate)
 {
+    if (gate != nullptr && *(const volatile int32_t *)gate == 0) return;
     const int r = blockIdx.y;
     if (r >= l.n) return;
     unsigned char *p = (unsigned char *)l.p[r];
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(256) void k_flush_clear(const gie_ctx c, const op_p
  * of other keys cannot break a probe sequence). */
 __global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int ncell)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     int found = -1;
     bool isnew = false;
@@ -407,6 +410,7 @@ __global__ __launch_bounds__(256) void k_cell_alloc(const gie_ctx c, const int n
  * k_cell_alloc has left and touch different data, so they share a launch. */
 __global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c, const int ninit, const int ntile)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     if ((int)blockIdx.x >= ninit) {
         const op_fuse_list f;
         const int nfl = (int)gridDim.x - ninit;
@@ -1309,6 +1313,7 @@ __device__ __forceinline__ void gie_vox_column(const gie_ctx &c, const F &f, con
 template <class F, bool STAGED, int LX>
 __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const int32_t *list, const int count_idx, const int always_list)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     const int n = c.cnt[count_idx];
     const int lane = threadIdx.x & 63;
     if (always_list == 2 && !gie_use_lists(c, n)) return;        /* the dense form is another kernel's (k_fuse_rows) */
@@ -3072,6 +3077,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     gie_wc_tile *const s_tiles = reinterpret_cast<gie_wc_tile *>(s_lds);      /* wave C: one 8x8x8 tile (+ halo) per wave */
     gie_wb_tile *const s_blocks = reinterpret_cast<gie_wb_tile *>(s_lds);     /* wave B: one 8x8x8 block of the global map (+ halo) per wave */
     __shared__ int s_fail, s_vis;
+    if (GIE_GATE_CLOSED(c)) return;              /* a refinement round nobody needs (gie_round_gate): same answer in every workgroup, before any barrier */
     if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
     /* (c.bar_fault: the timeout path on purpose — a barrier that waits for one workgroup more than there are, with a short limit) */
     gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x + (c.bar_fault ? 1 : 0), &s_fail, &s_vis, c.bar_fault ? (1 << 10) : GIE_BAR_SPIN_LIMIT };
@@ -3103,6 +3109,25 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
     gie_wave_c_run(c, gb, record_seeds, s_tiles);
     GIE_TS2(10, 0);
     GIE_WPROF_DUMP();
+}
+
+/* ------------------------------------------------------------------ exchange rounds without the host (gie_refine_dev / gie_round_end)
+ * One thread.  end == 0, after a refinement round: *changed = the voxels the round seeded from its ghosts (0 when the gate kept
+ * the round from running), stats[0] += 1 (rounds enqueued), stats[1] += 1 if it ran.  end == 1, after the last round of a map
+ * update: stats[2] += 1 (updates), stats[3] += 1 if `go` (the all-reduced "some tile changed" word of the last round) is still set —
+ * the bound on the rounds was too small for this update. */
+__global__ void k_round_note(const gie_ctx c, int32_t *changed, long long *stats, const int32_t *go, const int end)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!end) {
+        const bool open = !GIE_GATE_CLOSED(c);
+        if (changed) *changed = open ? c.cnt[GIE_CNT_FRONT_C] : 0;
+        stats[0] += 1;
+        if (open) stats[1] += 1;
+    } else {
+        stats[2] += 1;
+        if (go != nullptr && *(const volatile int32_t *)go != 0) stats[3] += 1;
+    }
 }
 
 #endif /* GIE_KERNELS_HIP_H */

@@ -168,7 +168,11 @@ typedef struct gie_ctx {
     int32_t *lvl_next, *lvl_vis; /* wave C: active tiles / visits per round (GIE_MAX_LEVELS words each) */
     int32_t *wc_list[2];         /* wave C: the active tiles of a round (parity of the round) */
     int32_t *wc_flag[2];         /*         ... and their membership flags, one word per tile */
+    const int32_t *gate;         /* gie_round_gate: null, or a device word — the kernels of a halo exchange round (export, ghost blocks, import,
+                                  * refinement) return at once while it holds 0 ("no tile changed in the round before") */
 } gie_ctx;
+/* a gated launch that has nothing to do (every kernel of an exchange round asks first; uniform over the grid) */
+#define GIE_GATE_CLOSED(c) ((c).gate != nullptr && *(const volatile int32_t *)(c).gate == 0)
 
 enum {
     GIE_CNT_A = 0, GIE_CNT_B, GIE_CNT_C,        /* seed counts from obtainFrontiers */

@@ -111,6 +111,16 @@ class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 24), ("total_ms", C.c_float), ("launches", C.c_int32)]
 
 
+# exchange rounds gated on the device: the device library and the test-only emulation of its logic (not the oracle, which has no device)
+ROUND_API = {
+    "round_gate": (C.c_int, [_H, C.c_void_p]),
+    "refine_dev": (C.c_int, [_H, C.c_void_p]),
+    "round_end": (C.c_int, [_H, C.c_void_p]),
+    "round_stats": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "halo_export_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "halo_import_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+}
+
 # entry points only the device library has
 DEVICE_ONLY = {
     "profile_enable": (C.c_int, [_H, C.c_int]),
@@ -120,8 +130,6 @@ DEVICE_ONLY = {
     "get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "ogm_pointcloud_dev": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "halo_export_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
-    "halo_export_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
-    "halo_import_all_dev": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "halo_import_dev": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "halo_export_sparse": (C.c_int, [_H, C.c_int, C.c_void_p, c_i32p]),
     "halo_import_sparse": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int32]),
@@ -131,6 +139,7 @@ DEVICE_ONLY = {
     "ogm_depth_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(CamParam)]),
     "ogm_labels_dev": (C.c_int, [_H, C.c_void_p]),
 }
+DEVICE_ONLY.update(ROUND_API)
 
 
 def bind(lib, prefix, extra=None):

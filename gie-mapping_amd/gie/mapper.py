@@ -208,6 +208,9 @@ class MapperBase:
         w = (C.c_int32 * 3)(*[int(v) for v in whole])
         self._chk(self._f["set_tile"](self._h, o, w))
 
+    def halo_count(self, face):
+        return self._f["halo_count"](self._h, face)
+
     def halo_export(self, face):
         n = self._f["halo_count"](self._h, face)
         out = np.empty(n, HALO_DTYPE)
@@ -235,6 +238,34 @@ class MapperBase:
         n = C.c_int32(0)
         self._chk(self._f["refine"](self._h, C.byref(n)))
         return n.value
+
+    def refine_async(self):
+        self._chk(self._f["refine"](self._h, None))
+
+    def halo_export_all_dev(self, dptrs):
+        """dptrs: {face: device pointer}; all faces in one launch."""
+        arr = (C.c_void_p * 6)(*[dptrs.get(f) for f in range(6)])
+        self._chk(self._f["halo_export_all_dev"](self._h, arr))
+
+    def halo_import_all_dev(self, dptrs):
+        arr = (C.c_void_p * 6)(*[dptrs.get(f) for f in range(6)])
+        self._chk(self._f["halo_import_all_dev"](self._h, arr))
+
+    # exchange rounds gated on the device (include/gie.h gie_round_gate ...): pointers are raw device addresses
+    def round_gate(self, d_go):
+        self._chk(self._f["round_gate"](self._h, C.c_void_p(d_go) if d_go else None))
+
+    def refine_dev(self, d_changed):
+        self._chk(self._f["refine_dev"](self._h, C.c_void_p(d_changed)))
+
+    def round_end(self, d_go):
+        self._chk(self._f["round_end"](self._h, C.c_void_p(d_go) if d_go else None))
+
+    def round_stats(self):
+        """{rounds_enqueued, rounds_run, updates, updates_unconverged} since the mapper was created (synchronises)."""
+        v = (C.c_int64 * 4)()
+        self._chk(self._f["round_stats"](self._h, v))
+        return {"rounds_enqueued": int(v[0]), "rounds_run": int(v[1]), "updates": int(v[2]), "updates_unconverged": int(v[3])}
 
     # --- changed-block streaming (GlbHashMap::streamPipeline, glb_hash_map.cu:209-247) --------
     def stream_enable(self, on=True):
@@ -324,26 +355,11 @@ class Mapper(MapperBase):
             raise RuntimeError(self._err())
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}
 
-    def halo_export_all_dev(self, dptrs):
-        """dptrs: {face: device pointer}; all faces in one launch."""
-        arr = (C.c_void_p * 6)(*[dptrs.get(f) for f in range(6)])
-        self._chk(self._f["halo_export_all_dev"](self._h, arr))
-
-    def halo_import_all_dev(self, dptrs):
-        arr = (C.c_void_p * 6)(*[dptrs.get(f) for f in range(6)])
-        self._chk(self._f["halo_import_all_dev"](self._h, arr))
-
     def stream_handle(self):
         """The mapper's HIP stream as an integer (for torch.cuda.ExternalStream)."""
         p = C.c_void_p()
         self._chk(self._f["get_stream"](self._h, C.byref(p)))
         return p.value or 0
-
-    def refine_async(self):
-        self._chk(self._f["refine"](self._h, None))
-
-    def halo_count(self, face):
-        return self._f["halo_count"](self._h, face)
 
     def halo_export_sparse_dev(self, face, dptr, dcount):
         self._chk(self._f["halo_export_sparse_dev"](self._h, face, C.c_void_p(dptr), C.c_void_p(dcount)))

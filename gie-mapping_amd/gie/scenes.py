@@ -40,12 +40,16 @@ class BoxWorld:
         on[t] = ((frame + self.phase[t]) % 2) == 0
         return on
 
-    def cast(self, origin, dirs, frame, chunk=65536):
-        """Nearest hit parameter t >= 0 along origin + t*dirs (dirs: [R,3]); inf when none."""
+    def cast(self, origin, dirs, frame, chunk=65536, device=None):
+        """Nearest hit parameter t >= 0 along origin + t*dirs (dirs: [R,3]); inf when none.
+        device: a torch device to run the slab test on (bench.py: the GPU; same float64 operations in the same order,
+        so the result is the numpy one) -- None = numpy."""
         on = self.active(frame)
         lo = self.lo[on]
         hi = self.hi[on]
         o = np.asarray(origin, dtype=np.float64)
+        if device is not None:
+            return self._cast_torch(o, lo, hi, dirs, chunk, device)
         out = np.full(dirs.shape[0], np.inf)
         for s in range(0, dirs.shape[0], chunk):
             d = dirs[s:s + chunk].astype(np.float64)
@@ -67,6 +71,37 @@ class BoxWorld:
             out[s:s + chunk] = tn.min(axis=1)
         return out
 
+    @staticmethod
+    def _cast_torch(o, lo, hi, dirs, chunk, device):
+        """cast() with torch tensors on `device`: the numpy statement above, operation for operation, in float64."""
+        import torch
+        f8 = torch.float64
+        lo_t = torch.from_numpy(np.ascontiguousarray(lo)).to(device)[None, :, :]
+        hi_t = torch.from_numpy(np.ascontiguousarray(hi)).to(device)[None, :, :]
+        o_t = torch.from_numpy(o).to(device)[None, None, :]
+        d_all = torch.from_numpy(np.ascontiguousarray(dirs, dtype=np.float64)).to(device)
+        pinf = torch.tensor(float("inf"), dtype=f8, device=device)
+        ninf = torch.tensor(float("-inf"), dtype=f8, device=device)
+        zero = torch.tensor(0.0, dtype=f8, device=device)
+        inside = (o_t >= lo_t) & (o_t <= hi_t)
+        out = torch.empty(d_all.shape[0], dtype=f8, device=device)
+        for s in range(0, d_all.shape[0], chunk):
+            d = d_all[s:s + chunk]
+            inv = (1.0 / d)[:, None, :]
+            t0 = (lo_t - o_t) * inv
+            t1 = (hi_t - o_t) * inv
+            tmin = torch.minimum(t0, t1)
+            tmax = torch.maximum(t0, t1)
+            par = (d == 0.0)[:, None, :]
+            tmin = torch.where(par, torch.where(inside, ninf, pinf), tmin)
+            tmax = torch.where(par, torch.where(inside, pinf, ninf), tmax)
+            tn = tmin.amax(dim=2)
+            tf = tmax.amin(dim=2)
+            hit = (tf >= tn) & (tf >= 0.0)
+            tn = torch.where(hit, torch.maximum(tn, zero), pinf)
+            out[s:s + chunk] = tn.amin(dim=1)
+        return out.cpu().numpy()
+
 
 def yaw_quat(yaw):
     return (math.cos(0.5 * yaw), 0.0, 0.0, math.sin(0.5 * yaw))
@@ -87,12 +122,12 @@ def pose(frame, voxel_width, delta_vox=4, yaw_deg=2.0, z=0.0):
 
 
 def depth_frame(world, frame, pos, quat, rows=480, cols=640, fx=525.0, fy=525.0, cx=319.5, cy=239.5,
-                max_depth=8.0):
+                max_depth=8.0, device=None):
     """Pinhole depth image (float32 [rows, cols]); NaN where nothing is hit within max_depth."""
     u, v = np.meshgrid(np.arange(cols, dtype=np.float64), np.arange(rows, dtype=np.float64))
     d_s = np.stack([np.ones_like(u), (cx - u) / fx, (cy - v) / fy], axis=-1).reshape(-1, 3)
     d_w = d_s @ rot_from_quat(quat).T
-    t = world.cast(pos, d_w, frame)
+    t = world.cast(pos, d_w, frame, device=device)
     depth = np.where(t <= max_depth, t, np.nan).astype(np.float32)
     return depth.reshape(rows, cols)
 
@@ -108,14 +143,14 @@ def depth_to_points(depth, fx=525.0, fy=525.0, cx=319.5, cy=239.5):
     return np.ascontiguousarray(pts, dtype=np.float32)
 
 
-def lidar_frame(world, frame, pos, quat, rings=16, az=1800, phi_min_deg=-15.0, phi_inc_deg=2.0, max_range=100.0):
+def lidar_frame(world, frame, pos, quat, rings=16, az=1800, phi_min_deg=-15.0, phi_inc_deg=2.0, max_range=100.0, device=None):
     """Multi-ring lidar: returns (points_sensor_frame [P,3] float32, hit range per (ring, az))."""
     phi = np.radians(phi_min_deg + phi_inc_deg * np.arange(rings))
     th = -np.pi + 2.0 * np.pi * (np.arange(az) + 0.5) / az
     ph, tt = np.meshgrid(phi, th, indexing="ij")
     d_s = np.stack([np.cos(ph) * np.cos(tt), np.cos(ph) * np.sin(tt), np.sin(ph)], axis=-1).reshape(-1, 3)
     d_w = d_s @ rot_from_quat(quat).T
-    t = world.cast(pos, d_w, frame)
+    t = world.cast(pos, d_w, frame, device=device)
     ok = t <= max_range
     pts = (d_s[ok] * t[ok, None]).astype(np.float32)
     return np.ascontiguousarray(pts), np.where(ok, t, np.inf).reshape(rings, az)

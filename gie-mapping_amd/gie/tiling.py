@@ -253,6 +253,133 @@ def exchange_rounds_device(mapper, dist, rank, world_size, device, bufs, rounds=
     return rounds
 
 
+def exchange_converged_device(mapper, dist, rank, world_size, device, bufs, max_rounds=4, group=None):
+    """rounds "until no GPU changed", ordered ON THE MAPPER'S STREAM with nobody waiting for the host.  Round 0 finishes
+    the merge with this update's ghosts.  Then at most `max_rounds` refinement rounds are enqueued back to back: export, RCCL send /
+    receive of the face layers, import, gie_refine_dev — which leaves the number of voxels it seeded in a device word —, and a 4-byte
+    all-reduce(max) of that word over the ranks on the same stream.  The result gates the NEXT round (gie_round_gate): once no tile
+    changed, every kernel of the remaining rounds returns at once (the transfers still run: a collective cannot be skipped by one
+    side).  gie_round_end counts an update whose last all-reduce was still non-zero as unconverged (Mapper.round_stats()): the
+    bound was too small — tests hold the bench's bound against the tiled oracle.  Works on the CPU too (emulated mappers, gloo):
+    `device` "cpu", the "device words" are then host memory.
+    Returns nothing the host could know without waiting: the rounds that ran are in round_stats()."""
+    import torch
+    cuda = getattr(device, "type", str(device)) == "cuda"
+    if "go" not in bufs:
+        nbs = neighbours(rank, world_size)
+        for face in nbs:
+            n = mapper.halo_count(face) * 20
+            bufs[face] = (torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
+        bufs["stream"] = torch.cuda.ExternalStream(mapper.stream_handle(), device=device) if cuda else None
+        bufs["out"] = {face: bufs[face][0].data_ptr() for face in nbs}
+        bufs["in"] = {face: bufs[face][1].data_ptr() for face in nbs}
+        ops = []
+        for face, nb in sorted(nbs.items()):
+            snd, rcv = bufs[face]
+            ops.append(dist.P2POp(dist.isend, snd, nb, group=group))
+            ops.append(dist.P2POp(dist.irecv, rcv, nb, group=group))
+        bufs["ops"] = ops
+        bufs["changed"] = torch.zeros(1, dtype=torch.int32, device=device)
+        bufs["go"] = torch.ones(1, dtype=torch.int32, device=device)
+    ops, changed, go = bufs["ops"], bufs["changed"], bufs["go"]
+
+    def transfer():
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()                                  # stream-level on RCCL: the current (= the mapper's) stream waits for the transfer
+
+    def rounds():
+        mapper.round_gate(None)
+        mapper.halo_export_all_dev(bufs["out"])
+        transfer()
+        mapper.halo_import_all_dev(bufs["in"])
+        mapper.merge_end()                                # round 0 finishes the merge with this update's ghosts
+        for k in range(1, max_rounds + 1):
+            mapper.round_gate(go.data_ptr() if k > 1 else None)
+            mapper.halo_export_all_dev(bufs["out"])
+            transfer()
+            mapper.halo_import_all_dev(bufs["in"])
+            mapper.refine_dev(changed.data_ptr())
+            go.copy_(changed)
+            dist.all_reduce(go, op=dist.ReduceOp.MAX, group=group)
+        mapper.round_end(go.data_ptr())
+
+    if cuda:
+        with torch.cuda.stream(bufs["stream"]):
+            rounds()
+    else:
+        rounds()
+
+
+def exchange_converged_local_device(mappers, grid, device, max_rounds=4, bufs=None):
+    """exchange_converged_device with all tiles in this process (one GPU, or emulated mappers with device "cpu"): the neighbour's
+    stream waits for an event on the exporter's stream instead of an RCCL transfer, and the all-reduce(max) of the "changed" words
+    is one reduction on a side stream that waits for every mapper's refinement and that every mapper's next round waits for."""
+    import torch
+    cuda = getattr(device, "type", str(device)) == "cuda"
+    world = grid[0] * grid[1] * grid[2]
+    own = bufs is None
+    bufs = {} if bufs is None else bufs
+    lay = _local_face_buffers(mappers, world, device, bufs)
+    if "go" not in bufs:
+        bufs["streams"] = [torch.cuda.ExternalStream(m.stream_handle(), device=device) for m in mappers] if cuda else [None] * world
+        bufs["side"] = torch.cuda.Stream(device=device) if cuda else None
+        bufs["imported"] = []
+        bufs["changed"] = torch.zeros(world, dtype=torch.int32, device=device)
+        bufs["go"] = torch.ones(1, dtype=torch.int32, device=device)
+    streams, side, changed, go = bufs["streams"], bufs["side"], bufs["changed"], bufs["go"]
+    esz = changed.element_size()
+
+    def record(r):
+        if not cuda:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(streams[r])
+        return ev
+
+    def wait(r, evs):
+        if cuda:
+            for ev in evs:
+                streams[r].wait_event(ev)
+
+    go_ready = []
+    for k in range(max_rounds + 1):
+        evs = []
+        for r, m in enumerate(mappers):
+            wait(r, bufs["imported"] + go_ready)          # the layers of the round before have been read; this round's gate is final
+            m.round_gate(go.data_ptr() if k > 1 else None)
+            m.halo_export_all_dev({face: lay[(r, face)].data_ptr() for face in neighbours(r, world)})
+            evs.append(record(r))
+        done, refined = [], []
+        for r, m in enumerate(mappers):
+            wait(r, evs)
+            m.halo_import_all_dev({face: lay[(nb, face ^ 1)].data_ptr() for face, nb in neighbours(r, world).items()})
+            done.append(record(r))
+            if k == 0:
+                m.merge_end()
+            else:
+                m.refine_dev(changed.data_ptr() + r * esz)
+                refined.append(record(r))
+        bufs["imported"] = done
+        if k > 0:                                         # the all-reduce(max): one reduction everybody's next round waits for
+            if cuda:
+                for ev in refined:
+                    side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    torch.amax(changed, dim=0, keepdim=True, out=go)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                go_ready = [ev]
+            else:
+                torch.amax(changed, dim=0, keepdim=True, out=go)
+    for r, m in enumerate(mappers):
+        wait(r, go_ready)
+        m.round_end(go.data_ptr())
+    if own:
+        for m in mappers:
+            m.sync()
+
+
 def exchange_rounds_local_device(mappers, grid, device, rounds=1, bufs=None):
     """The same stream-ordered rounds with all tiles in this process (one GPU): the neighbour's
     stream waits for an event on the exporter's stream instead of an RCCL transfer.  The face layers

@@ -279,6 +279,19 @@ int gie_halo_import_sparse_dev(gie_mapper *h, int face, const gie_halo_entry *d_
 int gie_halo_export_all_dev(gie_mapper *h, gie_halo_voxel *const d_out[6]);
 int gie_halo_import_all_dev(gie_mapper *h, const gie_halo_voxel *const d_in[6]);
 int gie_refine(gie_mapper *h, int32_t *seeded);   /* seeded == NULL: enqueue only (no synchronisation) */
+/* Exchange rounds "until no GPU changed"  WITHOUT the host in the loop.  A caller enqueues a fixed upper bound of
+ * rounds per map update on the mapper's stream — export, transfer, import, gie_refine_dev — and all-reduces (max) the word
+ * gie_refine_dev leaves over the ranks, on the same stream (RCCL), into a device word it hands to gie_round_gate before the
+ * next round: while that word is 0 every kernel of a round (export, ghost-block allocation, import, refinement) returns at once.
+ * gie_refine_dev = gie_refine(h, NULL) + *d_changed = voxels seeded from ghost neighbours by this round (0 when the gate kept
+ * it from running).  gie_round_gate(h, NULL) opens the gate (the first round of an update always runs).  gie_round_end closes a
+ * map update's rounds: opens the gate and counts the update as unconverged when *d_go (the all-reduced word of the LAST round;
+ * NULL = not known) is still non-zero.  gie_round_stats synchronises: out = { rounds enqueued, rounds that ran, map updates,
+ * map updates left unconverged } since gie_create.  No counterpart in the reference (single GPU). */
+int gie_round_gate(gie_mapper *h, const int32_t *d_go);
+int gie_refine_dev(gie_mapper *h, int32_t *d_changed);
+int gie_round_end(gie_mapper *h, const int32_t *d_go);
+int gie_round_stats(gie_mapper *h, int64_t out[4]);
 /* The HIP stream all work of this mapper is enqueued on (a hipStream_t), so that a caller can order
  * its own device work — e.g. the RCCL transfers of the halo layers — with it instead of
  * synchronising the host.  NULL for implementations without streams. */

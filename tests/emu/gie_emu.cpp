@@ -87,6 +87,7 @@ static void be_vox_list_col(const gie_ctx &c, const op_markc &f, int x, int y, i
 
 template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_ctx &c, const F &f, const int32_t *list, int count_idx, int always_list, int = 64)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     const int n = c.cnt[count_idx];
     if (always_list != 1 && !gie_use_lists(c, n)) { be_vox(b, c, f); return; }        /* the same choice the device kernel makes */
     for (int e = 0; e < n; e++) {
@@ -106,15 +107,21 @@ static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox
 static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx, const int32_t *, int)
 { be_list(b, c, op_tile_summary(), known, known_idx); be_vox(b, c, op_frontier()); }
 static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels) { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
-template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
+template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { if (GIE_GATE_CLOSED(c)) return; for (int i = 0; i < n; i++) f(c, i); }
 template <class F> static void be_range(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
-static void be_clear(be_state *, const gie_clear_list &l) { for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
+static void be_clear(be_state *, const gie_clear_list &l, const int32_t *gate = nullptr) { if (gate && *gate == 0) return; for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }
+static void be_round_note(be_state *, const gie_ctx &c, int32_t *changed, long long *stats, const int32_t *go, int end)
+{   /* k_round_note */
+    if (!end) { const bool open = !GIE_GATE_CLOSED(c); if (changed) *changed = open ? c.cnt[GIE_CNT_FRONT_C] : 0; stats[0] += 1; if (open) stats[1] += 1; }
+    else { stats[2] += 1; if (go && *go != 0) stats[3] += 1; }
+}
 static void be_flush_clear(be_state *b, const gie_ctx &c, const op_pair_flush &f, int n, const gie_clear_list &l) { be_lin(b, c, f, n); be_clear(b, l); }
 static void be_exclusive_scan(be_state *, const int32_t *flag, int32_t *rank, int n);
 static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, const int32_t *rank, int ncell);
 /* sequential allocHashTB: flag → rank → insert → initialise → table */
 static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *rank, int, int fuse_list_ntile = 0)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     /* the device's allocation (k_cell_alloc) asks the block table of the fuse before first: whatever that names has to be what the
      * hash finds (gie_cell_prev_slot) */
     for (int cell = 0; cell < ncell; cell++) {
@@ -580,6 +587,7 @@ static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int
 }
 static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seeds, int clear_first)
 {
+    if (GIE_GATE_CLOSED(c)) return;
     const int device_c = g_emu_wave_c_device;
     if (with_ab) { be_wave_a(b, c); be_wave_b(b, c); }
     if (device_c) be_wave_c_device(b, c, record_seeds, clear_first);

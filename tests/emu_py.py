@@ -29,7 +29,7 @@ def load():
                 os.replace(tmp, EMU_SO)
         global _lib
         lib = _lib = C.CDLL(EMU_SO)
-        _fns = _capi.bind(lib, "gie_", {"last_error": (C.c_char_p, []), "sync": (C.c_int, [C.c_void_p]),
+        _fns = _capi.bind(lib, "gie_", {**_capi.ROUND_API, "last_error": (C.c_char_p, []), "sync": (C.c_int, [C.c_void_p]),
                                         "halo_export_sparse": _capi.DEVICE_ONLY["halo_export_sparse"],
                                         "halo_import_sparse": _capi.DEVICE_ONLY["halo_import_sparse"]})
     return _fns

@@ -1,6 +1,7 @@
 """CPU suite: the device-side per-voxel / per-frontier-entry logic (gie_ops.h) and the frame
 orchestration (gie_api.inc.h), run through the test-only sequential emulation, must equal the
 oracle bit for bit on every stage of multi-frame scenarios that exercise waves A, B and C."""
+import numpy as np
 import pytest
 
 import parity
@@ -329,3 +330,47 @@ def test_device_schedule_of_wave_c_needs_the_unfiltered_round_0(oracle_lib):
         parity.run_and_compare(sc, OracleMapper, EmuMapper)
     finally:
         emu_py.wave_c_model(False)
+
+
+@pytest.mark.parametrize("retain", [0, 2])
+def test_halo_import_between_pose_and_fuse_keeps_the_block_table_honest(oracle_lib, retain):
+    """the ABI only asks gie_halo_import* for a pose, so an import may run between gie_set_pose and gie_fuse.  Its
+    ghost-block pass rebuilds the block table at the NEW pose's origin; the next gie_fuse took that table for "the table of the fuse
+    before" at the OLD origin and the shortcut of k_cell_alloc named slots of other blocks (with retain == 0 nothing checked them).
+    The emulation's allocation asserts, for every cell, that what the previous table names is what the hash finds — it aborted on
+    this sequence before the fix.  And the ghosts land on voxels of the previous volume whose stored pairs were still owed (fused
+    Mark + commit): those are flushed first now.  Two adjacent tiles that exchange their x faces right after the pose, then run a
+    plain update; the emulated device logic against the oracle."""
+    import gie
+    from gie import scenes, tiling
+    tile = (32, 24, 16)
+    whole = (64, 24, 16)
+    cfg = gie.make_config(0.05, tile, cutoff_dist=0.5, fast_mode=False, retain_radius_blocks=retain)
+    probes = np.stack(np.meshgrid(np.arange(-40, 110, 3), np.arange(-14, 14, 3), np.arange(-10, 10, 3), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    out = []
+    for make in (OracleMapper, EmuMapper):
+        ms = [make(cfg), make(cfg)]
+        try:
+            offs = [tiling.tile_offset_voxels(r, 2, tile) for r in range(2)]
+            for r, m in enumerate(ms):
+                m.set_tile(offs[r], whole)
+            for k, shift in enumerate((0, 16, 19, 40, 33)):
+                pos = (np.float32(shift * 0.05), np.float32(0.0), np.float32(0.0))
+                for m in ms:
+                    m.set_pose(pos)
+                if k > 0:                                   # the shared face, exchanged BEFORE this pose's fuse (the maps' state of the update before)
+                    a, b = ms[0].halo_export(1), ms[1].halo_export(0)
+                    ms[1].halo_import(0, a)
+                    ms[0].halo_import(1, b)
+                for r, m in enumerate(ms):
+                    m.ogm_labels(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, tile, offs[r]), tile, k, seed=7, p_occ=0.03).astype(np.int8))
+                    m.fuse(); m.batch_edt(); m.merge()
+            out.append([(m.read_local(), m.query_global(probes), m.stats()["blocks_total"]) for m in ms])
+        finally:
+            for m in ms:
+                m.close()
+    for (ra, ga, ba), (rb, gb, bb) in zip(*out):
+        assert ba == bb
+        for key in ("type", "dist_sq", "coc"):
+            assert np.array_equal(ra[key], rb[key]), key
+        assert np.array_equal(ga, gb), int((ga != gb).sum())

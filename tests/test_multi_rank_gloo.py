@@ -126,6 +126,69 @@ def test_two_ranks_halo_exchange_matches_in_process_exchange(oracle_lib, sparse)
             assert np.array_equal(g_coc, reads[t]["coc"])
 
 
+def _worker_gated(rank, world, port, out, max_rounds):
+    """One rank of the exchange `bench.py --gpus N` runs by default (tiling.exchange_converged_device), on the emulated device logic
+    over gloo: the "device words" are host tensors, the all-reduce(max) of the "changed" word is gloo's."""
+    sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import gie
+    from gie import scenes, tiling
+    from emu_py import EmuMapper
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tile = (24, 24, 24)
+    grid = tiling.tile_grid(world)
+    m = EmuMapper(gie.make_config(0.05, tile, cutoff_dist=0.5))
+    off = tiling.tile_offset_voxels(rank, world, tile)
+    m.set_tile(off, tuple(grid[i] * tile[i] for i in range(3)))
+    res, bufs = [], {}
+    for k in range(3):
+        pos, q = scenes.pose(k, 0.05, delta_vox=8, yaw_deg=2.0)
+        m.set_pose(pos, q)
+        m.ogm_labels(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, tile, off), tile, k, seed=5, p_occ=0.01).astype(np.int8))
+        m.step_begin_tiled()
+        tiling.exchange_converged_device(m, dist, rank, world, torch.device("cpu"), bufs, max_rounds=max_rounds)
+        r = m.read_local()
+        res.append((r["type"].copy(), r["dist_sq"].copy(), r["coc"].copy()))
+    st = m.round_stats()
+    m.close()
+    out.put((rank, res, st))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_gated_rounds_match_the_oracle_until_stable(oracle_lib, world):
+    """VERDICT r4 #3 on the CPU: two / four ranks (four: 2x2x1 tiles, information crosses two cuts and needs 2-3 rounds) run the gated rounds of the multi-GPU bench (export / send-receive / import / refine /
+    all-reduce(max) of the changed word, at most bench.HALO_MAX_ROUNDS per update) on the hash world; each rank must hold what the
+    oracle's "until no tile changes" gives its tile, and exactly the oracle's rounds must have RUN (the others hit a closed gate)."""
+    import bench
+    import test_tiling_halo as T
+    from oracle_py import OracleMapper
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gated, args=(r, world, port, q, bench.HALO_MAX_ROUNDS)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (res, st) for r, res, st in (q.get(timeout=600) for _ in procs)}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = T._run_c5_tiled(OracleMapper, (24, 24, 24), 3, world=world)
+    oracle_rounds = sum(n for _, n, _ in ref)
+    assert world == 2 or 1 < max(n for _, n, _ in ref) < bench.HALO_MAX_ROUNDS      # rounds ran beyond the first and were cut short
+    for t in range(world):
+        res, st = got[t]
+        assert st == {"rounds_enqueued": 3 * bench.HALO_MAX_ROUNDS, "rounds_run": oracle_rounds, "updates": 3, "updates_unconverged": 0}, st
+        for k, (reads, _, _) in enumerate(ref):
+            assert np.array_equal(res[k][0], reads[t]["type"])
+            assert np.array_equal(res[k][1], reads[t]["dist_sq"])
+            assert np.array_equal(res[k][2], reads[t]["coc"])
+
+
 def _worker_transport(rank, world, port, out):
     sys.path.insert(0, os.path.join(ROOT, "gie-mapping_amd"))
     import torch

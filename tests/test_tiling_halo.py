@@ -33,7 +33,9 @@ def _sensor_frames(n):
 KW = dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi, phi_inc=np.radians(2.5), phi_min=np.radians(-40.0))
 
 
-def _run_tiled(make, exchange=True, device=None, fixed_rounds=0, sparse=False, sent=None):
+def _run_tiled(make, exchange=True, device=None, fixed_rounds=0, sparse=False, sent=None, converged=0, stats=None):
+    """converged = N: tiling.exchange_converged_local_device with at most N gated rounds (needs `device`; "cpu" for emulated
+    mappers); `stats` (a list) then receives every mapper's round_stats() at the end."""
     cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
     ms = [make(cfg), make(cfg)]
     for r, m in enumerate(ms):
@@ -48,6 +50,9 @@ def _run_tiled(make, exchange=True, device=None, fixed_rounds=0, sparse=False, s
                 for m in ms:
                     m.merge_end()
                 rounds = 0
+            elif converged:
+                tiling.exchange_converged_local_device(ms, (2, 1, 1), device, max_rounds=converged, bufs=bufs)
+                rounds = -1
             elif device is not None and fixed_rounds:
                 tiling.exchange_rounds_local_device(ms, (2, 1, 1), device, rounds=fixed_rounds, bufs=bufs)
                 rounds = -1
@@ -56,6 +61,8 @@ def _run_tiled(make, exchange=True, device=None, fixed_rounds=0, sparse=False, s
             else:
                 rounds = tiling.exchange_until_stable_local(ms, (2, 1, 1), sparse=sparse, sent=sent)
             hist.append(([m.read_local() for m in ms], rounds, [m.pivot() for m in ms]))
+        if stats is not None:
+            stats.extend(m.round_stats() for m in ms)
     finally:
         for m in ms:
             m.close()
@@ -103,6 +110,47 @@ def test_tiles_are_adjacent_and_share_the_sensor():
 def test_emulated_tiled_matches_oracle_tiled(oracle_lib):
     from emu_py import EmuMapper
     _assert_same(_run_tiled(OracleMapper), _run_tiled(EmuMapper))
+
+
+def _assert_converged_like(want, got, stats, max_rounds, tiles):
+    """`got` ran gated rounds: the same maps as the oracle's "until no tile changes", and — the gate at work — exactly the
+    oracle's rounds RAN in every tile (its count includes the last round, which seeds nothing), the rest of the `max_rounds`
+    enqueued per update returned at once; no update left unconverged."""
+    for k, ((ra, _, pa), (rb, _, pb)) in enumerate(zip(want, got)):
+        assert pa == pb
+        for t in range(tiles):
+            for key in ("type", "dist_sq", "coc"):
+                assert np.array_equal(ra[t][key], rb[t][key]), (k, t, key)
+    oracle_rounds = sum(n for _, n, _ in want)
+    assert max(n for _, n, _ in want) <= max_rounds
+    assert len(stats) == tiles
+    for st in stats:
+        assert st == {"rounds_enqueued": max_rounds * len(want), "rounds_run": oracle_rounds, "updates": len(want), "updates_unconverged": 0}, (st, oracle_rounds)
+
+
+def test_emulated_tiled_gated_rounds_match_oracle_until_stable(oracle_lib):
+    """SURVEY 8(e) "until no GPU changed" without the host: a fixed bound of rounds enqueued per update, each gated by the
+    all-reduced "changed" word of the round before (gie_round_gate / gie_refine_dev / gie_round_end).  On the emulated device
+    logic, words in host memory."""
+    import torch
+    from emu_py import EmuMapper
+    stats = []
+    want = _run_tiled(OracleMapper)
+    got = _run_tiled(EmuMapper, device=torch.device("cpu"), converged=4, stats=stats)
+    _assert_converged_like(want, got, stats, 4, 2)      # (this scene settles in the first refinement round; the hash world below needs 2-3)
+
+
+def test_gated_rounds_report_an_update_the_bound_was_too_small_for(oracle_lib):
+    import torch
+    from emu_py import EmuMapper
+    tile, frames = (24, 24, 24), 3
+    want = _run_c5_tiled(OracleMapper, tile, frames)
+    deep = sum(1 for _, n, _ in want if n > 1)             # updates whose first refinement round still seeded something somewhere
+    assert deep > 0
+    stats = []
+    _run_c5_tiled(EmuMapper, tile, frames, device=torch.device("cpu"), converged=1, stats=stats)
+    for st in stats:
+        assert st["updates_unconverged"] == deep and st["rounds_run"] == len(want) == st["rounds_enqueued"]
 
 
 def test_sparse_face_layers_are_interchangeable_with_dense_ones(oracle_lib):
@@ -163,6 +211,16 @@ def test_hip_tiled_device_resident_exchange(oracle_lib):
 
 
 @pytest.mark.gpu
+def test_hip_tiled_gated_rounds(oracle_lib):
+    """The exchange `bench.py --gpus N` runs by default (tiling.exchange_converged_*): rounds gated on the device."""
+    import torch
+    stats = []
+    want = _run_tiled(OracleMapper)
+    got = _run_tiled(gie.Mapper, device=torch.device("cuda", 0), converged=4, stats=stats)
+    _assert_converged_like(want, got, stats, 4, 2)
+
+
+@pytest.mark.gpu
 def test_hip_tiled_stream_ordered_rounds(oracle_lib):
     """The exchange the multi-GPU bench uses: a fixed number of rounds enqueued on the mappers' own
     streams (gie_get_stream, gie_refine without a seed count), the host never waits.  Rounds
@@ -217,26 +275,29 @@ def test_eight_mappers_share_one_device(oracle_lib):
             assert np.array_equal(want[t][key], got[t][key]), (t, key)
 
 
-def _run_c5_tiled(make, tile, frames, device=None, fixed_rounds=0, delta_vox=8):
+def _run_c5_tiled(make, tile, frames, device=None, fixed_rounds=0, delta_vox=8, converged=0, stats=None, world=8):
     """BASELINE config 5 in small: the sensor-less hash world (full observation, a quarter of the obstacles toggles
-    per frame) on 2x2x2 tiles, every tile fed the label plane of its own part of the world."""
-    grid = tiling.tile_grid(8)
+    per frame) on 2x2x2 tiles (world = 8; 2: two tiles along x), every tile fed the label plane of its own part of the world."""
+    grid = tiling.tile_grid(world)
     whole = tuple(grid[i] * tile[i] for i in range(3))
     cfg = gie.make_config(0.05, tile, cutoff_dist=0.5)
     ms = []
-    for r in range(8):
-        m = make(cfg); m.set_tile(tiling.tile_offset_voxels(r, 8, tile), whole); ms.append(m)
+    for r in range(world):
+        m = make(cfg); m.set_tile(tiling.tile_offset_voxels(r, world, tile), whole); ms.append(m)
     out, bufs = [], {}
     try:
         for k in range(frames):
             pos, q = scenes.pose(k, 0.05, delta_vox=delta_vox, yaw_deg=2.0)
             for r, m in enumerate(ms):
-                pvt = scenes.local_pivot(pos, 0.05, tile, tiling.tile_offset_voxels(r, 8, tile))
+                pvt = scenes.local_pivot(pos, 0.05, tile, tiling.tile_offset_voxels(r, world, tile))
                 m.set_pose(pos, q)
                 assert tuple(m.pivot()) == tuple(pvt)
                 m.ogm_labels(scenes.hash_world_labels(pvt, tile, k, seed=5, p_occ=0.01).astype(np.int8))
                 m.step_begin_tiled()
-            if device is None:
+            if converged:
+                tiling.exchange_converged_local_device(ms, grid, device, max_rounds=converged, bufs=bufs)
+                rounds = -1
+            elif device is None:
                 rounds = tiling.exchange_until_stable_local(ms, grid)
             elif fixed_rounds:
                 tiling.exchange_rounds_local_device(ms, grid, device, rounds=fixed_rounds, bufs=bufs)
@@ -244,6 +305,8 @@ def _run_c5_tiled(make, tile, frames, device=None, fixed_rounds=0, delta_vox=8):
             else:
                 rounds = tiling.exchange_until_stable_local_device(ms, grid, device, bufs=bufs)
             out.append(([m.read_local() for m in ms], rounds, [tuple(m.pivot()) for m in ms]))
+        if stats is not None:
+            stats.extend(m.round_stats() for m in ms)
     finally:
         for m in ms:
             m.close()
@@ -300,6 +363,28 @@ def test_c5_hash_world_tiled_emulation(oracle_lib):
             for key in ("type", "dist_sq", "coc"):
                 assert np.array_equal(ra[t][key], rb[t][key]), (k, t, key)
     _c5_tiled_vs_whole(want, _run_c5_whole(OracleMapper, tile, frames))
+    # ... and with the gated rounds bench.py enqueues per update (its own bound)
+    import torch
+    import bench
+    stats = []
+    gated = _run_c5_tiled(EmuMapper, tile, frames, device=torch.device("cpu"), converged=bench.HALO_MAX_ROUNDS, stats=stats)
+    _assert_converged_like(want, gated, stats, bench.HALO_MAX_ROUNDS, 8)
+    assert any(n > 1 for _, n, _ in want) and any(n < bench.HALO_MAX_ROUNDS for _, n, _ in want)      # rounds ran beyond the first AND were cut short
+
+
+@pytest.mark.gpu
+def test_c5_hash_world_2x2x2_gated_rounds_with_the_bench_bound(oracle_lib):
+    """the exchange the multi-GPU bench times by default — at most bench.HALO_MAX_ROUNDS refinement rounds per
+    update, gated on the device by the all-reduced "changed" word — against the tiled oracle's "until no tile changes" on
+    BASELINE config 5's arrangement (2x2x2 tiles of 64^3): the same maps bit for bit, the oracle's number of rounds ran, and no
+    update was left unconverged."""
+    import torch
+    import bench
+    tile, frames = (64, 64, 64), 4
+    stats = []
+    want = _run_c5_tiled(OracleMapper, tile, frames)
+    got = _run_c5_tiled(gie.Mapper, tile, frames, device=torch.device("cuda", 0), converged=bench.HALO_MAX_ROUNDS, stats=stats)
+    _assert_converged_like(want, got, stats, bench.HALO_MAX_ROUNDS, 8)
 
 
 @pytest.mark.gpu
@@ -358,14 +443,15 @@ class _RankView:
 
     class ReduceOp:
         SUM = "sum"
+        MAX = "max"
 
     def all_reduce(self, t, op=None, group=None):
-        """sum of a one-element tensor over the two ranks (host-synchronous, like the caller's use)"""
+        """sum / max of a one-element tensor over the two ranks (host-synchronous — RCCL's would not be; the data flow is the same)"""
         n = self.seq[("ar",)] = self.seq.get(("ar",), 0) + 1
         with self.s.cv:
             self.s.reduce_in.setdefault(n, {})[self.rank] = int(t.item())
         self.s.meet.wait(timeout=60)
-        t.fill_(sum(self.s.reduce_in[n].values()))
+        t.fill_((max if op == "max" else sum)(self.s.reduce_in[n].values()))
 
     def __init__(self, shared, rank):
         self.s, self.rank, self.seq = shared, rank, {}
@@ -406,7 +492,7 @@ class _RankView:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["stream_ordered", "until_stable", "until_stable_sparse"])
+@pytest.mark.parametrize("form", ["stream_ordered", "until_stable", "until_stable_sparse", "converged"])
 def test_rank_exchange_code_path(oracle_lib, form):
     """tiling.exchange_rounds_device — the function bench.py calls once per map update on every
     rank of a multi-GPU run — with an in-process transport instead of RCCL: two tiles, two
@@ -418,7 +504,7 @@ def test_rank_exchange_code_path(oracle_lib, form):
     import threading
     import torch
     device = torch.device("cuda", 0)
-    want = _run_tiled(gie.Mapper, device=device, fixed_rounds=4 if form == "stream_ordered" else 0)
+    want = _run_tiled(gie.Mapper, device=device, fixed_rounds=4 if form in ("stream_ordered", "converged") else 0)
     cfg = gie.make_config(W, TILE, cutoff_dist=1.0)
     frames = _sensor_frames(FR)
     shared = _InProcessTransport()
@@ -436,10 +522,15 @@ def test_rank_exchange_code_path(oracle_lib, form):
                     m.update(pos, q, "multiscan", img, tiled=True, **KW)
                     if form == "stream_ordered":
                         tiling.exchange_rounds_device(m, dist, rank, 2, device, bufs, rounds=4)
+                    elif form == "converged":        # bench.py's default for N > 1
+                        tiling.exchange_converged_device(m, dist, rank, 2, device, bufs, max_rounds=4)
                     else:                            # bench.py's fall-back: host-synchronised rounds until no tile changes
                         tiling.exchange_until_stable_device(m, dist, rank, 2, device, bufs, sparse=form.endswith("sparse"))
                     hist[rank].append((m.read_local(), m.pivot()))
                     step_barrier.wait(timeout=120)
+                if form == "converged":
+                    st = m.round_stats()
+                    assert st["updates_unconverged"] == 0 and st["rounds_enqueued"] == 4 * len(frames) and FR <= st["rounds_run"] < 4 * len(frames), st
             finally:
                 m.close()
         except Exception as e:                       # noqa: BLE001 — reported by the main thread
