@@ -442,7 +442,8 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
     cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=fast_mode, device_id=local_rank, retain_radius_blocks=DRIVE["retain"],
-                          max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)))
+                          max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)),
+                          wave_workgroups=WAVE_GRID["wgs"], place_tries=PLACE_TRIES if os.environ.get("GIE_BENCH_SHARE_GPU") != "1" else 0)
     feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
     r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, group=group)
     first = r.warmup(W)
@@ -664,6 +665,75 @@ def accuracy_check(m, voxel):
             "how": "Gnd_truth_checker::cmp_dist (gt_checker.h:30-80) against the exact CPU EDT of the volume's own obstacles, after the last timed update"}
 
 
+def costmap_bench(torch, gie, scenes, dev, local_rank, K=10):
+    """Row a17 on the clock: the CostMap.msg payload (SeenDist, 8 B/voxel: LocMap::convertCostMap +
+    copy_*_2_host, local_batch.h:370-391) a for_motion_planner node publishes after every update.  BASELINE config 2's volume
+    (256^3: 134 MB per frame), frames of its depth camera: update + publish per frame through the blocking reader
+    (gie_read_costmap into pageable memory, the reference's way) and through gie_costmap_publish / _acquire (pinned memory, copy
+    stream: the copy of frame k overlaps update k + 1); and the payload alone at the headline's 512^3 (1.07 GB)."""
+    out = {}
+    p = PRESETS["c2_projective"]
+    cfg = gie.make_config(p["voxel"], p["size"], cutoff_dist=p["cutoff"], fast_mode=p["fast"], device_id=local_rank, for_motion_planner=True,
+                          wave_workgroups=WAVE_GRID["wgs"])
+    feed = make_feed("c2_projective", torch, scenes, dev, p["voxel"], p["size"], (0, 0, 0), 3 + 3 * K)
+    feed.prepare(0, 3 + 3 * K)
+    m = gie.Mapper(cfg)
+    n = p["size"][0] * p["size"][1] * p["size"][2]
+    try:
+        for i in range(3):
+            feed.step_input(m, i); m.step()
+        m.read_costmap(); m.costmap_publish(); m.costmap_acquire(copy=False)          # first use: staging and pinned buffers
+        m.sync()
+        i = 3
+        t0 = time.perf_counter()
+        for _ in range(K):
+            feed.step_input(m, i); m.step(); i += 1
+        m.sync()
+        t_upd = (time.perf_counter() - t0) / K
+        t0 = time.perf_counter()
+        for _ in range(K):
+            feed.step_input(m, i); m.step(); m.read_costmap(); i += 1
+        t_block = (time.perf_counter() - t0) / K
+        t0 = time.perf_counter()
+        for _ in range(K):
+            feed.step_input(m, i); m.step(); i += 1
+            m.costmap_acquire(copy=False)                 # frame k - 1's payload is in host memory by now (or we wait for it)
+            m.costmap_publish()
+        m.costmap_acquire(copy=False)
+        t_async = (time.perf_counter() - t0) / K
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.costmap_publish(); m.costmap_acquire(copy=False)
+        t_pub = (time.perf_counter() - t0) / 3
+    finally:
+        m.close()
+    out["c2_256"] = {"payload_mb": round(n * 8 / 1e6, 1), "update_ms": round(1e3 * t_upd, 3), "update_plus_blocking_read_ms": round(1e3 * t_block, 3),
+                     "update_plus_async_publish_ms": round(1e3 * t_async, 3), "publish_alone_ms": round(1e3 * t_pub, 3),
+                     "publish_gbps": round(n * 8 / t_pub / 1e9, 1), "frames": K}
+    size = (512, 512, 512)
+    m = gie.Mapper(gie.make_config(0.05, size, cutoff_dist=2.0, device_id=local_rank, for_motion_planner=True, wave_workgroups=WAVE_GRID["wgs"],
+                                   max_blocks=pool_blocks("c5", size, 8)))
+    n = size[0] * size[1] * size[2]
+    try:
+        hw = HashWorldFeed(torch, scenes, dev, 0.05, size, (0, 0, 0))
+        hw.prepare(0, 2)
+        for i in range(2):
+            hw.step_input(m, i); m.step()
+        m.costmap_publish(); m.costmap_acquire(copy=False); m.sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            m.costmap_publish(); m.costmap_acquire(copy=False)
+        t_pub = (time.perf_counter() - t0) / 2
+        t0 = time.perf_counter()
+        m.read_costmap()
+        t_block = time.perf_counter() - t0
+    finally:
+        m.close()
+    out["c5_512"] = {"payload_mb": round(n * 8 / 1e6, 1), "publish_alone_ms": round(1e3 * t_pub, 2), "publish_gbps": round(n * 8 / t_pub / 1e9, 1),
+                     "blocking_read_ms": round(1e3 * t_block, 2)}
+    return out
+
+
 TRAFFIC_FILE = "traffic_r04.json"
 
 
@@ -767,6 +837,8 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
     return out
 
 
+WAVE_GRID = {"wgs": 160}     # gie_config.wave_workgroups: a rank owns its device (160 of 256 measured best); ranks sharing a device: 192 / ranks
+PLACE_TRIES = 4              # gie_config.place_tries: gie_create re-draws the sweep's planes against a probe (0.76 vs 0.84 ms of Mark + commit)
 PARTIAL = {}     # per workload: the regions timed so far (printed with an "error" key if the run dies later on)
 FULL_FILE = os.path.join("profiles", "bench_last_full.json")
 LINE_LIMIT = 8000           # bytes of the ONE line on stdout (a 21.8 KB line left the driver's record unparsed)
@@ -783,7 +855,7 @@ def compact_roofline(r):
     return {k: r.get(k) for k in keys if k in r}
 
 
-def build_line(main_res, extras, cpu, n_gpus, metric="edt_map_update_throughput", full_file=FULL_FILE):
+def build_line(main_res, extras, cpu, n_gpus, metric="edt_map_update_throughput", full_file=FULL_FILE, costmap=None):
     """(line, full): `line` is what rank 0 prints — headline keys, ONE roofline (dominant kernel), cpu_baseline, per-workload step
     times and fractions, below LINE_LIMIT bytes, no string above 120 characters; `full` is everything (written to full_file)."""
     full = {"metric": metric, "value": main_res["value"], "unit": "Mvoxels/s", "n_gpus": n_gpus, "steps": main_res["steps"], "warmup": main_res["warmup"],
@@ -792,6 +864,8 @@ def build_line(main_res, extras, cpu, n_gpus, metric="edt_map_update_throughput"
     full["extra_runs"] = extras
     if cpu is not None:
         full["cpu_baseline"] = cpu
+    if costmap is not None:
+        full["costmap_publish"] = costmap
     full["notes"] = {
         "timing": "value / ms_per_step: median of the timed regions, each EXACTLY K steps between barrier + synchronize, MAX over ranks; kernels_ms_per_step and "
                   "the roofline objects: the first region replayed on a fresh mapper with start / stop events on every kernel's dispatch",
@@ -835,9 +909,11 @@ def build_line(main_res, extras, cpu, n_gpus, metric="edt_map_update_throughput"
             line["roofline_ogm"] = ogm
     if main_res.get("accuracy") is not None:
         line["accuracy"] = {k: _short(v) for k, v in main_res["accuracy"].items()}
+    if costmap is not None:          # row a17 (CostMap.msg payload, 8 B/voxel), off the timed region: never part of `value`
+        line["costmap_publish"] = costmap
     line["detail"] = full_file
     # the limit holds whatever a run produces: drop the least important blocks first
-    for k in ("roofline_ogm", "kernels_ms_per_step", "mvoxels_per_s_by_workload", "baseline_config_by_workload", "accuracy", "roofline_update", "step_ms"):
+    for k in ("roofline_ogm", "costmap_publish", "kernels_ms_per_step", "mvoxels_per_s_by_workload", "baseline_config_by_workload", "accuracy", "roofline_update", "step_ms"):
         if len(json.dumps(line)) <= LINE_LIMIT:
             break
         line.pop(k, None)
@@ -916,7 +992,7 @@ def run_bench():
         local_rank = 0
         # the wavefront kernel is persistent and takes a whole compute unit's LDS per workgroup (wave C's tiles): the grids of
         # all ranks have to be resident side by side on the one device, or their grid barriers wait for each other until they time out
-        os.environ.setdefault("GIE_WAVE_WGS", str(max(8, 192 // max(1, world))))
+        WAVE_GRID["wgs"] = max(8, 192 // max(1, world))
     torch.cuda.set_device(local_rank)
     dist = None
     group, transport_note = None, None
@@ -953,7 +1029,10 @@ def run_bench():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scenes, torch, dev, voxel, size, cutoff, args.workload, W)
-        line, full = build_line(main_res, extras, cpu, world)
+        costmap = None
+        if world == 1 and not args.no_extras:
+            costmap = costmap_bench(torch, gie, scenes, dev, local_rank)
+        line, full = build_line(main_res, extras, cpu, world, costmap=costmap)
         write_full(full)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -55,6 +55,8 @@ struct gie_mapper {
     int32_t next_off[3], next_whole[3];
     float us[4];
     int flushed_ct;                       /* map tick (c.map_ct) of the pose the owed pairs were last written for ahead of gie_fuse (gie_owed_pairs_before_import) */
+    /* CostMap publishing without a stall (gie_costmap_publish / gie_costmap_acquire): device staging + two pinned host buffers */
+    gie_seendist *d_cm; void *h_cm[2]; size_t cm_bytes; int cm_slot, cm_pending;
     long long *d_round_stats;             /* exchange rounds without the host: rounds enqueued / run, updates / updates left unconverged (k_round_note) */
 };
 
@@ -63,7 +65,7 @@ template <class T> static T *gie_dalloc(gie_mapper *m, size_t n, bool zero = tru
     void *p = be_alloc(&m->be, n * sizeof(T), zero);
     if (p) m->allocs.push_back(p);
     {   /* GIE_DEBUG_ALLOC=1: where the planes went (stderr) */
-        static const int dbg = getenv("GIE_DEBUG_ALLOC") ? atoi(getenv("GIE_DEBUG_ALLOC")) : 0;
+        static const int dbg = GIE_SWITCH("GIE_DEBUG_ALLOC", 0);
         if (dbg && (dbg > 1 || n * sizeof(T) >= (64u << 20))) fprintf(stderr, "[%d] gie alloc %2d: %p  %8.1f MiB\n", (int)getpid(), (int)m->allocs.size(), p, (double)(n * sizeof(T)) / 1048576.0);
     }
     return (T *)p;
@@ -101,7 +103,7 @@ static void gie_scratch_trim(gie_mapper *m)
  * faster placement.  Costs a few tens of milliseconds of gie_create for volumes of 16 M voxels and more, nothing below. */
 static void gie_place_calibrate(gie_mapper *m, size_t N, size_t GV)
 {
-    static const int tries = getenv("GIE_PLACE_TRIES") ? atoi(getenv("GIE_PLACE_TRIES")) : 4;
+    const int tries = m->cfg.place_tries;
     if (tries <= 1 || N < ((size_t)1 << 24) || !m->c.g_coc || !m->c.pair || !m->c.bcoc || !m->c.glb_type) return;
     gie_ctx &c = m->c;
     (void)be_place_probe(&m->be, c, 12);                      /* warm-up: a device that has been idle clocks up during the first milliseconds */
@@ -134,7 +136,7 @@ static void gie_place_calibrate(gie_mapper *m, size_t N, size_t GV)
             } else { *pl.pp = old; be_free(&m->be, alt); }
         }
     }
-    if (getenv("GIE_DEBUG_ALLOC")) fprintf(stderr, "[%d] gie placement: probe %.4f -> %.4f ms after %d re-draws\n", (int)getpid(), first, best, swaps);
+    if (GIE_SWITCH("GIE_DEBUG_ALLOC", 0)) fprintf(stderr, "[%d] gie placement: probe %.4f -> %.4f ms after %d re-draws\n", (int)getpid(), first, best, swaps);
 }
 
 static int gie_pow2_ge(long long v) { int p = 1; while ((long long)p < v) p <<= 1; return p; }
@@ -160,13 +162,15 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
     m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1;
+    m->d_cm = nullptr; m->h_cm[0] = m->h_cm[1] = nullptr; m->cm_bytes = 0; m->cm_slot = 0; m->cm_pending = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
     m->d_box_ll = m->d_box_ur = nullptr; m->d_box_act = nullptr; m->box_cap = 0;
     m->d_srank = m->d_slist = nullptr; m->d_stage[0] = m->d_stage[1] = m->h_stage[0] = m->h_stage[1] = nullptr;
     memset(m->h_cnt, 0, sizeof(m->h_cnt)); memset(m->us, 0, sizeof(m->us));
     m->scratch[0] = m->scratch[1] = nullptr; m->scratch_cap[0] = m->scratch_cap[1] = 0;
-    if (be_init(&m->be, cfg->device_id) != 0) { delete m; return nullptr; }
+    if (cfg->wave_workgroups < 0 || cfg->place_tries < 0) { gie_set_err("gie_create: bad config (wave_workgroups / place_tries are >= 0)"); delete m; return nullptr; }
+    if (be_init(&m->be, cfg->device_id, cfg->wave_workgroups) != 0) { delete m; return nullptr; }
     gie_ctx &c = m->c;
     memset(&c, 0, sizeof(c));
     c.X = X; c.Y = Y; c.Z = Z; c.N = X * Y * Z;
@@ -205,7 +209,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.zcount = gie_dalloc<int32_t>(m, 4);
     c.tl_known = gie_dalloc<int32_t>(m, ntile);
     c.tl_front = gie_dalloc<int32_t>(m, ntile);
-    { const char *force = getenv("GIE_TILE_LIST"); c.force_lists = force ? (atoi(force) != 0) : -1; }   /* tests force lists / sweeps */
+    { const int force = GIE_SWITCH("GIE_TILE_LIST", -1); c.force_lists = force < 0 ? -1 : (force != 0); }   /* tests force lists / sweeps */
     const int bdr = 2 * (X * Y + Y * Z + X * Z);
     c.lprop = gie_dalloc<uint64_t>(m, (size_t)bdr, false);
     c.cand[0] = gie_dalloc<uint64_t>(m, N, false);
@@ -264,8 +268,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     bool ok = c.cnt != nullptr;
     for (void *p : m->allocs) ok = ok && p != nullptr;
     if (!ok) { gie_set_err("gie_create: device allocation failed"); gie_destroy(m); return nullptr; }
-    if (const char *e = getenv("GIE_DEBUG_POOL_BASE")) {   /* tests: hand out slots from here on (voxel addresses beyond 2^31 without filling a pool) */
-        const long long b = atoll(e);
+    if (GIE_SWITCH("GIE_DEBUG_POOL_BASE", 0) > 0) {   /* tests: hand out slots from here on (voxel addresses beyond 2^31 without filling a pool) */
+        const long long b = GIE_SWITCH("GIE_DEBUG_POOL_BASE", 0);
         if (b > 0 && b < mb) {
             const int32_t v = (int32_t)b; be_h2d(&m->be, c.pool_count, &v, sizeof(v)); m->pool_base = (int)b;
             be_memset(&m->be, c.g_key, 0xff, (size_t)b * sizeof(uint64_t));    /* the slots below the base were never handed out: erasure and re-hash walk every slot below the pool top and must find them empty */
@@ -290,6 +294,8 @@ extern "C" void gie_destroy(gie_mapper *m)
     if (m->d_box_ll) { be_free(&m->be, m->d_box_ll); be_free(&m->be, m->d_box_ur); be_free(&m->be, m->d_box_act); }
     if (m->d_srank) { be_free(&m->be, m->d_srank); be_free(&m->be, m->d_slist); }
     for (int i = 0; i < 2; i++) if (m->scratch[i]) be_free(&m->be, m->scratch[i]);
+    if (m->d_cm) be_free(&m->be, m->d_cm);
+    for (int i = 0; i < 2; i++) if (m->h_cm[i]) be_host_free(&m->be, m->h_cm[i]);
     for (int i = 0; i < 2; i++) { if (m->d_stage[i]) be_free(&m->be, m->d_stage[i]); if (m->h_stage[i]) be_host_free(&m->be, m->h_stage[i]); }
     be_fini(&m->be);
     delete m;
@@ -501,7 +507,7 @@ extern "C" int gie_set_ext_boxes(gie_mapper *m, const float *ll, const float *ur
 static void gie_table_roll(gie_mapper *m)
 {
     gie_ctx &c = m->c;
-    static const int no_prev = getenv("GIE_NO_TAB_PREV") ? atoi(getenv("GIE_NO_TAB_PREV")) : 0;      /* (debugging: every block through the hash) */
+    static const int no_prev = GIE_SWITCH("GIE_NO_TAB_PREV", 0);      /* (debugging: every block through the hash) */
     if (m->tab_valid && !no_prev) {
         c.tab_prev = c.blk_tab;
         for (int i = 0; i < 3; i++) c.tab_prev_d[i] = c.tb0[i] - m->tab_tb0[i];
@@ -641,7 +647,7 @@ extern "C" int gie_fuse(gie_mapper *m)
  * GIE_FUSED=0 keeps the reference's order Mark -> obtainFrontiers -> waves -> commit (tests run both) */
 static int gie_fused_mode(const gie_mapper *m)
 {
-    static const int env = getenv("GIE_FUSED") ? atoi(getenv("GIE_FUSED")) : 1;
+    static const int env = GIE_SWITCH("GIE_FUSED", 1);
     return (env && !m->c.track) ? 1 : 0;
 }
 
@@ -654,7 +660,7 @@ extern "C" int gie_batch_edt(gie_mapper *m)
      * already — it depends on the previous update's bounds and this update's pose only.  If the merge ends up running in the
      * reference's order after all (gie_stream_enable in between) the flags are simply not looked at. */
     {
-        static const int use_bound = getenv("GIE_MARKC_BOUND") ? atoi(getenv("GIE_MARKC_BOUND")) : 1;     /* 0: always read the stored records (measurements) */
+        static const int use_bound = GIE_SWITCH("GIE_MARKC_BOUND", 1);     /* 0: always read the stored records (measurements) */
         m->c.oldskip = (gie_fused_mode(m) && m->c.prev_valid && use_bound) ? 1 : 0;
     }
     be_edt_prep(&m->be, m->c);          /* plane list + reader masks + tile skip flags */
@@ -739,7 +745,7 @@ static int gie_fetch_counters(gie_mapper *m)
     be_d2h(&m->be, m->h_cnt, m->c.cnt, sizeof(m->h_cnt));
     const int e = m->h_cnt[GIE_CNT_ERR];
     {   /* GIE_DEBUG_COUNTS=1: the lengths of the device-side lists of the last map update, on stderr */
-        static const int dbg = getenv("GIE_DEBUG_COUNTS") ? atoi(getenv("GIE_DEBUG_COUNTS")) : 0;
+        static const int dbg = GIE_SWITCH("GIE_DEBUG_COUNTS", 0);
         if (dbg) fprintf(stderr, "gie counts: tiles known %d, frontier tiles %d, fuse tiles %d, seeds A/B/C %d %d %d, tiles without a read of the stored records %d\n", m->h_cnt[GIE_CNT_TL_KNOWN],
                          m->h_cnt[GIE_CNT_TL_FRONT], m->h_cnt[GIE_CNT_TL_FUSE], m->h_cnt[GIE_CNT_SEED_A], m->h_cnt[GIE_CNT_SEED_B], m->h_cnt[GIE_CNT_SEED_C], m->h_cnt[GIE_CNT_TSKIP]);
     }
@@ -774,7 +780,7 @@ extern "C" int gie_read_local(gie_mapper *m, float *edt, int8_t *type, int32_t *
 {
     if (!m) { gie_set_err("gie_read_local: null handle"); return GIE_ERR_INVALID; }
     const size_t N = (size_t)m->c.N;
-    static const int edt_raw = getenv("GIE_EDT_RAW") ? atoi(getenv("GIE_EDT_RAW")) : 0;     /* measurement builds keep time stamps in the plane (tools/wave_timing.py) */
+    static const int edt_raw = GIE_SWITCH("GIE_EDT_RAW", 0);     /* measurement builds keep time stamps in the plane (tools/wave_timing.py) */
     if (edt && edt_raw) be_d2h(&m->be, edt, m->c.edt, N * sizeof(float));
     else if (edt) {      /* `_edt_D` is derived from the pairs where the reference would have written it (gie_ops.h gie_edt_value) */
         float *de = (float *)gie_scratch(m, 0, N * 4, "gie_read_local");
@@ -808,7 +814,7 @@ extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
 {
     if (!m) { gie_set_err("gie_read_batch_edt: null handle"); return GIE_ERR_INVALID; }
     const size_t N = (size_t)m->c.N;
-    if (m->edt_partial && !getenv("GIE_EDT_EXPORT_PARTIAL")) {   /* complete the tiles the map update itself never reads */
+    if (m->edt_partial && !GIE_SWITCH("GIE_EDT_EXPORT_PARTIAL", 0)) {   /* complete the tiles the map update itself never reads */
         be_edt_z(&m->be, m->c, 1);
         m->edt_partial = 0;
     }
@@ -824,6 +830,7 @@ extern "C" int gie_read_batch_edt(gie_mapper *m, int32_t *dist_sq, int32_t *coc)
     }
     return gie_sync(m);
 }
+static void gie_fill_costmap_hdr(const gie_mapper *m, gie_costmap_hdr *hdr);
 extern "C" int gie_read_costmap(gie_mapper *m, gie_seendist *payload, gie_costmap_hdr *hdr)
 {
     if (!m) { gie_set_err("gie_read_costmap: null handle"); return GIE_ERR_INVALID; }
@@ -836,12 +843,68 @@ extern "C" int gie_read_costmap(gie_mapper *m, gie_seendist *payload, gie_costma
         be_d2h(&m->be, payload, d, N * sizeof(gie_seendist));
         gie_scratch_trim(m);
     }
-    if (hdr) {
-        hdr->x_size = m->c.X; hdr->y_size = m->c.Y; hdr->z_size = m->c.Z;
-        hdr->x_origin = m->msg_origin[0]; hdr->y_origin = m->msg_origin[1]; hdr->z_origin = m->msg_origin[2];
-        hdr->width = m->c.voxel_width; hdr->type = 1; hdr->pad[0] = hdr->pad[1] = hdr->pad[2] = 0;
-    }
+    if (hdr) gie_fill_costmap_hdr(m, hdr);
     return gie_sync(m);
+}
+static void gie_fill_costmap_hdr(const gie_mapper *m, gie_costmap_hdr *hdr)
+{
+    hdr->x_size = m->c.X; hdr->y_size = m->c.Y; hdr->z_size = m->c.Z;
+    hdr->x_origin = m->msg_origin[0]; hdr->y_origin = m->msg_origin[1]; hdr->z_origin = m->msg_origin[2];
+    hdr->width = m->c.voxel_width; hdr->type = 1; hdr->pad[0] = hdr->pad[1] = hdr->pad[2] = 0;
+}
+/* the payload into a DEVICE buffer of the caller's (GPU planners), asynchronous on the mapper's stream */
+extern "C" int gie_read_costmap_dev(gie_mapper *m, gie_seendist *d_payload, gie_costmap_hdr *hdr)
+{
+    if (!m || !d_payload) { gie_set_err("gie_read_costmap_dev: bad arguments"); return GIE_ERR_INVALID; }
+    op_costmap op; op.out = d_payload;
+    be_lin(&m->be, m->c, op, m->c.N);
+    if (hdr) gie_fill_costmap_hdr(m, hdr);
+    return GIE_OK;
+}
+/* CostMap publishing that does not stall the mapper (include/gie.h): the SeenDist conversion on the mapper's stream into a device
+ * staging buffer, then ONE asynchronous copy into pinned host memory on the library's copy stream — the next map update's kernels
+ * do not queue up behind 8 bytes per voxel of PCIe traffic.  Two pinned buffers alternate: the one gie_costmap_acquire handed out
+ * last stays untouched during the next publish. */
+extern "C" int gie_costmap_publish(gie_mapper *m, gie_costmap_hdr *hdr)
+{
+    if (!m) { gie_set_err("gie_costmap_publish: null handle"); return GIE_ERR_INVALID; }
+    const size_t bytes = (size_t)m->c.N * sizeof(gie_seendist);
+    if (!m->d_cm) {
+        m->d_cm = (gie_seendist *)be_alloc(&m->be, bytes, false);
+        for (int i = 0; i < 2; i++) m->h_cm[i] = be_host_alloc(&m->be, bytes);
+        m->cm_bytes = bytes;
+        if (!m->d_cm || !m->h_cm[0] || !m->h_cm[1]) {
+            if (m->d_cm) be_free(&m->be, m->d_cm);
+            for (int i = 0; i < 2; i++) if (m->h_cm[i]) be_host_free(&m->be, m->h_cm[i]);
+            m->d_cm = nullptr; m->h_cm[0] = m->h_cm[1] = nullptr;
+            gie_set_err("gie_costmap_publish: staging allocation failed (8 bytes per voxel on the device, twice that in pinned host memory)"); return GIE_ERR_DEVICE;
+        }
+    }
+    m->cm_slot ^= 1;
+    op_costmap op; op.out = m->d_cm;
+    be_side_copy_begin(&m->be);                       /* (the staging buffer is free again: the mapper's stream waits for the copy before) */
+    be_lin(&m->be, m->c, op, m->c.N);
+    be_side_copy(&m->be, m->h_cm[m->cm_slot], m->d_cm, bytes);
+    m->cm_pending = 1;
+    if (hdr) gie_fill_costmap_hdr(m, hdr);
+    return GIE_OK;
+}
+extern "C" int gie_costmap_acquire(gie_mapper *m, const gie_seendist **payload)
+{
+    if (!m || !payload) { gie_set_err("gie_costmap_acquire: bad arguments"); return GIE_ERR_INVALID; }
+    if (!m->cm_pending && !m->h_cm[0]) { gie_set_err("gie_costmap_acquire: nothing has been published"); return GIE_ERR_INVALID; }
+    if (m->cm_pending) { if (be_side_copy_wait(&m->be) != 0) return GIE_ERR_DEVICE; m->cm_pending = 0; }
+    *payload = (const gie_seendist *)m->h_cm[m->cm_slot];
+    return GIE_OK;
+}
+/* GlbHashMap lookups for GPU planners: coordinates and results stay on the device, the kernel is enqueued on the mapper's stream */
+extern "C" int gie_query_global_dev(gie_mapper *m, const int32_t *d_xyz, int n, gie_voxel *d_out)
+{
+    if (!m || n < 0 || (n > 0 && (!d_xyz || !d_out))) { gie_set_err("gie_query_global_dev: bad arguments"); return GIE_ERR_INVALID; }
+    if (n == 0) return GIE_OK;
+    op_query op; op.xyz = d_xyz; op.out = d_out;
+    be_lin(&m->be, m->c, op, n);
+    return GIE_OK;
 }
 extern "C" int gie_query_global(gie_mapper *m, const int32_t *xyz, int n, gie_voxel *out)
 {
@@ -882,8 +945,7 @@ static const size_t GIE_STREAM_BLK_BYTES = (size_t)GIE_VBSZ * sizeof(gie_voxel);
  * small test volumes exercise the multi-chunk pipeline */
 static int gie_stream_chunk_blocks()
 {
-    const char *e = getenv("GIE_STREAM_CHUNK_BLOCKS");
-    const int v = e ? atoi(e) : 0;
+    const int v = GIE_SWITCH("GIE_STREAM_CHUNK_BLOCKS", 0);
     return (v >= 1 && v <= GIE_STREAM_CHUNK) ? v : GIE_STREAM_CHUNK;
 }
 
@@ -1192,6 +1254,7 @@ extern "C" int gie_get_stream(gie_mapper *m, void **stream)
     return GIE_OK;
 }
 
+#if defined(GIE_TEST_HOOKS)
 /* measurement aid (not in gie.h): the placement probe on this mapper's planes, median of `reps` launches in ms; only before the
  * first map update (it scribbles over the pair plane and clears it again) */
 extern "C" int gie_debug_place_probe(gie_mapper *m, int reps, float *ms)
@@ -1208,6 +1271,7 @@ extern "C" int gie_debug_fault_barrier(gie_mapper *m, int updates)
     m->bar_fault_left = updates;
     return GIE_OK;
 }
+#endif /* GIE_TEST_HOOKS */
 extern "C" int gie_profile_enable(gie_mapper *m, int on)
 {
     if (!m) { gie_set_err("gie_profile_enable: null handle"); return GIE_ERR_INVALID; }

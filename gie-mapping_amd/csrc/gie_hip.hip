@@ -29,6 +29,8 @@ struct be_state {
     void *scan_tmp; size_t scan_bytes;
     void *arena;                        /* GIE_ARENA_MB (placement experiments): be_arena */
     hipEvent_t copy_ev[2];              /* completion of the async D2H copies (changed-block streaming) */
+    hipStream_t side;                   /* copy stream of gie_costmap_publish (created on first use) */
+    hipEvent_t side_ready, side_done; int side_on, side_busy;
     /* per-kernel event profiling */
     int prof_on;
     std::vector<hipEvent_t> *pool;      /* event pool */
@@ -51,7 +53,7 @@ static hipEvent_t g_waves_event[64];
 static bool g_waves_event_set[64];
 static int g_live_mappers[64];          /* mappers alive per device: waves launches are chained only when there is more than one */
 
-static int be_init(be_state *b, int device)
+static int be_init(be_state *b, int device, int wave_workgroups)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { gie_set_err("no HIP device visible (libgie_hip.so needs an AMD GPU; there is no CPU fallback)"); return 1; }
@@ -60,8 +62,11 @@ static int be_init(be_state *b, int device)
     if (hipSetDevice(device) != hipSuccess) { gie_set_err("hipSetDevice failed"); return 1; }
     { hipDeviceProp_t pr; b->num_cu = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 64; }
     b->cu_total = b->num_cu;
-    b->num_cu = b->num_cu >= 64 ? (b->num_cu * 5) / 8 : b->num_cu;   /* wave grids: 160 of 256 workgroups measured best with the block rounds of rounds 3-4 (C5 waves 128: 0.270, 160: 0.261, 192: 0.266, 256: 0.271 ms; with the level-synchronous waves of round 2 it was 128: 64: 20.6, 128: 17.7, 256: 20.0 us per BFS level — a compute unit's request queue vs barrier fan-in) */
-    { const char *e = getenv("GIE_WAVE_WGS"); if (e && atoi(e) > 0 && atoi(e) <= 256) b->num_cu = atoi(e); }
+    /* the persistent wavefront grid: HALF the compute units by default, so that two mappers (or two processes) with default settings
+     * fit one device side by side (160 + 160 did not, for 3 % — C5 waves 128: 0.270, 160: 0.261, 192: 0.266, 256: 0.271 ms);
+     * gie_config.wave_workgroups asks for another size (bench.py: 160 on a device of its own; ranks that share a device: 192 / ranks) */
+    b->num_cu = b->num_cu >= 64 ? b->num_cu / 2 : b->num_cu;
+    if (wave_workgroups > 0) b->num_cu = wave_workgroups < b->cu_total ? wave_workgroups : b->cu_total;
     {   /* the waves kernel meets at a hand-rolled grid barrier: its grid must fit the device at once.  Checked here, once,
          * against the runtime's own occupancy answer (what hipLaunchCooperativeKernel would check at every launch, at
          * +15-19 us of host time each); what it cannot guard against — another PROCESS holding compute units — ends in a
@@ -77,7 +82,7 @@ static int be_init(be_state *b, int device)
     }
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { gie_set_err("hipStreamCreate failed"); return 1; }
     for (int i = 0; i < GIE_NEV; i++) { GIE_HIP_OK(hipEventCreate(&b->ev[i])); b->ev_set[i] = 0; }
-    b->scan_tmp = nullptr; b->scan_bytes = 0; b->arena = nullptr;
+    b->scan_tmp = nullptr; b->scan_bytes = 0; b->arena = nullptr; b->side_on = 0; b->side_busy = 0;
     for (int i = 0; i < 2; i++) GIE_HIP_OK(hipEventCreateWithFlags(&b->copy_ev[i], hipEventDisableTiming));
     b->prof_on = 0; b->cur_id = -1; b->pool = new std::vector<hipEvent_t>(); b->pending = new std::vector<int>(); b->pool_used = 0;
     for (int i = 0; i < 32; i++) { b->acc_ms[i] = 0; b->acc_n[i] = 0; }
@@ -96,6 +101,7 @@ static void be_fini(be_state *b)
     for (int i = 0; i < GIE_NEV; i++) (void)hipEventDestroy(b->ev[i]);
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(b->copy_ev[i]);
     (void)hipStreamDestroy(b->stream);
+    if (b->side_on) { (void)hipStreamSynchronize(b->side); (void)hipEventDestroy(b->side_ready); (void)hipEventDestroy(b->side_done); (void)hipStreamDestroy(b->side); }
     if (b->arena) { be_arena *a = (be_arena *)b->arena; if (a->base) (void)hipFree(a->base); delete a; b->arena = nullptr; }
 }
 /* Placement experiments ("placement bands"): GIE_ARENA_MB=<MiB> takes ONE allocation of that size per mapper and
@@ -103,6 +109,9 @@ static void be_fini(be_state *b)
  * 2 MiB-rounded end of the one before; smaller buffers and whatever does not fit go through hipMalloc as usual. */
 static be_arena *be_arena_of(be_state *b)
 {
+#if !defined(GIE_TEST_HOOKS)
+    (void)b; return nullptr;              /* (a measurement aid: test builds only) */
+#else
     static const char *e = getenv("GIE_ARENA_MB");
     if (!e || atoll(e) <= 0) return nullptr;
     if (!b->arena) {
@@ -113,6 +122,7 @@ static be_arena *be_arena_of(be_state *b)
         b->arena = a;
     }
     return (be_arena *)b->arena;
+#endif
 }
 static void *be_alloc(be_state *b, size_t bytes, bool zero)
 {
@@ -155,6 +165,35 @@ static void be_d2h_async(be_state *b, void *h, const void *d, size_t bytes, int 
     GIE_HIP_OK(hipEventRecord(b->copy_ev[slot], b->stream));
 }
 static void be_wait(be_state *b, int slot) { GIE_HIP_OK(hipEventSynchronize(b->copy_ev[slot])); }
+/* a copy that leaves the mapper's stream free: the side stream waits for what the mapper's stream has enqueued so far, copies into
+ * pinned host memory and records its completion; be_side_copy_begin makes the mapper's stream wait for the copy before (its source
+ * is about to be rewritten) */
+static void be_side_on(be_state *b)
+{
+    if (b->side_on) return;
+    (void)hipSetDevice(b->device);
+    GIE_HIP_OK(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    GIE_HIP_OK(hipEventCreateWithFlags(&b->side_ready, hipEventDisableTiming));
+    GIE_HIP_OK(hipEventCreateWithFlags(&b->side_done, hipEventDisableTiming));
+    b->side_on = 1;
+}
+static void be_side_copy_begin(be_state *b) { be_side_on(b); if (b->side_busy) GIE_HIP_OK(hipStreamWaitEvent(b->stream, b->side_done, 0)); }
+static void be_side_copy(be_state *b, void *h, const void *d, size_t bytes)
+{
+    be_side_on(b);
+    GIE_HIP_OK(hipEventRecord(b->side_ready, b->stream));
+    GIE_HIP_OK(hipStreamWaitEvent(b->side, b->side_ready, 0));
+    GIE_HIP_OK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, b->side));
+    GIE_HIP_OK(hipEventRecord(b->side_done, b->side));
+    b->side_busy = 1;
+}
+static int be_side_copy_wait(be_state *b)
+{
+    if (!b->side_busy) return 0;
+    const hipError_t e = hipEventSynchronize(b->side_done);
+    if (e != hipSuccess) { gie_set_err(std::string("hipEventSynchronize: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+}
 static void *be_stream_handle(be_state *b) { return (void *)b->stream; }
 static int be_sync(be_state *b)
 {
@@ -192,7 +231,7 @@ static int be_prof_event(be_state *b)
 }
 /* GIE_TRACE_LAUNCHES=1: every kernel launch is announced on stderr (process id, kernel) and waited for — the last line a
  * process prints before a device fault names the kernel */
-static int be_trace_on() { static const int on = getenv("GIE_TRACE_LAUNCHES") ? atoi(getenv("GIE_TRACE_LAUNCHES")) : 0; return on; }
+static int be_trace_on() { static const int on = GIE_SWITCH("GIE_TRACE_LAUNCHES", 0); return on; }
 #define GIE_LAUNCH(b, kern, grid, block, lds, ...) do { \
         if (be_trace_on()) { fprintf(stderr, "[%d] launch %s\n", (int)getpid(), #kern); fflush(stderr); } \
         GIE_LAUNCH_(b, kern, grid, block, lds, __VA_ARGS__); \
@@ -268,7 +307,7 @@ static void be_block_alloc(be_state *b, const gie_ctx &c, int ncell, int32_t *, 
 {
     if (clear_list) GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_NEWLIST], 0, sizeof(int32_t), b->stream));
     GIE_LAUNCH(b, k_cell_alloc, dim3((ncell + 255) / 256), dim3(256), 0, c, ncell);
-    static const int imult = getenv("GIE_INIT_MULT") ? atoi(getenv("GIE_INIT_MULT")) : 4;
+    static const int imult = GIE_SWITCH("GIE_INIT_MULT", 4);
     const int ninit = b->cu_total * imult;
     int nfl = (fuse_list_ntile + 255) / 256; if (nfl > 2 * b->cu_total) nfl = 2 * b->cu_total;
     GIE_LAUNCH(b, k_block_init_list, dim3(ninit + nfl), dim3(256), 0, c, ninit, fuse_list_ntile);
@@ -333,7 +372,7 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
 {
     /* workgroups per compute unit: 8 / 16 / 32 / 64 measured 0.33 / 0.27 / 0.25 / 0.25 ms for Mark on a densely known
      * volume (sweep side); the list side does not care */
-    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 32;
+    static const int mult = GIE_SWITCH("GIE_VOXA_MULT", 32);
     const dim3 g(b->cu_total * mult), t(256);
     if (lx == 32) GIE_LAUNCH(b, (k_voxa<F, STAGED, 32>), g, t, 0, c, f, list, count_idx, always_list);
     else if (lx == 16) GIE_LAUNCH(b, (k_voxa<F, STAGED, 16>), g, t, 0, c, f, list, count_idx, always_list);
@@ -343,9 +382,9 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
 /* Mark + commit as one sweep: its own kernel (k_markc); GIE_MARKC_GENERIC=1 keeps the staged functor sweep (tests run both) */
 static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
 {
-    static const int generic = getenv("GIE_MARKC_GENERIC") ? atoi(getenv("GIE_MARKC_GENERIC")) : 0;
-    static const int lx = getenv("GIE_MARKC_LX") ? atoi(getenv("GIE_MARKC_LX")) : 32;
-    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 64;     /* workgroups per compute unit of the dense sweep: 16 / 32 / 48 / 64 / 96 / 128 measured 1.00 / 0.80 / 0.78 / 0.76 / 0.78 / 0.79 ms at 512^3 (round 4; 64 = exactly four virtual workgroups each) */
+    static const int generic = GIE_SWITCH("GIE_MARKC_GENERIC", 0);
+    static const int lx = GIE_SWITCH("GIE_MARKC_LX", 32);
+    static const int mult = GIE_SWITCH("GIE_VOXA_MULT", 64);     /* workgroups per compute unit of the dense sweep: 16 / 32 / 48 / 64 / 96 / 128 measured 1.00 / 0.80 / 0.78 / 0.76 / 0.78 / 0.79 ms at 512^3 (round 4; 64 = exactly four virtual workgroups each) */
     if (generic) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0, lx == 16 || lx == 8 || lx == 32 ? lx : 64); return; }
     const dim3 g(b->cu_total * mult), t(256);
     if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list);
@@ -355,7 +394,7 @@ static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
 /* placement probe (k_place_probe): median of `reps` timed launches, ms */
 static float be_place_probe(be_state *b, const gie_ctx &c, int reps, int streams = 15)
 {
-    static const int mult = getenv("GIE_VOXA_MULT") ? atoi(getenv("GIE_VOXA_MULT")) : 64;     /* (the sweep's own grid: be_markc) */
+    static const int mult = GIE_SWITCH("GIE_VOXA_MULT", 64);     /* (the sweep's own grid: be_markc) */
     const long long ntile = (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
     const int nslot = (int)(ntile < c.max_blocks ? ntile : c.max_blocks);
     hipEvent_t e0, e1;
@@ -375,12 +414,12 @@ static float be_place_probe(be_state *b, const gie_ctx &c, int reps, int streams
     return ms.empty() ? -1.f : ms[ms.size() / 2];
 }
 /* dense (block-row) form of fuse; GIE_ROWS=0 keeps the thread-per-z-column sweep */
-static int be_rows_mode() { static const int v = getenv("GIE_ROWS") ? atoi(getenv("GIE_ROWS")) : 1; return v ? 2 : 0; }
+static int be_rows_mode() { static const int v = GIE_SWITCH("GIE_ROWS", 1); return v ? 2 : 0; }
 /* fuse: one launch — the kernel walks its tile list (a wave per tile) or sweeps the volume by block rows, whichever the list's
  * length calls for; GIE_ROWS=0: the thread-per-z-column sweep of k_voxa instead of the block rows */
 static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list)
 {
-    static const int mult = getenv("GIE_ROWS_MULT") ? atoi(getenv("GIE_ROWS_MULT")) : 32;     /* 8 / 16 / 32 / 48 workgroups per compute unit: 0.225 / 0.215 / 0.195 / 0.19 ms at 512^3 (round 4: with the byte-parallel filter the kernel is short enough for the tail of its last workgroups to show; 32 = one virtual wavefront per wavefront) */
+    static const int mult = GIE_SWITCH("GIE_ROWS_MULT", 32);     /* 8 / 16 / 32 / 48 workgroups per compute unit: 0.225 / 0.215 / 0.195 / 0.19 ms at 512^3 (round 4: with the byte-parallel filter the kernel is short enough for the tail of its last workgroups to show; 32 = one virtual wavefront per wavefront) */
     if (be_rows_mode()) {
         if (c.pntcld_mode) GIE_LAUNCH(b, k_fuse_rows<true>, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
         else GIE_LAUNCH(b, k_fuse_rows<false>, dim3(b->cu_total * mult), dim3(256), 0, c, op_fuse(), list);
@@ -403,7 +442,7 @@ static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *know
     /* (tried in round 4: the face voxels on a side stream next to the tiles, forked and joined with events — 2.352 against 2.352 ms per
      * C5 update: what the overlap saves the two stream hand-overs cost) */
     GIE_LAUNCH(b, k_frontier_faces, dim3(nsum + nface), dim3(64 * GIE_FF_WAVES), 0, c, fp, known, known_idx, nsum);
-    static int mult = getenv("GIE_FRONT_MULT") ? atoi(getenv("GIE_FRONT_MULT")) : 0;
+    static int mult = GIE_SWITCH("GIE_FRONT_MULT", 0);
     if (mult <= 0) {    /* as many workgroups as are resident at once: every wave walks the same share of the list (a second round of workgroups would start when the first is done) */
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_frontier_tiles), 64 * GIE_FR_WAVES, 0) != hipSuccess || per_cu < 1) per_cu = 2;
@@ -430,7 +469,7 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     /* one 32-voxel mask word per thread: with only the planes that hold obstacles at work, the
      * pass is bound by how many loads are in flight, not by bytes */
     /* X % 4 == 0: four columns per lane, dword loads / 8-byte stores (k_edt_y4) */
-    static const int y4 = getenv("GIE_EDTY4") ? atoi(getenv("GIE_EDTY4")) : 1;
+    static const int y4 = GIE_SWITCH("GIE_EDTY4", 1);
     if (y4 && (c.X & 3) == 0) {
         /* y4: 1 = 16 lanes x 4 columns per workgroup (more, smaller workgroups), 3 = 32 lanes */
         const int yb = c.Y > 512 ? 32 : 16, nq = (c.Y + yb - 1) / yb;

@@ -1253,18 +1253,22 @@ __global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx 
         }
         if (threadIdx.x == 0) *c.zcount = k;
     }
-    /* one wave per (x,y) tile column, lane = z tile: the ballot IS the mask */
-    const int col = blockIdx.x * GIE_PREP_WAVES + (threadIdx.x >> 6), tz = threadIdx.x & 63;
+    /* one wave per (x,y) tile column, lane = z tile: the ballot IS the mask (of the first 64 z tiles: pass Z only goes by the masks
+     * when there are no more, gie_batch_edt) */
+    const int col = blockIdx.x * GIE_PREP_WAVES + (threadIdx.x >> 6);
     const bool colok = col < ncol;
     const int tx = colok ? col % c.tfd[0] : 0, ty = colok ? col / c.tfd[0] : 0;
-    const int t = (tz * c.tfd[1] + ty) * c.tfd[0] + tx;
-    const bool k = colok && tz < c.tfd[2] && c.tknown[t];
-    const unsigned long long m = __ballot(k);
-    if (colok && tz == 0) c.zneed[col] = m;
-    /* the same tiles as a list (mark / commit / pass Z visit only these when they are few): one atomic per workgroup */
-    const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_KNOWN], k);
-    if (slot >= 0) c.tl_known[slot] = t;
-    if (c.oldskip && colok && tz < c.tfd[2]) gie_tile_oldskip(c, t);     /* (tskip is zero otherwise: the frame clear) */
+    for (int tz0 = 0; tz0 < c.tfd[2]; tz0 += 64) {           /* (volumes taller than 512 voxels: ADVICE r4 — their upper tiles were never listed nor flagged; uniform over the workgroup) */
+        const int tz = tz0 + (int)(threadIdx.x & 63);
+        const int t = (tz * c.tfd[1] + ty) * c.tfd[0] + tx;
+        const bool k = colok && tz < c.tfd[2] && c.tknown[t];
+        const unsigned long long m = __ballot(k);
+        if (colok && tz == 0) c.zneed[col] = m;
+        /* the same tiles as a list (mark / commit / pass Z visit only these when they are few): one atomic per workgroup */
+        const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_KNOWN], k);
+        if (slot >= 0) c.tl_known[slot] = t;
+        if (c.oldskip && colok && tz < c.tfd[2]) gie_tile_oldskip(c, t);     /* (tskip is zero otherwise: the frame clear) */
+    }
 }
 
 /* ------------------------------------------------------------------ adaptive sweeps */

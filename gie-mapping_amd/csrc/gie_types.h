@@ -286,4 +286,17 @@ GIE_HD int gie_bdr_index(const gie_ctx &c, int x, int y, int z)
     return 2 * YZ + 2 * XZ + XY + x + c.X * y;
 }
 
+/* Test / measurement switches.  The PRODUCTION library (built without -DGIE_TEST_HOOKS: libgie_hip.so) reads nothing from the
+ * environment: every switch is its default, a compile-time constant, and the gie_debug_* hooks do not exist — its results depend
+ * on its arguments only.  The test build of the same sources (libgie_hip_test.so, tests/hooks_py.py; the CPU emulation of tests/emu
+ * is always one) reads GIE_<NAME> once per process.  What a caller may legitimately tune is in gie_config (wave_workgroups,
+ * place_tries). */
+#if defined(GIE_TEST_HOOKS)
+#include <stdlib.h>
+static inline int gie_switch_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#define GIE_SWITCH(name, dflt) gie_switch_env(name, dflt)
+#else
+#define GIE_SWITCH(name, dflt) (dflt)
+#endif
+
 #endif /* GIE_TYPES_H */

@@ -28,7 +28,9 @@ class Config(C.Structure):
         ("max_blocks", C.c_int32),
         ("device_id", C.c_int32),
         ("retain_radius_blocks", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("wave_workgroups", C.c_int32),
+        ("place_tries", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -113,6 +115,10 @@ class KernelTime(C.Structure):
 
 # exchange rounds gated on the device: the device library and the test-only emulation of its logic (not the oracle, which has no device)
 ROUND_API = {
+    "read_costmap_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(CostMapHdr)]),
+    "costmap_publish": (C.c_int, [_H, C.POINTER(CostMapHdr)]),
+    "costmap_acquire": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "query_global_dev": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
     "round_gate": (C.c_int, [_H, C.c_void_p]),
     "refine_dev": (C.c_int, [_H, C.c_void_p]),
     "round_end": (C.c_int, [_H, C.c_void_p]),

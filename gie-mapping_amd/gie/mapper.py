@@ -33,7 +33,7 @@ def flt2grids_sq(rad, voxel_width):
 
 def make_config(voxel_width, local_size, occupancy_threshold=180, ogm_min_h=-1000.0, ogm_max_h=1000.0,
                 cutoff_dist=None, cutoff_grids_sq=None, fast_mode=False, for_motion_planner=False,
-                robot_r=0.4, max_blocks=0, device_id=0, retain_radius_blocks=0):
+                robot_r=0.4, max_blocks=0, device_id=0, retain_radius_blocks=0, wave_workgroups=0, place_tries=0):
     cfg = Config()
     cfg.voxel_width = voxel_width
     cfg.local_size[:] = [int(v) for v in local_size]
@@ -49,6 +49,8 @@ def make_config(voxel_width, local_size, occupancy_threshold=180, ogm_min_h=-100
     cfg.max_blocks = int(max_blocks)
     cfg.device_id = int(device_id)
     cfg.retain_radius_blocks = int(retain_radius_blocks)
+    cfg.wave_workgroups = int(wave_workgroups)
+    cfg.place_tries = int(place_tries)
     return cfg
 
 
@@ -185,6 +187,31 @@ class MapperBase:
         hdr = CostMapHdr()
         self._chk(self._f["read_costmap"](self._h, _ptr(pay), C.byref(hdr)))
         return pay, hdr
+
+    def read_costmap_dev(self, dptr):
+        """The SeenDist payload into a device buffer (raw device address), asynchronous on the mapper's stream; returns the header."""
+        hdr = CostMapHdr()
+        self._chk(self._f["read_costmap_dev"](self._h, C.c_void_p(dptr), C.byref(hdr)))
+        return hdr
+
+    def costmap_publish(self):
+        """Enqueue conversion + asynchronous copy into the library's pinned memory; returns the header at once."""
+        hdr = CostMapHdr()
+        self._chk(self._f["costmap_publish"](self._h, C.byref(hdr)))
+        return hdr
+
+    def costmap_acquire(self, copy=True):
+        """Wait for the last publish; the payload as an array over the library's pinned buffer (copy=False: a VIEW that the publish
+        after the next one overwrites)."""
+        p = C.c_void_p()
+        self._chk(self._f["costmap_acquire"](self._h, C.byref(p)))
+        buf = (C.c_uint8 * (self.n * SEENDIST_DTYPE.itemsize)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=SEENDIST_DTYPE).reshape(self._shape())
+        return a.copy() if copy else a
+
+    def query_global_dev(self, d_xyz, n, d_out):
+        """n lookups with coordinates (n x 3 int32) and results (n gie_voxel) in DEVICE buffers, enqueued on the mapper's stream."""
+        self._chk(self._f["query_global_dev"](self._h, C.c_void_p(d_xyz), int(n), C.c_void_p(d_out)))
 
     def query_global(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1, 3)

@@ -57,6 +57,7 @@ struct Parameters {
     bool fast_mode = true;               /* code default, parameters.h:93 */
     float cutoff_dist = 6.0f;
     int max_bucket = 10000, max_block = 19997;
+    int wave_workgroups = 0, place_tries = 0;   /* gie_config fields of the same name (no counterpart in the reference): "gpu/wave_workgroups", "gpu/place_tries" */
     bool is_ext_obsv_3D = false;
     std::vector<Vec3> obsbbx_ll{ { -3.6f, -3.2f, 0.2f } }, obsbbx_ur{ { 4.4f, 3.4f, 2.6f } };   /* the hard-coded fence */
 
@@ -101,6 +102,7 @@ struct Parameters {
         else if (k == "ogm/min_height") ogm_min_h = fl(); else if (k == "ogm/max_height") ogm_max_h = fl();
         else if (k == "wave/fast_mode") fast_mode = b(); else if (k == "wave/cutoff_dist") cutoff_dist = fl();
         else if (k == "hash/bucket_max") max_bucket = in(); else if (k == "hash/block_max") max_block = in();
+        else if (k == "gpu/wave_workgroups") wave_workgroups = in(); else if (k == "gpu/place_tries") place_tries = in();
         else if (k == "is_ext_obsv_3D") is_ext_obsv_3D = b();
     }
     gie_config to_config(int device_id = 0) const
@@ -117,6 +119,7 @@ struct Parameters {
         c.fast_mode = fast_mode; c.for_motion_planner = for_motion_planner; c.robot_r2_grids = robot_r2_grids();
         c.max_blocks = 0;            /* hash/block_max of the shipped yaml files (≈12-22 k) is far too small for big volumes */
         c.device_id = device_id;
+        c.wave_workgroups = wave_workgroups; c.place_tries = place_tries;
         return c;
     }
 };

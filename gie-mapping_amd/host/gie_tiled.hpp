@@ -89,6 +89,8 @@ struct HaloTransport {
     virtual void exchange(const std::map<int, int> &nbs, const std::map<int, void *> &send, const std::map<int, void *> &recv,
                           const std::map<int, size_t> &bytes, void *stream) = 0;
     virtual long long allreduce_sum(long long v, void *stream) = 0;
+    /* max over the ranks of a DEVICE word, in place, ordered on `stream` (gated rounds; device-resident transports only) */
+    virtual void allreduce_max_dev(int32_t *, void *) { throw std::runtime_error("this transport has no device-side all-reduce (gated rounds need a device-resident transport)"); }
 };
 
 /* TCP between the ranks of one host: rank r listens on base_port + r; a full mesh of connections, made once.
@@ -195,6 +197,11 @@ public:
         }
         ck(ncclGroupEnd());
     }
+    /* the "some tile changed" word of a gated round: max over the ranks, in place, on the stream — nobody waits */
+    void allreduce_max_dev(int32_t *d_word, void *stream) override
+    {
+        ck(ncclAllReduce(d_word, d_word, 1, ncclInt32, ncclMax, comm_, (hipStream_t)stream));
+    }
     long long allreduce_sum(long long v, void *stream) override
     {
         if (world_ == 1) return v;
@@ -217,7 +224,10 @@ private:
 class TiledMapper {
 public:
     /* p.local_size_* is the TILE's size; fixed_rounds > 0: that many refinement rounds per update, enqueued without a
-     * convergence test (device-resident transports: the host never waits); 0: rounds until no rank seeded anything */
+     * convergence test (device-resident transports: the host never waits); 0: rounds until no rank seeded anything, the host
+     * reading the all-reduced seed count after every round; < 0: at most -fixed_rounds rounds enqueued per update and GATED ON THE
+     * DEVICE by the all-reduced "changed" word of the round before (gie_round_gate / gie_refine_dev / gie_round_end: rounds until no
+     * tile changed without the host in the loop — device-resident transports only; round_stats() says what ran) */
     TiledMapper(const Parameters &p, const TileLayout &layout, HaloTransport &tr, int device_id = 0, int fixed_rounds = 0)
         : param(p), layout_(layout), tr_(tr), fixed_rounds_(fixed_rounds), cfg_(p.to_config(device_id))
     {
@@ -243,12 +253,19 @@ public:
             host_send_[fn.first].resize(n); host_recv_[fn.first].resize(n);
             send_[fn.first] = host_send_[fn.first].data(); recv_[fn.first] = host_recv_[fn.first].data();
         }
+        if (fixed_rounds_ < 0) {
+            if (!tr_.device_resident()) throw std::runtime_error("TiledMapper: gated rounds need a device-resident transport");
+#if defined(GIE_WITH_RCCL)
+            if (hipMalloc((void **)&d_words_, 2 * sizeof(int32_t)) != hipSuccess) throw std::runtime_error("TiledMapper: hipMalloc failed");
+#endif
+        }
     }
     ~TiledMapper()
     {
         if (m_) gie_destroy(m_);
 #if defined(GIE_WITH_RCCL)
         if (tr_.device_resident()) for (auto &kv : send_) { (void)hipFree(kv.second); (void)hipFree(recv_[kv.first]); }
+        if (d_words_) (void)hipFree(d_words_);
 #endif
     }
     TiledMapper(const TiledMapper &) = delete;
@@ -270,6 +287,7 @@ public:
         chk(gie_merge_begin_tiled(m_));
         round(true);                                       /* this update's face layers -> ghosts, then the rest of the merge */
         rounds = 0;
+        if (fixed_rounds_ < 0) { gated_rounds(-fixed_rounds_); chk(gie_sync(m_)); frame++; return; }
         for (;;) {
             if (fixed_rounds_ > 0 && rounds >= fixed_rounds_) break;
             const long long seeded = round(false);
@@ -282,6 +300,8 @@ public:
     }
     gie_mapper *handle() { return m_; }
     const gie_config &config() const { return cfg_; }
+    /* gated mode: { rounds enqueued, rounds that ran, map updates, map updates left unconverged } since construction */
+    void round_stats(int64_t out[4]) { chk(gie_round_stats(m_, out)); }
     Parameters param;
     int rounds = 0, frame = 0;
 private:
@@ -306,7 +326,32 @@ private:
         chk(gie_refine(m_, &seeded));
         return tr_.allreduce_sum(seeded, stream_);
     }
+    /* SURVEY 8(e) "until no GPU changed" with nobody waiting for the host: `bound` rounds enqueued, each but the first gated by the
+     * all-reduced (max) "changed" word of the round before — the sequence of gie/tiling.py exchange_converged_device */
+    void gated_rounds(int bound)
+    {
+#if defined(GIE_WITH_RCCL)
+        int32_t *d_changed = d_words_, *d_go = d_words_ + 1;
+        gie_halo_voxel *out[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+        const gie_halo_voxel *in[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+        for (const auto &fn : nbs_) { out[fn.first] = (gie_halo_voxel *)send_[fn.first]; in[fn.first] = (const gie_halo_voxel *)recv_[fn.first]; }
+        for (int k = 1; k <= bound; k++) {
+            chk(gie_round_gate(m_, k > 1 ? d_go : nullptr));
+            chk(gie_halo_export_all_dev(m_, out));
+            tr_.exchange(nbs_, send_, recv_, bytes_, stream_);
+            chk(gie_halo_import_all_dev(m_, in));
+            chk(gie_refine_dev(m_, d_changed));
+            if (hipMemcpyAsync(d_go, d_changed, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_) != hipSuccess) throw std::runtime_error("TiledMapper: copy failed");
+            tr_.allreduce_max_dev(d_go, stream_);
+        }
+        chk(gie_round_end(m_, d_go));
+        rounds = bound;
+#else
+        (void)bound; throw std::runtime_error("built without RCCL");
+#endif
+    }
     static void chk(int rc) { if (rc != GIE_OK) throw std::runtime_error(std::string("gie: ") + gie_last_error()); }
+    int32_t *d_words_ = nullptr;
     TileLayout layout_;
     HaloTransport &tr_;
     int fixed_rounds_;

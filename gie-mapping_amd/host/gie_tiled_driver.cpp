@@ -10,6 +10,8 @@
  * --transport rccl   : (built with -DGIE_WITH_RCCL) RCCL send / receive of the device buffers on the mapper's stream; the
  *                      sockets only carry the ncclUniqueId.  --device defaults to the rank.
  * --rounds N > 0     : N refinement rounds per update without a convergence test (stream ordered with rccl).
+ * --rounds N < 0     : at most -N rounds enqueued per update, gated on the device by the all-reduced "changed" word (rccl only;
+ *                      what bench.py --gpus N runs by default).
  * Outputs after the last frame: prefix.rR.{edt.f32,type.i8,dist.i32,coc.i32}; stdout: "rank R frames F rounds K".
  */
 #include "gie_tiled.hpp"
@@ -60,10 +62,10 @@ int main(int argc, char **argv)
 #endif
         {   /* Ranks that share a device (the socket transport puts every rank on device 0 unless told otherwise, and is what a single-device check uses): the persistent
              * grids of their wavefront kernels have to be resident side by side, or the grid barriers of two half-resident grids
-             * wait for each other until they time out (GIE_ERR_TIMEOUT).  The library reads GIE_WAVE_WGS at
-             * gie_create; a value the caller has set stands. */
+             * wait for each other until they time out (GIE_ERR_TIMEOUT): gie_config.wave_workgroups; a value the
+             * parameter file has set ("gpu/wave_workgroups") stands. */
             const int sharing = transport == "rccl" ? 1 : world;      /* (host-staged sockets: ranks of one host, as a rule of one device — also with an explicit --device) */
-            if (sharing > 1) { const std::string v = std::to_string(std::max(8, 192 / sharing)); setenv("GIE_WAVE_WGS", v.c_str(), 0); }
+            if (sharing > 1 && p.wave_workgroups == 0) p.wave_workgroups = std::max(8, 192 / sharing);
         }
         TiledMapper node(p, layout, *tr, transport == "rccl" ? (device >= 0 ? device : rank) : (device >= 0 ? device : 0), rounds);
         const size_t N = (size_t)tile[0] * tile[1] * tile[2];

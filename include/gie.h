@@ -65,7 +65,16 @@ typedef struct gie_config {
                                      of the local volume +-1 voxel are erased — their voxels revert to the defaults
                                      (UNKNOWN, EMPTY_VALUE, EMPTY_KEY) — and go back to the pool's free list, so a robot
                                      that drives on forever runs on a fixed pool.  Erased blocks are not streamed. */
-    int32_t reserved[5];
+    int32_t wave_workgroups;      /* workgroups of the persistent wavefront kernel (waves A / B / C; its grid barrier needs all of them resident
+                                     at once).  0 = half the device's compute units, so that two mappers or processes with default settings
+                                     share a device; a process that owns its device may ask for more (160 of 256 measured best on an MI355X),
+                                     N processes on one device for at most (compute units) / N each. */
+    int32_t place_tries;          /* 0 / 1 = off.  T > 1: gie_create times the Mark + commit sweep's memory pattern on the mapper's four large
+                                     planes and re-allocates each up to T - 1 times, keeping the faster physical placement (the same kernel runs
+                                     0.76 or 0.84 ms from one allocation to the next on an MI355X).  Costs tens of milliseconds and, transiently,
+                                     a second copy of one plane; only for volumes of 16 M voxels and more.  Off by default: create is then
+                                     deterministic and holds no more memory than the mapper keeps. */
+    int32_t reserved[3];
 } gie_config;
 
 /* MulScanParam, include/cuda_toolkit/occupancy/vlp16/multiscan_param.h:4-27 */
@@ -210,9 +219,24 @@ int gie_read_batch_edt(gie_mapper *h, int32_t *dist_sq, int32_t *coc_xyz_local);
 /* LocMap::convertCostMap (local_batch.h:382-391) + setupEDTmsg4Motion
  * (volumetric_mapper.cpp:375-389). payload: N gie_seendist. */
 int gie_read_costmap(gie_mapper *h, gie_seendist *payload, gie_costmap_hdr *hdr);
+/* The same payload for consumers that cannot afford the stall (at 512^3 it is 1.07 GB per frame; the reference's blocking copy into
+ * pageable memory, local_batch.h:370-391, was written for volumes 100x smaller):
+ *  gie_read_costmap_dev   into a DEVICE buffer of the caller's (a GPU planner), asynchronous on the mapper's stream;
+ *  gie_costmap_publish    conversion on the mapper's stream + ONE asynchronous copy into pinned host memory the library owns, on a
+ *                         copy stream of its own: returns at once, and the next map update does not queue up behind the copy;
+ *  gie_costmap_acquire    waits for the last publish and hands out its payload (N gie_seendist in pinned memory; valid until the
+ *                         publish after the next one — two buffers alternate). */
+int gie_read_costmap_dev(gie_mapper *h, gie_seendist *d_payload, gie_costmap_hdr *hdr);
+int gie_costmap_publish(gie_mapper *h, gie_costmap_hdr *hdr);
+int gie_costmap_acquire(gie_mapper *h, const gie_seendist **payload);
 /* Hash lookup + retrive_vox_D (voxmap_utils.cuh:94-132) for n global coords. Voxels of
  * unallocated blocks come back as a default GlbVoxel (UNKNOWN, EMPTY_VALUE, EMPTY_KEY). */
 int gie_query_global(gie_mapper *h, const int32_t *xyz, int n, gie_voxel *out);
+/* Device-side access to the global map for GPU planners — the integration the reference recommends (README.md:163-165:
+ * get_VB_key / get_voxID_in_VB / hash_table_D lookups inside the planner's own kernels, voxmap_utils.cuh:94-132): d_xyz (n x 3)
+ * and d_out (n) are DEVICE buffers, the lookup kernel is enqueued on the mapper's stream (gie_get_stream), nothing is copied and
+ * the host does not wait.  Same records as gie_query_global. */
+int gie_query_global_dev(gie_mapper *h, const int32_t *d_xyz, int n, gie_voxel *d_out);
 int gie_get_stats(gie_mapper *h, gie_frame_stats *out);
 
 /* ---- changed-block streaming: the CPU mirror the reference keeps for RViz and CPU planners.

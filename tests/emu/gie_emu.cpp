@@ -9,6 +9,7 @@
  * `pytest -m gpu` covers them.
  */
 #define GIE_HOST_EMU 1
+#define GIE_TEST_HOOKS 1      /* the emulation is test infrastructure: the switches of gie_api.inc.h read the environment here */
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -18,7 +19,7 @@
 
 struct be_state { int dummy; };
 static void gie_set_err(const std::string &s);
-static int be_init(be_state *, int) { return 0; }
+static int be_init(be_state *, int, int) { return 0; }
 static void be_fini(be_state *) {}
 static void *be_alloc(be_state *, size_t bytes, bool zero) { return zero ? calloc(bytes ? bytes : 1, 1) : malloc(bytes ? bytes : 1); }
 static void be_free(be_state *, void *p) { free(p); }
@@ -32,6 +33,9 @@ static void *be_host_alloc(be_state *, size_t bytes) { return malloc(bytes ? byt
 static void be_host_free(be_state *, void *p) { free(p); }
 static void be_d2h_async(be_state *, void *h, const void *d, size_t n, int) { memcpy(h, d, n); }
 static void be_wait(be_state *, int) {}
+static void be_side_copy_begin(be_state *) {}
+static void be_side_copy(be_state *, void *h, const void *d, size_t n) { memcpy(h, d, n); }
+static int be_side_copy_wait(be_state *) { return 0; }
 static void be_time(be_state *, int) {}
 static void be_prof(be_state *, int, int) {}
 static void be_prof_enable(be_state *, int) {}

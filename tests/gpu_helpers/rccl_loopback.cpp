@@ -94,6 +94,34 @@ int main(int argc, char **argv)
             hchk(hipMemcpy(d.data(), exp[f], bytes[f], hipMemcpyDeviceToHost), "hipMemcpy");
             if (memcmp(d.data(), h.data(), bytes[f]) != 0) throw std::runtime_error("device and host export of face " + std::to_string(f) + " differ");
         }
+        /* gated rounds (gie_round_gate / gie_refine_dev / gie_round_end) with the all-reduce(max) of the "changed" word over RCCL on the
+         * mapper's stream: one more update, three rounds enqueued.  The ring neighbour is this mapper, whose own face layers hold
+         * nothing closer than what it has: the first round seeds nothing, the others meet a closed gate. */
+        {
+            int32_t *d_words = nullptr;
+            hchk(hipMalloc((void **)&d_words, 8), "hipMalloc");
+            gchk(gie_set_pose(m, pos, quat));
+            gchk(gie_ogm_labels(m, lab.data()));
+            gchk(gie_fuse(m)); gchk(gie_batch_edt(m)); gchk(gie_merge_begin_tiled(m));
+            gie_halo_voxel *out[6] = { (gie_halo_voxel *)exp[0], (gie_halo_voxel *)exp[1], nullptr, nullptr, nullptr, nullptr };
+            const gie_halo_voxel *in[6] = { (const gie_halo_voxel *)recv[0], (const gie_halo_voxel *)recv[1], nullptr, nullptr, nullptr, nullptr };
+            gchk(gie_halo_export_all_dev(m, out)); tr->exchange(nbs, send, recv, bytes, stream); gchk(gie_halo_import_all_dev(m, in));
+            gchk(gie_merge_end(m));
+            for (int k = 1; k <= 3; k++) {
+                gchk(gie_round_gate(m, k > 1 ? d_words + 1 : nullptr));
+                gchk(gie_halo_export_all_dev(m, out)); tr->exchange(nbs, send, recv, bytes, stream); gchk(gie_halo_import_all_dev(m, in));
+                gchk(gie_refine_dev(m, d_words));
+                hchk(hipMemcpyAsync(d_words + 1, d_words, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync");
+                tr->allreduce_max_dev(d_words + 1, stream);
+            }
+            gchk(gie_round_end(m, d_words + 1));
+            int64_t st[4];
+            gchk(gie_round_stats(m, st));
+            if (st[0] != 3 || st[1] < 1 || st[1] > 3 || st[2] != 1 || st[3] != 0)
+                throw std::runtime_error("gated rounds: stats " + std::to_string(st[0]) + " " + std::to_string(st[1]) + " " + std::to_string(st[2]) + " " + std::to_string(st[3]));
+            printf("gated rounds over RCCL: %lld enqueued, %lld ran, unconverged %lld\n", (long long)st[0], (long long)st[1], (long long)st[3]);
+            (void)hipFree(d_words);
+        }
         long long s = tr->allreduce_sum(41, stream);
         if (s != 41) throw std::runtime_error("allreduce_sum over one rank changed the value");
         for (int f = 0; f < 2; f++) { (void)hipFree(exp[f]); (void)hipFree(recv[f]); }

@@ -34,6 +34,32 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def _dyn_symbols(path, undefined=False):
+    import subprocess
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else "nm"
+    out = subprocess.run([nm, "-D", "--undefined-only" if undefined else "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()})
+
+
+def test_production_library_exports_nothing_but_the_header_and_reads_no_environment():
+    """libgie_hip.so is what gie.h says and nothing else — no gie_debug_* hooks — and its results cannot
+    depend on the environment: not one GIE_* variable name is left in the binary (getenv itself stays imported: rocPRIM's scan
+    reads a variable of its own).  The switches and hooks live in the test build of the same sources (-DGIE_TEST_HOOKS,
+    tests/gpu_helpers/libgie_hip_test.so), which must have both."""
+    import __graft_entry__
+    if not os.path.exists(gie.LIB_PATH):
+        __graft_entry__.build_hip()
+    declared = set(_declared())
+    exported = {n for n in _dyn_symbols(gie.LIB_PATH) if n.startswith("gie_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    names = lambda path: sorted(set(re.findall(rb"GIE_[A-Z0-9_]{3,}(?=\x00)", open(path, "rb").read())))      # noqa: E731
+    assert names(gie.LIB_PATH) == []
+    test_so = __graft_entry__.build_hip_test_hooks()
+    texp = {n for n in _dyn_symbols(test_so) if n.startswith("gie_")}
+    assert declared <= texp and {"gie_debug_fault_barrier", "gie_debug_place_probe"} <= texp
+    assert {b"GIE_TILE_LIST", b"GIE_DEBUG_POOL_BASE", b"GIE_FUSED", b"GIE_STREAM_CHUNK_BLOCKS"} <= set(names(test_so))
+
+
 def test_no_cpu_fallback_without_gpu():
     try:
         import torch

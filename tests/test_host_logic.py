@@ -24,6 +24,8 @@ SCENARIOS = [
     # ray casting in thin volumes: rays cut by the maximum length 0.707*X*w (X = 16), and rays that leave the volume long before they end
     parity.Scenario("thin_x", (16, 200, 8), sensor="lidar_points", frames=6, delta_vox=5, yaw_deg=40.0, lidar_az=720),
     parity.Scenario("thin_y", (200, 16, 8), sensor="lidar_points", frames=6, delta_vox=5, yaw_deg=40.0, lidar_az=720),
+    # a volume taller than 512 voxels: more than 64 z tiles per tile column (the upper tiles were never listed nor flagged)
+    parity.Scenario("tall_z", (16, 24, 600), voxel=0.05, sensor="labels", frames=4, delta_vox=5, yaw_deg=2.0, seed=8, cutoff_dist=1.0, p_occ=0.004),
     # BASELINE C3's wave parameters (ugv yaml: cutoff 100 m => no cutoff at all, full waves A+B), small volume
     parity.Scenario("c3_no_cutoff", (56, 56, 20), voxel=0.1, sensor="multiscan", frames=10, delta_vox=6, yaw_deg=12.0,
                     cutoff_dist=100.0, extent=(5.0, 5.0, 1.5)),
@@ -374,3 +376,30 @@ def test_halo_import_between_pose_and_fuse_keeps_the_block_table_honest(oracle_l
         for key in ("type", "dist_sq", "coc"):
             assert np.array_equal(ra[key], rb[key]), key
         assert np.array_equal(ga, gb), int((ga != gb).sum())
+
+
+def test_device_reader_entry_points_on_the_emulated_backend(oracle_lib):
+    """gie_query_global_dev / gie_read_costmap_dev / gie_costmap_publish + _acquire through the shared orchestration code
+    (gie_api.inc.h) on the emulated backend, where a "device pointer" is host memory: the bytes of the host forms."""
+    sc = parity.Scenario("dev_readers_cpu", (40, 32, 16), sensor="mixed", frames=3, delta_vox=5, yaw_deg=20.0)
+    cfg = sc.config()
+    a, b = OracleMapper(cfg), EmuMapper(cfg)
+    X, Y, Z = sc.size
+    try:
+        for pos, q, kind, data, kw in sc.frames_iter():
+            for m in (a, b):
+                m.update(pos, q, kind, data, **kw)
+            b.costmap_publish()
+            pv = np.array(b.pivot())
+            probes = np.ascontiguousarray((np.stack(np.meshgrid(np.arange(-9, X + 9, 4), np.arange(-9, Y + 9, 4), np.arange(-9, Z + 9, 4), indexing="ij"), -1).reshape(-1, 3) + pv).astype(np.int32))
+            want = a.query_global(probes)
+            out = np.zeros(probes.shape[0], want.dtype)
+            b.query_global_dev(probes.ctypes.data, probes.shape[0], out.ctypes.data)
+            assert out.tobytes() == want.tobytes()
+            pa, _ = a.read_costmap()
+            cm = np.zeros(X * Y * Z * 8, np.uint8)
+            b.read_costmap_dev(cm.ctypes.data)
+            assert cm.tobytes() == pa.tobytes()
+            assert b.costmap_acquire().tobytes() == pa.tobytes()
+    finally:
+        a.close(); b.close()

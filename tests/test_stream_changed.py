@@ -115,9 +115,10 @@ def test_stream_in_several_chunks(monkeypatch):
 @pytest.mark.gpu
 def test_stream_on_gpu_matches_oracle(monkeypatch):
     monkeypatch.setenv("GIE_STREAM_CHUNK_BLOCKS", "500")      # several chunks: exercises the double-buffered copy
+    from hooks_py import HooksMapper                           # (the switch exists in the test build of the library only)
     sc = Scenario("stream_gpu", (160, 160, 64), sensor="mixed", frames=4, cutoff_dist=2.0, img=(240, 320, 260.0), max_depth=10.0,
                   extent=(7.0, 7.0, 2.5))
-    flagged = _run(gie.Mapper, sc)
+    flagged = _run(HooksMapper, sc)
     assert max(flagged) > 1000
 
 

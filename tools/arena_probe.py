@@ -5,19 +5,18 @@
 import os, subprocess, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "one":
-    sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd")]
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd"), os.path.join(ROOT, "tests")]
     import torch, gie, bench
     from gie import scenes
+    from hooks_py import HooksMapper      # the arena / launch-parameter switches and the placement probe exist in the test build of the library only
     dev = torch.device("cuda", 0)
     size = tuple(int(v) for v in os.environ.get("PROBE_SIZE", "512,512,512").split(","))
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False, max_blocks=bench.pool_blocks("c5", size, 40))
     for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
-        m = gie.Mapper(cfg)
+        m = HooksMapper(cfg)
         probe_ms = -1.0
         if os.environ.get("PROBE_PLACE"):
-            import ctypes as C
-            f = gie.mapper._lib.gie_debug_place_probe; f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
-            v = C.c_float(0); f(m._h, 5, C.byref(v)); probe_ms = v.value
+            probe_ms = m.debug_place_probe(5)
         feed = bench.make_feed("c5", torch, scenes, dev, 0.05, size, (0, 0, 0), 10)
         feed.prepare(0, 8)
         for i in range(3):

@@ -1,7 +1,10 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the C5 headline workload under a list of environment variants, one bench line each.
 #   tools/c5_variants.sh "NAME=VALUE ..." "NAME=VALUE ..." ...     ("" = defaults)
+# The GIE_* switches only exist in the TEST build of the library (tests/gpu_helpers/libgie_hip_test.so, -DGIE_TEST_HOOKS): the
+# package loads it through GIE_LIB; the product library reads no environment.
 set -u
+export GIE_LIB=$(pwd)/tests/gpu_helpers/libgie_hip_test.so
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/variants; mkdir -p $OUT
 i=0
 for v in "$@"; do
