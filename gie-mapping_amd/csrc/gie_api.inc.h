@@ -205,6 +205,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.ucol = gie_dalloc<uint8_t>(m, (((size_t)X * Y * ((Z + 7) / 8)) + 3) & ~(size_t)3);
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
+    c.zredo = gie_dalloc<uint32_t>(m, (size_t)((X + 15) / 16) * Y);
     c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
     c.zcount = gie_dalloc<int32_t>(m, 4);
     c.tl_known = gie_dalloc<int32_t>(m, ntile);
@@ -617,6 +618,7 @@ extern "C" int gie_fuse(gie_mapper *m)
         add(c.tflag, 5 * ntile);                                   /* tflag | tunk | tsum | tray | tact */
         add(c.tknown, ntile);
         add(c.zocc, (size_t)c.Z);
+        add(c.zredo, (size_t)((c.X + 15) / 16) * c.Y * sizeof(uint32_t));
         add(c.tmax, ntile * sizeof(int32_t));
         add(c.tskip, ntile);
         add(c.cnt, GIE_CNT_ERR * sizeof(int32_t));                 /* per-frame counters (the sticky error flag survives) */

@@ -362,7 +362,8 @@ static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass,
     else gie_launch_edt_xz<16>(b, c, zpass, full);
 }
 /* pass Z again over the whole volume (the passes before it are complete either way) */
-static void be_edt_z(be_state *b, const gie_ctx &c, int full) { gie_launch_edt_dim(b, c, c.Z, true, full); }
+static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full);
+static void be_edt_z(be_state *b, const gie_ctx &c, int full) { be_edt_z_stream(b, c, full); gie_launch_edt_dim(b, c, c.Z, true, full); }
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
 /* adaptive sweep (k_voxa): the kernel walks the list or sweeps the volume, whichever the list's
  * length calls for; staged = the functor's load1/load2/finish form; always_list = never sweep */
@@ -454,6 +455,27 @@ static void be_edt_z_direct(be_state *b, const gie_ctx &c)
 {
     GIE_LAUNCH(b, k_edt_z_direct, dim3(b->cu_total * 16), dim3(256), 0, c);
 }
+/* the streaming form of pass Z (k_edt_z_stream): a wave per (64 columns, y, z segment) */
+static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full)
+{
+    if (c.Z < 64 || c.Z > 1024) return;            /* (short columns: the column kernel) */
+    static const int on = GIE_SWITCH("GIE_ZSTREAM", 1);
+    if (!on) return;
+    const int nxr = (c.X + 63) / 64;
+    /* z segments so that the launch has about eight waves per SIMD to overlap its rows' round trips (a segment re-reads 16 planes) */
+    static const int target = GIE_SWITCH("GIE_ZSTREAM_WAVES", 8);
+    const long long want = (long long)b->cu_total * 4 * target;
+    int nseg = (int)((want + (long long)nxr * c.Y - 1) / ((long long)nxr * c.Y));
+    const int maxseg = c.Z / 64 > 0 ? c.Z / 64 : 1;
+    if (nseg > maxseg) nseg = maxseg; if (nseg < 1) nseg = 1;
+    int seg_len = ((c.Z + nseg - 1) / nseg + 31) & ~31;
+    nseg = (c.Z + seg_len - 1) / seg_len;
+    const long long waves = (long long)nxr * nseg * c.Y;
+    long long grid = (waves + 3) / 4;
+    const long long cap = (long long)b->cu_total * 8 * 4;
+    if (grid > cap) grid = cap;
+    GIE_LAUNCH(b, k_edt_z_stream, dim3((unsigned)grid), dim3(256), 0, c, full, nseg, seg_len);
+}
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {
     const int ncol = c.tfd[0] * c.tfd[1];
@@ -487,6 +509,7 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0);                                                              /* GIE_K_EDT_Z */
     if (!full) be_edt_z_direct(b, c);
+    be_edt_z_stream(b, c, full);                   /* dense fields: the whole pass; flags what it could not finish for the column kernel */
     gie_launch_edt_dim(b, c, c.Z, true, full);
     be_prof(b, 8, 1);
 

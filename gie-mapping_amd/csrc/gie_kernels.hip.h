@@ -995,6 +995,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
 {
     static_assert(TX == 16 && WAVES == 8, "a workgroup tile spans two 8-voxel tile columns, one column per wave and half");
     if (full == 0 && gie_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) return;   /* few known tiles: k_edt_z_direct (launched next to this one) does the pass */
+    const int repair = c.cnt[GIE_CNT_ZSTREAM];            /* the streaming form (k_edt_z_stream, launched before this one) has done the volume: only the tiles it flagged */
+    if (repair && c.cnt[GIE_CNT_ZFAIL] == 0) return;      /* ... and it finished every column (a walk over the flags of 16 K tiles was 40 us of nothing) */
     constexpr int LP = 64 * CP;
     constexpr int TS = TX + 1;
     constexpr int NT = 64 * WAVES;
@@ -1056,7 +1058,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
         const int txc_ = (((tt) % ntiles_x) * TX) >> 3, tyc_ = ((tt) / ntiles_x) >> 3; \
         const uint64_t *p_ = c.zneed + ((size_t)tyc_ * c.tfd[0] + txc_); \
         o0 = ~0ull; o1 = ~0ull; \
-        if (!full) { \
+        if (repair) { uint32_t r_; asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_) : "s"(c.zredo + (tt)) : "memory"); if (!r_) { o0 = 0ull; o1 = 0ull; } } \
+        if (!full && (o0 | o1) != 0ull) { \
             uint64_t a_, b_ = 0ull; \
             asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(a_) : "s"(p_) : "memory"); \
             if (txc_ + 1 < c.tfd[0]) asm volatile("s_load_dwordx2 %0, %1, 0x8\n\ts_waitcnt lgkmcnt(0)" : "=s"(b_) : "s"(p_) : "memory"); \
@@ -1229,6 +1232,116 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             }
         }
         __syncthreads();                                  /* tile is overwritten by the next trip */
+    }
+}
+
+/* ------------------------------------------------------------------ EDT pass Z, streaming form (dense fields)
+ * With obstacles a few voxels apart in every direction (BASELINE config 5: 1 % of the voxels) the closest obstacle of a voxel
+ * lies within a handful of planes, and the column kernel above — tile staged in LDS, per-column windows out of LDS, two workgroup
+ * barriers per tile, 4 waves per SIMD — spends its time waiting, not computing (round 4: 0.45 ms for 1.08 GB; SALU = VALU,
+ * a quarter of the LDS cycles conflicts).  This form has no LDS round trip at all: a wave owns 64 consecutive columns of one
+ * y (lane = x) and walks along z; every row of pass X's result it reads is one 256-byte run.  A window of
+ * 48 planes lives in REGISTERS as 32-bit keys
+ *     in-plane distance² (8 bits, <= 80) | plane index inside the window (6 bits) | x offset + 8 (5 bits) | y offset + 8 (5 bits) | 0 (8 bits)
+ * and position z takes  min over |d| <= R = 8 of  key[z + d] + (d² << 24):  one v_min3-able chain of static register operands —
+ * the minimum orders by distance², then by plane (the reference's tie rule: the smaller index), and carries the in-plane closest
+ * obstacle along.  EXACT whenever the result is below (R + 1)² = 81: a site outside the window, or one whose in-plane distance² is
+ * above 80 (stored as "none"), costs at least 81.  A column that meets a larger value anywhere makes its wave give the slab up and
+ * flag the four 16-column tiles it spans (c.zredo): the column kernel, launched behind this one, redoes exactly those (the
+ * envelope forms have no such limit).  GIE_ZS_C planes per trip: that many row loads in flight per wave, 2R keys carried over.
+ * Measured on the C5 volume (1.08 GB of rows): 0.26 ms = 4.1 TB/s against 0.45 ms of the column kernel; this device streams a
+ * read and a write of that size in 0.21 ms (tools/sweep_probe.hip).  R = 6 instead of 8 was tried: 457 of 134 M voxels have no
+ * obstacle within 7 planes, their slabs go to the column kernel, and the pass takes 0.50 ms — R = 8 leaves none on that field.
+ * Taken when the planes with obstacles are many (K > GIE_BAND_MAXK, the column kernel's own switch to its windowed form) and the
+ * volume is swept, not listed. */
+#ifndef GIE_ZS_R
+#define GIE_ZS_R 8
+#endif
+#ifndef GIE_ZS_C
+#define GIE_ZS_C 16                                       /* planes per trip: 32 measured 0.305 ms on the C5 volume (119 VGPRs, 4 waves per SIMD), 16: 0.296 (7 waves) */
+#endif
+#define GIE_ZS_W (GIE_ZS_C + 2 * GIE_ZS_R)
+#define GIE_ZS_NONE 0xb0000000u                           /* 176 << 24: + 64 stays below 2^8, and above every finished value */
+#define GIE_ZS_LIMIT ((uint32_t)((GIE_ZS_R + 1) * (GIE_ZS_R + 1)) << 24)
+__device__ __forceinline__ uint32_t gie_zs_key(const uint32_t v, const bool plane_ok, const int x8, const int y8, const int j)
+{
+    const uint32_t ux = (uint32_t)(x8 - (int)(v & 0xffffu)), uy = (uint32_t)(y8 - (int)(v >> 16));      /* offset + 8: 0 .. 16 when it can matter */
+    const int dx = (int)ux - 8, dy = (int)uy - 8;
+    const uint32_t a = (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy));
+    const bool ok = plane_ok && max(ux, uy) <= 16u && a < (uint32_t)((GIE_ZS_R + 1) * (GIE_ZS_R + 1));
+    return ok ? ((a << 24) | ((uint32_t)j << 18) | (ux << 13) | (uy << 8)) : (GIE_ZS_NONE | ((uint32_t)j << 18));
+}
+__global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int full, const int nseg, const int seg_len)
+{
+    __shared__ uint8_t s_occ[1024 + 2 * (32 + 2 * GIE_ZS_R)];        /* plane holds obstacles, for planes -W .. Z + W (0 outside the volume) */
+    const int Z = c.Z, X = c.X, Y = c.Y;
+    if (full == 0 && gie_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) return;   /* few known tiles: k_edt_z_direct does the pass */
+    if (*c.zcount <= GIE_BAND_MAXK) return;               /* planes with obstacles are few: the column kernel's envelope forms (same answer in every workgroup) */
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.cnt[GIE_CNT_ZSTREAM] = 1;
+    for (int i = threadIdx.x; i < Z + 2 * GIE_ZS_W; i += 256) { const int z = i - GIE_ZS_W; s_occ[i] = (z >= 0 && z < Z) ? c.zocc[z] : (uint8_t)0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nxr = (X + 63) >> 6;
+    const int total = nxr * nseg * Y;
+    const size_t plane = (size_t)X * Y;
+    const unsigned nbytes = (unsigned)((size_t)X * Y * Z * 4u);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(c.cxy2), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(c.bcoc, 0, nbytes, 0x00020000);
+    const unsigned pstride = (unsigned)(plane * 4u);
+    for (int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); w < total; w += (int)gridDim.x * 4) {
+        const int xr = w % nxr, seg = (w / nxr) % nseg, y = w / (nxr * nseg);
+        const int x = xr * 64 + lane;
+        const int z0 = seg * seg_len, z1 = min(Z, z0 + seg_len);
+        if (z0 >= Z) continue;
+        const unsigned voff = x < X ? (unsigned)(y * X + x) * 4u : GIE_BUF_OOB;
+        const int x8 = x + 8, y8 = y + 8;
+        uint32_t wk[GIE_ZS_W];
+        /* the planes z0 - R .. z0 + R - 1 of the first trip (window places 0 .. 2R - 1) */
+        {
+            const int zz = z0 - GIE_ZS_R + lane;
+            const unsigned long long pm = __ballot(lane < 2 * GIE_ZS_R && s_occ[zz + GIE_ZS_W] != 0);
+            uint32_t v[2 * GIE_ZS_R];
+#pragma unroll
+            for (int j = 0; j < 2 * GIE_ZS_R; j++) { const int zp = min(max(z0 - GIE_ZS_R + j, 0), Z - 1); v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (unsigned)zp * pstride, 0); }
+#pragma unroll
+            for (int j = 0; j < 2 * GIE_ZS_R; j++) wk[j] = gie_zs_key(v[j], (pm >> j) & 1ull, x8, y8, j);
+        }
+        bool failed = false;
+#pragma unroll 1
+        for (int zc = z0; zc < z1; zc += GIE_ZS_C) {
+            /* planes zc + R .. zc + C + R - 1 -> window places 2R .. W - 1 */
+            {
+                const int zz = zc + GIE_ZS_R + lane;
+                const unsigned long long pm = __ballot(lane < GIE_ZS_C && s_occ[zz + GIE_ZS_W] != 0);
+                uint32_t v[GIE_ZS_C];
+#pragma unroll
+                for (int j = 0; j < GIE_ZS_C; j++) { const int zp = min(zc + GIE_ZS_R + j, Z - 1); v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (unsigned)zp * pstride, 0); }
+#pragma unroll
+                for (int j = 0; j < GIE_ZS_C; j++) wk[2 * GIE_ZS_R + j] = gie_zs_key(v[j], (pm >> j) & 1ull, x8, y8, 2 * GIE_ZS_R + j);
+            }
+            uint32_t worst = 0;
+#pragma unroll
+            for (int t = 0; t < GIE_ZS_C; t++) {
+                const int p = GIE_ZS_R + t;
+                uint32_t b = wk[p];
+#pragma unroll
+                for (int d = 1; d <= GIE_ZS_R; d++) b = min(b, min(wk[p - d], wk[p + d]) + ((uint32_t)(d * d) << 24));
+                const bool in = zc + t < z1;              /* wave-uniform */
+                if (in) worst = max(worst, b);
+                const int s = zc - GIE_ZS_R + (int)((b >> 18) & 63u);
+                const int cx = x8 - (int)((b >> 13) & 31u), cy = y8 - (int)((b >> 8) & 31u);
+                /* stored at once (no second copy of the trip in registers); a slab given up below is redone as a whole by the column kernel */
+                __builtin_amdgcn_raw_buffer_store_b32(gie_pack_bcoc(cx, cy, s), rs_out, in ? voff : GIE_BUF_OOB, (unsigned)min(zc + t, Z - 1) * pstride, 0);
+            }
+            if (__any(x < X && worst >= GIE_ZS_LIMIT)) { failed = true; break; }      /* wave-uniform */
+#pragma unroll
+            for (int j = 0; j < 2 * GIE_ZS_R; j++) wk[j] = wk[GIE_ZS_C + j] - ((uint32_t)GIE_ZS_C << 18);      /* the last 2R planes are the next trip's first */
+        }
+        if (failed && lane < 4) {                         /* the column kernel redoes the slab's tiles (whole columns: every segment's stores are overwritten) */
+            const int tx16 = xr * 4 + lane;
+            if (tx16 * 16 < X) c.zredo[(size_t)y * ((X + 15) >> 4) + tx16] = 1u;
+            if (lane == 0) atomicAdd(&c.cnt[GIE_CNT_ZFAIL], 1);
+        }
     }
 }
 

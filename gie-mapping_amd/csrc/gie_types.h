@@ -115,6 +115,8 @@ typedef struct gie_ctx {
     int prev_shift[3];      /* previous local coordinate = local coordinate + prev_shift */
     uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */
     uint64_t *zneed;        /* per (x,y) tile column: bit tz set = somebody reads the batch EDT of tile (tx,ty,tz) */
+    uint32_t *zredo;        /* per workgroup tile of pass Z's column kernel (16 columns x one y): the streaming form (k_edt_z_stream) could not
+                             * finish a column of it — the column kernel does the tile (zero = the frame clear) */
     uint16_t *zlist;        /* the planes with obstacles, ascending */
     int32_t *zcount;        /* how many */
     int32_t *tl_known;      /* tiles that hold a known voxel (built by k_edt_prep); count in cnt[GIE_CNT_TL_KNOWN] */
@@ -184,8 +186,9 @@ enum {
     GIE_CNT_LVL_A, GIE_CNT_LVL_B, GIE_CNT_LVL_C,
     GIE_CNT_FRONT_B, GIE_CNT_FRONT_C,
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
-    GIE_CNT_SPARE0,                             /* (unused) */
-    GIE_CNT_STATE, GIE_CNT_STATE1, GIE_CNT_STATE2, /* (unused) */
+    GIE_CNT_ZSTREAM,                            /* pass Z: the streaming form has done the volume, the column kernel only repairs the tiles flagged in zredo */
+    GIE_CNT_ZFAIL,                              /* pass Z, streaming form: slabs it gave up (the column kernel has nothing to repair when 0) */
+    GIE_CNT_STATE1, GIE_CNT_STATE2,             /* (unused) */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
     GIE_CNT_BAR_B = 34,                         /* (unused; first word of the second cleared range) */
@@ -207,7 +210,7 @@ enum {
 #define GIE_ERRF_BARRIER 8
 
 /* regions zeroed by one launch at the start of a map update */
-#define GIE_CLEAR_MAX 12
+#define GIE_CLEAR_MAX 16
 typedef struct gie_clear_list { void *p[GIE_CLEAR_MAX]; uint32_t bytes[GIE_CLEAR_MAX]; int n; } gie_clear_list;
 
 /* stamps in ctx.wl (local) */
