@@ -54,6 +54,8 @@ struct gie_mapper {
     int32_t h_cnt[GIE_CNT_NUM];
     int32_t next_off[3], next_whole[3];
     float us[4];
+    int coc_pending;                      /* voxels of the current tskip tiles have their records in the pair plane only (gie_ops.h "deferred records") */
+    int tsp_pvt[3];                       /* the pivot tskip_prev's tiles refer to */
     int flushed_ct;                       /* map tick (c.map_ct) of the pose the owed pairs were last written for ahead of gie_fuse (gie_owed_pairs_before_import) */
     /* CostMap publishing without a stall (gie_costmap_publish / gie_costmap_acquire): device staging + two pinned host buffers */
     gie_seendist *d_cm; void *h_cm[2]; size_t cm_bytes; int cm_slot, cm_pending;
@@ -161,7 +163,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1; m->coc_pending = 0;
     m->d_cm = nullptr; m->h_cm[0] = m->h_cm[1] = nullptr; m->cm_bytes = 0; m->cm_slot = 0; m->cm_pending = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
@@ -201,7 +203,10 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tknown = c.tflag + 5 * ntile; c.tknown_prev = c.tflag + 6 * ntile;
     c.tmax = gie_dalloc<int32_t>(m, 2 * ntile);
     c.tmax_prev = c.tmax ? c.tmax + ntile : nullptr;
-    c.tskip = gie_dalloc<uint8_t>(m, ntile);
+    c.tskip = gie_dalloc<uint8_t>(m, 2 * ntile);
+    c.tskip_prev = c.tskip ? c.tskip + ntile : nullptr;
+    c.coc_defer = 0; c.qdefer = 0;
+    for (int i = 0; i < 3; i++) { c.ts_pvt[i] = 0; m->tsp_pvt[i] = 0; c.pp_pvt[i] = c.pp_upvt[i] = 0; }
     c.ucol = gie_dalloc<uint8_t>(m, (((size_t)X * Y * ((Z + 7) / 8)) + 3) & ~(size_t)3);
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
     c.zneed = gie_dalloc<uint64_t>(m, (size_t)c.tfd[0] * c.tfd[1]);
@@ -542,6 +547,10 @@ static int gie_flush_op(gie_mapper *m, op_pair_flush *out, int rehash)
     return op.b.n0 + op.b.n1 + op.b.n2;
 }
 
+static int gie_fused_mode(const gie_mapper *m);
+
+static int gie_fused_mode(const gie_mapper *m);
+
 /* ---- stages */
 extern "C" int gie_fuse(gie_mapper *m)
 {
@@ -612,6 +621,9 @@ extern "C" int gie_fuse(gie_mapper *m)
             int32_t *tm = c.tmax; c.tmax = c.tmax_prev; c.tmax_prev = tm;
             c.prev_valid = was_fused;
             for (int i = 0; i < 3; i++) c.prev_shift[i] = c.pvt[i] - m->commit_pvt[i];
+            uint8_t *ts = c.tskip; c.tskip = c.tskip_prev; c.tskip_prev = ts;          /* (cleared below; flagged again behind the occupancy fusion) */
+            for (int i = 0; i < 3; i++) { m->tsp_pvt[i] = c.ts_pvt[i]; c.ts_pvt[i] = c.pvt[i]; }
+            c.qdefer = 0;                 /* (until the flags are final: host-side state, no query can come in between) */
         }
         gie_clear_list l; l.n = 0;
         auto add = [&l](void *p, size_t bytes) { l.p[l.n] = p; l.bytes[l.n] = (uint32_t)bytes; l.n++; };
@@ -640,6 +652,26 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_prof(&m->be, GIE_K_FUSE, 0);
     be_fuse(&m->be, m->c, m->c.tl_front);
     be_prof(&m->be, GIE_K_FUSE, 1);
+    {   /* the tiles whose stored records this update's Mark need not read (gie_tile_oldskip: the previous update's bounds and this
+         * pose — and an obstacle somewhere in the volume, known now that the types are fused), then the records the previous update
+         * left to its pair plane for the tiles that are not among them any more (gie_ops.h "deferred records").  If the merge ends
+         * up running in the reference's order after all (gie_stream_enable in between), gie_merge_begin catches up the rest. */
+        gie_ctx &c = m->c;
+        static const int use_bound = GIE_SWITCH("GIE_MARKC_BOUND", 1);     /* 0: always read the stored records (measurements) */
+        c.oldskip = (gie_fused_mode(m) && c.prev_valid && use_bound) ? 1 : 0;
+        be_prof(&m->be, GIE_K_ALLOC, 0);
+        if (c.oldskip) be_tile_oldskip(&m->be, c);
+        if (m->coc_pending) {
+            op_coc_catchup op;
+            op.p.flags = c.tskip_prev; op.p.all = 0;
+            for (int i = 0; i < 3; i++) { op.p.fpvt[i] = m->tsp_pvt[i]; op.p.ppvt[i] = m->commit_pvt[i]; op.p.pupvt[i] = m->commit_upvt[i]; }
+            be_lin(&m->be, c, op, c.tfd[0] * c.tfd[1] * c.tfd[2] * 64);
+            m->coc_pending = c.oldskip;       /* what stays deferred lies in this update's tskip tiles (none without the bound) */
+        }
+        be_prof(&m->be, GIE_K_ALLOC, 1);
+        c.qdefer = m->coc_pending;
+        for (int i = 0; i < 3; i++) { c.pp_pvt[i] = m->commit_pvt[i]; c.pp_upvt[i] = m->commit_upvt[i]; }
+    }
     be_time(&m->be, 3);
     m->flush_tab_ok = 0;
     return GIE_OK;
@@ -653,19 +685,25 @@ static int gie_fused_mode(const gie_mapper *m)
     return (env && !m->c.track) ? 1 : 0;
 }
 
+/* every record still left to the pair plane, now (gie_ops.h "deferred records"): before something reads or writes stored records of
+ * voxels inside the volume out of turn — the reference's order of kernels, ghosts imported ahead of a pose's gie_fuse */
+static void gie_catchup_everything(gie_mapper *m)
+{
+    if (!m->coc_pending) return;
+    gie_ctx &c = m->c;
+    op_coc_catchup op;
+    op.p.flags = c.tskip; op.p.all = 1;
+    for (int i = 0; i < 3; i++) { op.p.fpvt[i] = c.ts_pvt[i]; op.p.ppvt[i] = c.pp_pvt[i]; op.p.pupvt[i] = c.pp_upvt[i]; }
+    be_lin(&m->be, c, op, c.tfd[0] * c.tfd[1] * c.tfd[2] * 64);
+    m->coc_pending = 0; c.qdefer = 0;
+}
+
 extern "C" int gie_batch_edt(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_batch_edt"); if (rc) return rc;
     be_time(&m->be, 4);
     be_prof(&m->be, GIE_K_EDT_ZFACES, 0);
-    /* + the tiles whose stored records Mark need not read (gie_tile_oldskip: a thread per tile, like the reader masks): known here
-     * already — it depends on the previous update's bounds and this update's pose only.  If the merge ends up running in the
-     * reference's order after all (gie_stream_enable in between) the flags are simply not looked at. */
-    {
-        static const int use_bound = GIE_SWITCH("GIE_MARKC_BOUND", 1);     /* 0: always read the stored records (measurements) */
-        m->c.oldskip = (gie_fused_mode(m) && m->c.prev_valid && use_bound) ? 1 : 0;
-    }
-    be_edt_prep(&m->be, m->c);          /* plane list + reader masks + tile skip flags */
+    be_edt_prep(&m->be, m->c);          /* plane list + reader masks (the tile skip flags are gie_fuse's since round 5) */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 1);
     const int partial = m->c.tfd[2] <= 64;
     be_edt(&m->be, m->c, partial ? 0 : 1);   /* brackets its three passes itself (GIE_K_EDT_Y/X/Z); pass Z only where the result is read */
@@ -687,13 +725,27 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     m->c.fused = gie_fused_mode(m);
     const int kmark = m->c.fused ? GIE_K_MARKC : GIE_K_MARK;
     be_prof(&m->be, kmark, 0);
-    /* (the tiles whose stored records need not be read — tskip — were flagged in gie_batch_edt's first launch) */
+    /* (the tiles whose stored records need not be read — tskip — were flagged by gie_fuse) */
+    {   /* deferred records (gie_ops.h): a tskip tile's voxels are not stored by the fused sweep — unless this mapper is one tile of
+         * several (its faces are exported every update).  The reference's order of kernels reads every stored record: what is
+         * still owed to the tskip tiles is written first, while the pair plane is the previous update's. */
+        gie_ctx &c = m->c;
+        int tiled = 0;
+        const int sz[3] = { c.X, c.Y, c.Z };
+        for (int i = 0; i < 3; i++) tiled |= (c.tile_off[i] != 0) || (c.whole_hi[i] - c.whole_lo[i] != sz[i]);
+        c.coc_defer = (c.fused && c.oldskip && !tiled) ? 1 : 0;
+        if (!c.fused) gie_catchup_everything(m);
+    }
     if (m->c.fused) be_markc(&m->be, m->c, m->c.tl_known);
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);
     m->merge_open = 1;
     if (m->c.fused) { m->deferred = 1; m->flush_tab_ok = 1; for (int i = 0; i < 3; i++) { m->commit_pvt[i] = m->c.pvt[i]; m->commit_upvt[i] = m->c.upvt[i]; m->commit_tb0[i] = m->c.tb0[i]; } }
     else m->deferred = 0;     /* the reference's order: its commit sweep stores every pair, also the ones an earlier fused update left out (gie_commit_finish) */
+    /* from here on the pair plane is THIS update's: what the sweep left to it (coc_defer), or nothing (it stored every record it passed) */
+    m->coc_pending = m->c.coc_defer;
+    m->c.qdefer = m->coc_pending;
+    for (int i = 0; i < 3; i++) { m->c.pp_pvt[i] = m->c.pvt[i]; m->c.pp_upvt[i] = m->c.upvt[i]; }
     return GIE_OK;
 }
 /* second half: obtainFrontiers, waves A / B / C, commit */
@@ -1030,6 +1082,7 @@ extern "C" int gie_get_pivot(gie_mapper *m, int32_t pvt[3])
 static void gie_owed_pairs_before_import(gie_mapper *m)
 {
     gie_ctx &c = m->c;
+    gie_catchup_everything(m);            /* (the records of tskip tiles too: a ghost may land on one of their voxels) */
     if (!m->deferred || m->flushed_ct == c.map_ct) return;
     if (m->commit_pvt[0] == c.pvt[0] && m->commit_pvt[1] == c.pvt[1] && m->commit_pvt[2] == c.pvt[2]) return;
     op_pair_flush op;

@@ -476,6 +476,11 @@ static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full)
     if (grid > cap) grid = cap;
     GIE_LAUNCH(b, k_edt_z_stream, dim3((unsigned)grid), dim3(256), 0, c, full, nseg, seg_len);
 }
+static void be_tile_oldskip(be_state *b, const gie_ctx &c)
+{
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    GIE_LAUNCH(b, k_tile_oldskip, dim3((ntile + 255) / 256), dim3(256), 0, c, ntile);
+}
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {
     const int ncol = c.tfd[0] * c.tfd[1];

@@ -1271,6 +1271,47 @@ __device__ __forceinline__ uint32_t gie_zs_key(const uint32_t v, const bool plan
     const bool ok = plane_ok && max(ux, uy) <= 16u && a < (uint32_t)((GIE_ZS_R + 1) * (GIE_ZS_R + 1));
     return ok ? ((a << 24) | ((uint32_t)j << 18) | (ux << 13) | (uy << 8)) : (GIE_ZS_NONE | ((uint32_t)j << 18));
 }
+/* One trip of a slab again, for the few positions whose closest obstacle lies beyond the register window (BASELINE config 5's hash
+ * world: about thirty of 134 M voxels per update have none within 8 planes — and sending their slabs to the column kernel cost
+ * 44 us of a 0.24 ms pass): a window of GIE_ZS_R2 planes on either side with full 32-bit keys (value << 10 | plane, no clamp on the
+ * in-plane distance), exact below (R2 + 1)².  Returns false when a position of the wave is still unfinished: the slab is given up. */
+#define GIE_ZS_R2 24
+__device__ __noinline__ bool gie_zs_wide_trip(const uint32_t *cxy2, uint32_t *bcoc, const unsigned nbytes, const unsigned voff, const unsigned pstride,
+                                              const int zc, const int z1, const int Z, const int x, const int y, const bool inx, const uint8_t *occ)
+{
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cxy2), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(bcoc, 0, nbytes, 0x00020000);
+    uint32_t best[GIE_ZS_C];
+#pragma unroll
+    for (int t = 0; t < GIE_ZS_C; t++) best[t] = 0xffffffffu;
+    const int lo = max(zc - GIE_ZS_R2, 0), hi = min(zc + GIE_ZS_C + GIE_ZS_R2, Z);
+#pragma unroll 1
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (unsigned)min(i0 + k, Z - 1) * pstride, 0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k;
+            if (i >= hi || !occ[i]) continue;             /* wave-uniform */
+            const int dx = x - (int)(v[k] & 0xffffu), dy = y - (int)(v[k] >> 16);
+            const uint32_t a = (v[k] == 0xffffffffu) ? 0x3fffffu : (uint32_t)(dx * dx + dy * dy);
+#pragma unroll
+            for (int t = 0; t < GIE_ZS_C; t++) { const int d = zc + t - i; best[t] = min(best[t], (min(a + (uint32_t)(d * d), 0x3fffffu) << 10) | (uint32_t)i); }
+        }
+    }
+    uint32_t worst = 0;
+#pragma unroll
+    for (int t = 0; t < GIE_ZS_C; t++) if (zc + t < z1) worst = max(worst, best[t]);
+    if (__any(inx && worst >= ((uint32_t)((GIE_ZS_R2 + 1) * (GIE_ZS_R2 + 1)) << 10))) return false;
+#pragma unroll
+    for (int t = 0; t < GIE_ZS_C; t++) {
+        const int sp = (int)(best[t] & 1023u);
+        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (unsigned)sp * pstride, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(gie_pack_bcoc((int)(v & 0xffffu), (int)(v >> 16), sp), rs_out, (zc + t < z1) ? voff : GIE_BUF_OOB, (unsigned)min(zc + t, Z - 1) * pstride, 0);
+    }
+    return true;
+}
 __global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int full, const int nseg, const int seg_len)
 {
     __shared__ uint8_t s_occ[1024 + 2 * (32 + 2 * GIE_ZS_R)];        /* plane holds obstacles, for planes -W .. Z + W (0 outside the volume) */
@@ -1307,6 +1348,7 @@ __global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int
             for (int j = 0; j < 2 * GIE_ZS_R; j++) wk[j] = gie_zs_key(v[j], (pm >> j) & 1ull, x8, y8, j);
         }
         bool failed = false;
+        int wide = 0, wz0 = 0, wz1 = 0;                   /* trips of this slab to redo with the wide window (more than two: a sparse field — the column kernel's) */
 #pragma unroll 1
         for (int zc = z0; zc < z1; zc += GIE_ZS_C) {
             /* planes zc + R .. zc + C + R - 1 -> window places 2R .. W - 1 */
@@ -1333,10 +1375,16 @@ __global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int
                 /* stored at once (no second copy of the trip in registers); a slab given up below is redone as a whole by the column kernel */
                 __builtin_amdgcn_raw_buffer_store_b32(gie_pack_bcoc(cx, cy, s), rs_out, in ? voff : GIE_BUF_OOB, (unsigned)min(zc + t, Z - 1) * pstride, 0);
             }
-            if (__any(x < X && worst >= GIE_ZS_LIMIT)) { failed = true; break; }      /* wave-uniform */
+            if (__any(x < X && worst >= GIE_ZS_LIMIT)) {  /* wave-uniform: a position of this trip has no obstacle inside the window */
+                if (wide == 2) { failed = true; break; }
+                if (wide == 0) wz0 = zc; else wz1 = zc;   /* redone with the wide window when the slab is through (no call inside this loop: registers) */
+                wide++;
+            }
 #pragma unroll
             for (int j = 0; j < 2 * GIE_ZS_R; j++) wk[j] = wk[GIE_ZS_C + j] - ((uint32_t)GIE_ZS_C << 18);      /* the last 2R planes are the next trip's first */
         }
+        if (!failed && wide > 0) failed = !gie_zs_wide_trip(c.cxy2, c.bcoc, nbytes, voff, pstride, wz0, z1, Z, x, y, x < X, s_occ + GIE_ZS_W);
+        if (!failed && wide > 1) failed = !gie_zs_wide_trip(c.cxy2, c.bcoc, nbytes, voff, pstride, wz1, z1, Z, x, y, x < X, s_occ + GIE_ZS_W);
         if (failed && lane < 4) {                         /* the column kernel redoes the slab's tiles (whole columns: every segment's stores are overwritten) */
             const int tx16 = xr * 4 + lane;
             if (tx16 * 16 < X) c.zredo[(size_t)y * ((X + 15) >> 4) + tx16] = 1u;
@@ -1380,8 +1428,22 @@ __global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx 
         /* the same tiles as a list (mark / commit / pass Z visit only these when they are few): one atomic per workgroup */
         const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_KNOWN], k);
         if (slot >= 0) c.tl_known[slot] = t;
-        if (c.oldskip && colok && tz < c.tfd[2]) gie_tile_oldskip(c, t);     /* (tskip is zero otherwise: the frame clear) */
+        /* (the tiles whose stored records Mark need not read — tskip — are flagged by gie_fuse since round 5: be_tile_oldskip) */
     }
+}
+
+/* ------------------------------------------------------------------ tskip (gie_fuse, after the occupancy fusion)
+ * a thread per tile: gie_tile_oldskip — unless the volume holds no obstacle at all (no plane flagged by fuse): that update's Mark
+ * commits nothing, so no tile may count on its pair plane ("deferred records", gie_ops.h) */
+__global__ __launch_bounds__(256) void k_tile_oldskip(const gie_ctx c, const int ntile)
+{
+    int any = 0;
+    for (int z = threadIdx.x; z < c.Z; z += 256) any |= c.zocc[z];
+    any = __syncthreads_or(any);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntile) return;
+    if (!any) { c.tskip[t] = 0; return; }
+    gie_tile_oldskip(c, t);
 }
 
 /* ------------------------------------------------------------------ adaptive sweeps */
@@ -1477,9 +1539,10 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
         const size_t id = id0 + (size_t)(k < nz ? k : 0) * plane;
         ty[k] = c.glb_type[id]; bc[k] = c.bcoc[id];
     }
-    const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
-    const int slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
     const int skipold = c.tskip[t];
+    const bool nostore = c.coc_defer && skipold;          /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
+    const int slot_lo = nostore ? 0 : c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
+    const int slot_hi = nostore ? 0 : c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
     const size_t ui = gie_ucol_index(c, x, y, z0);
     const unsigned ub = c.ucol[ui];                     /* indices that have just turned known: their old pair says nothing about `_edt_D` */
     gie_vaddr a[8]; int dold[8]; uint64_t oc[8];
@@ -1513,7 +1576,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
             flag |= ft;
             gie_edt_before_keep(c, (int)id, pr, (ub >> k) & 1u);
             c.pair[id] = pr;
-            gie_commit_pair<false>(c, (int)id, a[k], pr);
+            if (!nostore) gie_commit_pair<false>(c, (int)id, a[k], pr);
             const int d = gie_pair_dist(pr);
             r = d == c.empty_value ? GIE_TMAX_INF : d + 1;
         }

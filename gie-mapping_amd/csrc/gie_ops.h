@@ -1186,7 +1186,7 @@ GIE_DEV int gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         if ((ub >> (z & 7)) & 1u) *u = (uint8_t)(ub & ~(1u << (z & 7)));
     }
     c.pair[id] = pr;
-    gie_commit_pair<false>(c, id, s.a, pr);
+    if (!(c.coc_defer && s.skipold)) gie_commit_pair<false>(c, id, s.a, pr);       /* (skip tile: the pair plane is the record — "deferred records" below) */
     const int d = gie_pair_dist(pr);
     return d == c.empty_value ? GIE_TMAX_INF : d + 1;
 }
@@ -1199,6 +1199,56 @@ GIE_DEV int gie_markc_voxel(const gie_ctx &c, int x, int y, int z)
     gie_markc_load2(c, s);
     return gie_markc_finish(c, id, x, y, z, s);
 }
+/* ================================================================== deferred records (fused Mark + commit)
+ * UpdateHashBatch stores (dist², closest obstacle, pair) in the GlbVoxel of every observed voxel, every update
+ * (unify_helper.cuh:448-523).  For a voxel INSIDE the volume the stored copy is only ever read
+ *   (a) by the next update's MarkLimitedObserve — and not at all in the tiles gie_tile_oldskip clears (tskip: deeper inside the
+ *       volume than any stored distance reaches, 84 % of the C5 volume),
+ *   (b) by readers of single voxels (gie_query_global, the changed-block gather, halo export of a face),
+ *   (c) once the voxel has left the volume (waves A / B, obtainFrontiers' outside branch).
+ * So in a tskip tile the fused sweep writes the pair plane only (8 of its 16 written bytes per voxel; rounds 3-4 had already
+ * deferred the stored PAIR this way).  The record of such a voxel IS its pair-plane entry — every voxel of a tskip tile was
+ * committed by the update before (gie_tile_oldskip's condition), and an update that cannot commit (no obstacle in the volume:
+ * every pair EMPTY) clears no tile — until one of these brings the stored copy up to date:
+ *   - gie_pair_flush_voxel when the voxel leaves the volume (as for the pair);
+ *   - gie_coc_catchup_column, in the next gie_fuse, when its tile is not a tskip tile any more (the robot came closer to it; a
+ *     fuse without a merge in between, which trusts no bound; an update without obstacles);
+ *   - wave C, which commits what it merges on the spot.
+ * (b) looks into the pair plane for a voxel of a tskip tile (gie_query_voxel); faces never lie in tskip tiles; a tiled mapper
+ * (gie_set_tile: its faces are exported every update) and the reference's order of kernels (changed-block flags on) do not defer. */
+struct gie_catchup { const uint8_t *flags; int fpvt[3]; int ppvt[3], pupvt[3]; int all; };   /* flags: the tskip plane that marks the deferred tiles, at pivot fpvt; all: none of them stays deferred */
+/* thread i = (tile i >> 6, column i & 63 of the tile): the records of the column's voxels, if they do not stay deferred */
+GIE_DEV void gie_coc_catchup_column(const gie_ctx &c, const gie_catchup &p, int i)
+{
+    const int t = i >> 6, l = i & 63;
+    if (!p.flags[t]) return;
+    const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+    const int x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+    if (x >= c.X || y >= c.Y) return;
+    const int gx = x + p.fpvt[0], gy = y + p.fpvt[1];
+    int slot = -1, slot_bz = 0x7fffffff;
+    for (int k = 0; k < 8; k++) {
+        const int z = tz * 8 + k;
+        if (z >= c.Z) break;
+        const int gz = z + p.fpvt[2];
+        if (!p.all) {                                      /* the voxel's tile of THIS update is a tskip tile again: the new pair plane takes over */
+            const int nx = gx - c.pvt[0], ny = gy - c.pvt[1], nz = gz - c.pvt[2];
+            if (gie_in_loc(c, nx, ny, nz) && c.tskip[gie_tile_index(c, nx, ny, nz)]) continue;
+        }
+        const int px = gx - p.ppvt[0], py = gy - p.ppvt[1], pz = gz - p.ppvt[2];
+        if (!gie_in_loc(c, px, py, pz)) continue;          /* (cannot happen: a tskip tile lies inside the volume of the merge before) */
+        const uint64_t pr = c.pair[gie_lid(c, px, py, pz)];
+        if (gie_pair_dist(pr) == c.empty_value) continue;  /* (cannot happen either: such an update clears no tile) */
+        if ((gz >> 3) != slot_bz) { slot_bz = gz >> 3; slot = gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3); }
+        if (slot < 0) continue;
+        const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+        int cw[3];
+        gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+        c.g_pair[a] = pr;
+        c.g_coc[a] = gie_pack_crd(cw[0] + p.pupvt[0], cw[1] + p.pupvt[1], cw[2] + p.pupvt[2]);
+    }
+}
+
 /* ================================================================== halo exchange between tiles */
 /* face f: axis f/2, side f%2.  Layer index i ↔ the two remaining axes (a fastest). */
 GIE_DEV void gie_face_coord(const gie_ctx &c, int face, int i, int depth_off, int *x, int *y, int *z)
@@ -1391,6 +1441,21 @@ GIE_DEV void gie_query_voxel(const gie_ctx &c, const int32_t *xyz, int i, gie_vo
 {
     const gie_vaddr a = gie_gvox_hash(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     out[i].pad = 0;
+    if (a >= 0 && c.qdefer) {                              /* a voxel of a tskip tile: its record is its pair-plane entry ("deferred records") */
+        const int lx = xyz[3 * i] - c.ts_pvt[0], ly = xyz[3 * i + 1] - c.ts_pvt[1], lz = xyz[3 * i + 2] - c.ts_pvt[2];
+        if (gie_in_loc(c, lx, ly, lz) && c.tskip[gie_tile_index(c, lx, ly, lz)]) {
+            const int px = xyz[3 * i] - c.pp_pvt[0], py = xyz[3 * i + 1] - c.pp_pvt[1], pz = xyz[3 * i + 2] - c.pp_pvt[2];
+            const uint64_t pr = gie_in_loc(c, px, py, pz) ? c.pair[gie_lid(c, px, py, pz)] : gie_pair_make(c.empty_value, GIE_PAR_NONE);
+            if (gie_pair_dist(pr) != c.empty_value) {
+                int cw[3];
+                gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+                const uint64_t cc = gie_pack_crd(cw[0] + c.pp_upvt[0], cw[1] + c.pp_upvt[1], cw[2] + c.pp_upvt[2]);      /* what the commit would have stored */
+                out[i].occ_val = c.g_occ[a]; out[i].vox_type = c.g_type[a]; out[i].dist_sq = gie_gdist(c, cc, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+                gie_unpack_crd(cc, &out[i].coc[0], &out[i].coc[1], &out[i].coc[2]);
+                return;
+            }
+        }
+    }
     if (a < 0) {
         out[i].occ_val = 0; out[i].vox_type = GIE_VOX_UNKNOWN; out[i].dist_sq = c.empty_value;
         out[i].coc[0] = out[i].coc[1] = out[i].coc[2] = GIE_EMPTY_VALUE;

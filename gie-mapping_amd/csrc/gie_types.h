@@ -110,7 +110,13 @@ typedef struct gie_ctx {
                                 * the tile was not committed; 0: the tile was not looked at */
     uint8_t *ucol;          /* per z-column of eight voxels (index ((z >> 3) * Y + y) * X + x), bit z & 7: the local index has turned from unknown to known and Mark has not written its pair since (gie_ops.h "`_edt_D` is derived") */
     int oldskip;            /* this update's batch EDT flags the tiles whose stored records Mark need not read (gie_tile_oldskip) */
-    uint8_t *tskip;         /* per tile: Mark need not read the stored global records of this tile (gie_tile_oldskip) */
+    uint8_t *tskip;         /* per tile: Mark need not read the stored global records of this tile (gie_tile_oldskip) — and, with coc_defer, does
+                             * not WRITE them either: the pair plane is the record of such a tile's voxels until they are caught up or leave */
+    uint8_t *tskip_prev;    /* tskip of the gie_fuse before (the two alternate), for the catch-up of the deferred records */
+    int ts_pvt[3];          /* the pivot tskip's tiles refer to (= the pose of the last gie_fuse; c.pvt moves with gie_set_pose) */
+    int coc_defer;          /* Mark + commit leaves the stored obstacle of skip tiles' voxels unwritten this update (gie_ops.h "deferred records") */
+    int qdefer;             /* readers of single global voxels (gie_query_global*): a voxel of a tskip tile has its record in the pair plane ... */
+    int pp_pvt[3], pp_upvt[3]; /* ... which was written at this pivot / wave-range pivot */
     int prev_valid;         /* tmax_prev describes the map update right before this one */
     int prev_shift[3];      /* previous local coordinate = local coordinate + prev_shift */
     uint8_t *zocc;          /* per z-plane: holds an OCCUPIED voxel after this frame's fuse (EDT passes skip empty planes) */

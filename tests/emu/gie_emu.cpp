@@ -168,7 +168,13 @@ static void be_edt_prep(be_state *, const gie_ctx &c)
 {
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     for (int t = 0; t < ntile; t++) if (c.tknown[t]) c.tl_known[c.cnt[GIE_CNT_TL_KNOWN]++] = t;
-    if (c.oldskip) for (int t = 0; t < ntile; t++) gie_tile_oldskip(c, t);
+}
+static void be_tile_oldskip(be_state *, const gie_ctx &c)
+{   /* k_tile_oldskip */
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    int any = 0;
+    for (int z = 0; z < c.Z; z++) any |= c.zocc[z];
+    for (int t = 0; t < ntile; t++) { if (!any) c.tskip[t] = 0; else gie_tile_oldskip(c, t); }
 }
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
 static void be_edt(be_state *, const gie_ctx &c, int)
