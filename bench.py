@@ -54,7 +54,8 @@ ALG_BYTES = {
 # on when no PMC profile of this exact build is committed (a lower bound of the kernel's real traffic, so frac stays <= 1)
 LAYOUT_BYTES = {
     "ogm_classify": 1, "fuse": 6, "edt_pass_y": 3, "edt_pass_x": 6, "edt_pass_z": 8,
-    "mark": 25, "frontiers": 9, "commit": 25, "mark_commit": 21,    # (round 4: `_edt_D` is derived from the pairs, no 4-byte store)
+    "mark": 25, "frontiers": 9, "commit": 25, "mark_commit": 13,    # (round 4: `_edt_D` is derived from the pairs, no 4-byte store; round 5: the stored
+                                                                    #  obstacle of a tskip tile's voxels is left to the pair plane: type 1 + batch obstacle 4 + pair 8)
 }
 WAVE_VISIT_BYTES = 64      # own record + six 8-byte read-modify-writes
 RAY_CELL_BYTES = 13        # row R: 1 B label read + 4 B atomic + 4 B return + ray state amortised

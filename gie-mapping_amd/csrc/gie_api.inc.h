@@ -333,6 +333,8 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
         c.tb0[i] = (c.pvt[i] - 1) >> 3;
         c.vb_lo[i] = (c.pvt[i] - 1) >> 3; c.vb_hi[i] = (c.pvt[i] + sz[i]) >> 3;
     }
+    c.wr_inside = 1;
+    for (int i = 0; i < 3; i++) if (c.pvt[i] - c.upvt[i] < 0 || c.pvt[i] - c.upvt[i] + sz[i] > c.wr[i]) c.wr_inside = 0;
     c.tab_prev = nullptr;                                 /* the block table belongs to the pose before: the next gie_fuse builds this one's (from it) */
     const uint32_t f = (uint32_t)c.map_ct & 0x3ffffu;
     if (f == 0) {                                         /* stamp wrap: clear the stamp planes once */
@@ -662,10 +664,10 @@ extern "C" int gie_fuse(gie_mapper *m)
         be_prof(&m->be, GIE_K_ALLOC, 0);
         if (c.oldskip) be_tile_oldskip(&m->be, c);
         if (m->coc_pending) {
-            op_coc_catchup op;
-            op.p.flags = c.tskip_prev; op.p.all = 0;
-            for (int i = 0; i < 3; i++) { op.p.fpvt[i] = m->tsp_pvt[i]; op.p.ppvt[i] = m->commit_pvt[i]; op.p.pupvt[i] = m->commit_upvt[i]; }
-            be_lin(&m->be, c, op, c.tfd[0] * c.tfd[1] * c.tfd[2] * 64);
+            gie_catchup p;
+            p.flags = c.tskip_prev; p.all = 0;
+            for (int i = 0; i < 3; i++) { p.fpvt[i] = m->tsp_pvt[i]; p.ppvt[i] = m->commit_pvt[i]; p.pupvt[i] = m->commit_upvt[i]; }
+            be_coc_catchup(&m->be, c, p);
             m->coc_pending = c.oldskip;       /* what stays deferred lies in this update's tskip tiles (none without the bound) */
         }
         be_prof(&m->be, GIE_K_ALLOC, 1);
@@ -691,10 +693,10 @@ static void gie_catchup_everything(gie_mapper *m)
 {
     if (!m->coc_pending) return;
     gie_ctx &c = m->c;
-    op_coc_catchup op;
-    op.p.flags = c.tskip; op.p.all = 1;
-    for (int i = 0; i < 3; i++) { op.p.fpvt[i] = c.ts_pvt[i]; op.p.ppvt[i] = c.pp_pvt[i]; op.p.pupvt[i] = c.pp_upvt[i]; }
-    be_lin(&m->be, c, op, c.tfd[0] * c.tfd[1] * c.tfd[2] * 64);
+    gie_catchup p;
+    p.flags = c.tskip; p.all = 1;
+    for (int i = 0; i < 3; i++) { p.fpvt[i] = c.ts_pvt[i]; p.ppvt[i] = c.pp_pvt[i]; p.pupvt[i] = c.pp_upvt[i]; }
+    be_coc_catchup(&m->be, c, p);
     m->coc_pending = 0; c.qdefer = 0;
 }
 

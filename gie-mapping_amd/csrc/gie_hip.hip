@@ -481,6 +481,11 @@ static void be_tile_oldskip(be_state *b, const gie_ctx &c)
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     GIE_LAUNCH(b, k_tile_oldskip, dim3((ntile + 255) / 256), dim3(256), 0, c, ntile);
 }
+static void be_coc_catchup(be_state *b, const gie_ctx &c, const gie_catchup &p)
+{
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    GIE_LAUNCH(b, k_coc_catchup, dim3((ntile + 255) / 256), dim3(256), 0, c, p, ntile);
+}
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {
     const int ncol = c.tfd[0] * c.tfd[1];

@@ -1217,11 +1217,27 @@ GIE_DEV int gie_markc_voxel(const gie_ctx &c, int x, int y, int z)
  * (b) looks into the pair plane for a voxel of a tskip tile (gie_query_voxel); faces never lie in tskip tiles; a tiled mapper
  * (gie_set_tile: its faces are exported every update) and the reference's order of kernels (changed-block flags on) do not defer. */
 struct gie_catchup { const uint8_t *flags; int fpvt[3]; int ppvt[3], pupvt[3]; int all; };   /* flags: the tskip plane that marks the deferred tiles, at pivot fpvt; all: none of them stays deferred */
-/* thread i = (tile i >> 6, column i & 63 of the tile): the records of the column's voxels, if they do not stay deferred */
-GIE_DEV void gie_coc_catchup_column(const gie_ctx &c, const gie_catchup &p, int i)
+/* does tile t (of the flags' plane) hold a voxel whose record has to be stored now?  Not when every tile of THIS update's volume
+ * that its voxels lie in is a tskip tile again (the usual case: one comparison per old tile, a handful of byte loads) */
+GIE_DEV int gie_coc_catchup_tile(const gie_ctx &c, const gie_catchup &p, int t)
 {
-    const int t = i >> 6, l = i & 63;
-    if (!p.flags[t]) return;
+    if (!p.flags[t]) return 0;
+    if (p.all) return 1;
+    const int tc[3] = { t % c.tfd[0], (t / c.tfd[0]) % c.tfd[1], t / (c.tfd[0] * c.tfd[1]) };
+    const int sz[3] = { c.X, c.Y, c.Z };
+    int n0[3], n1[3];
+    for (int a = 0; a < 3; a++) {
+        const int v0 = tc[a] * 8 + p.fpvt[a] - c.pvt[a], v1 = (tc[a] * 8 + 7 < sz[a] ? tc[a] * 8 + 7 : sz[a] - 1) + p.fpvt[a] - c.pvt[a];   /* this update's local coordinates */
+        if (v0 < 0 || v1 >= sz[a]) return 1;              /* (partly) outside this update's volume */
+        n0[a] = v0 >> 3; n1[a] = v1 >> 3;
+    }
+    for (int z = n0[2]; z <= n1[2]; z++) for (int y = n0[1]; y <= n1[1]; y++) for (int x = n0[0]; x <= n1[0]; x++)
+        if (!c.tskip[(z * c.tfd[1] + y) * c.tfd[0] + x]) return 1;
+    return 0;
+}
+/* column l (0..63) of tile t: the records of the column's voxels, if they do not stay deferred */
+GIE_DEV void gie_coc_catchup_column(const gie_ctx &c, const gie_catchup &p, int t, int l)
+{
     const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
     const int x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
     if (x >= c.X || y >= c.Y) return;

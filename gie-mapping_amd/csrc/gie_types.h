@@ -114,6 +114,7 @@ typedef struct gie_ctx {
                              * not WRITE them either: the pair plane is the record of such a tile's voxels until they are caught up or leave */
     uint8_t *tskip_prev;    /* tskip of the gie_fuse before (the two alternate), for the catch-up of the deferred records */
     int ts_pvt[3];          /* the pivot tskip's tiles refer to (= the pose of the last gie_fuse; c.pvt moves with gie_set_pose) */
+    int wr_inside;          /* every voxel of the local volume lies inside the wave range (always, unless a tile offset pushes the volume out of it) */
     int coc_defer;          /* Mark + commit leaves the stored obstacle of skip tiles' voxels unwritten this update (gie_ops.h "deferred records") */
     int qdefer;             /* readers of single global voxels (gie_query_global*): a voxel of a tskip tile has its record in the pair plane ... */
     int pp_pvt[3], pp_upvt[3]; /* ... which was written at this pivot / wave-range pivot */

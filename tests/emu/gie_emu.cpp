@@ -169,6 +169,11 @@ static void be_edt_prep(be_state *, const gie_ctx &c)
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     for (int t = 0; t < ntile; t++) if (c.tknown[t]) c.tl_known[c.cnt[GIE_CNT_TL_KNOWN]++] = t;
 }
+static void be_coc_catchup(be_state *, const gie_ctx &c, const gie_catchup &p)
+{   /* k_coc_catchup */
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    for (int t = 0; t < ntile; t++) if (gie_coc_catchup_tile(c, p, t)) for (int l = 0; l < 64; l++) gie_coc_catchup_column(c, p, t, l);
+}
 static void be_tile_oldskip(be_state *, const gie_ctx &c)
 {   /* k_tile_oldskip */
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
