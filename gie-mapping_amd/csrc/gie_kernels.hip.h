@@ -1556,10 +1556,41 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     }
     const int skipold = c.tskip[t];
     const bool nostore = c.coc_defer && skipold;          /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
-    const int slot_lo = nostore ? 0 : c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
-    const int slot_hi = nostore ? 0 : c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
     const size_t ui = gie_ucol_index(c, x, y, z0);
     const unsigned ub = c.ucol[ui];                     /* indices that have just turned known: their old pair says nothing about `_edt_D` */
+    if (nostore && c.wr_inside) {
+        /* A tskip tile with deferred records — 82 % of the C5 volume — and nothing to decide: no stored record can win (dold is
+         * "infinite"), the batch obstacle lies inside the volume and the volume inside the wave range, so MarkLimitedObserve's
+         * answer is (batch distance, batch obstacle in wave-range coordinates), no tile flag, no `_edt_D` to keep, and nothing goes
+         * to the global map — no block slot, no voxel address.  A voxel without a batch obstacle cannot occur here (an update
+         * without obstacles clears no tile); if one does, the general path below takes the column. */
+        unsigned want = 0;
+        bool plain = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < nz && ty[k] != GIE_VOX_UNKNOWN) { want |= 1u << k; if (bc[k] == GIE_BCOC_NONE) plain = false; }
+        if (plain) {
+            const uint32_t ox = (uint32_t)(c.pvt[0] - c.upvt[0]), oy = (uint32_t)(c.pvt[1] - c.upvt[1]), oz = (uint32_t)(c.pvt[2] - c.upvt[2]);
+            int vmax = 0;
+            uint64_t *const pp = c.pair + id0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (!((want >> k) & 1u)) continue;
+                const uint32_t b = bc[k];
+                const uint32_t cx = b & 1023u, cy = (b >> 10) & 1023u, cz = b >> 20;
+                const int dx = x - (int)cx, dy = y - (int)cy, dz = z0 + k - (int)cz;
+                const uint32_t d = (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz));
+                const uint32_t wz = cz + oz;
+                const uint32_t lo = (cx + ox) | ((cy + oy) << 14) | (wz << 28), hi = (wz >> 4) | (d << (GIE_PAIR_DIST_SHIFT - 32));
+                pp[(size_t)k * plane] = ((uint64_t)hi << 32) | lo;      /* = gie_pair_make(d, gie_pack_wr(cx + ox, cy + oy, cz + oz)) */
+                vmax = (int)d + 1 > vmax ? (int)d + 1 : vmax;
+            }
+            if (ub & want) c.ucol[ui] = (uint8_t)(ub & ~want);
+            gie_markc_column(c, x, y, z0, want, (1u << nz) - 1u, vmax);
+            return;
+        }
+    }
+    const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
+    const int slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
     gie_vaddr a[8]; int dold[8]; uint64_t oc[8];
     unsigned want = 0;
 #pragma unroll
@@ -1578,36 +1609,6 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     }
     unsigned known = 0, valid = 0;
     int vmax = 0, flag = 0;
-    if (nostore && c.wr_inside) {
-        /* A tskip tile with deferred records — 82 % of the C5 volume — and nothing to decide: no stored record can win (dold is
-         * "infinite"), the batch obstacle lies inside the volume and the volume inside the wave range, so MarkLimitedObserve's
-         * answer is (batch distance, batch obstacle in wave-range coordinates), no tile flag, no `_edt_D` to keep, and nothing goes
-         * to the global map.  About 25 vector instructions per voxel instead of the general path's 139 (the sweep was bound by
-         * their issue: 291 M wave instructions per launch on SIMDs that take two cycles each).  A voxel without a batch obstacle
-         * cannot occur here (an update without obstacles clears no tile); if one does, the general path below takes the column. */
-        bool plain = true;
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && bc[k] == GIE_BCOC_NONE) plain = false;
-        if (plain) {
-            const uint32_t ox = (uint32_t)(c.pvt[0] - c.upvt[0]), oy = (uint32_t)(c.pvt[1] - c.upvt[1]), oz = (uint32_t)(c.pvt[2] - c.upvt[2]);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k < nz) valid |= 1u << k;
-                if (!((want >> k) & 1u)) continue;
-                const uint32_t b = bc[k];
-                const uint32_t cx = b & 1023u, cy = (b >> 10) & 1023u, cz = b >> 20;
-                const int dx = x - (int)cx, dy = y - (int)cy, dz = z0 + k - (int)cz;
-                const uint32_t d = (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy) + __mul24(dz, dz));
-                const uint32_t wz = cz + oz;
-                const uint32_t lo = (cx + ox) | ((cy + oy) << 14) | (wz << 28), hi = (wz >> 4) | (d << (GIE_PAIR_DIST_SHIFT - 32));
-                c.pair[id0 + (size_t)k * plane] = ((uint64_t)hi << 32) | lo;      /* = gie_pair_make(d, gie_pack_wr(cx + ox, cy + oy, cz + oz)) */
-                known |= 1u << k; vmax = (int)d + 1 > vmax ? (int)d + 1 : vmax;
-            }
-            if (ub & known) c.ucol[ui] = (uint8_t)(ub & ~known);
-            gie_markc_column(c, x, y, z0, known, valid, vmax);
-            return;
-        }
-    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if (k < nz) valid |= 1u << k;
@@ -1621,7 +1622,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
             flag |= ft;
             gie_edt_before_keep(c, (int)id, pr, (ub >> k) & 1u);
             c.pair[id] = pr;
-            if (!nostore) gie_commit_pair<false>(c, (int)id, a[k], pr);
+            if (!nostore) gie_commit_pair<false>(c, (int)id, a[k], pr);      /* (a tskip tile that did not take the short way above) */
             const int d = gie_pair_dist(pr);
             r = d == c.empty_value ? GIE_TMAX_INF : d + 1;
         }

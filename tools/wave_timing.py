@@ -6,7 +6,7 @@ LIB = os.environ.get("GIE_WT_LIB") or os.path.join(ROOT, "tools", "ablate", "lib
 if sys.argv[1] == "build":
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-                           "-DGIE_WAVE_TIMING=1", os.path.join(ROOT, "gie-mapping_amd", "csrc", "gie_hip.hip"), "-o", LIB])
+                           "-DGIE_WAVE_TIMING=1", "-DGIE_TEST_HOOKS", os.path.join(ROOT, "gie-mapping_amd", "csrc", "gie_hip.hip"), "-o", LIB])
     sys.exit(0)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd")]
 import numpy as np, torch, bench, gie
