@@ -817,6 +817,9 @@ __device__ __forceinline__ void gie_row_argmin_banded_lin(const int2 *mb, const 
 template <int CP>
 __device__ __forceinline__ bool gie_row_window(const uint32_t *sk, const int L, const int lane, uint32_t (&best)[CP], const unsigned bandneed = ~0u)
 {
+    /* (round 5: a form without the per-band masks, tests and branches — scalar instructions, about as many as the vector ones they
+     * steer — with all bands running until the last one has finished was measured on the 512^3 C5 volume: pass X 0.274 -> 0.299 ms.
+     * The trips the early bands are spared outweigh the scalar work.) */
     /* (a position beyond the row starts at 0 and stays there: the finish test below is one comparison per band, without a mask) */
 #pragma unroll
     for (int m = 0; m < CP; m++) best[m] = (64 * m + lane < L) ? sk[64 * m + lane] : 0u;
@@ -1526,8 +1529,13 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
          * measured a little faster than striding through the volume (fuse 0.18 -> 0.155 ms, dense) */
         const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
-        for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++)
-            gie_vox_column<F, STAGED>(c, f, (v % gx) * LX + lx, ((v / gx) % gy) * WY + ly, (v / (gx * gy)) * 8);
+        int v = (int)blockIdx.x * per;
+        const int vend = min(nv, ((int)blockIdx.x + 1) * per);
+        int vx = v % gx, vy = (v / gx) % gy, vz = v / (gx * gy);
+        for (; v < vend; v++) {
+            gie_vox_column<F, STAGED>(c, f, vx * LX + lx, vy * WY + ly, vz * 8);
+            if (++vx == gx) { vx = 0; if (++vy == gy) { vy = 0; vz++; } }
+        }
     }
 }
 
@@ -1650,8 +1658,15 @@ __global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *l
         const int nv = gx * gy * gz;
         const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
-        for (int v = blockIdx.x * per; v < nv && v < (int)(blockIdx.x + 1) * per; v++)
-            gie_markc_column_fast(c, (v % gx) * LX + lx, ((v / gx) % gy) * WY + ly, (v / (gx * gy)) * 8);
+        /* (the virtual workgroup's coordinates by carry, not by three divisions per trip: the scalar unit is shared by the four
+         * SIMDs of a compute unit, and round 5's counters had this sweep issue 108 M scalar against 190 M vector instructions) */
+        int v = (int)blockIdx.x * per;
+        const int vend = min(nv, ((int)blockIdx.x + 1) * per);
+        int vx = v % gx, vy = (v / gx) % gy, vz = v / (gx * gy);
+        for (; v < vend; v++) {
+            gie_markc_column_fast(c, vx * LX + lx, vy * WY + ly, vz * 8);
+            if (++vx == gx) { vx = 0; if (++vy == gy) { vy = 0; vz++; } }
+        }
     }
 }
 
