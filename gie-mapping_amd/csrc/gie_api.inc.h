@@ -624,7 +624,8 @@ extern "C" int gie_fuse(gie_mapper *m)
             c.prev_valid = was_fused;
             for (int i = 0; i < 3; i++) c.prev_shift[i] = c.pvt[i] - m->commit_pvt[i];
             uint8_t *ts = c.tskip; c.tskip = c.tskip_prev; c.tskip_prev = ts;          /* (cleared below; flagged again behind the occupancy fusion) */
-            for (int i = 0; i < 3; i++) { m->tsp_pvt[i] = c.ts_pvt[i]; c.ts_pvt[i] = c.pvt[i]; }
+            c.skip2_ok = was_fused;       /* (... and tskip_prev is that update's: flagged at its pose, which is the merge's) */
+            for (int i = 0; i < 3; i++) { if (c.ts_pvt[i] != m->commit_pvt[i]) c.skip2_ok = 0; m->tsp_pvt[i] = c.ts_pvt[i]; c.ts_pvt[i] = c.pvt[i]; }
             c.qdefer = 0;                 /* (until the flags are final: host-side state, no query can come in between) */
         }
         gie_clear_list l; l.n = 0;
@@ -662,14 +663,18 @@ extern "C" int gie_fuse(gie_mapper *m)
         static const int use_bound = GIE_SWITCH("GIE_MARKC_BOUND", 1);     /* 0: always read the stored records (measurements) */
         c.oldskip = (gie_fused_mode(m) && c.prev_valid && use_bound) ? 1 : 0;
         be_prof(&m->be, GIE_K_ALLOC, 0);
-        if (c.oldskip) be_tile_oldskip(&m->be, c);
-        if (m->coc_pending) {
+        /* the usual case: tskip_prev is the update before's and lies at its pose (prev_shift) — the launch that flags this update's
+         * tiles finds the ones to bring up to date on the way; otherwise (a fuse without a merge since; no bound to go by) the
+         * tiles of the flags' own plane are enumerated (be_coc_catchup) */
+        c.catchup_fast = (m->coc_pending && c.oldskip && c.skip2_ok) ? 1 : 0;
+        if (c.oldskip) be_tile_oldskip(&m->be, c, m->commit_upvt);
+        if (m->coc_pending && !c.catchup_fast) {
             gie_catchup p;
             p.flags = c.tskip_prev; p.all = 0;
             for (int i = 0; i < 3; i++) { p.fpvt[i] = m->tsp_pvt[i]; p.ppvt[i] = m->commit_pvt[i]; p.pupvt[i] = m->commit_upvt[i]; }
             be_coc_catchup(&m->be, c, p);
-            m->coc_pending = c.oldskip;       /* what stays deferred lies in this update's tskip tiles (none without the bound) */
         }
+        if (m->coc_pending) m->coc_pending = c.oldskip;       /* what stays deferred lies in this update's tskip tiles (none without the bound) */
         be_prof(&m->be, GIE_K_ALLOC, 1);
         c.qdefer = m->coc_pending;
         for (int i = 0; i < 3; i++) { c.pp_pvt[i] = m->commit_pvt[i]; c.pp_upvt[i] = m->commit_upvt[i]; }

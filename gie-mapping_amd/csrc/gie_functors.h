@@ -123,7 +123,7 @@ struct op_markc { static constexpr bool rolled = false;
     /* per z-column: which voxels were committed and the largest value finish() returned (the tile's bound for the next map update) */
     GIE_DEVM void column_max(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax) const { gie_markc_column(c, x, y, z0, known, valid, vmax); }
     GIE_DEVM int operator()(const gie_ctx &c, int x, int y, int z) const { return gie_markc_voxel(c, x, y, z); } };
-struct op_tile_oldskip { GIE_DEVM void operator()(const gie_ctx &c, int t) const { gie_tile_oldskip(c, t); } };
+struct op_tile_oldskip { GIE_DEVM void operator()(const gie_ctx &c, int t) const { (void)gie_tile_oldskip(c, t); } };
 struct op_commit { static constexpr bool rolled = false;
     typedef gie_commit_st st;
     /* a map update whose waves were cut short by a barrier timeout commits nothing (GIE_ERR_TIMEOUT, include/gie.h): the flag of

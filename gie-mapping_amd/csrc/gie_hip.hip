@@ -284,7 +284,8 @@ template <class F> static void be_lin(be_state *b, const gie_ctx &c, const F &f,
 }
 static void be_flush_clear(be_state *b, const gie_ctx &c, const op_pair_flush &f, int n, const gie_clear_list &l)
 {
-    GIE_LAUNCH(b, k_flush_clear, dim3(32 * l.n + (n + 255) / 256), dim3(256), 0, c, f, n, l);
+    const int nclr = gie_clear_total_wgs(l);
+    GIE_LAUNCH(b, k_flush_clear, dim3(nclr + (n + 255) / 256), dim3(256), 0, c, f, n, l, nclr);
 }
 static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels)
 {
@@ -295,7 +296,7 @@ static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels)
 }
 static void be_clear(be_state *b, const gie_clear_list &l, const int32_t *gate = nullptr)
 {
-    if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(32, l.n), dim3(256), 0, l, gate);
+    if (l.n > 0) GIE_LAUNCH(b, k_clear, dim3(gie_clear_total_wgs(l)), dim3(256), 0, l, gate);
 }
 static void be_round_note(be_state *b, const gie_ctx &c, int32_t *changed, long long *stats, const int32_t *go, int end)
 {
@@ -476,15 +477,24 @@ static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full)
     if (grid > cap) grid = cap;
     GIE_LAUNCH(b, k_edt_z_stream, dim3((unsigned)grid), dim3(256), 0, c, full, nseg, seg_len);
 }
-static void be_tile_oldskip(be_state *b, const gie_ctx &c)
+/* tskip for this update; with c.catchup_fast the tiles whose deferred records have to be stored are listed and stored (pupvt: the
+ * wave-range pivot of the update that left them) */
+static void be_tile_oldskip(be_state *b, const gie_ctx &c, const int pupvt[3])
 {
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
-    GIE_LAUNCH(b, k_tile_oldskip, dim3((ntile + 255) / 256), dim3(256), 0, c, ntile);
+    /* the list lives in wave C's tile list (ntile words, not in use between two merges), its length in a spare counter */
+    int32_t *const count = &c.cnt[GIE_CNT_STATE1];        /* (zero: the frame clear) */
+    GIE_LAUNCH(b, k_tile_oldskip, dim3((ntile + 255) / 256), dim3(256), 0, c, ntile, c.wc_list[0], count);
+    if (c.catchup_fast) GIE_LAUNCH(b, k_coc_catchup_new, dim3(b->cu_total * 8), dim3(256), 0, c, pupvt[0], pupvt[1], pupvt[2], c.wc_list[0], count);
 }
 static void be_coc_catchup(be_state *b, const gie_ctx &c, const gie_catchup &p)
 {
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
-    GIE_LAUNCH(b, k_coc_catchup, dim3((ntile + 255) / 256), dim3(256), 0, c, p, ntile);
+    /* the list lives in wave C's tile list (ntile words, not in use between two merges), its length in a spare counter */
+    int32_t *const count = &c.cnt[GIE_CNT_STATE1];
+    GIE_HIP_OK(hipMemsetAsync(count, 0, sizeof(int32_t), b->stream));
+    GIE_LAUNCH(b, k_coc_catchup_list, dim3((ntile + 255) / 256), dim3(256), 0, c, p, ntile, c.wc_list[0], count);
+    GIE_LAUNCH(b, k_coc_catchup_run, dim3(b->cu_total * 4), dim3(256), 0, c, p, c.wc_list[0], count);
 }
 static void be_edt_prep(be_state *b, const gie_ctx &c)
 {

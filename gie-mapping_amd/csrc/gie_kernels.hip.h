@@ -315,39 +315,35 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
 }
 
 /* ------------------------------------------------------------------ frame clear */
-/* every small array that has to be zero when a map update starts, in one launch (blockIdx.y = region) */
-__global__ __launch_bounds__(256) void k_clear(const gie_clear_list l, const int32_t *gate)
+/* every array that has to be zero when a map update starts, in one launch: workgroup w of the clear part zeroes its share of the
+ * region it falls into (gie_clear_wgs workgroups per region, by size) */
+__device__ __forceinline__ void gie_clear_part(const gie_clear_list &l, int w)
 {
-    if (gate != nullptr && *(const volatile int32_t *)gate == 0) return;
-    const int r = blockIdx.y;
-    if (r >= l.n) return;
+    int r = 0, nw = gie_clear_wgs(l.bytes[0]);
+    while (w >= nw && r + 1 < l.n) { w -= nw; r++; nw = gie_clear_wgs(l.bytes[r]); }      /* uniform over the workgroup; at most GIE_CLEAR_MAX trips */
+    if (w >= nw) return;
     unsigned char *p = (unsigned char *)l.p[r];
     const uint32_t bytes = l.bytes[r];
     const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) < bytes ? (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) : bytes;
     const uint32_t nvec = (bytes - head) / 16u, tail0 = head + nvec * 16u;
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const uint32_t tid = (uint32_t)w * 256u + threadIdx.x, nth = (uint32_t)nw * 256u;
     for (uint32_t i = tid; i < head; i += nth) p[i] = 0;
     uint4 *v = (uint4 *)(p + head);
     for (uint32_t i = tid; i < nvec; i += nth) v[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tail0 + tid; i < bytes; i += nth) p[i] = 0;
 }
+__global__ __launch_bounds__(256) void k_clear(const gie_clear_list l, const int32_t *gate)
+{
+    if (gate != nullptr && *(const volatile int32_t *)gate == 0) return;
+    gie_clear_part(l, (int)blockIdx.x);
+}
 
 /* the frame clear and the flush of the stored pairs a fused update left out (gie_pair_flush_voxel) in one launch: the first
- * 32 * l.n workgroups clear, the others flush — they touch different arrays */
-__global__ __launch_bounds__(256) void k_flush_clear(const gie_ctx c, const op_pair_flush f, const int n, const gie_clear_list l)
+ * `nclr` workgroups clear, the others flush — they touch different arrays */
+__global__ __launch_bounds__(256) void k_flush_clear(const gie_ctx c, const op_pair_flush f, const int n, const gie_clear_list l, const int nclr)
 {
-    const int nclr = 32 * l.n;
     if ((int)blockIdx.x >= nclr) { const int i = ((int)blockIdx.x - nclr) * 256 + (int)threadIdx.x; if (i < n) f(c, i); return; }
-    const int r = blockIdx.x >> 5, bx = blockIdx.x & 31;
-    unsigned char *p = (unsigned char *)l.p[r];
-    const uint32_t bytes = l.bytes[r];
-    const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) < bytes ? (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) : bytes;
-    const uint32_t nvec = (bytes - head) / 16u, tail0 = head + nvec * 16u;
-    const uint32_t tid = bx * 256 + threadIdx.x, nth = 32 * 256;
-    for (uint32_t i = tid; i < head; i += nth) p[i] = 0;
-    uint4 *v = (uint4 *)(p + head);
-    for (uint32_t i = tid; i < nvec; i += nth) v[i] = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = tail0 + tid; i < bytes; i += nth) p[i] = 0;
+    gie_clear_part(l, (int)blockIdx.x);
 }
 
 /* ------------------------------------------------------------------ block allocation */
@@ -1438,30 +1434,48 @@ __global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx 
 /* ------------------------------------------------------------------ tskip (gie_fuse, after the occupancy fusion)
  * a thread per tile: gie_tile_oldskip — unless the volume holds no obstacle at all (no plane flagged by fuse): that update's Mark
  * commits nothing, so no tile may count on its pair plane ("deferred records", gie_ops.h) */
-__global__ __launch_bounds__(256) void k_tile_oldskip(const gie_ctx c, const int ntile)
+__global__ __launch_bounds__(256) void k_tile_oldskip(const gie_ctx c, const int ntile, int32_t *list, int32_t *count)
 {
     int any = 0;
     for (int z = threadIdx.x; z < c.Z; z += 256) any |= c.zocc[z];
     any = __syncthreads_or(any);
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntile) return;
-    if (!any) { c.tskip[t] = 0; return; }
-    gie_tile_oldskip(c, t);
+    /* without an obstacle no tile is cleared — and every tile whose records the update before left to its pair plane is listed */
+    bool need = false;
+    if (t < ntile) need = gie_tile_oldskip(c, t, any) != 0;
+    /* (one counter update per WORKGROUP: a thousand wavefronts adding to the same word, each waiting for its answer, was 44 us of
+     * this launch's 49 — same-address atomics with a return serialise at their L2 slice) */
+    const int slot = gie_wg_reserve(count, need);
+    if (slot >= 0) list[slot] = t;
+}
+/* a wave per tile k_tile_oldskip has listed, a lane per z-column */
+__global__ __launch_bounds__(256) void k_coc_catchup_new(const gie_ctx c, const int pu0, const int pu1, const int pu2, const int32_t *list, const int32_t *count)
+{
+    const int n = *count;
+    const int lane = threadIdx.x & 63;
+    const int pupvt[3] = { pu0, pu1, pu2 };
+    for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) gie_coc_catchup_newcolumn(c, pupvt, list[e], lane);
 }
 
 /* the records a fused update left to its pair plane, for the tiles that are no tskip tiles any more (gie_ops.h "deferred records"):
- * a thread per tile of the flags' plane decides (gie_coc_catchup_tile — nearly always "nothing to do"), then the wave takes the
- * tiles its lanes found one after the other, a lane per z-column */
-__global__ __launch_bounds__(256) void k_coc_catchup(const gie_ctx c, const gie_catchup p, const int ntile)
+ * k_coc_catchup_list — a thread per tile of the flags' plane decides (gie_coc_catchup_tile: nearly always "nothing to do") and the
+ * tiles found go onto a list (one atomic per wave); k_coc_catchup_run — a wave per listed tile, a lane per z-column.  Two launches
+ * because tiles that flip together are neighbours: a wave that stored the records of the tiles its own lanes found would, when
+ * a whole layer of tiles flips (a lidar's flood wave moving the bounds), store 64 tiles one after the other while the rest of
+ * the launch is through (round 5: up to 0.35 ms on the projective lidar workload); spreading the TEST over the waves instead
+ * makes its byte loads uncoalesced (0.55 ms on the C5 volume). */
+__global__ __launch_bounds__(256) void k_coc_catchup_list(const gie_ctx c, const gie_catchup p, const int ntile, int32_t *list, int32_t *count)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool need = t < ntile && gie_coc_catchup_tile(c, p, t);
+    const int slot = gie_wg_reserve(count, need);
+    if (slot >= 0) list[slot] = t;
+}
+__global__ __launch_bounds__(256) void k_coc_catchup_run(const gie_ctx c, const gie_catchup p, const int32_t *list, const int32_t *count)
+{
+    const int n = *count;
     const int lane = threadIdx.x & 63;
-    unsigned long long need = __ballot(t < ntile && gie_coc_catchup_tile(c, p, t));
-    while (need) {                                        /* wave-uniform */
-        const int j = __ffsll((long long)need) - 1;
-        need &= need - 1ull;
-        gie_coc_catchup_column(c, p, (t - lane) + j, lane);
-    }
+    for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) gie_coc_catchup_column(c, p, list[e], lane);
 }
 
 /* ------------------------------------------------------------------ adaptive sweeps */
@@ -1563,7 +1577,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
         ty[k] = c.glb_type[id]; bc[k] = c.bcoc[id];
     }
     const int skipold = c.tskip[t];
-    const bool nostore = c.coc_defer && skipold;          /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
+    const bool nostore = c.coc_defer && skipold == 2;     /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
     const size_t ui = gie_ucol_index(c, x, y, z0);
     const unsigned ub = c.ucol[ui];                     /* indices that have just turned known: their old pair says nothing about `_edt_D` */
     if (nostore && c.wr_inside) {

@@ -966,7 +966,10 @@ GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, in
     } else slot = gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3);
     if (slot < 0) return;
     const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
-    if (b.rehash && !(c.g_coc[a] & GIE_COC_STALEPAIR)) return;    /* never committed in this stay, or flushed by an earlier fuse (and waves A / B may have rewritten it since) */
+    if (b.rehash && !(c.g_coc[a] & GIE_COC_STALEPAIR)) return;    /* never committed in this stay, or flushed by an earlier fuse (and waves A / B may have rewritten it since);
+                                                                   * (a voxel of a cleared tile whose record was left to the pair plane carries no mark either: those are
+                                                                   * brought up to date by the catch-up over the OLD tiles, which gie_fuse runs whenever this form of the
+                                                                   * flush does — gie_coc_catchup_column stores the ones outside the new volume too) */
     const uint64_t pr = c.pair[id];
     if (gie_pair_dist(pr) != c.empty_value) {         /* committed by that update: the pair it would have stored */
         int cw[3];
@@ -1071,30 +1074,93 @@ struct gie_markc_st { uint32_t bc; gie_vaddr a; int dold; uint64_t ococ; int ski
  * that update was the previous one, ran fused, and covered every voxel of the tile (a voxel it did not commit may hold
  * anything: its tile's bound is "infinite"). */
 #define GIE_TMAX_INF 0x7fffffff
-GIE_DEV void gie_tile_oldskip(const gie_ctx &c, int t)
+/* returns 1 when the tile is NOT cleared but holds voxels whose records the update before left to its pair plane (its tiles flagged
+ * 2 in tskip_prev; only asked for with c.catchup_fast): gie_fuse brings exactly those tiles' stored copies up to date */
+GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* allow = 0: no tile is cleared (an update without obstacles) */
 {
     const int tc[3] = { t % c.tfd[0], (t / c.tfd[0]) % c.tfd[1], t / (c.tfd[0] * c.tfd[1]) };
     const int sz[3] = { c.X, c.Y, c.Z };
     int o0[3], o1[3];
     long long reach2 = 0x7fffffffffffll;              /* (smallest distance to a face of the whole volume)^2, conservative per axis */
+    bool inside_old = true, can = true;
     for (int a = 0; a < 3; a++) {
         const int v0 = tc[a] * 8, v1 = (v0 + 7 < sz[a] ? v0 + 7 : sz[a] - 1);
         o0[a] = (v0 + c.prev_shift[a]) >> 3; o1[a] = (v1 + c.prev_shift[a]) >> 3;      /* the previous update's tiles that hold these voxels */
-        if (v0 + c.prev_shift[a] < 0 || v1 + c.prev_shift[a] >= sz[a]) { c.tskip[t] = 0; return; }   /* (partly) new in the volume */
+        if (v0 + c.prev_shift[a] < 0 || v1 + c.prev_shift[a] >= sz[a]) { inside_old = false; can = false; }   /* (partly) new in the volume: straddles
+                                                                                            * the old volume's face, whose tiles are never cleared ones */
         const long long m = (long long)(v0 - c.whole_lo[a] < c.whole_hi[a] - 1 - v1 ? v0 - c.whole_lo[a] : c.whole_hi[a] - 1 - v1);
-        if (m < 0) { c.tskip[t] = 0; return; }
-        if (m * m < reach2) reach2 = m * m;
+        if (m < 0) can = false;
+        else if (m * m < reach2) reach2 = m * m;
     }
-    long long d = 0;
-    for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++) {
-        const int v = c.tmax_prev[(z * c.tfd[1] + y) * c.tfd[0] + x];
-        if (v <= 0 || v == GIE_TMAX_INF) { c.tskip[t] = 0; return; }
-        if (v - 1 > d) d = v - 1;
-    }
-    c.tskip[t] = (uint8_t)(d < reach2 ? 1 : 0);      /* |obstacle - voxel| <= sqrt(d) < distance to the nearest face, on every axis */
+    int v = 0;
+    if (can && allow) {
+        long long d = 0;
+        for (int z = o0[2]; z <= o1[2] && can; z++) for (int y = o0[1]; y <= o1[1] && can; y++) for (int x = o0[0]; x <= o1[0]; x++) {
+            const int w = c.tmax_prev[(z * c.tfd[1] + y) * c.tfd[0] + x];
+            if (w <= 0 || w == GIE_TMAX_INF) { can = false; break; }
+            if (w - 1 > d) d = w - 1;
+        }
+        /* |obstacle - voxel| <= sqrt(d) < distance to the nearest face, on every axis.  2 = ... and the voxels' tiles of the update before
+         * were such tiles too: only then does the sweep leave the tile's records to the pair plane ("deferred records").  A tile at the
+         * rim of the cleared region flips from update to update (a lidar's flood waves move the bounds), and every flip back costs a
+         * catch-up of its 512 records — more than the stores it saves (round 5, the projective lidar workload: 0.07 ms per update). */
+        if (can && d < reach2) {
+            v = 1;
+            if (c.skip2_ok) {
+                v = 2;
+                for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++)
+                    if (!c.tskip_prev[(z * c.tfd[1] + y) * c.tfd[0] + x]) v = 1;
+            }
 #if defined(GIE_HOST_EMU)
-    if (d < reach2) c.cnt[GIE_CNT_TSKIP] += 1;
+            c.cnt[GIE_CNT_TSKIP] += 1;
 #endif
+        }
+    }
+    c.tskip[t] = (uint8_t)v;
+    if (v != 0 || !c.catchup_fast || !inside_old) return 0;
+    for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++)
+        if (c.tskip_prev[(z * c.tfd[1] + y) * c.tfd[0] + x] == 2) return 1;
+    return 0;
+}
+/* column l of tile t of THIS update's volume (a tile gie_tile_oldskip returned 1 for): the records of its voxels that lay in a
+ * tile flagged 2 of the update before, from that update's pair plane (indices by prev_shift, wave-range pivot pupvt) */
+GIE_DEV void gie_coc_catchup_newcolumn(const gie_ctx &c, const int pupvt[3], int t, int l)
+{
+    const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+    const int x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+    if (x >= c.X || y >= c.Y) return;
+    const int px = x + c.prev_shift[0], py = y + c.prev_shift[1];
+    const int gx = x + c.pvt[0], gy = y + c.pvt[1];
+    const int z0 = tz * 8, nz = c.Z - z0 < 8 ? c.Z - z0 : 8;
+    /* every load of the column in one batch (flags, pairs, the column's two block slots), then the stores: the launch is a few
+     * thousand tiles, bound by how many round trips a lane makes one after the other */
+    const bool cin = px >= 0 && px < c.X && py >= 0 && py < c.Y;
+    uint8_t fl[8]; uint64_t pr[8];
+#if !defined(GIE_HOST_EMU)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) {
+        const int pz = z0 + k + c.prev_shift[2];
+        const bool in = k < nz && cin && pz >= 0 && pz < c.Z;
+        fl[k] = in ? c.tskip_prev[gie_tile_index(c, px, py, pz)] : (uint8_t)0;
+        pr[k] = in ? c.pair[gie_lid(c, px, py, pz)] : gie_pair_make(c.empty_value, GIE_PAR_NONE);
+    }
+    const int gz0 = z0 + c.pvt[2];
+    const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)], slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
+#if !defined(GIE_HOST_EMU)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) {
+        if (fl[k] != 2 || gie_pair_dist(pr[k]) == c.empty_value) continue;   /* (EMPTY cannot happen: an update without obstacles clears no tile) */
+        const int gz = gz0 + k;
+        const int slot = ((gz >> 3) == (gz0 >> 3)) ? slot_lo : slot_hi;
+        if (slot < 0) continue;
+        const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+        int cw[3];
+        gie_unpack_wr(gie_pair_par(pr[k]), &cw[0], &cw[1], &cw[2]);
+        c.g_pair[a] = pr[k];
+        c.g_coc[a] = gie_pack_crd(cw[0] + pupvt[0], cw[1] + pupvt[1], cw[2] + pupvt[2]);
+    }
 }
 /* the column's share of its tile's bound (known != valid: a voxel of the column was not committed) */
 GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax)
@@ -1186,7 +1252,7 @@ GIE_DEV int gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         if ((ub >> (z & 7)) & 1u) *u = (uint8_t)(ub & ~(1u << (z & 7)));
     }
     c.pair[id] = pr;
-    if (!(c.coc_defer && s.skipold)) gie_commit_pair<false>(c, id, s.a, pr);       /* (skip tile: the pair plane is the record — "deferred records" below) */
+    if (!(c.coc_defer && s.skipold == 2)) gie_commit_pair<false>(c, id, s.a, pr);       /* (a tskip tile of the second update running: the pair plane is the record — "deferred records" below) */
     const int d = gie_pair_dist(pr);
     return d == c.empty_value ? GIE_TMAX_INF : d + 1;
 }
@@ -1221,7 +1287,9 @@ struct gie_catchup { const uint8_t *flags; int fpvt[3]; int ppvt[3], pupvt[3]; i
  * that its voxels lie in is a tskip tile again (the usual case: one comparison per old tile, a handful of byte loads) */
 GIE_DEV int gie_coc_catchup_tile(const gie_ctx &c, const gie_catchup &p, int t)
 {
-    if (!p.flags[t]) return 0;
+    if (p.all ? p.flags[t] == 0 : p.flags[t] != 2) return 0;   /* (1: the sweep stored the tile's records itself — in the update the flags are from; with `all`
+                                                                 * the flags are THIS update's, whose sweep may not have run yet: a tile flagged 1 may hold voxels the
+                                                                 * update before left to its pair plane) */
     if (p.all) return 1;
     const int tc[3] = { t % c.tfd[0], (t / c.tfd[0]) % c.tfd[1], t / (c.tfd[0] * c.tfd[1]) };
     const int sz[3] = { c.X, c.Y, c.Z };
@@ -1247,15 +1315,20 @@ GIE_DEV void gie_coc_catchup_column(const gie_ctx &c, const gie_catchup &p, int 
         const int z = tz * 8 + k;
         if (z >= c.Z) break;
         const int gz = z + p.fpvt[2];
+        bool in_new = false;                               /* inside THIS update's volume (whose block table is built: gie_fuse's catch-up) */
         if (!p.all) {                                      /* the voxel's tile of THIS update is a tskip tile again: the new pair plane takes over */
             const int nx = gx - c.pvt[0], ny = gy - c.pvt[1], nz = gz - c.pvt[2];
-            if (gie_in_loc(c, nx, ny, nz) && c.tskip[gie_tile_index(c, nx, ny, nz)]) continue;
+            in_new = gie_in_loc(c, nx, ny, nz);
+            if (in_new && c.tskip[gie_tile_index(c, nx, ny, nz)]) continue;
         }
         const int px = gx - p.ppvt[0], py = gy - p.ppvt[1], pz = gz - p.ppvt[2];
         if (!gie_in_loc(c, px, py, pz)) continue;          /* (cannot happen: a tskip tile lies inside the volume of the merge before) */
         const uint64_t pr = c.pair[gie_lid(c, px, py, pz)];
         if (gie_pair_dist(pr) == c.empty_value) continue;  /* (cannot happen either: such an update clears no tile) */
-        if ((gz >> 3) != slot_bz) { slot_bz = gz >> 3; slot = gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3); }
+        if ((gz >> 3) != slot_bz) {                        /* (one coalesced table read instead of a chain of hash probes where the table covers the voxel) */
+            slot_bz = gz >> 3;
+            slot = in_new ? c.blk_tab[gie_tab_index(c, gx, gy, gz)] : gie_hash_find(c, gx >> 3, gy >> 3, gz >> 3);
+        }
         if (slot < 0) continue;
         const gie_vaddr a = (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
         int cw[3];

@@ -115,6 +115,8 @@ typedef struct gie_ctx {
     uint8_t *tskip_prev;    /* tskip of the gie_fuse before (the two alternate), for the catch-up of the deferred records */
     int ts_pvt[3];          /* the pivot tskip's tiles refer to (= the pose of the last gie_fuse; c.pvt moves with gie_set_pose) */
     int wr_inside;          /* every voxel of the local volume lies inside the wave range (always, unless a tile offset pushes the volume out of it) */
+    int skip2_ok;           /* tskip_prev describes the tiles of the update right before this one, at the pose prev_shift refers to: a tile may be flagged 2 */
+    int catchup_fast;       /* gie_tile_oldskip also says which tiles of this update need their deferred records stored (tskip_prev is the update before's, at prev_shift) */
     int coc_defer;          /* Mark + commit leaves the stored obstacle of skip tiles' voxels unwritten this update (gie_ops.h "deferred records") */
     int qdefer;             /* readers of single global voxels (gie_query_global*): a voxel of a tskip tile has its record in the pair plane ... */
     int pp_pvt[3], pp_upvt[3]; /* ... which was written at this pivot / wave-range pivot */
@@ -219,6 +221,11 @@ enum {
 /* regions zeroed by one launch at the start of a map update */
 #define GIE_CLEAR_MAX 16
 typedef struct gie_clear_list { void *p[GIE_CLEAR_MAX]; uint32_t bytes[GIE_CLEAR_MAX]; int n; } gie_clear_list;
+/* workgroups a region of `bytes` gets in the clear launches: one per 16 KB (a region of a few MB cleared by a fixed 32 workgroups was
+ * 20 us of every map update), at least one, at most 256 */
+#define GIE_CLEAR_WG_BYTES 16384u
+GIE_HD int gie_clear_wgs(uint32_t bytes) { const uint32_t n = (bytes + GIE_CLEAR_WG_BYTES - 1u) / GIE_CLEAR_WG_BYTES; return n < 1u ? 1 : (n > 256u ? 256 : (int)n); }
+GIE_HD int gie_clear_total_wgs(const gie_clear_list &l) { int t = 0; for (int i = 0; i < l.n; i++) t += gie_clear_wgs(l.bytes[i]); return t; }
 
 /* stamps in ctx.wl (local) */
 #define GIE_WL_SEED(c) ((c).stamp_base + 1u)

@@ -174,12 +174,14 @@ static void be_coc_catchup(be_state *, const gie_ctx &c, const gie_catchup &p)
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     for (int t = 0; t < ntile; t++) if (gie_coc_catchup_tile(c, p, t)) for (int l = 0; l < 64; l++) gie_coc_catchup_column(c, p, t, l);
 }
-static void be_tile_oldskip(be_state *, const gie_ctx &c)
-{   /* k_tile_oldskip */
+static void be_tile_oldskip(be_state *, const gie_ctx &c, const int pupvt[3])
+{   /* k_tile_oldskip + k_coc_catchup_new */
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     int any = 0;
     for (int z = 0; z < c.Z; z++) any |= c.zocc[z];
-    for (int t = 0; t < ntile; t++) { if (!any) c.tskip[t] = 0; else gie_tile_oldskip(c, t); }
+    std::vector<int> list;
+    for (int t = 0; t < ntile; t++) if (gie_tile_oldskip(c, t, any)) list.push_back(t);
+    if (c.catchup_fast) for (int t : list) for (int l = 0; l < 64; l++) gie_coc_catchup_newcolumn(c, pupvt, t, l);
 }
 static void be_edt_z(be_state *, const gie_ctx &, int) {}          /* the emulation always computes every voxel */
 static void be_edt(be_state *, const gie_ctx &c, int)
