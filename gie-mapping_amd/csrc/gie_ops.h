@@ -724,17 +724,24 @@ GIE_DEV void gie_mark_voxel(const gie_ctx &c, int x, int y, int z)
 /* obtainFrontiers' branch for a 6-neighbour outside the local volume (unify_helper.cuh:346-438).
  * Returns bit0 = the voxel became a C seed (*seed set), bit1 = the neighbour is unknown. */
 /* *push = 1: the neighbour joins frontier B, 2: frontier A (appended by the caller, wave-aggregated), *pa = its address */
+/* the record of the outside neighbour in direction k, fetched ahead by the caller (k_frontier_faces: the neighbour across the
+ * patch's own face is known before anything of the voxel has been read — its table lookup and record go out with the voxel's own
+ * loads instead of behind them); nobody else touches that record during the launch (an outside voxel next to a face has ONE
+ * neighbour inside the volume) */
+struct gie_out_pre { int k; gie_vaddr a; int8_t nty; uint64_t ncoc; };
 GIE_DEV_COLD int gie_frontier_outside(const gie_ctx &c, int x, int y, int z, int nx, int ny, int nz,
-                                      const int cl[3], const int cw[3], int cd, uint64_t *seed, int *push, gie_vaddr *pa)
+                                      const int cl[3], const int cw[3], int cd, uint64_t *seed, int *push, gie_vaddr *pa,
+                                      int k = -1, const gie_out_pre *pre = nullptr)
 {
     *push = 0; *pa = -1;
     int cur_in_q = 0;
     const int ng[3] = { nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2] };
-    const gie_vaddr a = gie_gvox_tab(c, ng[0], ng[1], ng[2]);
+    const bool have = pre != nullptr && pre->k == k;
+    const gie_vaddr a = have ? pre->a : gie_gvox_tab(c, ng[0], ng[1], ng[2]);
     if (a < 0) return 2;
     /* the neighbour's record in one batch of loads (a face voxel is a chain of dependent round trips) */
-    const int8_t nty = c.g_type[a];
-    const uint64_t ncoc = c.g_coc[a];
+    const int8_t nty = have ? pre->nty : c.g_type[a];
+    const uint64_t ncoc = have ? pre->ncoc : c.g_coc[a];
     const int nd = gie_gdist(c, ncoc, ng[0], ng[1], ng[2]);
     if (nty == GIE_VOX_UNKNOWN) return 2;
     if (gie_invalid_dist(c, nd)) return 0;
@@ -819,7 +826,7 @@ struct gie_absink_queues {
         gie_push64a_wave(c, c.qa, c.qa_a, &c.cnt[GIE_CNT_A], c.qcap_ab, push == 2, crd, a);
     } };
 template <class NB, class SINK>
-GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s, const NB &nb, const SINK &sink)
+GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s, const NB &nb, const SINK &sink, const gie_out_pre *pre = nullptr)
 {
     const int8_t ty = (int8_t)(s.tys & 15u);
     if (ty == GIE_VOX_UNKNOWN) return 0;
@@ -857,7 +864,7 @@ GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z
              * line so that the hot interior path stays small */
             int opush = 0;
             gie_vaddr oaddr = -1;
-            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed, &opush, &oaddr);
+            const int r = gie_frontier_outside(c, x, y, z, nx, ny, nz, cl, cw, cd, &seed, &opush, &oaddr, k, pre);
             cur_in_q |= r & 1; has_unknown |= (r >> 1) & 1;
             /* a neighbour outside the volume that seeds wave B / wave A (the sinks only look at executing lanes) */
             sink.ab(c, opush, gie_pack_crd(nx + c.pvt[0], ny + c.pvt[1], nz + c.pvt[2]), oaddr);
