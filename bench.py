@@ -838,7 +838,7 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
     return out
 
 
-WAVE_GRID = {"wgs": 160}     # gie_config.wave_workgroups: a rank owns its device (160 of 256 measured best); ranks sharing a device: 192 / ranks
+WAVE_GRID = {"wgs": int(os.environ.get("GIE_BENCH_WAVE_WGS", "160"))}     # gie_config.wave_workgroups: a rank owns its device (160 of 256 measured best); ranks sharing a device: 192 / ranks
 PLACE_TRIES = 4              # gie_config.place_tries: gie_create re-draws the sweep's planes against a probe (0.76 vs 0.84 ms of Mark + commit)
 PARTIAL = {}     # per workload: the regions timed so far (printed with an "error" key if the run dies later on)
 FULL_FILE = os.path.join("profiles", "bench_last_full.json")

@@ -661,7 +661,9 @@ extern "C" int gie_fuse(gie_mapper *m)
          * up running in the reference's order after all (gie_stream_enable in between), gie_merge_begin catches up the rest. */
         gie_ctx &c = m->c;
         static const int use_bound = GIE_SWITCH("GIE_MARKC_BOUND", 1);     /* 0: always read the stored records (measurements) */
-        c.oldskip = (gie_fused_mode(m) && c.prev_valid && use_bound) ? 1 : 0;
+        /* (not for ray-cast scans: a scan observes well under 1 % of the volume, no tile is ever cleared — the launch would be 5 us of
+         * a 0.2 - 0.4 ms update for nothing) */
+        c.oldskip = (gie_fused_mode(m) && c.prev_valid && use_bound && !c.pntcld_mode) ? 1 : 0;
         be_prof(&m->be, GIE_K_ALLOC, 0);
         /* the usual case: tskip_prev is the update before's and lies at its pose (prev_shift) — the launch that flags this update's
          * tiles finds the ones to bring up to date on the way; otherwise (a fuse without a merge since; no bound to go by) the

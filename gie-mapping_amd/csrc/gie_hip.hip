@@ -363,8 +363,8 @@ static void gie_launch_edt_dim(be_state *b, const gie_ctx &c, int L, bool zpass,
     else gie_launch_edt_xz<16>(b, c, zpass, full);
 }
 /* pass Z again over the whole volume (the passes before it are complete either way) */
-static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full);
-static void be_edt_z(be_state *b, const gie_ctx &c, int full) { be_edt_z_stream(b, c, full); gie_launch_edt_dim(b, c, c.Z, true, full); }
+static int be_edt_z_stream(be_state *b, const gie_ctx &c, int full);
+static void be_edt_z(be_state *b, const gie_ctx &c, int full) { (void)be_edt_z_stream(b, c, full); gie_launch_edt_dim(b, c, c.Z, true, full); }
 /* EDT_OCC::batchEDTUpdate, local_edt.cu:7-28 */
 /* adaptive sweep (k_voxa): the kernel walks the list or sweeps the volume, whichever the list's
  * length calls for; staged = the functor's load1/load2/finish form; always_list = never sweep */
@@ -457,11 +457,12 @@ static void be_edt_z_direct(be_state *b, const gie_ctx &c)
     GIE_LAUNCH(b, k_edt_z_direct, dim3(b->cu_total * 16), dim3(256), 0, c);
 }
 /* the streaming form of pass Z (k_edt_z_stream): a wave per (64 columns, y, z segment) */
-static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full)
+/* returns 1 when launched: the launch also carries the list form of the pass (k_edt_z_direct's body) when `full` is 0 */
+static int be_edt_z_stream(be_state *b, const gie_ctx &c, int full)
 {
-    if (c.Z < 64 || c.Z > 1024) return;            /* (short columns: the column kernel) */
+    if (c.Z < 64 || c.Z > 1024) return 0;          /* (short columns: the column kernel) */
     static const int on = GIE_SWITCH("GIE_ZSTREAM", 1);
-    if (!on) return;
+    if (!on) return 0;
     const int nxr = (c.X + 63) / 64;
     /* z segments so that the launch has about eight waves per SIMD to overlap its rows' round trips (a segment re-reads 16 planes) */
     static const int target = GIE_SWITCH("GIE_ZSTREAM_WAVES", 8);
@@ -475,7 +476,9 @@ static void be_edt_z_stream(be_state *b, const gie_ctx &c, int full)
     long long grid = (waves + 3) / 4;
     const long long cap = (long long)b->cu_total * 8 * 4;
     if (grid > cap) grid = cap;
+    if (!full && grid < (long long)b->cu_total * 16) grid = (long long)b->cu_total * 16;      /* (the list form's grid: be_edt_z_direct) */
     GIE_LAUNCH(b, k_edt_z_stream, dim3((unsigned)grid), dim3(256), 0, c, full, nseg, seg_len);
+    return 1;
 }
 /* tskip for this update; with c.catchup_fast the tiles whose deferred records have to be stored are listed and stored (pupvt: the
  * wave-range pivot of the update that left them) */
@@ -528,8 +531,9 @@ static void be_edt(be_state *b, const gie_ctx &c, int full)
     be_prof(b, 6, 1);
     be_prof(b, 7, 0); gie_launch_edt_dim(b, c, c.X, false, 1); be_prof(b, 7, 1);   /* GIE_K_EDT_X */
     be_prof(b, 8, 0);                                                              /* GIE_K_EDT_Z */
-    if (!full) be_edt_z_direct(b, c);
-    be_edt_z_stream(b, c, full);                   /* dense fields: the whole pass; flags what it could not finish for the column kernel */
+    /* dense fields: the streaming form does the whole pass and flags what it could not finish for the column kernel; few known
+     * tiles: the list form — in the same launch */
+    if (!be_edt_z_stream(b, c, full) && !full) be_edt_z_direct(b, c);
     gie_launch_edt_dim(b, c, c.Z, true, full);
     be_prof(b, 8, 1);
 

@@ -97,18 +97,16 @@ def pmc(fetch_db, write_db):
         out.append("")
         out.append("per MAP UPDATE and stage (the names of gie_profile_read; a stage may be several kernels), MB: "
                    + ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])))
-        tot = 0.0
-        for k in set(f) | set(w):
-            if k.startswith("__"):
-                continue
-            fk, n = f.get(k, (0.0, 0)); wk, n2 = w.get(k, (0.0, 0))
-            tot += (2.0 * fk * n / steps_f + wk * n2 / steps_w) * 1024.0
+        # the map update's own kernels only: torch's label generation between the timed regions, the copies and fills of the harness
+        # and gie_create's placement probe are not part of an update (83.8 GB "per map update")
+        tot = sum(v for k, v in per_step.items() if k != "create")
         js["_per_step_total_bytes"] = round(tot)
         out.append("")
-        out.append("all kernels of one map update together: %.1f MB (%d / %d map updates in the FETCH / WRITE pass)" % (tot / 1e6, steps_f, steps_w))
+        out.append("the kernels of one map update together (without gie_create's probe, the harness's torch kernels and copies): %.1f MB (%d / %d map updates in the FETCH / WRITE pass)" % (tot / 1e6, steps_f, steps_w))
     out.append("")
-    out.append("per launch = mean over the launches of the run; fetch_corrected = 2 x FETCH_SIZE (gfx950 wide-stream correction,")
-    out.append("MI355X_MICROARCH.md §HBM; uncalibrated for scattered 4/8-byte accesses); hbm_bytes = fetch_corrected + WRITE_SIZE.")
+    out.append("per launch = mean over the launches of the run; fetch_corrected = 2 x FETCH_SIZE: calibrated on this pool for coalesced streams of")
+    out.append("1, 2, 4, 8 and 16 bytes per lane and for 8-byte records in 64-byte runs (profiles/r05_pmc_calibration.txt: factor 2.000, runs 1.99);")
+    out.append("WRITE_SIZE is exact for 4 / 8 / 16-byte stores (1-byte stores: 0.955); hbm_bytes = fetch_corrected + WRITE_SIZE.")
     return "\n".join(out), js
 
 
