@@ -488,6 +488,8 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     rounds_per_step = r.rounds_total / float(max(1, r.updates))
     halo_mode = r.halo_mode
     round_stats = None
+    if r.exchange and backend != "nccl":
+        halo_mode = "stable"                          # (host-staged layers: rounds until no tile changes, the host reading every count)
     if r.exchange and halo_mode == "converged":      # what the gated rounds did is counted on the device (gie_round_stats)
         round_stats = r.m.round_stats()
         rounds_per_step = round_stats["rounds_run"] / float(max(1, round_stats["updates"]))

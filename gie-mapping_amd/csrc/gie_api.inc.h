@@ -735,14 +735,10 @@ extern "C" int gie_merge_begin(gie_mapper *m)
     const int kmark = m->c.fused ? GIE_K_MARKC : GIE_K_MARK;
     be_prof(&m->be, kmark, 0);
     /* (the tiles whose stored records need not be read — tskip — were flagged by gie_fuse) */
-    {   /* deferred records (gie_ops.h): a tskip tile's voxels are not stored by the fused sweep — unless this mapper is one tile of
-         * several (its faces are exported every update).  The reference's order of kernels reads every stored record: what is
-         * still owed to the tskip tiles is written first, while the pair plane is the previous update's. */
+    {   /* deferred records (gie_ops.h): a tskip tile's voxels are not stored by the fused sweep.  The reference's order of kernels reads
+         * every stored record: what is still owed to the tskip tiles is written first, while the pair plane is the previous update's. */
         gie_ctx &c = m->c;
-        int tiled = 0;
-        const int sz[3] = { c.X, c.Y, c.Z };
-        for (int i = 0; i < 3; i++) tiled |= (c.tile_off[i] != 0) || (c.whole_hi[i] - c.whole_lo[i] != sz[i]);
-        c.coc_defer = (c.fused && c.oldskip && !tiled) ? 1 : 0;
+        c.coc_defer = (c.fused && c.oldskip) ? 1 : 0;      /* (also for one tile of several: the face layers are exported through gie_deferred_coc) */
         if (!c.fused) gie_catchup_everything(m);
     }
     if (m->c.fused) be_markc(&m->be, m->c, m->c.tl_known);

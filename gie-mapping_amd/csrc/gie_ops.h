@@ -1287,8 +1287,8 @@ GIE_DEV int gie_markc_voxel(const gie_ctx &c, int x, int y, int z)
  *   - gie_coc_catchup_column, in the next gie_fuse, when its tile is not a tskip tile any more (the robot came closer to it; a
  *     fuse without a merge in between, which trusts no bound; an update without obstacles);
  *   - wave C, which commits what it merges on the spot.
- * (b) looks into the pair plane for a voxel of a tskip tile (gie_query_voxel); faces never lie in tskip tiles; a tiled mapper
- * (gie_set_tile: its faces are exported every update) and the reference's order of kernels (changed-block flags on) do not defer. */
+ * (b) looks into the pair plane for a voxel of a tskip tile (gie_deferred_coc: gie_query_voxel, and gie_halo_record — a face of a
+ * TILE can lie deep inside the whole volume); the reference's order of kernels (changed-block flags on) does not defer. */
 struct gie_catchup { const uint8_t *flags; int fpvt[3]; int ppvt[3], pupvt[3]; int all; };   /* flags: the tskip plane that marks the deferred tiles, at pivot fpvt; all: none of them stays deferred */
 /* does tile t (of the flags' plane) hold a voxel whose record has to be stored now?  Not when every tile of THIS update's volume
  * that its voxels lie in is a tskip tile again (the usual case: one comparison per old tile, a handful of byte loads) */
@@ -1345,6 +1345,23 @@ GIE_DEV void gie_coc_catchup_column(const gie_ctx &c, const gie_catchup &p, int 
     }
 }
 
+/* the stored closest obstacle of global voxel g as a reader of single voxels must see it: for a voxel of a tskip tile whose record
+ * was left to the pair plane, what the commit would have stored (true, *cc); false: the stored copy is the record */
+GIE_DEV bool gie_deferred_coc(const gie_ctx &c, int gx, int gy, int gz, uint64_t *cc)
+{
+    if (!c.qdefer) return false;
+    const int lx = gx - c.ts_pvt[0], ly = gy - c.ts_pvt[1], lz = gz - c.ts_pvt[2];
+    if (!gie_in_loc(c, lx, ly, lz) || !c.tskip[gie_tile_index(c, lx, ly, lz)]) return false;
+    const int px = gx - c.pp_pvt[0], py = gy - c.pp_pvt[1], pz = gz - c.pp_pvt[2];
+    if (!gie_in_loc(c, px, py, pz)) return false;
+    const uint64_t pr = c.pair[gie_lid(c, px, py, pz)];
+    if (gie_pair_dist(pr) == c.empty_value) return false;
+    int cw[3];
+    gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+    *cc = gie_pack_crd(cw[0] + c.pp_upvt[0], cw[1] + c.pp_upvt[1], cw[2] + c.pp_upvt[2]);
+    return true;
+}
+
 /* ================================================================== halo exchange between tiles */
 /* face f: axis f/2, side f%2.  Layer index i ↔ the two remaining axes (a fastest). */
 GIE_DEV void gie_face_coord(const gie_ctx &c, int face, int i, int depth_off, int *x, int *y, int *z)
@@ -1371,8 +1388,10 @@ GIE_DEV gie_halo_voxel gie_halo_record(const gie_ctx &c, int face, int i)
         h.vox_type = GIE_VOX_UNKNOWN; h.dist_sq = c.empty_value; h.coc[0] = h.coc[1] = h.coc[2] = GIE_EMPTY_VALUE;
     } else {
         h.vox_type = c.g_type[a]; h.occ_val = c.g_occ[a];
-        h.dist_sq = gie_gdist(c, c.g_coc[a], x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
-        gie_unpack_crd(c.g_coc[a], &h.coc[0], &h.coc[1], &h.coc[2]);
+        uint64_t cc = c.g_coc[a];
+        (void)gie_deferred_coc(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2], &cc);      /* (a face of a TILE may lie in a tskip tile: deep inside the whole volume) */
+        h.dist_sq = gie_gdist(c, cc, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
+        gie_unpack_crd(cc, &h.coc[0], &h.coc[1], &h.coc[2]);
     }
     return h;
 }
@@ -1537,20 +1556,11 @@ GIE_DEV void gie_query_voxel(const gie_ctx &c, const int32_t *xyz, int i, gie_vo
 {
     const gie_vaddr a = gie_gvox_hash(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     out[i].pad = 0;
-    if (a >= 0 && c.qdefer) {                              /* a voxel of a tskip tile: its record is its pair-plane entry ("deferred records") */
-        const int lx = xyz[3 * i] - c.ts_pvt[0], ly = xyz[3 * i + 1] - c.ts_pvt[1], lz = xyz[3 * i + 2] - c.ts_pvt[2];
-        if (gie_in_loc(c, lx, ly, lz) && c.tskip[gie_tile_index(c, lx, ly, lz)]) {
-            const int px = xyz[3 * i] - c.pp_pvt[0], py = xyz[3 * i + 1] - c.pp_pvt[1], pz = xyz[3 * i + 2] - c.pp_pvt[2];
-            const uint64_t pr = gie_in_loc(c, px, py, pz) ? c.pair[gie_lid(c, px, py, pz)] : gie_pair_make(c.empty_value, GIE_PAR_NONE);
-            if (gie_pair_dist(pr) != c.empty_value) {
-                int cw[3];
-                gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
-                const uint64_t cc = gie_pack_crd(cw[0] + c.pp_upvt[0], cw[1] + c.pp_upvt[1], cw[2] + c.pp_upvt[2]);      /* what the commit would have stored */
-                out[i].occ_val = c.g_occ[a]; out[i].vox_type = c.g_type[a]; out[i].dist_sq = gie_gdist(c, cc, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-                gie_unpack_crd(cc, &out[i].coc[0], &out[i].coc[1], &out[i].coc[2]);
-                return;
-            }
-        }
+    uint64_t dcc;
+    if (a >= 0 && gie_deferred_coc(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &dcc)) {      /* a voxel of a tskip tile: its record is its pair-plane entry ("deferred records") */
+        out[i].occ_val = c.g_occ[a]; out[i].vox_type = c.g_type[a]; out[i].dist_sq = gie_gdist(c, dcc, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        gie_unpack_crd(dcc, &out[i].coc[0], &out[i].coc[1], &out[i].coc[2]);
+        return;
     }
     if (a < 0) {
         out[i].occ_val = 0; out[i].vox_type = GIE_VOX_UNKNOWN; out[i].dist_sq = c.empty_value;

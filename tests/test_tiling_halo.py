@@ -352,9 +352,11 @@ def _c5_tiled_vs_whole(tiled, whole):
 
 
 def test_c5_hash_world_tiled_emulation(oracle_lib):
-    """2x2x2 tiles of 24^3 (CPU: oracle against the emulated device logic, and against the single 48^3 volume)."""
+    """2x2x2 tiles of 24^3 (CPU: oracle against the emulated device logic, and against the single 48^3 volume).  Six updates: from the
+    third on the tiles' inner 8x8x8 tiles leave their records to the pair plane (deferred records), and the face layers that
+    cross them are exported through gie_deferred_coc."""
     from emu_py import EmuMapper
-    tile, frames = (24, 24, 24), 4
+    tile, frames = (24, 24, 24), 6
     want = _run_c5_tiled(OracleMapper, tile, frames)
     got = _run_c5_tiled(EmuMapper, tile, frames)
     for k, ((ra, na, pa), (rb, nb, pb)) in enumerate(zip(want, got)):
