@@ -1003,7 +1003,18 @@ def run_bench():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane on gloo; the face layers over RCCL if its pre-flight passes on every rank, else staged through the host
-        tr = tiling.init_transport(torch, dist, rank, world, torch.device("cuda", local_rank), want=backend)
+        # (gloo announces its connections on the process's stdout, from C++: the ONE line of this program is the only thing that
+        #  belongs there, so file descriptor 1 points at stderr while the groups are set up)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            tr = tiling.init_transport(torch, dist, rank, world, torch.device("cuda", local_rank), want=backend)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         backend, group, transport_note = tr["backend"], tr["group"], tr["note"]
         if transport_note and rank == 0:
             sys.stderr.write("bench: %s\n" % transport_note)
