@@ -97,7 +97,10 @@ C5_TURN = 24             # like the lidar robot below, the c5 robot drives 24 fr
                          # leaves behind is bounded however many regions a command times (round 2: a straight line forever ran
                          # the default block pool dry after ~157 updates and the driver's --steps 20 --warmup 5 died in it)
 MAX_REGIONS = 12         # timed regions per workload at most
-HALO_MAX_ROUNDS = 4      # N > 1: refinement rounds enqueued per map update at most (the tail rounds exit on the device-side flag)
+HALO_MAX_ROUNDS = 3      # N > 1: refinement rounds enqueued per map update at most (the tail rounds exit on the device-side flag).  The hash world
+                         # needs 2 - 3 on 2x2x2 tiles whatever the tile size (the tiled oracle on 24^3 and 64^3 tiles: 2, 2, 3, 2) — the last of them
+                         # is the round that seeds nothing; an update that would need more is counted (config.updates_unconverged).  A round that
+                         # meets a closed gate still costs its launches and its transfers (a collective cannot be skipped by one side): ~0.15 ms
 
 
 SENSORS = LIDARS

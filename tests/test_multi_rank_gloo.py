@@ -179,7 +179,7 @@ def test_ranks_gated_rounds_match_the_oracle_until_stable(oracle_lib, world):
         assert p.exitcode == 0
     ref = T._run_c5_tiled(OracleMapper, (24, 24, 24), 3, world=world)
     oracle_rounds = sum(n for _, n, _ in ref)
-    assert world == 2 or 1 < max(n for _, n, _ in ref) < bench.HALO_MAX_ROUNDS      # rounds ran beyond the first and were cut short
+    assert world == 2 or (1 < max(n for _, n, _ in ref) <= bench.HALO_MAX_ROUNDS and min(n for _, n, _ in ref) < bench.HALO_MAX_ROUNDS)      # rounds ran beyond the first, and were cut short
     for t in range(world):
         res, st = got[t]
         assert st == {"rounds_enqueued": 3 * bench.HALO_MAX_ROUNDS, "rounds_run": oracle_rounds, "updates": 3, "updates_unconverged": 0}, st
