@@ -54,6 +54,7 @@ struct gie_mapper {
     int32_t h_cnt[GIE_CNT_NUM];
     int32_t next_off[3], next_whole[3];
     float us[4];
+    const int8_t *labels_pending;         /* the last scan is a label plane left in place (c.scan_labels until gie_fuse): materialised into `_inst_type` if anything else wants it */
     int coc_pending;                      /* voxels of the current tskip tiles have their records in the pair plane only (gie_ops.h "deferred records") */
     int tsp_pvt[3];                       /* the pivot tskip_prev's tiles refer to */
     int flushed_ct;                       /* map tick (c.map_ct) of the pose the owed pairs were last written for ahead of gie_fuse (gie_owed_pairs_before_import) */
@@ -163,7 +164,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1; m->coc_pending = 0;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1; m->coc_pending = 0; m->labels_pending = nullptr;
     m->d_cm = nullptr; m->h_cm[0] = m->h_cm[1] = nullptr; m->cm_bytes = 0; m->cm_slot = 0; m->cm_pending = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
@@ -205,7 +206,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tmax_prev = c.tmax ? c.tmax + ntile : nullptr;
     c.tskip = gie_dalloc<uint8_t>(m, 2 * ntile);
     c.tskip_prev = c.tskip ? c.tskip + ntile : nullptr;
-    c.coc_defer = 0; c.qdefer = 0;
+    c.coc_defer = 0; c.qdefer = 0; c.scan_labels = nullptr;
     for (int i = 0; i < 3; i++) { c.ts_pvt[i] = 0; m->tsp_pvt[i] = 0; c.pp_pvt[i] = c.pp_upvt[i] = 0; }
     c.ucol = gie_dalloc<uint8_t>(m, (((size_t)X * Y * ((Z + 7) / 8)) + 3) & ~(size_t)3);
     c.zocc = gie_dalloc<uint8_t>(m, (size_t)c.Z);
@@ -353,8 +354,18 @@ static int gie_need_pose(gie_mapper *m, const char *who)
     return GIE_OK;
 }
 
+/* a label scan left in place (gie_ogm_labels_dev) becomes an ordinary one: its labels go into `_inst_type` now — before another scan
+ * is laid over it, or a reader asks for the plane */
+static void gie_labels_materialise(gie_mapper *m)
+{
+    if (!m->labels_pending) return;
+    be_labels(&m->be, m->c, m->labels_pending, 0);
+    m->labels_pending = nullptr; m->c.scan_labels = nullptr;
+}
+
 static int gie_stage_sensor(gie_mapper *m, const float *host, size_t n)
 {
+    gie_labels_materialise(m);            /* (the plane of a label scan before this one may live in the staging buffer) */
     if (n > m->sensor_cap) {
         if (m->d_sensor) { be_sync(&m->be); be_free(&m->be, m->d_sensor); }
         m->d_sensor = (float *)be_alloc(&m->be, n * sizeof(float), false);
@@ -370,6 +381,7 @@ extern "C" int gie_ogm_depth_dev(gie_mapper *m, const float *d_depth, const gie_
 {
     int rc = gie_need_pose(m, "gie_ogm_depth"); if (rc) return rc;
     if (!d_depth || !p || p->rows < 1 || p->cols < 1) { gie_set_err("gie_ogm_depth: bad arguments"); return GIE_ERR_INVALID; }
+    gie_labels_materialise(m);
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_depth op; op.img = d_depth; op.p = *p;
@@ -389,6 +401,7 @@ extern "C" int gie_ogm_multiscan_dev(gie_mapper *m, const float *d_ranges, const
 {
     int rc = gie_need_pose(m, "gie_ogm_multiscan"); if (rc) return rc;
     if (!d_ranges || !p || p->scan_num < 1 || p->ring_num < 1) { gie_set_err("gie_ogm_multiscan: bad arguments"); return GIE_ERR_INVALID; }
+    gie_labels_materialise(m);
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_multiscan op; op.img = d_ranges; op.p = *p;
@@ -416,6 +429,7 @@ extern "C" int gie_ogm_scan2d(gie_mapper *m, const float *ranges, const gie_scan
     int rc = gie_need_pose(m, "gie_ogm_scan2d"); if (rc) return rc;
     if (!ranges || !p || p->scan_num < 1) { gie_set_err("gie_ogm_scan2d: bad arguments"); return GIE_ERR_INVALID; }
     rc = gie_stage_sensor(m, ranges, (size_t)p->scan_num); if (rc) return rc;
+    gie_labels_materialise(m);
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
     op_classify_scan2d op; op.img = m->d_sensor; op.p = *p;
@@ -428,10 +442,16 @@ extern "C" int gie_ogm_labels_dev(gie_mapper *m, const int8_t *d_labels)
 {
     int rc = gie_need_pose(m, "gie_ogm_labels"); if (rc) return rc;
     if (!d_labels) { gie_set_err("gie_ogm_labels: bad arguments"); return GIE_ERR_INVALID; }
+    gie_labels_materialise(m);
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
-    be_prof(&m->be, GIE_K_CLASSIFY, 0); be_labels(&m->be, m->c, d_labels); be_prof(&m->be, GIE_K_CLASSIFY, 1);
+    /* The plane stays where it is when the device form applies: this launch only flags the blocks of the observed voxels, gie_fuse
+     * reads the labels from d_labels itself (1 byte written and 1 byte re-read and reset per voxel less: 0.4 GB of a 512^3 update).
+     * d_labels must not change before gie_fuse has run (include/gie.h). */
+    const int in_place = be_labels_in_place_ok(m->c, d_labels);
+    be_prof(&m->be, GIE_K_CLASSIFY, 0); be_labels(&m->be, m->c, d_labels, in_place); be_prof(&m->be, GIE_K_CLASSIFY, 1);
     be_time(&m->be, 1);
+    if (in_place) { m->labels_pending = d_labels; m->c.scan_labels = d_labels; }
     m->has_ogm = 1;
     return GIE_OK;
 }
@@ -439,6 +459,7 @@ extern "C" int gie_ogm_labels(gie_mapper *m, const int8_t *labels)
 {
     int rc = gie_need_pose(m, "gie_ogm_labels"); if (rc) return rc;
     if (!labels) { gie_set_err("gie_ogm_labels: bad arguments"); return GIE_ERR_INVALID; }
+    gie_labels_materialise(m);                                      /* (the plane of a scan before this one may live in the staging buffer) */
     const size_t nfl = ((size_t)m->c.N + 3) / 4;                    /* the staging buffer is counted in floats */
     if (nfl > m->sensor_cap) {
         if (m->d_sensor) { be_sync(&m->be); be_free(&m->be, m->d_sensor); }
@@ -459,6 +480,7 @@ extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
         m->pts_cap = m->d_pts_g ? (size_t)n * 3 : 0;
         if (!m->d_pts_g) { gie_set_err("point buffer allocation failed"); return GIE_ERR_DEVICE; }
     }
+    gie_labels_materialise(m);
     m->c.pntcld_mode = 1;
     be_time(&m->be, 0);
     if (n > 0) {
@@ -655,6 +677,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     be_prof(&m->be, GIE_K_FUSE, 0);
     be_fuse(&m->be, m->c, m->c.tl_front);
     be_prof(&m->be, GIE_K_FUSE, 1);
+    m->labels_pending = nullptr; m->c.scan_labels = nullptr;      /* (a label plane left in place has been read) */
     {   /* the tiles whose stored records this update's Mark need not read (gie_tile_oldskip: the previous update's bounds and this
          * pose — and an obstacle somewhere in the volume, known now that the types are fused), then the records the previous update
          * left to its pair plane for the tiles that are not among them any more (gie_ops.h "deferred records").  If the merge ends
@@ -865,6 +888,7 @@ extern "C" int gie_read_ogm(gie_mapper *m, int8_t *inst_type, int32_t *ray_count
 {
     if (!m) { gie_set_err("gie_read_ogm: null handle"); return GIE_ERR_INVALID; }
     if (m->ogm_unlabelled) { be_vox(&m->be, m->c, op_raycast_finalize()); m->ogm_unlabelled = 0; }   /* the scan labels of a ray-cast scan, on demand */
+    gie_labels_materialise(m);                                                                        /* ... and of a label plane left in place */
     if (inst_type) be_d2h(&m->be, inst_type, m->c.inst_type, (size_t)m->c.N);
     if (ray_count) be_d2h(&m->be, ray_count, m->c.ray_count, (size_t)m->c.N * 4);
     return gie_sync(m);

@@ -287,11 +287,15 @@ static void be_flush_clear(be_state *b, const gie_ctx &c, const op_pair_flush &f
     const int nclr = gie_clear_total_wgs(l);
     GIE_LAUNCH(b, k_flush_clear, dim3(nclr + (n + 255) / 256), dim3(256), 0, c, f, n, l, nclr);
 }
-static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels)
+/* can the scan stay where it is (be_labels with in_place: only the blocks are flagged, gie_fuse reads the plane itself)? */
+static int be_labels_in_place_ok(const gie_ctx &c, const int8_t *labels)
+{ return (c.X & 15) == 0 && !c.for_motion_planner && ((uintptr_t)labels & 15) == 0; }
+static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels, int in_place = 0)
 {
     if ((c.X & 15) == 0 && !c.for_motion_planner && ((uintptr_t)labels & 15) == 0) {
         const int nvec = c.N >> 4;
-        GIE_LAUNCH(b, k_labels16, dim3((nvec + 255) / 256), dim3(256), 0, c, labels, nvec);
+        if (in_place) GIE_LAUNCH(b, k_labels16<false>, dim3((nvec + 255) / 256), dim3(256), 0, c, labels, nvec);
+        else GIE_LAUNCH(b, k_labels16<true>, dim3((nvec + 255) / 256), dim3(256), 0, c, labels, nvec);
     } else { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
 }
 static void be_clear(be_state *b, const gie_clear_list &l, const int32_t *gate = nullptr)

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void k_lin(const gie_ctx c, const F f, const i
 
 /* gie_ogm_labels for X % 16 == 0 without a robot sphere: a thread moves 16 voxels of a row (one
  * 16-byte load, one 16-byte store) and flags the (at most three) blocks its observed voxels lie in */
+template <bool STORE>
 __global__ __launch_bounds__(256) void k_labels16(const gie_ctx c, const int8_t *labels, const int nvec)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void k_labels16(const gie_ctx c, const int8_t 
             known |= (ok ? 1u : 0u) << (4 * j + b);
         }
     }
-    reinterpret_cast<uint4 *>(c.inst_type)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (STORE) reinterpret_cast<uint4 *>(c.inst_type)[v] = make_uint4(w[0], w[1], w[2], w[3]);      /* (!STORE: gie_fuse reads the caller's plane itself, c.scan_labels) */
     if (!known) return;
     const int gx0 = x0 + c.pvt[0], gy = y + c.pvt[1], gz = z + c.pvt[2];
     const int cell0 = (((gz >> 3) - c.tb0[2]) * c.tdim[1] + ((gy >> 3) - c.tb0[1])) * c.tdim[0] - c.tb0[0];
@@ -2151,7 +2152,7 @@ __global__ __launch_bounds__(256, PNT ? 3 : 4) void k_fuse_rows(const gie_ctx c,
             bool occ_here = false;
             if (live) {
                 const long long id = id0 + (long long)k * plane;
-                const uint64_t it8 = gie_row_ld8(c.inst_type, id, w);
+                const uint64_t it8 = gie_row_ld8(c.scan_labels ? c.scan_labels : c.inst_type, id, w);
                 const uint64_t gt8 = gie_row_ld8(c.glb_type, id, w);
                 uint32_t rc[8];
                 if (PNT) gie_row_ld32(reinterpret_cast<const uint32_t *>(c.ray_count), id, w, rc);
@@ -2202,7 +2203,7 @@ __global__ __launch_bounds__(256, PNT ? 3 : 4) void k_fuse_rows(const gie_ctx c,
                     if (w.full) { gie_st16u(c.ray_count + id, make_uint4(0, 0, 0, 0)); gie_st16u(c.ray_count + id + 4, make_uint4(0, 0, 0, 0)); }
                     else for (int i = w.xlo; i < w.xhi; i++) c.ray_count[id + i] = 0;
                 }
-                if (it8 != 0ull) gie_row_st8(c.inst_type, id, w, 0ull);
+                if (it8 != 0ull && !c.scan_labels) gie_row_st8(c.inst_type, id, w, 0ull);
                 if (ng8 != gt8) gie_row_st8(c.glb_type, id, w, ng8);
                 if (w.slot >= 0) {
                     if (no8 != go8) *reinterpret_cast<uint64_t *>(p_occ + a) = no8;        /* bytes of voxels outside the volume keep their value */

@@ -522,7 +522,7 @@ struct gie_fuse_st { int count; int8_t nt, gt0; gie_vaddr a; uint8_t occ; int8_t
 GIE_DEV void gie_fuse_load1(const gie_ctx &c, int id, int x, int y, int z, gie_fuse_st &s)
 {
     s.count = c.pntcld_mode ? c.ray_count[id] : 0;
-    s.nt = c.inst_type[id];
+    s.nt = c.scan_labels ? c.scan_labels[id] : c.inst_type[id];      /* (labels other than FREE / OCCUPIED count as "not observed": gie_fuse_logic) */
     s.gt0 = c.glb_type[id];
     s.a = gie_gvox_tab(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2]);
 }
@@ -603,7 +603,7 @@ GIE_DEV int gie_fuse_finish(const gie_ctx &c, int id, int x, int y, int z, const
     const int count = s.count;
     if (count != 0) c.ray_count[id] = 0;                                 /* write only what changes */
     const int8_t nt = s.nt;
-    if (nt != GIE_VOX_UNKNOWN) c.inst_type[id] = GIE_VOX_UNKNOWN;
+    if (nt != GIE_VOX_UNKNOWN && !c.scan_labels) c.inst_type[id] = GIE_VOX_UNKNOWN;
     const int8_t gt0 = s.gt0;
     const gie_vaddr a = s.a;
     if (a < 0) { if (gt0 != GIE_VOX_UNKNOWN) c.glb_type[id] = GIE_VOX_UNKNOWN; return 0; }

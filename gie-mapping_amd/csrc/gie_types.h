@@ -114,6 +114,8 @@ typedef struct gie_ctx {
                              * not WRITE them either: the pair plane is the record of such a tile's voxels until they are caught up or leave */
     uint8_t *tskip_prev;    /* tskip of the gie_fuse before (the two alternate), for the catch-up of the deferred records */
     int ts_pvt[3];          /* the pivot tskip's tiles refer to (= the pose of the last gie_fuse; c.pvt moves with gie_set_pose) */
+    const int8_t *scan_labels; /* non-null: the scan is a label plane the caller (or the library's staging buffer) still holds — gie_ogm_labels_dev
+                             * has only flagged its blocks — and gie_fuse reads the labels from there: `_inst_type` is neither written nor reset */
     int wr_inside;          /* every voxel of the local volume lies inside the wave range (always, unless a tile offset pushes the volume out of it) */
     int skip2_ok;           /* tskip_prev describes the tiles of the update right before this one, at the pose prev_shift refers to: a tile may be flagged 2 */
     int catchup_fast;       /* gie_tile_oldskip also says which tiles of this update need their deferred records stored (tskip_prev is the update before's, at prev_shift) */

@@ -175,6 +175,9 @@ int gie_ogm_scan2d(gie_mapper *h, const float *ranges, const gie_scan_param *p);
  * of BASELINE config 5 (occupancy from a hash of the voxel, full observation) is
  * fed.  The robot sphere of for_motion_planner is forced FREE as in every OGM kernel. */
 int gie_ogm_labels(gie_mapper *h, const int8_t *labels);
+/* _dev: the plane may be read IN PLACE by gie_fuse (no copy into `_inst_type`): d_labels must stay unchanged until the gie_fuse /
+ * gie_step of this map update has been executed on the mapper's stream (gie_get_stream) — or until another gie_ogm_* /
+ * gie_read_ogm call, which copies it first. */
 int gie_ogm_labels_dev(gie_mapper *h, const int8_t *d_labels);
 
 /* Ext_Obs_Wrapper boxes as consumed by the fuse kernels (pre_map.cu:80-101,

@@ -110,7 +110,8 @@ static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox
  * the tile summary does not rule out (op_frontier::tile_skip / skip), same decisions per voxel */
 static void be_frontier_tiles(be_state *b, const gie_ctx &c, const int32_t *known, int known_idx, const int32_t *, int)
 { be_list(b, c, op_tile_summary(), known, known_idx); be_vox(b, c, op_frontier()); }
-static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels) { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
+static int be_labels_in_place_ok(const gie_ctx &, const int8_t *) { return 0; }     /* (a device shortcut: the emulation always copies the plane into _inst_type) */
+static void be_labels(be_state *b, const gie_ctx &c, const int8_t *labels, int = 0) { op_classify_labels op; op.labels = labels; be_vox(b, c, op); }
 template <class F> static void be_lin(be_state *, const gie_ctx &c, const F &f, int n) { if (GIE_GATE_CLOSED(c)) return; for (int i = 0; i < n; i++) f(c, i); }
 template <class F> static void be_range(be_state *, const gie_ctx &c, const F &f, int n) { for (int i = 0; i < n; i++) f(c, i); }
 static void be_clear(be_state *, const gie_clear_list &l, const int32_t *gate = nullptr) { if (gate && *gate == 0) return; for (int i = 0; i < l.n; i++) memset(l.p[i], 0, l.bytes[i]); }

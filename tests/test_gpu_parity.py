@@ -311,6 +311,53 @@ def test_device_resident_readers_give_the_host_forms_bytes(oracle_lib):
         a.close(); b.close()
 
 
+def test_label_plane_read_in_place_or_copied_gives_the_same_map(oracle_lib):
+    """gie_ogm_labels_dev may leave the plane where it is and let gie_fuse read it (round 5: `_inst_type` neither written nor reset) —
+    unless something wants `_inst_type` first (gie_read_ogm, a second scan laid over it), which copies it after all.  Three HIP
+    mappers fed the same device-resident planes — in place; read back in between; a point cloud on top — against the oracle fed the
+    same way."""
+    import torch
+    from gie import scenes
+    size = (64, 48, 40)                                   # X % 16 == 0: the in-place form applies
+    cfg = gie.make_config(0.05, size, cutoff_dist=1.0)
+    dev = torch.device("cuda", 0)
+    ms = {k: gie.Mapper(cfg) for k in ("in_place", "read_back", "two_scans")}
+    os_ = {k: OracleMapper(cfg) for k in ("plain", "two_scans")}
+    rng = np.random.default_rng(3)
+    try:
+        for k in range(5):
+            pos, q = scenes.pose(k, 0.05, delta_vox=5, yaw_deg=2.0)
+            lab = np.ascontiguousarray(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, size), size, k, seed=9, p_occ=0.02).astype(np.int8))
+            lab[rng.random(lab.shape) < 0.3] = 0            # a partly observed volume
+            pts = (rng.uniform(-0.8, 0.8, size=(200, 3))).astype(np.float32)
+            d_lab = torch.from_numpy(lab).to(dev)
+            torch.cuda.synchronize()
+            for name, m in ms.items():
+                m.set_pose(pos, q)
+                m.ogm_labels_dev(d_lab.data_ptr())
+                if name == "read_back":
+                    got = m.read_ogm()["inst_type"]
+                    assert np.array_equal(got, lab)
+                if name == "two_scans":
+                    m.ogm_pointcloud(pts)
+                m.step()
+                m.sync()                                  # (d_lab is overwritten by the next frame's upload)
+            for name, o in os_.items():
+                o.set_pose(pos, q)
+                o.ogm_labels(lab)
+                if name == "two_scans":
+                    o.ogm_pointcloud(pts)
+                o.fuse(); o.batch_edt(); o.merge()
+            for name, m in ms.items():
+                want = os_["two_scans" if name == "two_scans" else "plain"].read_local()
+                got = m.read_local()
+                for key in ("type", "dist_sq", "coc"):
+                    assert np.array_equal(want[key], got[key]), (k, name, key)
+    finally:
+        for m in list(ms.values()) + list(os_.values()):
+            m.close()
+
+
 def test_full_size_512_cube(oracle_lib):
     """BASELINE size: 512^3 @ 0.05 m (outside the reference's 11/11/10-bit envelope → wide mode).
     Two map updates against the oracle, every array bit for bit, plus size-independent
