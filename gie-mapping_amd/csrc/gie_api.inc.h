@@ -54,6 +54,7 @@ struct gie_mapper {
     int32_t h_cnt[GIE_CNT_NUM];
     int32_t next_off[3], next_whole[3];
     float us[4];
+    int track_want;                       /* gie_stream_enable: taken over by the next gie_fuse (an update runs in ONE order of kernels from its fuse to its merge) */
     const int8_t *labels_pending;         /* the last scan is a label plane left in place (c.scan_labels until gie_fuse): materialised into `_inst_type` if anything else wants it */
     int coc_pending;                      /* voxels of the current tskip tiles have their records in the pair plane only (gie_ops.h "deferred records") */
     int tsp_pvt[3];                       /* the pivot tskip_prev's tiles refer to */
@@ -164,7 +165,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     }
     gie_mapper *m = new gie_mapper();
     m->cfg = *cfg;
-    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1; m->coc_pending = 0; m->labels_pending = nullptr;
+    m->has_pose = m->has_ogm = 0; m->merge_open = 0; m->bar_fault_left = 0; m->c.bar_fault = 0; m->edt_partial = 0; m->ogm_unlabelled = 0; m->evictions = 0; m->tomb_bound = 0; m->retain_box_valid = 0; m->deferred = 0; m->flush_tab_ok = 0; m->fuse_fresh = 0; m->flushed_ct = -1; m->coc_pending = 0; m->labels_pending = nullptr; m->track_want = 0;
     m->d_cm = nullptr; m->h_cm[0] = m->h_cm[1] = nullptr; m->cm_bytes = 0; m->cm_slot = 0; m->cm_pending = 0;
     for (int i = 0; i < 3; i++) { m->next_off[i] = 0; m->next_whole[i] = cfg->local_size[i]; }
     m->d_sensor = nullptr; m->sensor_cap = 0; m->d_pts_g = nullptr; m->pts_cap = 0;
@@ -582,6 +583,7 @@ extern "C" int gie_fuse(gie_mapper *m)
     if (!m->has_ogm) { gie_set_err("gie_fuse: no scan has been fed since the last fuse (call gie_ogm_* first)"); return GIE_ERR_INVALID; }
     m->has_ogm = 0;
     m->ogm_unlabelled = 0;                /* fuse consumes the scan */
+    m->c.track = m->track_want;           /* the order of kernels of this update — fused sweep or the reference's, with the changed-block flags — is settled here */
     const int unmerged = m->deferred && !m->flush_tab_ok;   /* types and block table are no longer those of the last fused merge: a gie_fuse
                                                               without a merge came in between (the staged ABI allows it) */
     m->fuse_fresh = 1;
@@ -1035,7 +1037,7 @@ static int gie_stream_chunk_blocks()
 extern "C" int gie_stream_enable(gie_mapper *m, int on)
 {
     if (!m) { gie_set_err("gie_stream_enable: null handle"); return GIE_ERR_INVALID; }
-    m->c.track = on ? 1 : 0;
+    m->track_want = on ? 1 : 0;           /* (from the next gie_fuse on: include/gie.h) */
     return GIE_OK;
 }
 extern "C" int gie_stream_changed(gie_mapper *m, int32_t *keys, gie_voxel *blocks, int max_blocks, int32_t *n_changed)

@@ -256,6 +256,8 @@ int gie_get_stats(gie_mapper *h, gie_frame_stats *out);
  * keys/blocks only counts.  One gather kernel + one batched copy per chunk instead of the
  * reference's 20 KB memcpy per block. */
 #define GIE_BLOCK_VOXELS 512
+/* (takes effect with the next gie_fuse: a map update runs in one order of kernels — the fused Mark + commit sweep, or the reference's
+ * Mark ... commit with the flags — from its fuse to its merge) */
 int gie_stream_enable(gie_mapper *h, int on);
 int gie_stream_changed(gie_mapper *h, int32_t *keys, gie_voxel *blocks, int max_blocks, int32_t *n_changed);
 
