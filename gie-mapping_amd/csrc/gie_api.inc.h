@@ -243,6 +243,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.free_list = gie_dalloc<int32_t>(m, c.retain > 0 ? (size_t)mb : 1, false);
     const size_t GV = (size_t)mb * GIE_VBSZ;
     c.g_key = gie_dalloc<uint64_t>(m, (size_t)mb, false);
+    c.g_nbr = gie_dalloc<int32_t>(m, 8 * (size_t)mb, false);
     c.g_occ = gie_dalloc<uint8_t>(m, GV, false);
     c.g_type = gie_dalloc<int8_t>(m, GV, false);
     c.g_coc = gie_dalloc<uint64_t>(m, GV, false);

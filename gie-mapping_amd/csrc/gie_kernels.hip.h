@@ -427,6 +427,7 @@ __global__ __launch_bounds__(256) void k_block_init_list(const gie_ctx c, const 
         if (slot < 0) continue;
         gie_init_voxel(c, slot, threadIdx.x);
         gie_init_voxel(c, slot, threadIdx.x + 256);
+        if (threadIdx.x < 6) gie_nbr_link(c, slot, (int)threadIdx.x);
     }
 }
 
@@ -2462,6 +2463,7 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_gridbar &
     uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
     const gie_vaddr base = (gie_vaddr)slot * GIE_VBSZ;
     GIE_WPROF_DECL;
+    const int32_t nraw = gie_ld(&c.g_nbr[8 * (size_t)slot + (lane < 6 ? lane : 0)]);      /* the six neighbour slots: first in the queue, in flight with everything below */
     const uint64_t bkey = gie_ld(&c.g_key[slot]);
     uint64_t cv[8], cc8[8];
     int8_t ty8[8];
@@ -2480,21 +2482,21 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_gridbar &
     for (int j = 0; j < 8; j++) vl8[j] = gie_wa_vanish_lid(c, cc8[j]);
 #pragma unroll
     for (int j = 0; j < 8; j++) vt8[j] = c.glb_type[vl8[j] < 0 ? 0 : vl8[j]];              /* one batch, in flight with the neighbour lookups */
-    if (lane < 6) {
-        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
-        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
-    }
+    if (lane < 6) L.nslot[lane] = nraw;
     gie_wave_sync();
-    GIE_WPROF_MARK(0);                                                   /* 0: neighbour lookups (own loads in flight) */
+    GIE_WPROF_MARK(0);                                                   /* 0: neighbour slots (own loads in flight) */
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int np = 0;
     {
         const int p = lane & 7, q = lane >> 3;
         const int hidx[6] = { 7 | (p << 3) | (q << 6), 0 | (p << 3) | (q << 6), p | (7 << 3) | (q << 6), p | (0 << 3) | (q << 6), p | (q << 3) | (7 << 6), p | (q << 3) | (0 << 6) };
         const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
-        uint64_t hc[6]; int8_t ht[6]; int32_t hw[6];
+        uint64_t hc[6], nk[6]; int8_t ht[6]; int32_t hw[6];
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const int ns = L.nslot[f];
             const gie_vaddr an = (ns < 0 ? base : (gie_vaddr)ns * GIE_VBSZ) + hidx[f];
+            nk[f] = gie_ld(&c.g_key[ns < 0 ? slot : ns]);              /* does the slot still hold that neighbour?  (fetched with its records) */
             hc[f] = gie_ld(&c.g_coc[an]) & ~GIE_COC_STALEPAIR; ht[f] = gie_ld(&c.g_type[an]); hw[f] = gie_ld(&c.g_wl[an]);
         }
         int hl[6]; int8_t hv[6];
@@ -2502,33 +2504,37 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_gridbar &
         for (int f = 0; f < 6; f++) hl[f] = gie_wa_vanish_lid(c, hc[f]);
 #pragma unroll
         for (int f = 0; f < 6; f++) hv[f] = c.glb_type[hl[f] < 0 ? 0 : hl[f]];          /* one batch */
+        /* the block's own records go into LDS while that batch is in flight */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int v = lane + 64 * j;
+            int ncx, ncy, ncz;
+            gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
+            const bool ok = ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+                            && !gie_invalid_dist(c, gie_gdist(c, cc8[j], g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j));
+            L.coc[v] = cc8[j]; L.prop[v] = cv[j];
+            L.flag[v] = (uint8_t)((ok ? GIE_WA_OK : 0u) | (wl8[j] == -c.map_ct ? GIE_WA_RAISED : 0u) | ((vl8[j] >= 0 && vt8[j] != GIE_VOX_OCCUPIED) ? GIE_WA_VANISHED : 0u));
+            const bool have = cv[j] != GIE_NOPROP;
+            const unsigned long long m = __ballot(have);
+            if (have) L.pend[0][np + __popcll(m & lt)] = (uint16_t)v;
+            np += __popcll(m);
+        }
+        unsigned live = 0;
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             int ncx, ncy, ncz;
             gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
-            const bool ok = L.nslot[f] >= 0 && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+            const bool there = L.nslot[f] >= 0 && nk[f] == gie_pack_crd(bk[0] + (f == 1) - (f == 0), bk[1] + (f == 3) - (f == 2), bk[2] + (f == 5) - (f == 4));
+            if (there) live |= 1u << f;
+            const bool ok = there && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
                             && !gie_invalid_dist(c, gie_gdist(c, hc[f], g0[0] + hx[f], g0[1] + hy[f], g0[2] + hz[f]));
             L.halo[f][lane] = hc[f];
             L.hflag[f][lane] = (uint8_t)((ok ? GIE_WA_OK : 0u) | (hw[f] == -c.map_ct ? GIE_WA_RAISED : 0u) | ((hl[f] >= 0 && hv[f] != GIE_VOX_OCCUPIED) ? GIE_WA_VANISHED : 0u));
         }
+        if (lane < 6 && !((live >> lane) & 1u)) L.nslot[lane] = -1;      /* (an erased neighbour: its row of the table outlived it) */
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int np = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int v = lane + 64 * j;
-        int ncx, ncy, ncz;
-        gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
-        const bool ok = ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
-                        && !gie_invalid_dist(c, gie_gdist(c, cc8[j], g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j));
-        L.coc[v] = cc8[j]; L.prop[v] = cv[j];
-        L.flag[v] = (uint8_t)((ok ? GIE_WA_OK : 0u) | (wl8[j] == -c.map_ct ? GIE_WA_RAISED : 0u) | ((vl8[j] >= 0 && vt8[j] != GIE_VOX_OCCUPIED) ? GIE_WA_VANISHED : 0u));
-        const bool have = cv[j] != GIE_NOPROP;
-        if (have) gie_st(&rd[base + v], (uint64_t)GIE_NOPROP);         /* consumed */
-        const unsigned long long m = __ballot(have);
-        if (have) L.pend[0][np + __popcll(m & lt)] = (uint16_t)v;
-        np += __popcll(m);
-    }
+    for (int j = 0; j < 8; j++) if (cv[j] != GIE_NOPROP) gie_st(&rd[base + lane + 64 * j], (uint64_t)GIE_NOPROP);         /* consumed */
     if (lane == 0) { L.npend[0] = np; L.npend[1] = 0; }
     gie_wave_sync();
     GIE_WPROF_MARK(0);                                                   /* 1: halo + own records into LDS */
@@ -2684,9 +2690,15 @@ __device__ __forceinline__ void gie_wave_a_block(const gie_ctx &c, gie_gridbar &
         for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
         const bool act = lane < 6 && ((any6 >> lane) & 1u);
         const int ns = act ? L.nslot[lane] : 0;
+        /* ONE atomic instruction for both (a returning atomic is paid per instruction, whatever its lanes address): the flag is
+         * "was 0 before", so an add serves as the exchange */
         int32_t r1 = 1;
-        if (act) r1 = gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1);
-        if (lane == 63 && npush > 0) r1 = gie_aadd32(&c.cnt[GIE_CNT_B], npush);
+        {
+            int32_t *ap = nullptr; int av = 0;
+            if (act) { ap = &c.wb_flag[(round + 1) & 1][ns]; av = 1; }
+            if (lane == 63 && npush > 0) { ap = &c.cnt[GIE_CNT_B]; av = npush; }
+            if (ap != nullptr) r1 = gie_aadd32(ap, av);
+        }
         const int qbase = __shfl(r1, 63);
         const bool first = act && r1 == 0;
         const unsigned long long fm = __ballot(first);
@@ -2800,6 +2812,7 @@ struct gie_wb_tile { uint64_t pair[512], prop[512], halo[6][64]; uint32_t sdist[
                                                            * distance of an unknown one), fetched with the block — the levels never wait for memory */
 __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &gb, gie_wb_tile &L, const int slot, const int round, const int lane)
 {
+    const int32_t nraw = gie_ld(&c.g_nbr[8 * (size_t)slot + (lane < 6 ? lane : 0)]);      /* the six neighbour slots (see gie_wave_a_block) */
     int bk[3];
     gie_unpack_crd(gie_ld(&c.g_key[slot]), &bk[0], &bk[1], &bk[2]);
     const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };              /* global coordinate of the block's first voxel */
@@ -2820,23 +2833,21 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
         ty8[j] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[a]);
     }
     if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);     /* may be activated again (for round + 2) from now on */
-    /* ---- the six neighbour blocks (lane k < 6 probes for block k) with the block's own records in flight */
-    if (lane < 6) {
-        const int dxk = (lane == 0) ? -1 : (lane == 1) ? 1 : 0, dyk = (lane == 2) ? -1 : (lane == 3) ? 1 : 0, dzk = (lane == 4) ? -1 : (lane == 5) ? 1 : 0;
-        L.nslot[lane] = gie_hash_find(c, bk[0] + dxk, bk[1] + dyk, bk[2] + dzk);
-    }
+    /* ---- the six neighbour blocks, out of the block's row of the neighbour table, with the block's own records in flight */
+    if (lane < 6) L.nslot[lane] = nraw;
     gie_wave_sync();                                                    /* the neighbour slots */
     GIE_WPROF_MARK(8);
     {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the lane's position (a, b) on it -> in-block index of the voxel across the face */
         const int p = lane & 7, q = lane >> 3;
         const int hidx[6] = { 7 | (p << 3) | (q << 6), 0 | (p << 3) | (q << 6), p | (7 << 3) | (q << 6), p | (0 << 3) | (q << 6), p | (q << 3) | (7 << 6), p | (q << 3) | (0 << 6) };
         const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
-        uint64_t hp[6], hc[6]; int8_t ht[6];
+        uint64_t hp[6], hc[6], nk[6]; int8_t ht[6];
         unsigned hinv = 0;
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const int ns = L.nslot[f];
             const gie_vaddr an = (ns < 0 ? base : (gie_vaddr)ns * GIE_VBSZ) + hidx[f];
+            nk[f] = gie_ld(&c.g_key[ns < 0 ? slot : ns]);
             const int nb[3] = { g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2] };
             const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
             const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
@@ -2844,8 +2855,11 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
             hp[f] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[an]) & ~GIE_PAIR_NEW; hc[f] = gie_ld(&c.g_coc[an]);
             ht[f] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[an]);
         }
+        unsigned live = 0;
 #pragma unroll
         for (int f = 0; f < 6; f++) {
+            const bool there = L.nslot[f] >= 0 && nk[f] == gie_pack_crd(bk[0] + (f == 1) - (f == 0), bk[1] + (f == 3) - (f == 2), bk[2] + (f == 5) - (f == 4));
+            if (there) live |= 1u << f;
             if ((hinv >> f) & 1u) {
                 if (ht[f] == GIE_VOX_UNKNOWN)
                     hp[f] = gie_pair_make(gie_batch_dist_direct(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]), 0);
@@ -2854,10 +2868,11 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
             }
             int ncx, ncy, ncz;
             gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
-            const bool ok = L.nslot[f] >= 0 && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+            const bool ok = there && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
                             && !gie_in_whole(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]);   /* (tiling: not into another tile's territory) */
             L.halo[f][lane] = hp[f]; L.hflag[f][lane] = ok ? GIE_WB_OK : 0u;
         }
+        if (lane < 6 && !((live >> lane) & 1u)) L.nslot[lane] = -1;      /* (an erased neighbour) */
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     int np0 = 0;
@@ -3022,8 +3037,12 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
         const int total = anyhit ? __shfl(incl, 63) : 0;
         /* stage 2: lane 0 appends to the list of voxels, lane 1 to the list of blocks */
         int base = 0;
-        if (lane == 0 && total > 0) base = gie_aadd32(&c.cnt[GIE_CNT_INL], total);
-        if (lane == 1 && fm != 0ull) base = gie_aadd32(&c.lvlb_next[round + 1], __popcll(fm));
+        {   /* (one atomic instruction: see gie_wave_a_block) */
+            int32_t *ap = nullptr; int av = 0;
+            if (lane == 0 && total > 0) { ap = &c.cnt[GIE_CNT_INL]; av = total; }
+            if (lane == 1 && fm != 0ull) { ap = &c.lvlb_next[round + 1]; av = __popcll(fm); }
+            if (ap != nullptr) base = gie_aadd32(ap, av);
+        }
         const int qb0 = __shfl(base, 0), ab0 = __shfl(base, 1);
         if (first) gie_st(&c.wb_list[(round + 1) & 1][ab0 + __popcll(fm & ((1ull << lane) - 1ull))], (int32_t)ns);
         if (total > 0) {
@@ -3364,8 +3383,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, con
 #endif
     GIE_TS2(0, 0);
     if (with_ab) {
-        gie_wave_a_run(c, gb, s_ablocks);
-        gie_grid_sync(gb, c);               /* wave B starts from the queue and the counters wave A leaves */
+        gie_wave_a_run(c, gb, s_ablocks);   /* (ends behind the barrier of its last round: wave B starts from the queue and the counters it leaves) */
         GIE_TS2(8, 0);
         gie_wave_b_run(c, gb, s_blocks);
         gie_grid_sync(gb, c);

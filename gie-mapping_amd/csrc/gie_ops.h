@@ -430,6 +430,20 @@ GIE_DEV void gie_rehash_slot(const gie_ctx &c, int slot)
     gie_key_insert(c, key, b[0], b[1], b[2], slot);
 }
 
+/* row `slot` of the neighbour table (c.g_nbr), direction k (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the slot of the block across that face,
+ * and this block's slot into that neighbour's row.  Called for every block that is initialised (new, or a slot handed out again),
+ * after the launch that inserted the keys: two blocks that are new together write the same two words.  This library's own
+ * structure — the reference probes its hash per voxel and direction (wave_core.cuh:139-150, 283-296). */
+GIE_DEV void gie_nbr_link(const gie_ctx &c, int slot, int k)
+{
+    int b[3];
+    gie_unpack_crd(c.g_key[slot], &b[0], &b[1], &b[2]);
+    b[k >> 1] += (k & 1) ? 1 : -1;
+    const int ns = gie_hash_find(c, b[0], b[1], b[2]);
+    c.g_nbr[8 * (size_t)slot + k] = ns;
+    if (ns >= 0) c.g_nbr[8 * (size_t)ns + (k ^ 1)] = slot;
+}
+
 /* GlbVoxel defaults (voxmap_utils.cuh:30-43) for voxel i of a fresh block */
 GIE_DEV void gie_init_voxel(const gie_ctx &c, int slot, int i)
 {

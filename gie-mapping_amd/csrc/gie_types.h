@@ -154,6 +154,9 @@ typedef struct gie_ctx {
     int retain;             /* gie_config.retain_radius_blocks (0: blocks are never erased) */
     int vb_lo[3], vb_hi[3]; /* block box of the local volume +-1 voxel */
     uint64_t *g_key;        /* block key per slot */
+    int32_t *g_nbr;         /* per slot: the slots of the six face neighbours (-x +x -y +y -z +z; 8 words per block), written when a block is
+                             * initialised, for itself and into its neighbours' rows; an entry may outlive its block (erasure): the reader
+                             * holds the named slot's key against the key it expects (waves A / B, fetched with the halo) */
     uint8_t *g_occ;         /* planes, 512 per slot, in-block index x | y<<3 | z<<6 */
     int8_t *g_type;
     uint64_t *g_coc;        /* packed global coord */
