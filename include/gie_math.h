@@ -1,9 +1,11 @@
 /*
- * gie_math.h — deterministic fp32 geometry shared by the HIP kernels and the CPU oracle.
+ * gie_math.h — deterministic fp32 geometry of the HIP kernels (and of the host layers above the C-ABI).
  *
  * Voxelisation must agree bit-for-bit between the GPU path and the CPU checker, so everything
  * here is spelled as explicit IEEE-754 binary32 +,-,*,/,sqrt,floor in a fixed evaluation order
- * and both sides are compiled with -ffp-contract=off (no FMA contraction).  No libm
+ * and both sides are compiled with -ffp-contract=off (no FMA contraction).  The oracle does NOT include
+ * this header (since round 5): oracle/oracle_math.h states the same geometry on its own, and
+ * tests/test_independent_checks.py holds the two against each other bit for bit and each against float64.  No libm
  * transcendental is used: atan2 is a fixed polynomial (Cephes-style atanf reduction), because
  * device and host libm differ in the last ulp and a one-ulp difference flips floor() bins.
  *

@@ -30,7 +30,7 @@
 #include <stdio.h>
 #include <math.h>
 #include "../include/gie.h"
-#include "../include/gie_math.h"
+#include "oracle_math.h"      /* the oracle's own statement of the fp32 geometry: shares nothing with the product's include/gie_math.h */
 
 #define VB 8
 #define VBSZ 512
@@ -73,7 +73,7 @@ typedef struct gie_oracle {
     int invalid_dist_min; /* invalid_dist_glb threshold (900000) */
     int wide;
     int map_ct;
-    gie_se3 L2G, G2L;
+    om_pose L2G, G2L;
     float origin[3];
     int pvt[3], upvt[3];
     int tile_off[3], next_off[3], next_whole[3], whole_lo[3], whole_hi[3];
@@ -229,7 +229,7 @@ gie_oracle *go_create(const gie_config *cfg)
     o->blocks_cap = 1024; o->blocks = (oblock **)malloc(sizeof(oblock *) * 1024);
     o->hcap = 4096; o->htab = (int32_t *)malloc(sizeof(int32_t) * 4096);
     for (int i = 0; i < o->hcap; i++) o->htab[i] = -1;
-    o->L2G = gie_se3_from_quat(1, 0, 0, 0, 0, 0, 0); o->G2L = gie_se3_inv(o->L2G);
+    { const float q1[4] = { 1, 0, 0, 0 }, t0[3] = { 0, 0, 0 }; o->L2G = om_from_quat(q1, t0); o->G2L = om_inverse(o->L2G); }
     o->next_whole[0] = o->X; o->next_whole[1] = o->Y; o->next_whole[2] = o->Z;
     return o;
 }
@@ -254,13 +254,13 @@ int go_set_pose(gie_oracle *o, const float pos[3], const float q[4])
     o->map_ct++;
     memset(&o->st, 0, sizeof(o->st));
     o->st.frame = o->map_ct;
-    o->L2G = gie_se3_from_quat(q[0], q[1], q[2], q[3], pos[0], pos[1], pos[2]);
-    o->G2L = gie_se3_inv(o->L2G);
+    o->L2G = om_from_quat(q, pos);
+    o->G2L = om_inverse(o->L2G);
     const float w = o->cfg.voxel_width;
     const int sz[3] = { o->X, o->Y, o->Z };
     for (int i = 0; i < 3; i++) {
         o->origin[i] = pos[i];
-        const int c = gie_pos2coord(pos[i], w);
+        const int c = om_voxel_of(pos[i], w);
         o->tile_off[i] = o->next_off[i];
         o->whole_lo[i] = -(o->next_whole[i] / 2) + sz[i] / 2 - o->next_off[i];
         o->whole_hi[i] = o->whole_lo[i] + o->next_whole[i];
@@ -287,7 +287,7 @@ static void ray_cast(gie_oracle *o, const float p0[3], const float p1[3], float 
 {
     const float w = o->cfg.voxel_width;
     int i0[3], i1[3];
-    for (int i = 0; i < 3; i++) { i0[i] = gie_pos2coord(p0[i], w); i1[i] = gie_pos2coord(p1[i], w); }
+    for (int i = 0; i < 3; i++) { i0[i] = om_voxel_of(p0[i], w); i1[i] = om_voxel_of(p1[i], w); }
     clear_ray(o, i0[0] - o->pvt[0], i0[1] - o->pvt[1], i0[2] - o->pvt[2]);
     if (i0[0] == i1[0] && i0[1] == i1[1] && i0[2] == i1[2]) return;
     float dir[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
@@ -326,18 +326,18 @@ int go_ogm_pointcloud(gie_oracle *o, const float *xyz, int n)
     o->pntcld_mode = 1;
     float *g = (float *)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
     for (int i = 0; i < n; i++) {
-        gie_se3_apply(o->L2G, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &g[3 * i], &g[3 * i + 1], &g[3 * i + 2]);
+        om_transform(o->L2G, &xyz[3 * i], &g[3 * i]);
         const float gz = g[3 * i + 2];
-        if (gie_point_ok(g[3 * i], g[3 * i + 1], gz) && gz >= o->cfg.ogm_min_h && gz <= o->cfg.ogm_max_h) {
-            const int lx = gie_pos2coord(g[3 * i], w) - o->pvt[0];
-            const int ly = gie_pos2coord(g[3 * i + 1], w) - o->pvt[1];
-            const int lz = gie_pos2coord(gz, w) - o->pvt[2];
+        if (om_point_usable(&g[3 * i]) && gz >= o->cfg.ogm_min_h && gz <= o->cfg.ogm_max_h) {
+            const int lx = om_voxel_of(g[3 * i], w) - o->pvt[0];
+            const int ly = om_voxel_of(g[3 * i + 1], w) - o->pvt[1];
+            const int lz = om_voxel_of(gz, w) - o->pvt[2];
             if (in_loc(o, lx, ly, lz)) { const int id = lid(o, lx, ly, lz); o->inst_type[id] = GIE_VOX_OCCUPIED; o->ray_count[id] += 1; }
         }
     }
     const float max_len = 0.707f * (float)o->X * w;   /* pntcld_raycast.cu:79 */
     for (int i = 0; i < n; i++)
-        if (gie_point_ok(g[3 * i], g[3 * i + 1], g[3 * i + 2])) ray_cast(o, o->origin, &g[3 * i], max_len);   /* gie_math.h: non-finite points are ignored */
+        if (om_point_usable(&g[3 * i])) ray_cast(o, o->origin, &g[3 * i], max_len);   /* (non-finite points are ignored: oracle_math.h) */
     free(g);
     /* getAllocKeys: robot sphere → count = -1; count>0 OCC, <0 FREE (the block key it also
      * writes is "this voxel was observed", which is inst_type != UNKNOWN here). */
@@ -375,13 +375,15 @@ int go_ogm_multiscan(gie_oracle *o, const float *ranges, const gie_multiscan_par
         const int id = lid(o, x, y, z);
         if (robot_sphere(o, x, y, z)) { o->inst_type[id] = GIE_VOX_FREE; continue; }
         const float gx = (float)(x + o->pvt[0]) * w, gy = (float)(y + o->pvt[1]) * w, gz = (float)(z + o->pvt[2]) * w;
-        float lx, ly, lz;
-        gie_se3_apply(o->G2L, gx, gy, gz, &lx, &ly, &lz);
-        const float theta = gie_atan2f(ly, lx);
+        const float gp[3] = { gx, gy, gz };
+        float lp[3];
+        om_transform(o->G2L, gp, lp);
+        const float lx = lp[0], ly = lp[1], lz = lp[2];
+        const float theta = om_atan2(ly, lx);
         int theta_idx = (int)floorf((theta - p->theta_min) / p->theta_inc + 0.5f);
         theta_idx = pos_mod(theta_idx, p->scan_num);
         const float range_hor = sqrtf(ly * ly + lx * lx);
-        const float phi = gie_atan2f(lz, range_hor);
+        const float phi = om_atan2(lz, range_hor);
         const int phi_idx = (int)floorf((phi - p->phi_min) / p->phi_inc + 0.5f);
         if (phi_idx < 0 || phi_idx >= p->ring_num) continue;          /* depth = -1 */
         const float ideal = sqrtf(lx * lx + ly * ly);
@@ -424,8 +426,10 @@ int go_ogm_depth(gie_oracle *o, const float *depth, const gie_cam_param *p)
         const int id = lid(o, x, y, z);
         if (robot_sphere(o, x, y, z)) { o->inst_type[id] = GIE_VOX_FREE; continue; }
         const float gx = (float)(x + o->pvt[0]) * w, gy = (float)(y + o->pvt[1]) * w, gz = (float)(z + o->pvt[2]) * w;
-        float lx, ly, lz;
-        gie_se3_apply(o->G2L, gx, gy, gz, &lx, &ly, &lz);
+        const float gp[3] = { gx, gy, gz };
+        float lp[3];
+        om_transform(o->G2L, gp, lp);
+        const float lx = lp[0], ly = lp[1], lz = lp[2];
         const float ideal = lx;
         if (ideal <= 0.3f || ideal > 6.0f) continue;
         const float fpx = floorf(-ly * p->fx / ideal + p->cx + 0.5f);
@@ -451,9 +455,11 @@ int go_ogm_scan2d(gie_oracle *o, const float *ranges, const gie_scan_param *p)
         const int id = lid(o, x, y, z);
         if (robot_sphere(o, x, y, z)) { o->inst_type[id] = GIE_VOX_FREE; continue; }
         const float gx = (float)(x + o->pvt[0]) * w, gy = (float)(y + o->pvt[1]) * w, gz = (float)(z + o->pvt[2]) * w;
-        float lx, ly, lz;
-        gie_se3_apply(o->G2L, gx, gy, gz, &lx, &ly, &lz);
-        const float theta = gie_atan2f(ly, lx);
+        const float gp[3] = { gx, gy, gz };
+        float lp[3];
+        om_transform(o->G2L, gp, lp);
+        const float lx = lp[0], ly = lp[1], lz = lp[2];
+        const float theta = om_atan2(ly, lx);
         int theta_idx = (int)floorf((theta - p->theta_min) / p->theta_inc + 0.5f);
         theta_idx = pos_mod(theta_idx, p->scan_num);
         if (!(fabsf(lz) < w)) continue;                                 /* depth = -1 */

@@ -27,12 +27,10 @@ SHIM_SRC = os.path.join(HERE, "shims", "math_shim.c")
 SHIM_SO = os.path.join(HERE, "shims", "libmath_shim.so")
 
 
-@pytest.fixture(scope="module")
-def ms():
-    hdr = os.path.join(os.path.dirname(HERE), "include", "gie_math.h")
-    if not os.path.exists(SHIM_SO) or os.path.getmtime(SHIM_SO) < max(os.path.getmtime(SHIM_SRC), os.path.getmtime(hdr)):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", SHIM_SRC, "-o", SHIM_SO, "-lm"])
-    lib = C.CDLL(SHIM_SO)
+def _load_shim(src, so, hdr):
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", so, "-lm"])
+    lib = C.CDLL(so)
     fp = C.POINTER(C.c_float)
     lib.ms_from_quat.argtypes = [fp, fp, fp]
     lib.ms_inv.argtypes = [fp, fp]
@@ -41,7 +39,60 @@ def ms():
     lib.ms_pos2coord.restype = C.c_int
     lib.ms_atan2f.argtypes = [C.c_float, C.c_float]
     lib.ms_atan2f.restype = C.c_float
+    lib.ms_point_ok.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.ms_point_ok.restype = C.c_int
     return lib
+
+
+def _product_math():
+    return _load_shim(SHIM_SRC, SHIM_SO, os.path.join(os.path.dirname(HERE), "include", "gie_math.h"))
+
+
+def _oracle_math():
+    return _load_shim(os.path.join(HERE, "shims", "oracle_math_shim.c"), os.path.join(HERE, "shims", "liboracle_math_shim.so"),
+                      os.path.join(os.path.dirname(HERE), "oracle", "oracle_math.h"))
+
+
+# every check below runs on BOTH statements of the geometry: the product's include/gie_math.h and the oracle's own oracle/oracle_math.h
+@pytest.fixture(scope="module", params=["product", "oracle"])
+def ms(request):
+    return _product_math() if request.param == "product" else _oracle_math()
+
+
+def test_the_two_statements_of_the_geometry_agree_bit_for_bit():
+    """include/gie_math.h (kernels) and oracle/oracle_math.h (oracle) share no line since round 5; voxelisation floors their
+    results, so they have to round identically everywhere: random and hand-picked inputs, every output compared as raw bits."""
+    a, b = _product_math(), _oracle_math()
+    rng = np.random.default_rng(2025)
+    bits = lambda x: np.asarray(x, np.float32).view(np.uint32)
+    quats = [(1, 0, 0, 0), (0, 0, 0, 1), (0, 1, 0, 0), (0.5, 0.5, 0.5, 0.5), (math.sqrt(0.5), 0, 0, -math.sqrt(0.5))]
+    for _ in range(3000):
+        v = rng.standard_normal(4)
+        quats.append(tuple(v / np.linalg.norm(v)))
+    for q in quats:
+        t = rng.uniform(-2000, 2000, 3) * rng.choice([1.0, 1e-3, 1.0])
+        ma, mb = _se3(a, q, t), _se3(b, q, t)
+        assert np.array_equal(bits(ma), bits(mb)), q
+        ia, ib = np.zeros(12, np.float32), np.zeros(12, np.float32)
+        a.ms_inv(_f(ma.ravel())[1], ia.ctypes.data_as(C.POINTER(C.c_float)))
+        b.ms_inv(_f(mb.ravel())[1], ib.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(bits(ia), bits(ib)), q
+        for _k in range(4):
+            pt = rng.uniform(-300, 300, 3)
+            oa, ob = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            for lib, m, o in ((a, ia, oa), (b, ib, ob)):
+                lib.ms_apply(_f(m)[1], _f(pt)[1], o.ctypes.data_as(C.POINTER(C.c_float)))
+            assert np.array_equal(bits(oa), bits(ob)), (q, pt)
+    ys = np.concatenate([rng.standard_normal(40000), [0.0, -0.0, 1.0, -1.0, 1e-30, -1e-30, 1e30, 0.41421357, 2.4142137, 0.41421354, 2.4142134]]).astype(np.float32)
+    xs = np.concatenate([rng.standard_normal(40000), [0.0, 1.0, -1.0, 0.0, 1.0, -1.0, 1.0, 1.0, 1.0, 1.0, 1.0]]).astype(np.float32)
+    ta = np.array([a.ms_atan2f(float(y), float(x)) for y, x in zip(ys, xs)], np.float32)
+    tb = np.array([b.ms_atan2f(float(y), float(x)) for y, x in zip(ys, xs)], np.float32)
+    assert np.array_equal(bits(ta), bits(tb))
+    for w in (0.05, 0.1, 0.2, 0.25):
+        ps = np.concatenate([rng.uniform(-60, 60, 20000), (np.arange(-400, 400) + 0.5) * w, np.arange(-400, 400) * w]).astype(np.float32)
+        assert all(a.ms_pos2coord(float(p), w) == b.ms_pos2coord(float(p), w) for p in ps)
+    for g in [(0, 0, 0), (1e6, -1e6, 5), (1.0000001e6, 0, 0), (0, float("nan"), 0), (float("inf"), 0, 0), (0, 0, -float("inf")), (3, 4, -2e6)]:
+        assert a.ms_point_ok(*[float(v) for v in g]) == b.ms_point_ok(*[float(v) for v in g]), g
 
 
 def _f(a):
