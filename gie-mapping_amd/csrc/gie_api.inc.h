@@ -1358,6 +1358,18 @@ extern "C" int gie_debug_fault_barrier(gie_mapper *m, int updates)
     m->bar_fault_left = updates;
     return GIE_OK;
 }
+/* test hook (not in gie.h): rows of the neighbour table of waves A / B (c.g_nbr) that disagree with the hash, over every live block */
+extern "C" int gie_debug_nbr_check(gie_mapper *m, int32_t *mismatches)
+{
+    if (!m || !mismatches) { gie_set_err("gie_debug_nbr_check: bad arguments"); return GIE_ERR_INVALID; }
+    int32_t *d = (int32_t *)gie_scratch(m, 0, sizeof(int32_t), "gie_debug_nbr_check");
+    if (!d) return GIE_ERR_DEVICE;
+    be_memset(&m->be, d, 0, sizeof(int32_t));
+    op_nbr_check op; op.bad = d;
+    be_lin(&m->be, m->c, op, 6 * m->c.max_blocks);
+    be_d2h(&m->be, mismatches, d, sizeof(int32_t));
+    return gie_sync(m);
+}
 #endif /* GIE_TEST_HOOKS */
 extern "C" int gie_profile_enable(gie_mapper *m, int on)
 {

@@ -244,6 +244,24 @@ struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
 #endif
     } };
 struct op_pair_flush { gie_flush_boxes b; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_pair_flush_voxel(c, b, i); } };
+/* test hook (gie_debug_nbr_check): item i = (slot, direction); counts the rows of the neighbour table that do not say what the hash says —
+ * a row naming a slot whose key is not the neighbour's counts as "no neighbour" (the readers' rule, gie_wave_a_block) */
+struct op_nbr_check { int32_t *bad; GIE_DEVM void operator()(const gie_ctx &c, int i) const {
+        const int slot = i / 6, k = i - 6 * slot;
+        if (slot >= c.pool_count[0] || c.g_key[slot] == GIE_KEY_EMPTY) return;
+        int b[3];
+        gie_unpack_crd(c.g_key[slot], &b[0], &b[1], &b[2]);
+        b[k >> 1] += (k & 1) ? 1 : -1;
+        const int row = c.g_nbr[8 * (size_t)slot + k];
+        const int named = (row >= 0 && row < c.max_blocks && c.g_key[row] == gie_pack_crd(b[0], b[1], b[2])) ? row : -1;
+        if (named != gie_hash_find(c, b[0], b[1], b[2])) {
+#if defined(GIE_HOST_EMU)
+            *bad += 1;
+#else
+            atomicAdd(bad, 1);
+#endif
+        }
+    } };
 struct op_evict { GIE_DEVM void operator()(const gie_ctx &c, int slot) const { if (slot < c.pool_count[0]) gie_evict_slot(c, slot); } };
 struct op_rehash { GIE_DEVM void operator()(const gie_ctx &c, int slot) const { if (slot < c.pool_count[0]) gie_rehash_slot(c, slot); } };
 struct op_stream_list { const int32_t *rank; int32_t *list; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_stream_list(c, rank, list, i); } };

@@ -157,6 +157,12 @@ static void be_block_init(be_state *, const gie_ctx &c, const int32_t *flag, con
         if (slot >= c.max_blocks) continue;
         for (int i = 0; i < GIE_VBSZ; i++) gie_init_voxel(c, slot, i);
     }
+    for (int cell = 0; cell < ncell; cell++) {            /* the neighbour table (k_block_init_list: every key of the pass is in the hash by now) */
+        if (!flag[cell]) continue;
+        const int slot = gie_emu_slot(c, rank[cell]);
+        if (slot >= c.max_blocks) continue;
+        for (int k = 0; k < 6; k++) gie_nbr_link(c, slot, k);
+    }
     const int total = rank[ncell - 1] + flag[ncell - 1];
     const int nfree = c.retain > 0 ? c.pool_count[1] : 0, from_free = total < nfree ? total : nfree;
     int pc = c.pool_count[0] + (total - from_free); if (pc > c.max_blocks) pc = c.max_blocks;

@@ -45,3 +45,11 @@ def wave_c_model(device, r0filter=False):
 class EmuMapper(MapperBase):
     def __init__(self, cfg):
         super().__init__(load(), cfg)
+
+    def debug_nbr_check(self):
+        """rows of the neighbour table of waves A / B that disagree with the hash, over every live block (test hook)"""
+        bad = C.c_int32(-1)
+        _lib.gie_debug_nbr_check.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        if _lib.gie_debug_nbr_check(self._h, C.byref(bad)):
+            raise RuntimeError(self._err())
+        return bad.value

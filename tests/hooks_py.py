@@ -28,6 +28,7 @@ def load():
         _fns = _capi.bind(_lib, "gie_", _capi.DEVICE_ONLY)
         _lib.gie_debug_fault_barrier.argtypes = [C.c_void_p, C.c_int]
         _lib.gie_debug_place_probe.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        _lib.gie_debug_nbr_check.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     return _fns
 
 
@@ -46,3 +47,10 @@ class HooksMapper(Mapper):
         if rc:
             raise RuntimeError(self._err())
         return ms.value
+
+    def debug_nbr_check(self):
+        """rows of the neighbour table of waves A / B that disagree with the hash, over every live block"""
+        bad = C.c_int32(-1)
+        if _lib.gie_debug_nbr_check(self._h, C.byref(bad)):
+            raise RuntimeError(self._err())
+        return bad.value
