@@ -844,8 +844,8 @@ def cpu_baseline(scenes, torch, dev, voxel, size, cutoff_dist, workload, W):
 
 
 WAVE_GRID = {"wgs": int(os.environ.get("GIE_BENCH_WAVE_WGS", "160"))}     # gie_config.wave_workgroups: a rank owns its device (160 of 256 measured best); ranks sharing a device: 192 / ranks
-PLACE_TRIES = 0              # gie_config.place_tries: off.  Rounds 3-4 re-drew the sweep's planes against a probe (0.76 vs 0.84 ms of Mark + commit by placement); with the
-                             # round-5 sweep — one large write stream, non-temporal — eight fresh mappers ran it in 0.472 - 0.493 ms as allocated (tools/place_variance.py)
+PLACE_TRIES = 4              # gie_config.place_tries: gie_create re-draws the sweep's planes against a probe.  Round 4: 0.76 vs 0.84 ms of Mark + commit by placement;
+                             # round 5 (one large non-temporal write stream): 0.471 - 0.474 ms placed against 0.472 - 0.497 as allocated (tools/place_variance.py, A/B on one box)
 PARTIAL = {}     # per workload: the regions timed so far (printed with an "error" key if the run dies later on)
 FULL_FILE = os.path.join("profiles", "bench_last_full.json")
 LINE_LIMIT = 8000           # bytes of the ONE line on stdout (a 21.8 KB line left the driver's record unparsed)
