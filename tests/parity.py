@@ -166,6 +166,9 @@ def run_and_compare(sc, make_a, make_b, check_stats=True, verbose=False, product
                 for key in ("seeds_a", "seeds_b", "seeds_c", "levels_a", "levels_b", "levels_c", "visits_a", "visits_b", "visits_c",
                             "blocks_total"):
                     assert sa[key] == sb[key], "%s frame %d: stat %s %d != %d" % (sc.name, k, key, sa[key], sb[key])
+            if hasattr(b, "debug_nbr_check"):       # test builds (emulation, -DGIE_TEST_HOOKS): the neighbour table of waves A / B against the hash
+                bad = b.debug_nbr_check()
+                assert bad == 0, "%s frame %d: %d rows of the neighbour table disagree with the hash" % (sc.name, k, bad)
             if verbose:
                 print(sc.name, k, {kk: sa[kk] for kk in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_b",
                                                          "visits_c", "levels_a", "levels_b", "levels_c")},
