@@ -1103,12 +1103,11 @@ GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* all
     const int sz[3] = { c.X, c.Y, c.Z };
     int o0[3], o1[3];
     long long reach2 = 0x7fffffffffffll;              /* (smallest distance to a face of the whole volume)^2, conservative per axis */
-    bool inside_old = true, can = true;
+    bool can = true;
     for (int a = 0; a < 3; a++) {
         const int v0 = tc[a] * 8, v1 = (v0 + 7 < sz[a] ? v0 + 7 : sz[a] - 1);
         o0[a] = (v0 + c.prev_shift[a]) >> 3; o1[a] = (v1 + c.prev_shift[a]) >> 3;      /* the previous update's tiles that hold these voxels */
-        if (v0 + c.prev_shift[a] < 0 || v1 + c.prev_shift[a] >= sz[a]) { inside_old = false; can = false; }   /* (partly) new in the volume: straddles
-                                                                                            * the old volume's face, whose tiles are never cleared ones */
+        if (v0 + c.prev_shift[a] < 0 || v1 + c.prev_shift[a] >= sz[a]) can = false;   /* (partly) new in the volume */
         const long long m = (long long)(v0 - c.whole_lo[a] < c.whole_hi[a] - 1 - v1 ? v0 - c.whole_lo[a] : c.whole_hi[a] - 1 - v1);
         if (m < 0) can = false;
         else if (m * m < reach2) reach2 = m * m;
@@ -1138,7 +1137,14 @@ GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* all
         }
     }
     c.tskip[t] = (uint8_t)v;
-    if (v != 0 || !c.catchup_fast || !inside_old) return 0;
+    if (v != 0 || !c.catchup_fast) return 0;
+    /* a tile that straddles the old volume's face is looked at too (round 6): with a side that is no multiple of 8 its
+     * voxels reach past the old face tile (never a cleared one) into the old tile before it, which may be flagged 2.  Old tile
+     * coordinates are clamped to the old volume; gie_coc_catchup_newcolumn tests every old coordinate itself. */
+    for (int a = 0; a < 3; a++) {
+        if (o0[a] < 0) o0[a] = 0;
+        if (o1[a] > c.tfd[a] - 1) o1[a] = c.tfd[a] - 1;
+    }
     for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++)
         if (c.tskip_prev[(z * c.tfd[1] + y) * c.tfd[0] + x] == 2) return 1;
     return 0;

@@ -11,7 +11,7 @@ class Scenario:
     def __init__(self, name, size, voxel=0.1, sensor="depth", frames=6, delta_vox=5, yaw_deg=40.0, seed=2,
                  cutoff_dist=2.0, fast_mode=False, n_boxes=30, extent=(4.0, 4.0, 1.5), for_motion_planner=False,
                  img=(120, 160, 130.0), toggle=0.25, lidar_az=360, ext_boxes=False, min_h=-1000.0, max_h=1000.0,
-                 max_depth=6.0, p_occ=0.01, retain=0, max_blocks=0, probe_margin=12, turn=0):
+                 max_depth=6.0, p_occ=0.01, retain=0, max_blocks=0, probe_margin=12, turn=0, steps=None):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -27,6 +27,10 @@ class Scenario:
         for k in range(self.frames):
             kp = k if not self.turn else (k % (2 * self.turn) if k % (2 * self.turn) <= self.turn else 2 * self.turn - k % (2 * self.turn))
             pos, q = scenes.pose(kp, self.voxel, delta_vox=self.delta_vox, yaw_deg=self.yaw_deg)     # turn > 0: out and back
+            if self.steps is not None:
+                # a drive given step by step: frame k stands at the sum of the first k displacements (voxels, any axis, any sign)
+                at = np.sum(np.asarray(self.steps[:k], np.int64).reshape(-1, 3), axis=0)
+                pos = tuple(np.float32(int(at[i]) * self.voxel) for i in range(3))
             kind = self.sensor
             if kind == "mixed":
                 kind = ("depth", "pointcloud", "multiscan")[k % 3]
@@ -64,6 +68,20 @@ class Scenario:
                 yield pos, q, "scan2d", r, dict(theta_inc=2.0 * np.pi / 360, theta_min=-np.pi + np.pi / 360)
             else:
                 raise ValueError(kind)
+
+
+# Drives that change speed and direction in volumes whose sides are no multiples of 8 (round 6): slow updates leave
+# tiles flagged 2 ("deferred records") next to the partial tile of a face, then a jump of 6-9 voxels puts a NEW tile across the old
+# volume's face — it reaches past the old face tile into such a tile, whose records gie_tile_oldskip used not to catch up.  The
+# first is the advisor's reproduction, the second a find of the same search on the unfixed sources; both fail there.
+UNEVEN_DRIVES = [
+    Scenario("uneven_drive_40x29x40", (40, 29, 40), sensor="labels", seed=893, p_occ=0.03, toggle=0.5, frames=4,
+             steps=[(1, 0, -1), (-1, 0, 0), (-8, 7, -4)]),
+    Scenario("uneven_drive_21x21x43", (21, 21, 43), voxel=0.05, sensor="labels", seed=245, p_occ=0.03, toggle=0.5, frames=7, cutoff_dist=1.0,
+             steps=[(-1, -1, 0), (0, 0, -1), (-8, 7, -9), (9, 8, -9), (0, 1, -6), (-8, 6, 1)]),
+    Scenario("uneven_drive_lidar_37x29x35", (37, 29, 35), sensor="mixed", seed=11, frames=8, extent=(3.2, 3.2, 1.9),
+             steps=[(1, 0, 0), (0, 1, 0), (7, -6, 0), (0, 0, 1), (-1, 1, 0), (-9, 8, 6), (1, 0, -1)]),
+]
 
 
 def _feed(m, kind, data, kw):

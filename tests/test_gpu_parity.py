@@ -80,6 +80,13 @@ def test_hip_matches_oracle(oracle_lib, sc):
     parity.run_and_compare(sc, OracleMapper, gie.Mapper)
 
 
+@pytest.mark.parametrize("sc", parity.UNEVEN_DRIVES, ids=[s.name for s in parity.UNEVEN_DRIVES])
+@pytest.mark.parametrize("production", [False, True], ids=["staged", "production"])
+def test_uneven_drives_catch_up_the_deferred_records(oracle_lib, sc, production):
+    """drives that change speed and direction in volumes whose sides are no multiples of 8 (parity.UNEVEN_DRIVES)."""
+    parity.run_and_compare(sc, OracleMapper, gie.Mapper, production=production)
+
+
 def test_voxel_addresses_beyond_2_to_31(oracle_lib, monkeypatch):
     """voxel addresses (slot * 512 + index) are 64-bit.  A pool of 4.3 M blocks (84 GB of planes on the device) whose
     slots are handed out from 4.25 M on (GIE_DEBUG_POOL_BASE): every address of the run lies beyond 2^31.  Slot numbers are not

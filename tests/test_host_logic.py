@@ -61,6 +61,13 @@ def test_emulated_device_logic_matches_oracle(oracle_lib, sc):
     assert len(stats) == sc.frames
 
 
+@pytest.mark.parametrize("sc", parity.UNEVEN_DRIVES, ids=[s.name for s in parity.UNEVEN_DRIVES])
+@pytest.mark.parametrize("production", [False, True], ids=["staged", "production"])
+def test_uneven_drives_catch_up_the_deferred_records_emulation(oracle_lib, sc, production):
+    """a new tile that straddles the old volume's face must have its deferred records caught up too."""
+    parity.run_and_compare(sc, OracleMapper, EmuMapper, production=production)
+
+
 @pytest.mark.parametrize("sc", [s for s in SCENARIOS if s.name in ("raycast", "mixed", "c5_hash_world")], ids=lambda s: s.name)
 def test_production_sequence_emulation(oracle_lib, sc):
     """set_pose / ogm / step() only (no readers between the stages)."""

@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gie-mapping_amd"), os.path.join(ROOT, "tests")]
 
 
-def random_scenario(rng, i, big=False, focus=None):
+def random_scenario(rng, i, big=False, focus=None, drive=None):
     import parity
-    dims = [96, 120, 128, 152, 160, 192] if big else [8, 16, 24, 29, 32, 37, 40, 48, 56, 64, 72, 96]
+    dims = [96, 120, 125, 128, 152, 157, 160, 192] if big else [8, 13, 16, 21, 24, 29, 32, 35, 37, 40, 43, 48, 51, 56, 64, 72, 96]
     size = tuple(int(rng.choice(dims)) for _ in range(3))
     if rng.random() < 0.15:
         size = (size[0], size[1], int(rng.choice([1, 8, 11, 16])))
@@ -27,6 +27,17 @@ def random_scenario(rng, i, big=False, focus=None):
               p_occ=float(rng.choice([0.003, 0.01, 0.03])), toggle=float(rng.choice([0.0, 0.25, 0.5])),
               retain=int(rng.choice([0, 0, 0, 1, 2])), turn=int(rng.choice([0, 0, 3, 5])), probe_margin=int(rng.choice([12, 40])),
               lidar_az=int(rng.choice([180, 360, 720])))
+    if drive == "random" or (drive is None and rng.random() < 0.5):
+        # a drive that changes speed and direction (round 6): mostly steps of 0-1 voxels on every axis, now and then a jump
+        # of 6-9 either way on some axes -- the tskip / prev_shift / catch-up state machine sees slow updates followed by a jump
+        steps = []
+        for _ in range(kw["frames"]):
+            st = rng.integers(-1, 2, size=3)
+            if rng.random() < 0.3:
+                jump = rng.integers(6, 10, size=3) * rng.choice([-1, 1], size=3)
+                st = np.where(rng.random(3) < 0.6, jump, st)
+            steps.append(tuple(int(v) for v in st))
+        kw["steps"] = steps
     if focus == "retain":          # block erasure on a robot that turns round: long drives, small radii, frequent turns
         kw.update(retain=int(rng.choice([1, 1, 2, 3])), turn=int(rng.choice([2, 3, 4, 5, 7])), frames=int(rng.integers(8, 17)),
                   delta_vox=int(rng.integers(3, 17)), probe_margin=40)
@@ -91,6 +102,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="volume sides of 96 ... 192 voxels (thousands of active blocks per wave round)")
     ap.add_argument("--only", type=int, default=-1, help="run scenario number N of the seed only")
     ap.add_argument("--device-wave-c", action="store_true", help="with --emu: the emulation runs its model of the DEVICE's wave C tile rounds (gie_emu.cpp be_wave_c_device) instead of the canonical statement")
+    ap.add_argument("--drive", default=None, choices=[None, "line", "random"], help="line: constant steps along x (rounds 1-5); random: per-frame steps on all axes with jumps; default: half and half")
     ap.add_argument("--focus", default=None, choices=[None, "retain"], help="retain: every scenario erases blocks (retain_radius_blocks 1-3) on a drive that turns round")
     args = ap.parse_args()
     import gie
@@ -114,12 +126,12 @@ def main():
         i += 1; ok += 1
         print("ok %s | visits %d/%d/%d" % (desc, v[0], v[1], v[2]), flush=True)
     while not args.tiled and time.time() - t0 < 60.0 * args.minutes:
-        sc = random_scenario(rng, i, args.big, args.focus)
+        sc = random_scenario(rng, i, args.big, args.focus, args.drive)
         i += 1
         if args.only >= 0 and i - 1 != args.only:
             continue
         desc = "%s %s voxel %.2f %s frames %d delta %d cutoff %.1f fast %d planner %d boxes %d retain %d turn %d" % (
-            sc.name, sc.size, sc.voxel, sc.sensor, sc.frames, sc.delta_vox, sc.cutoff_dist, sc.fast_mode, sc.for_motion_planner, sc.ext_boxes, sc.retain, sc.turn)
+            sc.name, sc.size, sc.voxel, sc.sensor, sc.frames, sc.delta_vox, sc.cutoff_dist, sc.fast_mode, sc.for_motion_planner, sc.ext_boxes, sc.retain, sc.turn) + (" steps %s" % (sc.steps,) if sc.steps else "")
         try:
             st = parity.run_and_compare(sc, OracleMapper, Under, production=bool(i % 2))
         except AssertionError as e:
