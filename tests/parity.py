@@ -104,6 +104,38 @@ def probe_coords(pvt, size, rng, n=4000, margin=12):
     return rng.integers(lo, hi, size=(n, 3)).astype(np.int32)
 
 
+def probe_left_behind(prev_pvt, pvt, size, rng, n=6000):
+    """Global voxels of the volume at `prev_pvt` that the volume at `pvt` no longer holds (the slabs the robot has just left: their
+    records were the pair plane's until the voxels left — gie_ops.h "deferred records").  Drawn slab by slab (the part of the old
+    box beyond the new one on each axis), so a slow drive gets its n probes too; empty when the volume did not move."""
+    lo, sz, new = np.array(prev_pvt, np.int64), np.array(size, np.int64), np.array(pvt, np.int64)
+    out = []
+    for ax in range(3):
+        d = int(new[ax] - lo[ax])
+        if d == 0:
+            continue
+        w = min(abs(d), int(sz[ax]))
+        a0 = lo[ax] if d > 0 else lo[ax] + sz[ax] - w          # the old box's layers the new box has left behind on this axis
+        xyz = rng.integers(lo, lo + sz, size=(n, 3))
+        xyz[:, ax] = rng.integers(a0, a0 + w, size=n)
+        out.append(xyz)
+    if not out:
+        return np.zeros((0, 3), np.int32)
+    xyz = np.concatenate(out)
+    gone = ((xyz < new) | (xyz >= new + sz)).any(-1)
+    assert gone.all()
+    return np.ascontiguousarray(xyz[rng.permutation(len(xyz))[:n]], dtype=np.int32)
+
+
+def compare_global(tag, a, b, xyz):
+    if len(xyz) == 0:
+        return
+    ga, gb = a.query_global(xyz), b.query_global(xyz)
+    for key in ("occ_val", "vox_type", "dist_sq", "coc"):
+        assert np.array_equal(ga[key], gb[key]), "%s: global %s differs in %d of %d probes" % (
+            tag, key, int((ga[key] != gb[key]).reshape(len(xyz), -1).any(-1).sum()), len(xyz))
+
+
 def _compare_after_merge(sc, k, a, b, rng, check_stats):
     ra, rb = a.read_local(), b.read_local()
     for key in ("type", "dist_sq", "coc"):

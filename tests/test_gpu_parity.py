@@ -555,21 +555,33 @@ def test_full_size_512_cube_ray_casting(oracle_lib):
 @pytest.mark.gpu
 def test_full_size_512_cube_c5_headline(oracle_lib):
     """The bench's headline workload ITSELF at full size: BASELINE config 5's hash world on one 512^3 tile @ 0.05 m, every voxel
-    observed, a quarter of the obstacles toggling, the robot moving 8 voxels per update — three map updates against the oracle,
+    observed, a quarter of the obstacles toggling, the robot moving 8 voxels per update — six map updates against the oracle,
     every array bit for bit and every wave statistic (waves A / B / C visit 24 k / 36 k / 20 k voxels per update here; the small
-    scenarios above have a few hundred).  tools/soak_fullsize.py --c5 is the longer form (profiles/r03_soak_fullsize_c5_6_updates.log)."""
+    scenarios above have a few hundred).  tools/soak_fullsize.py --c5 is the longer form (profiles/r03_soak_fullsize_c5_6_updates.log).
+    Round 6: the GLOBAL map is compared after every update too — 20 000 probes in and around the volume and 6 000
+    in the slabs the robot has just left — because at this size 82 % of the tiles are `tskip` tiles whose stored records live in
+    the pair plane ("deferred records"): update 2 is the first that defers, update 3 jumps sideways (tiles lose flag 2 in bulk:
+    k_coc_catchup_new with 64 z-tiles per column), update 4 runs with the changed-block flags on (the reference's order of kernels:
+    gie_catchup_everything at 512^3 — unify_helper.cuh:448-523 stores every observed voxel every frame), update 5 is fused again."""
     import bench
     from gie import scenes
     size = (512, 512, 512)
     cfg = gie.make_config(0.05, size, cutoff_dist=2.0, fast_mode=False)
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
+    rng = np.random.default_rng(2026)
+    extra = {3: (19, -13, 6), 4: (19, -13, 6), 5: (19, -13, 6)}       # voxels on top of the drive from update 3 on: a jump off the block grid
+    prev_pvt = None
     try:
-        for k in range(3):
+        for k in range(6):
             pos, q = bench.c5_pose(scenes, k, 0.05)
+            pos = tuple(np.float32(float(pos[i]) + extra.get(k, (0, 0, 0))[i] * 0.05) for i in range(3))
             lab = np.ascontiguousarray(scenes.hash_world_labels(scenes.local_pivot(pos, 0.05, size), size, k, seed=bench.C5["seed"],
                                                                 p_occ=bench.C5["p_occ"], toggle_frac=bench.C5["toggle_frac"]).astype(np.int8))
             for m in (a, b):
+                m.stream_enable(k == 4)
                 m.update(pos, q, "labels", lab)
+            if k == 4:
+                assert a.stream_count() == b.stream_count() > 250000      # (blocks flagged as changed; not drained: 2.9 GB per mapper)
             ra, rb = a.read_local(), b.read_local()
             for key in ("type", "dist_sq", "coc"):
                 assert np.array_equal(ra[key], rb[key]), (k, key)
@@ -580,6 +592,13 @@ def test_full_size_512_cube_c5_headline(oracle_lib):
             if k > 0:
                 assert sb["visits_a"] > 10000 and sb["visits_b"] > 10000 and sb["visits_c"] > 10000
             del ra, rb, lab
+            assert a.pivot() == b.pivot()
+            parity.compare_global("update %d, in and around the volume" % k, a, b, parity.probe_coords(a.pivot(), size, rng, n=20000, margin=12))
+            if prev_pvt is not None:
+                gone = parity.probe_left_behind(prev_pvt, a.pivot(), size, rng)
+                assert len(gone) > 1000
+                parity.compare_global("update %d, the slabs just left" % k, a, b, gone)
+            prev_pvt = a.pivot()
     finally:
         a.close(); b.close()
 

@@ -39,6 +39,9 @@ def main():
     a, b = OracleMapper(cfg), gie.Mapper(cfg)
     bad = 0
     t_cpu = t_gpu = 0.0
+    import parity
+    rng = np.random.default_rng(77)
+    prev_pvt = None
     for k in range(args.frames):
         s = "c" if args.c5 else args.pattern[k % len(args.pattern)]
         if s == "c":
@@ -66,6 +69,16 @@ def main():
             diff.append("edt")
         diff += [key for key in ("seeds_a", "seeds_b", "seeds_c", "visits_a", "visits_b", "visits_c", "levels_a", "levels_b", "levels_c", "blocks_total")
                  if sa[key] != sb[key]]
+        # the global map in and around the volume and in the slabs just left (round 6: a tskip tile's stored records live in the pair
+        # plane until they are caught up or leave — gie_ops.h "deferred records")
+        probes = [parity.probe_coords(a.pivot(), size, rng, n=20000, margin=12)]
+        if prev_pvt is not None:
+            probes.append(parity.probe_left_behind(prev_pvt, a.pivot(), size, rng))
+        prev_pvt = a.pivot()
+        for xyz in probes:
+            if len(xyz):
+                ga, gb = a.query_global(xyz), b.query_global(xyz)
+                diff += ["global " + key for key in ("occ_val", "vox_type", "dist_sq", "coc") if not np.array_equal(ga[key], gb[key])]
         bad += bool(diff)
         print("update %3d %s known %.4f seeds %d/%d/%d visits %d/%d/%d levels_c %d blocks %d %s" % (
             k, s, float((rb["type"] != 0).mean()), sb["seeds_a"], sb["seeds_b"], sb["seeds_c"], sb["visits_a"], sb["visits_b"],
