@@ -1291,7 +1291,7 @@ extern "C" int gie_refine(gie_mapper *m, int32_t *seeded)
     {   /* what the second waves launch of this map update needs zeroed, in one launch */
         gie_clear_list l; l.n = 0;
         l.p[l.n] = c.cnt + GIE_CNT_C; l.bytes[l.n++] = sizeof(int32_t);
-        l.p[l.n] = c.cnt + GIE_CNT_BAR_C; l.bytes[l.n++] = sizeof(int32_t);
+        l.p[l.n] = c.cnt + GIE_CNT_BAR_B; l.bytes[l.n++] = 2 * sizeof(int32_t);      /* (the barrier words of the two waves launches: wave C's, waves A / B's) */
         l.p[l.n] = c.lvl_next; l.bytes[l.n++] = 2 * GIE_MAX_LEVELS * sizeof(int32_t);
         be_clear(&m->be, l, c.gate);
     }

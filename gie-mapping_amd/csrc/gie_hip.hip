@@ -71,10 +71,12 @@ static int be_init(be_state *b, int device, int wave_workgroups)
          * against the runtime's own occupancy answer (what hipLaunchCooperativeKernel would check at every launch, at
          * +15-19 us of host time each); what it cannot guard against — another PROCESS holding compute units — ends in a
          * bounded spin and GIE_ERR_TIMEOUT (include/gie.h). */
-        int per_cu = 0;
-        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_waves), GIE_WAVE_THREADS, 0);
+        int per_cu = 0, per_cu_c = 0;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_waves_ab), GIE_WAVE_THREADS, 0);
+        if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, reinterpret_cast<const void *>(&k_waves_c), GIE_WAVE_THREADS, 0);
+        if (per_cu_c < per_cu) per_cu = per_cu_c;
         if (oe != hipSuccess || per_cu < 1) {
-            gie_set_err(std::string("the wavefront kernel cannot be resident on this device (occupancy query: ") + hipGetErrorString(oe) + ", " + std::to_string(per_cu) + " workgroups per compute unit)");
+            gie_set_err(std::string("the wavefront kernels cannot be resident on this device (occupancy query: ") + hipGetErrorString(oe) + ", " + std::to_string(per_cu) + " workgroups per compute unit)");
             (void)hipGetLastError();
             return 1;
         }
@@ -561,10 +563,11 @@ static void be_waves(be_state *b, const gie_ctx &c, int with_ab, int record_seed
         else { GIE_HIP_OK(hipEventCreateWithFlags(&g_waves_event[dv], hipEventDisableTiming)); g_waves_event_set[dv] = true; }
     }
     if (clear_first) {
-        GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_C], 0, sizeof(int32_t), b->stream));
+        GIE_HIP_OK(hipMemsetAsync(&c.cnt[GIE_CNT_BAR_B], 0, 2 * sizeof(int32_t), b->stream));      /* (BAR_B, BAR_C: the barrier words of the two launches) */
         GIE_HIP_OK(hipMemsetAsync(c.lvl_next, 0, 2 * GIE_MAX_LEVELS * sizeof(int32_t), b->stream));
     }
-    GIE_LAUNCH(b, k_waves, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, with_ab, record_seeds);
+    if (with_ab) GIE_LAUNCH(b, k_waves_ab, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c);
+    GIE_LAUNCH(b, k_waves_c, dim3(b->num_cu), dim3(GIE_WAVE_THREADS), 0, c, with_ab, record_seeds);
     if (chain) GIE_HIP_OK(hipEventRecord(g_waves_event[dv], b->stream));
 }
 

@@ -1663,7 +1663,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     gie_markc_column(c, x, y, z0, known, valid, vmax);
 }
 template <int LX>
-__global__ __launch_bounds__(256) void k_markc(const gie_ctx c, const int32_t *list)
+__global__ __launch_bounds__(256, 5) void k_markc(const gie_ctx c, const int32_t *list)   /* (five waves per SIMD: 96 registers; one more costs the sweep a tenth of its time) */
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
     const int lane = threadIdx.x & 63;
@@ -2385,9 +2385,9 @@ __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : h
         float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * g_ts_i; \
         p_[0] = (float)(wall_clock64() & 0xffffff); p_[1] = (float)((tag) * 1000000 + ((n) < 999999 ? (n) : 999999)); g_ts_i++; } } while (0)
 static __device__ int g_ts_i;
-/* ... and per-section clock sums of the block routines (wave A: 0-7, wave B: 8-15): [base + i] = ticks between marks i and i + 1, [base + 6] = levels inside
+/* ... and per-section clock sums of the block routines (wave A: 0-7, wave B: 8-15, wave C: 16-23): [base + i] = ticks between marks i and i + 1, [base + 6] = levels inside
  * blocks, [base + 7] = blocks */
-static __device__ unsigned int g_wprof[256 * 16][16];          /* one row per (workgroup, wave): no atomics, nothing shared while the waves run */
+static __device__ unsigned int g_wprof[256 * 16][32];          /* one row per (workgroup, wave): no atomics, nothing shared while the waves run */
 #define GIE_WPROF_DECL unsigned long long wp_t_ = wall_clock64(), wp_s_ = 0; const unsigned long long wp_t0_ = wp_t_; int wp_i_ = 0; unsigned int *const wp_ = g_wprof[blockIdx.x * 16 + (threadIdx.x >> 6)]
 #define GIE_WPROF_MARK(base) do { const unsigned long long n_ = wall_clock64(); if (lane == 0) wp_[(base) + wp_i_] += (unsigned int)(n_ - wp_t_); wp_i_++; wp_t_ = n_; } while (0)
 #define GIE_WPROF_ADD(i, v) do { if (lane == 0) wp_[i] += (unsigned int)(v); } while (0)
@@ -2395,11 +2395,12 @@ static __device__ unsigned int g_wprof[256 * 16][16];          /* one row per (w
 #define GIE_WPROF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define GIE_WPROF_SUBSTART() wp_s_ = wall_clock64()
 #define GIE_WPROF_SUB(i) do { const unsigned long long n_ = wall_clock64(); if (lane == 0) wp_[i] += (unsigned int)(n_ - wp_s_); wp_s_ = n_; } while (0)
-#define GIE_WPROF_DUMP() do { gie_grid_sync(gb, c); if (blockIdx.x == 0 && threadIdx.x < 16) { unsigned long long s_ = 0; \
+#define GIE_WPROF_CLK() wall_clock64()
+#define GIE_WPROF_DUMP() do { gie_grid_sync(gb, c); if (blockIdx.x == 0 && threadIdx.x < 32) { unsigned long long s_ = 0; \
         const bool mx_ = (threadIdx.x & 7) == 4 || (threadIdx.x & 7) == 5; \
-        for (int r_ = 0; r_ < 256 * 16; r_++) { const unsigned int v_ = __hip_atomic_load(&g_wprof[r_][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (mx_) { if (16ull * v_ > s_) s_ = 16ull * v_; } else s_ += v_; __hip_atomic_store(&g_wprof[r_][threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } \
+        for (int r_ = 0; r_ < 256 * 16; r_++) { const unsigned int v_ = __hip_atomic_load(&g_wprof[r_][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (mx_) { if (64ull * v_ > s_) s_ = 64ull * v_; } else s_ += v_; __hip_atomic_store(&g_wprof[r_][threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } \
         float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * (g_ts_i + (int)threadIdx.x); \
-        p_[0] = 0.0f; p_[1] = (float)((20 + (int)threadIdx.x) * 1000000 + (int)((s_ / 16) < 999999 ? (s_ / 16) : 999999)); } } while (0)
+        p_[0] = 0.0f; p_[1] = (float)((20 + (int)threadIdx.x) * 1000000 + (int)((s_ / 64) < 999999 ? (s_ / 64) : 999999)); } } while (0)
 #else
 #define GIE_TS2(tag, n) do { } while (0)
 #define GIE_WPROF_DECL do { } while (0)
@@ -2410,6 +2411,7 @@ static __device__ unsigned int g_wprof[256 * 16][16];          /* one row per (w
 #define GIE_WPROF_SUB(i) do { } while (0)
 #define GIE_WPROF_SUBSTART() do { } while (0)
 #define GIE_WPROF_DUMP() do { } while (0)
+#define GIE_WPROF_CLK() 0ull
 #endif
 
 /* append `value` to a list for every lane with `first`: one counter update per wave (hundreds of single appends to one word
@@ -3142,174 +3144,244 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
  *           takes the tile, set by whoever activates it for round r + 2);
  *   rule:   a proposal replaces a pair on a strict distance improvement over the value at the start of the (sub-)level,
  *           among proposals the smaller (dist, parent) wins; the seeds of round 0 are assignments. */
-#define GIE_WC_WAVES GIE_WAVE_SLOTS(10)                                   /* waves of a workgroup that take tiles: 14.6 KB of LDS each */
-struct gie_wc_tile { uint64_t pair[512], prop[512], halo[6][64]; uint16_t list[512], pend[2][512]; int32_t npend[2]; };   /* 14.6 KB */
+#define GIE_WC_WAVES GIE_WAVE_SLOTS(10)                                   /* waves of a workgroup that take tiles: 16 KB of LDS each */
+/* the tile WITH its one-voxel halo, 10 x 10 x 10: cell (ex, ey, ez), each in -1 .. 8, at GIE_WC_P; the edges and corners are not used */
+struct gie_wc_tile { uint64_t pair[1000], prop[1000]; };                  /* 16 KB */
+#define GIE_WC_P(ex, ey, ez) ((ex) + 10 * (ey) + 100 * (ez) + 111)
 
+/* Round 6: the BFS inside the tile by instruction count.  A wavefront alone on its SIMD issues an instruction every ~5 cycles: what
+ * a level costs is its instructions, not its LDS round trips (rounds 2-5: pending list, entry list, returning LDS atomics, a branch
+ * per direction for "inside the tile or halo, inside the volume or not": ~1 100 instructions = 2.5 us per level, and a flood crosses
+ * a tile in up to 25 levels — the projective lidar workloads: 10 M visits in 50 rounds of 35 us).  Now
+ *  - every lane OWNS eight voxels of the tile, one per z-layer, placed as a Latin cube — layer j: x = (lane & 7) - j,
+ *    y = (lane >> 3) - j (mod 8) — so that the voxels of ANY axis-aligned plane of the tile (a flood front's usual shape) belong to
+ *    64 different lanes;
+ *  - the halo lives INSIDE the LDS arrays (10 x 10 x 10 cells): the six neighbours of a voxel are six fixed offsets, a proposal
+ *    across the border is the same LDS minimum as one inside, and the halo's proposal cells go to the other candidate plane in one
+ *    pass when the tile is through.  A cell outside the volume holds distance 0 (never improved, never proposed to); in round 0 a
+ *    halo cell inside the volume holds the largest distance (every proposal is sent on: see below);
+ *  - a level is (a) every lane looks at the proposal cells of its own eight voxels and takes the ones that improve (the same test as
+ *    before: strictly nearer than the voxel's pair at the start of the level), (b) every lane expands the voxels it took, one after
+ *    the other (one for a plane front): d(neighbour) = d(voxel) -+ 2 c + 1 per direction, seven LDS reads, minima without a return
+ *    value.  About 250 instructions.
+ * What a level does — which proposals exist, who wins, what is counted as a visit — is the canonical schedule's as before. */
 __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &gb, gie_wc_tile &L, const int t, const int round, const int lane)
 {
     const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
     const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int x = x0 + lx, y = y0 + ly;
-    const bool colin = x < c.X && y < c.Y;
+    const int la = lane & 7, lb = lane >> 3;
     uint64_t *const rd = c.cand[(round + 1) & 1], *const wr = c.cand[round & 1];
-    const size_t plane = (size_t)c.X * c.Y;
-    const size_t col = (size_t)y * c.X + x;
-    /* ---- one batch of loads: the tile's pairs and proposals, the halo's pairs */
-    uint64_t pv[8], cv[8], hv[6];
-    uint64_t tys = 0;                                     /* the column's eight types, for the commit of what changes */
-    int slot_lo = -1, slot_hi = -1;                       /* block slots of the column's first / last voxel (at most two blocks) */
+    const int plane = c.X * c.Y;
+    GIE_WPROF_DECL;
+    /* ---- one batch of loads: the lane's eight voxels (pair, proposal, type), the halo's pairs, the tile's `ucol` bytes and block slots */
+    int curd[8];                                          /* the distances of the lane's eight voxels (the pairs live in L.pair) */
+    uint64_t pv[8];                                       /* ... their pairs as loaded (for `_edt_D` of an UNKNOWN voxel that changes) */
+    uint64_t tys = 0;                                     /* ... and their types, for the commit of what changes */
+    /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z), the lane's position (la, lb) on it */
+    const int hcell[6] = { GIE_WC_P(-1, la, lb), GIE_WC_P(8, la, lb), GIE_WC_P(la, -1, lb), GIE_WC_P(la, 8, lb), GIE_WC_P(la, lb, -1), GIE_WC_P(la, lb, 8) };
+    const int hx[6] = { x0 - 1, x0 + 8, x0 + la, x0 + la, x0 + la, x0 + la };
+    const int hy[6] = { y0 + la, y0 + la, y0 - 1, y0 + 8, y0 + lb, y0 + lb };
+    const int hz[6] = { z0 + lb, z0 + lb, z0 + lb, z0 + lb, z0 - 1, z0 + 8 };
+    unsigned hin = 0;                                     /* my halo cells inside the volume */
+    {
+        uint64_t cv[8], hv[6];
+        unsigned vin = 0;                                 /* my voxels inside the volume (kept as bits in a register: sixteen lane masks held across the loads cost more scalar registers than the kernel has) */
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const bool in = colin && z0 + j < c.Z;
-        const size_t id = in ? (size_t)(z0 + j) * plane + col : 0;
-        pv[j] = gie_ld(&c.pair[id]);
-        cv[j] = gie_ld(&rd[id]);
-        tys |= (uint64_t)(uint8_t)c.glb_type[id] << (8 * j);
-        if (!in) { pv[j] = 0ull; cv[j] = GIE_NOPROP; }                    /* a voxel outside the volume: distance 0, never improved */
-    }
-    if (c.fused && colin) {
-        const int zl = min(z0 + 7, c.Z - 1);
-        slot_lo = c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z0 + c.pvt[2])];
-        slot_hi = c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], zl + c.pvt[2])];
-    }
-    {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z), the lane's position (a, b) on it */
-        const int a = lane & 7, b = lane >> 3;
-        const int hx[6] = { x0 - 1, x0 + 8, x0 + a, x0 + a, x0 + a, x0 + a };
-        const int hy[6] = { y0 + a, y0 + a, y0 - 1, y0 + 8, y0 + b, y0 + b };
-        const int hz[6] = { z0 + b, z0 + b, z0 + b, z0 + b, z0 - 1, z0 + 8 };
+        for (int j = 0; j < 8; j++) {
+            const int x = x0 + ((la - j) & 7), y = y0 + ((lb - j) & 7), z = z0 + j;
+            const bool in = x < c.X && y < c.Y && z < c.Z;
+            const int id = in ? z * plane + y * c.X + x : 0;
+            vin |= (in ? 1u : 0u) << j;
+            pv[j] = gie_ld(&c.pair[id]);
+            cv[j] = gie_ld(&rd[id]);
+            tys |= (uint64_t)(uint8_t)c.glb_type[id] << (8 * j);
+        }
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const bool in = gie_in_loc(c, hx[f], hy[f], hz[f]);
             hv[f] = gie_ld(&c.pair[in ? gie_lid(c, hx[f], hy[f], hz[f]) : 0]);
-            if (!in) hv[f] = 0ull;
+            hin |= (in ? 1u : 0u) << f;
         }
-    }
-    if (lane == 0) gie_st(&c.wc_flag[round & 1][t], (int32_t)0);          /* may be activated again (for round + 2) from now on */
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int np0 = 0;                                          /* the voxels with a proposal from the round before: the first pending list */
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int v = lane + 64 * j;
-        L.pair[v] = pv[j]; L.prop[v] = cv[j];
-        const bool have = cv[j] != GIE_NOPROP;
-        if (have) gie_st(&rd[(size_t)(z0 + j) * plane + col], (uint64_t)GIE_NOPROP);      /* consumed */
-        const unsigned long long m = __ballot(have);
-        if (have) L.pend[0][np0 + __popcll(m & lt)] = (uint16_t)v;
-        np0 += __popcll(m);
-    }
+        for (int j = 0; j < 8; j++) if (!((vin >> j) & 1u)) { pv[j] = 0ull; cv[j] = GIE_NOPROP; }      /* a voxel outside the volume: distance 0, never improved */
+        /* (the pre-read of a neighbour's pair only drops proposals that cannot improve: values only decrease; a halo pair is the
+         * neighbour's at the start of the round.  NOT in round 0: the neighbour may be a seed its own tile is about to ASSIGN, and the
+         * seed wave B leaves on an unknown face voxel — accepted against the batch distance, wave_core.cuh:334 — can lie ABOVE the
+         * stale pair the plane still holds for it: a proposal between the two was dropped here and the voxel kept the seed's
+         * distance (round-4 fuzz, seed 83 #63).  Sent on, it meets the assigned pair in round 1 — what the sequential schedule does.) */
 #pragma unroll
-    for (int f = 0; f < 6; f++) L.halo[f][lane] = hv[f];
-    if (lane == 0) { L.npend[0] = np0; L.npend[1] = 0; }
+        for (int f = 0; f < 6; f++) { if (!((hin >> f) & 1u)) hv[f] = 0ull; else if (round == 0) hv[f] = GIE_NOPROP; }
+        if (lane == 0) gie_st(&c.wc_flag[round & 1][t], (int32_t)0);      /* may be activated again (for round + 2) from now on */
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int ex = (la - j) & 7, ey = (lb - j) & 7;
+            const int v = GIE_WC_P(ex, ey, j);
+            curd[j] = gie_pair_dist(pv[j]);
+            L.pair[v] = pv[j]; L.prop[v] = cv[j];
+            if (cv[j] != GIE_NOPROP) {
+                gie_st(&rd[(z0 + j) * plane + (y0 + ey) * c.X + (x0 + ex)], (uint64_t)GIE_NOPROP);      /* consumed */
+                if (round == 0) curd[j] = 0x400000;                      /* the seeds of round 0 are assignments: any proposal is "nearer" */
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 6; f++) { L.pair[hcell[f]] = hv[f]; L.prop[hcell[f]] = GIE_NOPROP; }
+    }
+    /* the z-column (x0 + la, y0 + lb)'s byte of `ucol` (its eight voxels belong to eight lanes: the column's lane writes the byte back) */
+    const bool colin = x0 + la < c.X && y0 + lb < c.Y;
+    uint8_t *const ucp = &c.ucol[gie_ucol_index(c, colin ? x0 + la : 0, colin ? y0 + lb : 0, z0)];
+    const unsigned ub = gie_ld(ucp);
+    int myslot = -1;                                      /* lanes 0-7: the slot of block (lane & 1, lane >> 1 & 1, lane >> 2) of the (at most) 2x2x2 global blocks the tile overlaps */
+    if (c.fused && lane < 8) {
+        const int bx = ((x0 + c.pvt[0]) >> 3) + (lane & 1) - c.tb0[0], by = ((y0 + c.pvt[1]) >> 3) + ((lane >> 1) & 1) - c.tb0[1], bz = ((z0 + c.pvt[2]) >> 3) + (lane >> 2) - c.tb0[2];
+        if (bx < c.tdim[0] && by < c.tdim[1] && bz < c.tdim[2]) myslot = c.blk_tab[(bz * c.tdim[1] + by) * c.tdim[0] + bx];
+    }
     gie_wave_sync();
-    /* ---- BFS inside the tile, driven by lists (a level costs what its entries cost, not a scan of the tile): the PENDING
-     * list holds the voxels with a proposal; (a) one pending voxel per lane: merge, the ones that improved are compacted
-     * (ballot) into the entry list; (b) one entry per lane: expand; a proposal that turns a voxel's slot from "none" into a
-     * value appends the voxel to the other pending list (the returning LDS minimum says so). */
-    unsigned xmask = 0;                                   /* neighbour tiles that received a proposal */
+    GIE_WPROF_MARK(16);                                                  /* 16: the tile and its halo into LDS */
+    /* ---- BFS inside the tile */
+    unsigned dirty = 0;                                   /* my voxels whose pair has changed */
     int nvis = 0;
-    int np = np0;
-    for (int sub = 0;; sub++) {
-        const int pi = sub & 1;
-        int nent = 0;
-        for (int e0 = 0; e0 < np; e0 += 64) {
-            const int e = e0 + lane;
-            bool take = false;
-            int v = 0;
-            if (e < np) {
-                v = L.pend[pi][e];
-                const uint64_t cd = L.prop[v];
-                L.prop[v] = GIE_NOPROP;
-                take = (round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(L.pair[v]);
-                if (take) { L.pair[v] = cd; nvis++; }
+    /* the closest obstacle of local voxel (x0, y0, z0) relative to it is (wave-range coordinate) + off */
+    const int off0 = c.upvt[0] - c.pvt[0] - x0, off1 = c.upvt[1] - c.pvt[1] - y0, off2 = c.upvt[2] - c.pvt[2] - z0;
+    const int emax = c.empty_value;
+    unsigned long long wq0 = GIE_WPROF_CLK(), wq_merge = 0, wq_exp = 0; int wq_pass = 0;
+    for (;;) {
+        unsigned tk = 0;                                  /* (a) my voxels that take their proposal in this level */
+        {
+            uint64_t cd[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) cd[j] = L.prop[GIE_WC_P((la - j) & 7, (lb - j) & 7, j)];       /* eight reads in flight */
+#pragma unroll
+            for (int j = 0; j < 8; j++) L.prop[GIE_WC_P((la - j) & 7, (lb - j) & 7, j)] = GIE_NOPROP;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                /* "no proposal" carries the largest distance there is: never below a voxel's own — except a seed's of round 0 (0x400000
+                 * above), and a seed has its proposal */
+                const int pd = gie_pair_dist(cd[j]);
+                const bool take = pd < curd[j];
+                curd[j] = take ? pd : curd[j];
+                tk |= (take ? 1u : 0u) << j;
+                if (take) L.pair[GIE_WC_P((la - j) & 7, (lb - j) & 7, j)] = cd[j];
             }
-            const unsigned long long m = __ballot(take);
-            if (take) L.list[nent + __popcll(m & lt)] = (uint16_t)v;
-            nent += __popcll(m);
         }
-        if (lane == 0) L.npend[pi] = 0;                   /* free for the level after the next */
-        if (nent == 0) break;                             /* wave-uniform */
+        nvis += __popc(tk);
+        dirty |= tk;
+        if (__ballot(tk != 0u) == 0ull) break;            /* wave-uniform */
+        GIE_WPROF_ADD(22, 1);
         gie_wave_sync();
-        for (int e = lane; e < nent; e += 64) {
-            const int v = L.list[e];
-            const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
-            const uint64_t par = gie_pair_par(L.pair[v]);
-            int cw[3];
-            gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
-            const int cx = cw[0] + c.upvt[0] - c.pvt[0] - (x0 + ex), cy = cw[1] + c.upvt[1] - c.pvt[1] - (y0 + ey), cz = cw[2] + c.upvt[2] - c.pvt[2] - (z0 + ez);
-            const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
-            int d[6];
-            uint64_t seen[6];
-            unsigned okm = 0, inm = 0;
+        { const unsigned long long n_ = GIE_WPROF_CLK(); wq_merge += n_ - wq0; wq0 = n_; }
+        while (__ballot(tk != 0u) != 0ull) {              /* (b) expand them: as many trips as the busiest lane took voxels */
+            wq_pass++;
+            if (tk != 0u) {
+                const int ez = __ffs((int)tk) - 1;
+                tk &= tk - 1u;
+                const int ex = (la - ez) & 7, ey = (lb - ez) & 7;
+                uint64_t *const pb = &L.pair[GIE_WC_P(ex, ey, ez) - 100];           /* (non-negative offsets from here: -z 0, -y 90, -x 99, self 100, +x 101, +y 110, +z 200) */
+                const uint32_t *const ph = reinterpret_cast<const uint32_t *>(pb) + 1;   /* a pair's distance is in its upper word */
+                const uint64_t own = pb[100];
+                const uint32_t s0 = ph[2 * 99], s1 = ph[2 * 101], s2 = ph[2 * 90], s3 = ph[2 * 110], s4 = ph[0], s5 = ph[2 * 200];
+                const uint64_t par = gie_pair_par(own);
+                int cw[3];
+                gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
+                const int cx = cw[0] + off0 - ex, cy = cw[1] + off1 - ey, cz = cw[2] + off2 - ez;
+                /* |closest obstacle - neighbour|^2 = |closest obstacle - voxel|^2 +- 2 c + 1; 32 bits: wave-range coordinates are below 2^14 */
+                const int d0 = cx * cx + cy * cy + cz * cz + 1;
+                const int d[6] = { d0 + 2 * cx, d0 - 2 * cx, d0 + 2 * cy, d0 - 2 * cy, d0 + 2 * cz, d0 - 2 * cz };
+                const uint32_t s[6] = { s0, s1, s2, s3, s4, s5 };
+                const int po[6] = { 99, 101, 90, 110, 0, 200 };
+                const uint32_t plo = (uint32_t)par, phi = (uint32_t)(par >> 32);
 #pragma unroll
-            for (int k = 0; k < 6; k++) {                 /* the six neighbours' current pairs (tile or halo) in flight together */
-                const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
-                const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
-                const int hp = (k < 2) ? (ey + 8 * ez) : ((k < 4) ? (ex + 8 * ez) : (ex + 8 * ey));
-                seen[k] = inside ? L.pair[ux + 8 * uy + 64 * uz] : L.halo[k][hp];
-                /* |closest obstacle - neighbour|^2 in 32 bits: wave-range coordinates are below 2^14 */
-                const int ax = cx - dx[k], ay = cy - dy[k], az = cz - dz[k];
-                d[k] = ax * ax + ay * ay + az * az;
-                if (gie_in_loc(c, x0 + ux, y0 + uy, z0 + uz) && d[k] < c.empty_value) okm |= 1u << k;
-                if (inside) inm |= 1u << k;
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                /* (the pre-read only drops proposals that cannot improve: values only decrease; a halo pair is the neighbour's at the start of the round.
-                 * NOT in round 0 across a tile border: the neighbour may be a seed its own tile is about to ASSIGN, and the seed wave B leaves
-                 * on an unknown face voxel — accepted against the batch distance, wave_core.cuh:334 — can lie ABOVE the stale pair the plane
-                 * still holds for it: a proposal between the two was dropped here and the voxel kept the seed's distance (round-4 fuzz,
-                 * seed 83 #63).  Sent on, it meets the assigned pair in round 1 — what the sequential schedule does.) */
-                if (!((okm >> k) & 1u)) continue;
-                if (!(d[k] < gie_pair_dist(seen[k])) && (((inm >> k) & 1u) || round != 0)) continue;
-                const uint64_t key = gie_pair_make(d[k], par);
-                const int ux = ex + dx[k], uy = ey + dy[k], uz = ez + dz[k];
-                if ((inm >> k) & 1u) {
-                    const int nv = ux + 8 * uy + 64 * uz;
-                    if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
-                        L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
-                } else { gie_amin64(&wr[(size_t)(z0 + uz) * plane + (size_t)(y0 + uy) * c.X + (x0 + ux)], key); xmask |= 1u << k; }
+                for (int k = 0; k < 6; k++) {
+                    /* a proposal that cannot improve is dropped (values only decrease); cells outside the volume hold distance 0 */
+                    if (d[k] < emax && (uint32_t)d[k] < (s[k] >> 10)) {
+                        const uint64_t key = ((uint64_t)(((uint32_t)d[k] << 10) | phi) << 32) | plo;
+                        (void)__hip_atomic_fetch_min(&pb[1000 + po[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
             }
         }
         gie_wave_sync();
-        np = L.npend[pi ^ 1];
+        { const unsigned long long n_ = GIE_WPROF_CLK(); wq_exp += n_ - wq0; wq0 = n_; }
     }
-    /* which of my eight voxels changed: the pair in LDS against the one loaded */
-    unsigned dirty = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (L.pair[lane + 64 * j] != pv[j]) dirty |= 1u << j;
-    /* ---- write back what changed (wave C is the only writer of these pairs; agent-scope: another XCD's wave takes the tile next time) */
-#pragma unroll 1
-    for (int j = 0; j < 8; j++) {
-        if (!((dirty >> j) & 1u)) continue;
-        const int z = z0 + j;
-        const size_t id = (size_t)z * plane + col;
-        const uint64_t pr = L.pair[lane + 64 * j];
-        if ((int8_t)(tys >> (8 * j)) == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, (int)id, x, y, z, pv[j]);     /* (`_edt_D` is derived from the pairs: gie_ops.h) */
-        gie_st(&c.pair[id], pr);
-        if (c.fused) {
-            const int slot = (((z + c.pvt[2]) >> 3) == ((z0 + c.pvt[2]) >> 3)) ? slot_lo : slot_hi;
-            gie_commit_merged(c, (int)id, (int8_t)(tys >> (8 * j)), slot, x, y, z, pr);
-        }
-    }
-    /* ---- neighbour tiles that received a proposal take part in the next round */
+    GIE_WPROF_ADD(24, wq_merge); GIE_WPROF_ADD(25, wq_exp); GIE_WPROF_ADD(26, wq_pass);
+    /* ---- what the tile proposes to its neighbours' voxels: the halo's proposal cells into the other candidate plane */
+    unsigned xmask = 0;                                   /* neighbour tiles that received a proposal */
     {
-        unsigned any6 = 0;
+        uint64_t hp[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
-        if (lane < 6 && ((any6 >> lane) & 1u)) {            /* lane k activates the neighbour across face k: the six in flight together */
-            const int dt = (lane == 0) ? -1 : (lane == 1) ? 1 : (lane == 2) ? -c.tfd[0] : (lane == 3) ? c.tfd[0]
-                         : (lane == 4) ? -c.tfd[0] * c.tfd[1] : c.tfd[0] * c.tfd[1];
-            const int nt = t + dt;
-            gie_list_append_wave(c.wc_list[(round + 1) & 1], &c.lvl_next[round + 1], gie_axchg32(&c.wc_flag[(round + 1) & 1][nt], (int32_t)1) == 0, nt);
+        for (int f = 0; f < 6; f++) hp[f] = L.prop[hcell[f]];
+#pragma unroll
+        for (int f = 0; f < 6; f++)
+            if (hp[f] != GIE_NOPROP) { gie_amin64(&wr[hz[f] * plane + hy[f] * c.X + hx[f]], hp[f]); xmask |= 1u << f; }      /* (only cells inside the volume receive proposals) */
+    }
+    GIE_WPROF_SUBSTART();
+    GIE_WPROF_DRAIN();
+    GIE_WPROF_SUB(27);
+    GIE_WPROF_MARK(16);                                                  /* 17: levels inside the tile (drained: the proposals across the border) */
+    /* ---- neighbour tiles that received a proposal take part in the next round: the exchanges on their flags are issued now and
+     * looked at behind the write-back */
+    unsigned any6 = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
+    const bool actl = lane < 6 && ((any6 >> lane) & 1u);                    /* lane k activates the neighbour across face k: the six in flight together */
+    int nt = 0, act_old = 1;
+    if (actl) {
+        const int dt = (lane == 0) ? -1 : (lane == 1) ? 1 : (lane == 2) ? -c.tfd[0] : (lane == 3) ? c.tfd[0]
+                     : (lane == 4) ? -c.tfd[0] * c.tfd[1] : c.tfd[0] * c.tfd[1];
+        nt = t + dt;
+        act_old = gie_axchg32(&c.wc_flag[(round + 1) & 1][nt], (int32_t)1);
+    }
+    /* ---- write back what changed (wave C is the only writer of these pairs; agent-scope: another XCD's wave takes the tile next time) */
+    if (__ballot(dirty != 0u) != 0ull) {
+        /* `_edt_D` is derived from the pairs (gie_ops.h gie_edt_unknown_touch): a wave that changes the pair of an UNKNOWN voxel stores
+         * the value of the pair before the change and marks the index in `ucol` — once.  The eight voxels of a z-column lie with
+         * eight lanes: the column's lane gathers their marks out of ballots and writes the byte, a voxel's lane pulls the byte. */
+        unsigned du = 0;                                  /* my voxels that changed and are UNKNOWN */
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (((dirty >> j) & 1u) && (int8_t)(tys >> (8 * j)) == GIE_VOX_UNKNOWN) du |= 1u << j;
+        if (__ballot(du != 0u) != 0ull) {
+            unsigned newbits = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned long long mj = __ballot((du >> j) & 1u);
+                newbits |= (unsigned)((mj >> (((la + j) & 7) + 8 * ((lb + j) & 7))) & 1ull) << j;
+                const unsigned ubc = (unsigned)__shfl((int)ub, ((la - j) & 7) + 8 * ((lb - j) & 7));
+                if (((du >> j) & 1u) && !((ubc >> j) & 1u) && !gie_pair_keeps_edt(c, pv[j]))       /* marked now: the byte did not hold the bit */
+                    gie_st(&c.edt[(z0 + j) * plane + (y0 + ((lb - j) & 7)) * c.X + (x0 + ((la - j) & 7))], gie_edt_of_pair(c, pv[j]));
+            }
+            if (colin && (newbits & ~ub) != 0u) gie_st(ucp, (uint8_t)(ub | newbits));
+        }
+        unsigned dm = dirty;
+        while (__ballot(dm != 0u) != 0ull) {              /* as many trips as the busiest lane has changed voxels; stores only */
+            const int j = dm != 0u ? __ffs((int)dm) - 1 : 0;
+            const int ex = (la - j) & 7, ey = (lb - j) & 7;
+            const int x = x0 + ex, y = y0 + ey, z = z0 + j;
+            int slot = -1;
+            if (c.fused) {
+                const int which = (((x + c.pvt[0]) >> 3) - ((x0 + c.pvt[0]) >> 3)) | ((((y + c.pvt[1]) >> 3) - ((y0 + c.pvt[1]) >> 3)) << 1) | ((((z + c.pvt[2]) >> 3) - ((z0 + c.pvt[2]) >> 3)) << 2);
+                slot = __shfl(myslot, which);
+            }
+            if (dm != 0u) {
+                const int id = z * plane + y * c.X + x;
+                const uint64_t pr = L.pair[GIE_WC_P(ex, ey, j)];
+                gie_st(&c.pair[id], pr);
+                if (c.fused) gie_commit_merged(c, id, (int8_t)(tys >> (8 * j)), slot, x, y, z, pr);
+            }
+            dm &= dm - 1u;
         }
     }
+    GIE_WPROF_DRAIN();
+    GIE_WPROF_MARK(16);                                                  /* 18: write-back (+ the flags' round trip) */
+    if (any6 != 0u) gie_list_append_wave(c.wc_list[(round + 1) & 1], &c.lvl_next[round + 1], actl && act_old == 0, nt);
     {   /* visits of the tile (one atomic per wave) */
         int s = nvis;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0 && s > 0) GIE_VIS_ADD(&c.lvl_vis[round], s);
     }
+    GIE_WPROF_DRAIN();
+    GIE_WPROF_MARK(16);                                                  /* 19: activation of the neighbours */
+    GIE_WPROF_ADD(23, 1);
+    GIE_WPROF_END(16);
     gie_wave_sync();                                       /* the LDS block is reused for the wave's next tile */
 }
 
@@ -3335,12 +3407,21 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
     GIE_TS2(12, n);
     int round = 0;
     while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
+        /* the round's length and the wave's first list entry in ONE round trip (the entry is only looked at when it exists; the list
+         * has a word per tile and the grid is no larger than that... or the index is clamped) */
+        const int32_t *list = c.wc_list[round & 1];
+        const int i0 = (int)blockIdx.x + (int)gridDim.x * wave;
+        const int i0c = i0 < c.tfd[0] * c.tfd[1] * c.tfd[2] ? i0 : 0;
         const int nt = gie_ld(&c.lvl_next[round]);
+        int tnext = gie_ld(&list[i0c]);
         if (nt <= 0) break;                    /* same everywhere */
         if (wave < GIE_WC_WAVES) {
-            const int32_t *list = c.wc_list[round & 1];
-            for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WC_WAVES)      /* (spread over the workgroups first) */
-                gie_wave_c_tile(c, gb, tiles[wave], gie_ld(&list[i]), round, lane);
+            for (int i = i0; i < nt; i += (int)gridDim.x * GIE_WC_WAVES) {      /* (spread over the workgroups first) */
+                const int t = tnext;
+                const int in = i + (int)gridDim.x * GIE_WC_WAVES;
+                if (in < nt) tnext = gie_ld(&list[in]);            /* (in flight while the tile runs) */
+                gie_wave_c_tile(c, gb, tiles[wave], t, round, lane);
+            }
         }
         gie_grid_sync(gb, c, &c.lvl_vis[round]);
         GIE_TS2(11, nt);
@@ -3356,44 +3437,61 @@ __device__ __forceinline__ void gie_wave_c_run(const gie_ctx &c, gie_gridbar &gb
     }
 }
 
-/* waves A, B (unless fast_mode / refinement) and C in one launch */
-__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves(const gie_ctx c, const int with_ab, const int record_seeds)
+/* Waves A and B in one launch, wave C in the next (round 6; rounds 2-5: all three in one).  The boundary between the two launches
+ * stands where a grid barrier stood (wave C starts from the seeds waves A / B leave), and each kernel is compiled on its own: the
+ * block routines of waves A / B need the whole register file, wave C's tile routine 196 registers — together the register
+ * allocator spilled (and ROCm 7.2's stack-slot colouring gave up on the result). */
+__device__ __forceinline__ gie_gridbar gie_waves_bar(const gie_ctx &c, int32_t *word, int *s_fail, int *s_vis)
 {
-    constexpr size_t lds_a = sizeof(gie_wa_tile) * GIE_WA_WAVES, lds_b = sizeof(gie_wb_tile) * GIE_WB_WAVES, lds_c = sizeof(gie_wc_tile) * GIE_WC_WAVES;
-    __shared__ __attribute__((aligned(16))) unsigned char s_lds[lds_a > lds_b ? (lds_a > lds_c ? lds_a : lds_c) : (lds_b > lds_c ? lds_b : lds_c)];
+    /* (c.bar_fault: the timeout path on purpose — a barrier that waits for one workgroup more than there are, with a short limit) */
+    gie_gridbar gb = { word, 0, 0, (int)gridDim.x + (c.bar_fault ? 1 : 0), s_fail, s_vis, c.bar_fault ? (1 << 10) : GIE_BAR_SPIN_LIMIT };
+    return gb;
+}
+__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves_ab(const gie_ctx c)
+{
+    constexpr size_t lds_a = sizeof(gie_wa_tile) * GIE_WA_WAVES, lds_b = sizeof(gie_wb_tile) * GIE_WB_WAVES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[lds_a > lds_b ? lds_a : lds_b];
     gie_wa_tile *const s_ablocks = reinterpret_cast<gie_wa_tile *>(s_lds);    /* wave A: one 8x8x8 block of the global map (+ halo) per wave */
-    gie_wc_tile *const s_tiles = reinterpret_cast<gie_wc_tile *>(s_lds);      /* wave C: one 8x8x8 tile (+ halo) per wave */
     gie_wb_tile *const s_blocks = reinterpret_cast<gie_wb_tile *>(s_lds);     /* wave B: one 8x8x8 block of the global map (+ halo) per wave */
     __shared__ int s_fail, s_vis;
-    if (GIE_GATE_CLOSED(c)) return;              /* a refinement round nobody needs (gie_round_gate): same answer in every workgroup, before any barrier */
+    if (GIE_GATE_CLOSED(c)) return;
     if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
-    /* (c.bar_fault: the timeout path on purpose — a barrier that waits for one workgroup more than there are, with a short limit) */
-    gie_gridbar gb = { &c.cnt[GIE_CNT_BAR_C], 0, 0, (int)gridDim.x + (c.bar_fault ? 1 : 0), &s_fail, &s_vis, c.bar_fault ? (1 << 10) : GIE_BAR_SPIN_LIMIT };
-    {   /* nothing seeded anywhere (the usual case of a sparse scan over a settled map): nothing can be
-         * produced either, so the launch ends here — same counters for every workgroup, no barrier */
-        const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]), nc = gie_ld(&c.cnt[GIE_CNT_C]);
-        if ((with_ab ? (na | nb | nc) : nc) == 0) {
+#if defined(GIE_WAVE_TIMING)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
+#endif
+    gie_gridbar gb = gie_waves_bar(c, &c.cnt[GIE_CNT_BAR_C], &s_fail, &s_vis);
+    {   /* nothing seeded outside the volume (the usual case of a sparse scan over a settled map): the launch ends here — same
+         * counters for every workgroup, no barrier */
+        const int na = gie_ld(&c.cnt[GIE_CNT_A]), nb = gie_ld(&c.cnt[GIE_CNT_B]);
+        if ((na | nb) == 0) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
-                if (with_ab) { c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0; c.cnt[GIE_CNT_SEED_C] = 0; }
-                c.cnt[GIE_CNT_FRONT_C] = 0;
-                if (record_seeds) { c.cnt[GIE_CNT_SEED_C] = 0; c.cnt[GIE_CNT_SEED_A] = na; c.cnt[GIE_CNT_SEED_B] = nb; }
+                c.cnt[GIE_CNT_SEED_A] = 0; c.cnt[GIE_CNT_SEED_B] = 0; c.cnt[GIE_CNT_FRONT_B] = 0; c.cnt[GIE_CNT_SEED_C] = gie_ld(&c.cnt[GIE_CNT_C]);
             }
             return;
         }
     }
     __syncthreads();
-#if defined(GIE_WAVE_TIMING)
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
-#endif
     GIE_TS2(0, 0);
-    if (with_ab) {
-        gie_wave_a_run(c, gb, s_ablocks);   /* (ends behind the barrier of its last round: wave B starts from the queue and the counters it leaves) */
-        GIE_TS2(8, 0);
-        gie_wave_b_run(c, gb, s_blocks);
-        gie_grid_sync(gb, c);
-        GIE_TS2(9, 0);
-    }
-    gie_wave_c_run(c, gb, record_seeds, s_tiles);
+    gie_wave_a_run(c, gb, s_ablocks);   /* (ends behind the barrier of its last round: wave B starts from the queue and the counters it leaves) */
+    GIE_TS2(8, 0);
+    gie_wave_b_run(c, gb, s_blocks);
+    GIE_TS2(9, 0);
+}
+__global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves_c(const gie_ctx c, const int with_ab, const int record_seeds)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[sizeof(gie_wc_tile) * GIE_WC_WAVES];
+    gie_wc_tile *const s_tiles = reinterpret_cast<gie_wc_tile *>(s_lds);      /* wave C: one 8x8x8 tile (+ halo) per wave */
+    __shared__ int s_fail, s_vis;
+    if (GIE_GATE_CLOSED(c)) return;              /* a refinement round nobody needs (gie_round_gate): same answer in every workgroup, before any barrier */
+    if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
+#if defined(GIE_WAVE_TIMING)
+    if (!with_ab && blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
+#endif
+    gie_gridbar gb = gie_waves_bar(c, &c.cnt[GIE_CNT_BAR_B], &s_fail, &s_vis);
+    if (gie_ld(&c.cnt[GIE_CNT_BARFAIL]) != 0) gb.failed = 1;       /* a barrier of waves A / B timed out: the update is incomplete (GIE_ERR_TIMEOUT) */
+    __syncthreads();
+    if (!with_ab) GIE_TS2(0, 0);
+    gie_wave_c_run(c, gb, record_seeds, s_tiles);                  /* (no seeds: the counters, and out — no barrier) */
     GIE_TS2(10, 0);
     GIE_WPROF_DUMP();
 }

@@ -205,8 +205,8 @@ enum {
     GIE_CNT_STATE1, GIE_CNT_STATE2,             /* (unused) */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
-    GIE_CNT_BAR_B = 34,                         /* (unused; first word of the second cleared range) */
-    GIE_CNT_BAR_C = 35,                         /* grid-barrier word of the waves launch */
+    GIE_CNT_BAR_B = 34,                         /* grid-barrier word of wave C's launch (first word of the second cleared range) */
+    GIE_CNT_BAR_C = 35,                         /* grid-barrier word of the launch of waves A / B */
     GIE_CNT_NEWLIST = 36,                       /* entries in the list of blocks to initialise (blk_new) */
     GIE_CNT_TL_KNOWN = 37, GIE_CNT_TL_FRONT = 38, /* entries in the tile lists tl_known / tl_front */
     GIE_CNT_BAR_AB2 = 39,                       /* (unused) */

@@ -3,7 +3,7 @@ python tools/kernel_resources.py [extra hipcc flags].  A kernel with scratch has
 outstanding memory operations of the wave (vmcnt counts in order), which undoes any prefetch the kernel was written around."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-no-stack-slot-sharing", "-shared", "-fPIC",
                       "-Rpass-analysis=kernel-resource-usage", os.path.join(ROOT, "gie-mapping_amd", "csrc", "gie_hip.hip"), "-o", "/tmp/_kr.so"] + sys.argv[1:],
                      capture_output=True, text=True).stderr
 cur = None
