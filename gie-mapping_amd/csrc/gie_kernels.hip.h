@@ -2807,11 +2807,15 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
  *   rule:   a proposal replaces a pair on a strict distance improvement over the value at the start of the (sub-)level, among
  *           proposals the smaller (dist, parent) wins; the seeds of round 0 enter with the pair they hold; a voxel that is
  *           taken up is committed and expanded unless the distance stored in it BEFORE the commit exceeds the cut-off (:262-266). */
-struct gie_wb_tile { uint64_t pair[512], prop[512], halo[6][64]; uint32_t sdist[512]; uint8_t flag[512], hflag[6][64];
-                     uint16_t list[512], pend[2][512]; int32_t npend[2], nslot[6]; };                                   /* 17.3 KB */
+/* Round 6: the block WITH its one-voxel halo, 10 x 10 x 10 cells (cell (ex, ey, ez), each in -1 .. 8, at GIE_WB_P), owned by the
+ * lanes as a Latin cube and run without lists — see gie_wave_c_tile, whose twin this is.  What is different here: a cell has a
+ * CLASS next to its pair (may be lowered / lies inside the volume / neither), a voxel that is taken up is only expanded when the
+ * distance stored in it before passes the cut-off, and a proposal to a position inside the volume goes into that cell's PAIR (the
+ * running minimum of the block-run, marked GIE_PAIR_NEW), not into its proposal cell. */
+struct gie_wb_tile { uint64_t pair[1000], prop[1000]; uint8_t flag[1000]; int32_t nslot[8]; };                           /* 17 KB */
+#define GIE_WB_P(ex, ey, ez) ((ex) + 10 * (ey) + 100 * (ez) + 111)
 #define GIE_WB_WAVES GIE_WAVE_SLOTS(9)                                    /* waves of a workgroup that take blocks */
 #define GIE_WB_OK 1u                                      /* the voxel may be lowered: known, and its stored obstacle is valid */
-#define GIE_WB_DONE 2u                                    /* committed in this round */
 
 #define GIE_WB_INVOL 4u                                   /* the position lies inside the volume: its slot holds the distance a proposal has to beat
                                                            * (`_aux[n]`, wave_core.cuh:334: the Mark-time pair's distance of an observed voxel, the batch
@@ -2824,177 +2828,213 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
     const int g0[3] = { bk[0] * 8, bk[1] * 8, bk[2] * 8 };              /* global coordinate of the block's first voxel */
     uint64_t *const rd = ((round + 1) & 1) ? c.g_prop : c.g_prop2, *const wr = (round & 1) ? c.g_prop : c.g_prop2;
     const gie_vaddr base = (gie_vaddr)slot * GIE_VBSZ;
+    /* (the lane number through an opaque move: everything below that depends on the lane alone — forty cell addresses — would
+     * otherwise be computed once per launch, ahead of the rounds, and kept in registers the block routine then lacks: 75 spilled) */
+    int lane_here = lane;
+    asm volatile("" : "+v"(lane_here));
+    const int la = lane_here & 7, lb = lane_here >> 3;
     GIE_WPROF_DECL;
-    uint64_t pv[8], cv[8], cc8[8];
-    int8_t ty8[8];
-    unsigned inv8 = 0;
+    /* the lane's eight voxels (layer j: x = la - j, y = lb - j mod 8; their pairs live in L.pair): */
+    unsigned sdok = 0;                                    /* ... the distance STORED in the voxel does not exceed the cut-off (wave_core.cuh:262-266) */
+    unsigned inv8 = 0;                                    /* ... the voxel lies inside the volume */
+    unsigned seedm = 0;                                   /* ... which hold a proposal of the round before (round 0: the seeds) */
+    unsigned bdm = 0;                                     /* my cells inside the volume whose voxel is UNKNOWN (bits 0-7: my voxels, 8-13: my halo cells): the distance to beat is the batch distance */
+    {
+        uint64_t pv[8], cv[8], cc8[8];
+        int8_t ty8[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {                                       /* voxel lane + 64 j = (x, y) = lane, z = j */
-        const gie_vaddr a = base + lane + 64 * j;
-        const int nb[3] = { g0[0] + (lane & 7) - c.pvt[0], g0[1] + (lane >> 3) - c.pvt[1], g0[2] + j - c.pvt[2] };
-        const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
-        const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
-        if (inv) inv8 |= 1u << j;
-        pv[j] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[a]) & ~GIE_PAIR_NEW; cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]);
-        ty8[j] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[a]);
-    }
-    if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0);     /* may be activated again (for round + 2) from now on */
-    /* ---- the six neighbour blocks, out of the block's row of the neighbour table, with the block's own records in flight */
-    if (lane < 6) L.nslot[lane] = nraw;
-    gie_wave_sync();                                                    /* the neighbour slots */
-    GIE_WPROF_MARK(8);
-    {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the lane's position (a, b) on it -> in-block index of the voxel across the face */
-        const int p = lane & 7, q = lane >> 3;
-        const int hidx[6] = { 7 | (p << 3) | (q << 6), 0 | (p << 3) | (q << 6), p | (7 << 3) | (q << 6), p | (0 << 3) | (q << 6), p | (q << 3) | (7 << 6), p | (q << 3) | (0 << 6) };
-        const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
-        uint64_t hp[6], hc[6], nk[6]; int8_t ht[6];
-        unsigned hinv = 0;
-#pragma unroll
-        for (int f = 0; f < 6; f++) {
-            const int ns = L.nslot[f];
-            const gie_vaddr an = (ns < 0 ? base : (gie_vaddr)ns * GIE_VBSZ) + hidx[f];
-            nk[f] = gie_ld(&c.g_key[ns < 0 ? slot : ns]);
-            const int nb[3] = { g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2] };
+        for (int j = 0; j < 8; j++) {
+            const int ex = (la - j) & 7, ey = (lb - j) & 7;
+            const gie_vaddr a = base + (ex | (ey << 3) | (j << 6));
+            const int nb[3] = { g0[0] + ex - c.pvt[0], g0[1] + ey - c.pvt[1], g0[2] + j - c.pvt[2] };
             const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
             const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
-            if (inv) hinv |= 1u << f;
-            hp[f] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[an]) & ~GIE_PAIR_NEW; hc[f] = gie_ld(&c.g_coc[an]);
-            ht[f] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[an]);
+            inv8 |= (inv ? 1u : 0u) << j;
+            pv[j] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[a]) & ~GIE_PAIR_NEW; cv[j] = gie_ld(&rd[a]); cc8[j] = gie_ld(&c.g_coc[a]);
+            ty8[j] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[a]);
         }
-        unsigned live = 0;
+        if (lane == 0) gie_st(&c.wb_flag[round & 1][slot], (int32_t)0); /* may be activated again (for round + 2) from now on */
+        /* ---- the six neighbour blocks, out of the block's row of the neighbour table, with the block's own records in flight */
+        if (lane < 6) L.nslot[lane] = nraw;
+        gie_wave_sync();                                                /* the neighbour slots */
+        GIE_WPROF_MARK(8);
+        {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z): the lane's position (la, lb) on it -> in-block index of the voxel across the face */
+            const int hidx[6] = { 7 | (la << 3) | (lb << 6), 0 | (la << 3) | (lb << 6), la | (7 << 3) | (lb << 6), la | (0 << 3) | (lb << 6), la | (lb << 3) | (7 << 6), la | (lb << 3) | (0 << 6) };
+            const int hx[6] = { -1, 8, la, la, la, la }, hy[6] = { la, la, -1, 8, lb, lb }, hz[6] = { lb, lb, lb, lb, -1, 8 };
+            uint64_t hp[6], hc[6], nk[6]; int8_t ht[6];
+            unsigned hinv = 0;
 #pragma unroll
-        for (int f = 0; f < 6; f++) {
-            const bool there = L.nslot[f] >= 0 && nk[f] == gie_pack_crd(bk[0] + (f == 1) - (f == 0), bk[1] + (f == 3) - (f == 2), bk[2] + (f == 5) - (f == 4));
-            if (there) live |= 1u << f;
-            if ((hinv >> f) & 1u) {
-                if (ht[f] == GIE_VOX_UNKNOWN)
-                    hp[f] = gie_pair_make(gie_batch_dist_direct(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]), 0);
-                L.halo[f][lane] = hp[f]; L.hflag[f][lane] = GIE_WB_INVOL;
+            for (int f = 0; f < 6; f++) {
+                const int ns = L.nslot[f];
+                const gie_vaddr an = (ns < 0 ? base : (gie_vaddr)ns * GIE_VBSZ) + hidx[f];
+                nk[f] = gie_ld(&c.g_key[ns < 0 ? slot : ns]);
+                const int nb[3] = { g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2] };
+                const bool inv = gie_in_loc(c, nb[0], nb[1], nb[2]);
+                const int nid = inv ? gie_lid(c, nb[0], nb[1], nb[2]) : 0;
+                if (inv) hinv |= 1u << f;
+                hp[f] = gie_ld(inv ? &c.pair[nid] : &c.g_pair[an]) & ~GIE_PAIR_NEW; hc[f] = gie_ld(&c.g_coc[an]);
+                ht[f] = gie_ld(inv ? &c.glb_type[nid] : &c.g_type[an]);
+            }
+            unsigned live = 0;
+#pragma unroll
+            for (int f = 0; f < 6; f++) {
+                const int cell = GIE_WB_P(hx[f], hy[f], hz[f]);
+                const bool there = L.nslot[f] >= 0 && nk[f] == gie_pack_crd(bk[0] + (f == 1) - (f == 0), bk[1] + (f == 3) - (f == 2), bk[2] + (f == 5) - (f == 4));
+                if (there) live |= 1u << f;
+                L.prop[cell] = GIE_NOPROP;
+                if ((hinv >> f) & 1u) {
+                    if (ht[f] == GIE_VOX_UNKNOWN) bdm |= 1u << (8 + f);                   /* (its batch distance: below, one copy of the code) */
+                    L.pair[cell] = hp[f]; L.flag[cell] = GIE_WB_INVOL;
+                    continue;
+                }
+                int ncx, ncy, ncz;
+                gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
+                const bool ok = there && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
+                                && !gie_in_whole(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]);   /* (tiling: not into another tile's territory) */
+                L.pair[cell] = hp[f]; L.flag[cell] = ok ? GIE_WB_OK : 0u;
+            }
+            if (lane < 6 && !((live >> lane) & 1u)) L.nslot[lane] = -1;      /* (an erased neighbour) */
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int ex = (la - j) & 7, ey = (lb - j) & 7;
+            const int cell = GIE_WB_P(ex, ey, j);
+            const int nb[3] = { g0[0] + ex - c.pvt[0], g0[1] + ey - c.pvt[1], g0[2] + j - c.pvt[2] };
+            if ((inv8 >> j) & 1u) {
+                if (ty8[j] == GIE_VOX_UNKNOWN) bdm |= 1u << j;
+                L.pair[cell] = pv[j]; L.prop[cell] = GIE_NOPROP; L.flag[cell] = GIE_WB_INVOL;
                 continue;
             }
             int ncx, ncy, ncz;
-            gie_unpack_crd(hc[f], &ncx, &ncy, &ncz);
-            const bool ok = there && ht[f] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz)
-                            && !gie_in_whole(c, g0[0] + hx[f] - c.pvt[0], g0[1] + hy[f] - c.pvt[1], g0[2] + hz[f] - c.pvt[2]);   /* (tiling: not into another tile's territory) */
-            L.halo[f][lane] = hp[f]; L.hflag[f][lane] = ok ? GIE_WB_OK : 0u;
+            gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
+            L.pair[cell] = pv[j]; L.prop[cell] = cv[j];
+            L.flag[cell] = (ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz) && !gie_in_whole(c, nb[0], nb[1], nb[2])) ? GIE_WB_OK : 0u;
+            if (gie_gdist(c, cc8[j], g0[0] + ex, g0[1] + ey, g0[2] + j) <= c.cutoff_sq) sdok |= 1u << j;
+            if (cv[j] != GIE_NOPROP) { seedm |= 1u << j; gie_st(&rd[base + (ex | (ey << 3) | (j << 6))], (uint64_t)GIE_NOPROP); }      /* consumed */
         }
-        if (lane < 6 && !((live >> lane) & 1u)) L.nslot[lane] = -1;      /* (an erased neighbour) */
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int np0 = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int v = lane + 64 * j;
-        const int nb[3] = { g0[0] + (lane & 7) - c.pvt[0], g0[1] + (lane >> 3) - c.pvt[1], g0[2] + j - c.pvt[2] };
-        L.prop[v] = GIE_NOPROP;
-        if ((inv8 >> j) & 1u) {
-            if (ty8[j] == GIE_VOX_UNKNOWN) pv[j] = gie_pair_make(gie_batch_dist_direct(c, nb[0], nb[1], nb[2]), 0);
-            L.pair[v] = pv[j]; L.flag[v] = GIE_WB_INVOL; L.sdist[v] = 0u;
-            continue;
-        }
-        int ncx, ncy, ncz;
-        gie_unpack_crd(cc8[j], &ncx, &ncy, &ncz);
-        L.pair[v] = pv[j]; L.prop[v] = cv[j];
-        L.flag[v] = (ty8[j] != GIE_VOX_UNKNOWN && !gie_invalid_coc(ncx, ncy, ncz) && !gie_in_whole(c, nb[0], nb[1], nb[2])) ? GIE_WB_OK : 0u;
-        L.sdist[v] = (uint32_t)gie_gdist(c, cc8[j], g0[0] + (lane & 7), g0[1] + (lane >> 3), g0[2] + j);
+    while (bdm != 0u) {                                   /* (rare: only blocks at the volume's faces; no wave-level operation inside) */
+        const int t = __ffs((int)bdm) - 1;
+        bdm &= bdm - 1u;
+        const int f = t - 8;
+        const int ux = t < 8 ? ((la - t) & 7) : (f == 0 ? -1 : f == 1 ? 8 : la), uy = t < 8 ? ((lb - t) & 7) : (f < 2 ? la : f == 2 ? -1 : f == 3 ? 8 : lb),
+                  uz = t < 8 ? t : (f < 4 ? lb : f == 4 ? -1 : 8);
+        L.pair[GIE_WB_P(ux, uy, uz)] = gie_pair_make(gie_batch_dist_direct(c, g0[0] + ux - c.pvt[0], g0[1] + uy - c.pvt[1], g0[2] + uz - c.pvt[2]), 0);
     }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int v = lane + 64 * j;
-        const bool have = !((inv8 >> j) & 1u) && cv[j] != GIE_NOPROP;
-        if (have) gie_st(&rd[base + v], (uint64_t)GIE_NOPROP);         /* consumed */
-        const unsigned long long m = __ballot(have);
-        if (have) L.pend[0][np0 + __popcll(m & lt)] = (uint16_t)v;
-        np0 += __popcll(m);
-    }
-    if (lane == 0) { L.npend[0] = np0; L.npend[1] = 0; }
     gie_wave_sync();
     GIE_WPROF_MARK(8);
-    /* ---- BFS inside the block (see gie_wave_c_tile): pending voxels -> merge -> the ones taken up are committed (or cut off) -> entries expand */
-    unsigned xmask = 0;
+    /* ---- BFS inside the block: (a) every lane looks at the proposal cells of its eight voxels: the ones that improve are taken up and
+     * committed, and expanded unless the distance stored before exceeds the cut-off; (b) every lane expands its entries, one after the other */
+    unsigned done = 0, chg = 0;                           /* my voxels committed in this round / whose pair has changed */
     int nvis = 0;
-    int np = np0;
-    for (int sub = 0;; sub++) {
-        const int pi = sub & 1;
-        int nent = 0;
-        for (int e0 = 0; e0 < np; e0 += 64) {
-            const int e = e0 + lane;
-            bool entry = false;
-            int v = 0;
-            if (e < np) {
-                v = L.pend[pi][e];
-                const uint64_t cd = L.prop[v];
-                L.prop[v] = GIE_NOPROP;
-                GIE_WPROF_ADD(14, e == 0 ? 1 : 0);
-                const bool take = (round == 0 && sub == 0) || gie_pair_dist(cd) < gie_pair_dist(L.pair[v]);
+    const int emax = c.empty_value;
+    bool first = round == 0;                              /* round 0, first level: the seeds enter with the pair they hold */
+    for (;;) {
+        unsigned tk = 0;                                  /* my voxels that become entries in this level */
+        {
+            uint64_t cd[8];
+            uint32_t ch[8];                               /* the upper word of my voxels' pairs: their distances */
+#pragma unroll
+            for (int j = 0; j < 8; j++) {                 /* sixteen reads in flight */
+                cd[j] = L.prop[GIE_WB_P((la - j) & 7, (lb - j) & 7, j)];
+                ch[j] = reinterpret_cast<const uint32_t *>(&L.pair[GIE_WB_P((la - j) & 7, (lb - j) & 7, j)])[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) L.prop[GIE_WB_P((la - j) & 7, (lb - j) & 7, j)] = GIE_NOPROP;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                /* ("no proposal" carries the largest distance there is: never below a voxel's own; a voxel inside the volume has no proposal cell in use) */
+                const int pd = gie_pair_dist(cd[j]), od = (int)(ch[j] >> 10);
+                const bool take = first ? ((seedm >> j) & 1u) != 0u : (pd < od && !((inv8 >> j) & 1u));
                 if (take) {
-                    if (!(round == 0 && sub == 0)) L.pair[v] = cd;                  /* (a seed enters with the pair it holds) */
+                    GIE_WPROF_ADD(14, j == 0 ? 1 : 0);
+                    if (!first) { L.pair[GIE_WB_P((la - j) & 7, (lb - j) & 7, j)] = cd[j]; chg |= 1u << j; }
                     nvis++;
-                    if ((int)L.sdist[v] <= c.cutoff_sq) {                        /* the distance stored before the commit */
-                        L.sdist[v] = (uint32_t)gie_pair_dist(L.pair[v]);
-                        L.flag[v] |= GIE_WB_DONE;
-                        entry = true;
+                    /* the distance stored before the commit: the one loaded with the block, or — the voxel has been committed in this
+                     * block-run before — the one that commit stored: its pair's until now */
+                    if (((done >> j) & 1u) ? od <= c.cutoff_sq : ((sdok >> j) & 1u) != 0u) { done |= 1u << j; tk |= 1u << j; }
+                }
+            }
+        }
+        first = false;
+        if (__ballot(tk != 0u) == 0ull) break;            /* wave-uniform */
+        gie_wave_sync();
+        while (__ballot(tk != 0u) != 0ull) {
+            if (tk != 0u) {
+                const int ez = __ffs((int)tk) - 1;
+                tk &= tk - 1u;
+                const int ex = (la - ez) & 7, ey = (lb - ez) & 7;
+                const int cell = GIE_WB_P(ex, ey, ez) - 100;                                  /* (non-negative offsets from here: -z 0, -y 90, -x 99, self 100, +x 101, +y 110, +z 200) */
+                uint64_t *const pb = &L.pair[cell];
+                const uint32_t *const ph = reinterpret_cast<const uint32_t *>(pb) + 1;         /* a pair's distance is in its upper word */
+                const uint8_t *const fb = &L.flag[cell];
+                const uint64_t own = pb[100];
+                const uint32_t s[6] = { ph[2 * 99], ph[2 * 101], ph[2 * 90], ph[2 * 110], ph[0], ph[2 * 200] };
+                const unsigned nf[6] = { fb[99], fb[101], fb[90], fb[110], fb[0], fb[200] };
+                const int po[6] = { 99, 101, 90, 110, 0, 200 };
+                const uint64_t par = gie_pair_par(own);
+                int cw[3];
+                gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
+                const int cg[3] = { cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2] };          /* the entry's closest obstacle, global */
+                const int cx = cg[0] - (g0[0] + ex), cy = cg[1] - (g0[1] + ey), cz = cg[2] - (g0[2] + ez);
+                /* |closest obstacle - neighbour|^2 = |closest obstacle - voxel|^2 +- 2 c + 1, in 32 bits while the obstacle is less than
+                 * 2^14 voxels away on every axis; farther (gie_d2 saturates there) no candidate is below any stored distance */
+                const bool near = (unsigned)(cx + 16384) < 32768u && (unsigned)(cy + 16384) < 32768u && (unsigned)(cz + 16384) < 32768u;
+                const int d0 = cx * cx + cy * cy + cz * cz + 1;
+                const int d[6] = { d0 + 2 * cx, d0 - 2 * cx, d0 + 2 * cy, d0 - 2 * cy, d0 + 2 * cz, d0 - 2 * cz };
+                /* a neighbour inside the volume (only blocks at its faces have any): not from an obstacle in another tile's territory (tiling: gie_frontier_outside) */
+                const int cl3[3] = { cg[0] - c.pvt[0], cg[1] - c.pvt[1], cg[2] - c.pvt[2] };
+                const bool invol_ok = !(gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2]));
+                const uint32_t plo = (uint32_t)par, phi = (uint32_t)(par >> 32);
+                if (near) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const uint32_t sdk = s[k] >> 10;
+                        /* a voxel that may be lowered: a strict improvement goes into its proposal cell; a position inside the volume: its
+                         * cell holds the distance to beat, a proposal (marked) that beats it replaces it — the running minimum of this
+                         * block-run, handed to the face table once, with the write-back (at equal distance the stored reference — no mark —
+                         * stays below every proposal; among proposals the parent decides) */
+                        const bool an = (nf[k] & GIE_WB_OK) && d[k] < emax && (uint32_t)d[k] < sdk;
+                        const bool ai = (nf[k] & GIE_WB_INVOL) && invol_ok && (uint32_t)d[k] <= sdk;
+                        if (an | ai) {
+                            const uint64_t key = ((uint64_t)(((uint32_t)d[k] << 10) | phi | (ai ? (uint32_t)(GIE_PAIR_NEW >> 32) : 0u)) << 32) | plo;
+                            (void)__hip_atomic_fetch_min(&pb[(ai ? 0 : 1000) + po[k]], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
             }
-            const unsigned long long m = __ballot(entry);
-            if (entry) L.list[nent + __popcll(m & lt)] = (uint16_t)v;
-            nent += __popcll(m);
-        }
-        if (lane == 0) L.npend[pi] = 0;
-        if (nent == 0) break;                             /* wave-uniform */
-        gie_wave_sync();
-        /* one lane per (entry, direction): see gie_wave_a_block */
-        for (int idx = lane; idx < nent * 6; idx += 64) {
-            const int e = idx / 6, k = idx - 6 * e;
-            const int v = L.list[e];
-            const int ex = v & 7, ey = (v >> 3) & 7, ez = v >> 6;
-            const uint64_t par = gie_pair_par(L.pair[v]);
-            int cw[3];
-            gie_unpack_wr(par, &cw[0], &cw[1], &cw[2]);
-            const int cg[3] = { cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2] };          /* the entry's closest obstacle, global */
-            const int ax = k >> 1, sg = (k & 1) ? 1 : -1;
-            const int ux = ex + (ax == 0 ? sg : 0), uy = ey + (ax == 1 ? sg : 0), uz = ez + (ax == 2 ? sg : 0);
-            const int ng[3] = { g0[0] + ux, g0[1] + uy, g0[2] + uz };
-            const int cand = gie_d2(cg[0], cg[1], cg[2], ng[0], ng[1], ng[2]);
-            const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
-            const int hp = (ax == 0) ? (ey + 8 * ez) : ((ax == 1) ? (ex + 8 * ez) : (ex + 8 * ey));
-            const int nv = (ux & 7) + 8 * (uy & 7) + 64 * (uz & 7);
-            const uint64_t seen = inside ? L.pair[nv] : L.halo[k][hp];
-            const unsigned nf = inside ? L.flag[nv] : L.hflag[k][hp];
-            const uint64_t key = gie_pair_make(cand, par);
-            if (nf & GIE_WB_INVOL) {
-                /* a neighbour inside the volume (only blocks at its faces get here): the face table takes the minimum of the whole wave */
-                const int cl3[3] = { cg[0] - c.pvt[0], cg[1] - c.pvt[1], cg[2] - c.pvt[2] };
-                if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) continue;      /* (tiling: gie_frontier_outside) */
-                /* the slot holds the distance to beat; a proposal (marked: GIE_PAIR_NEW) that beats it replaces it — the running minimum
-                 * of this block-run, handed to the face table once, with the write-back */
-                if (gie_pair_dist(seen) >= cand)             /* (at equal distance the stored reference — no mark — stays below every proposal; among proposals the parent decides) */
-                    __hip_atomic_fetch_min(inside ? &L.pair[nv] : &L.halo[k][hp], key | GIE_PAIR_NEW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
-            }
-            if (!(nf & GIE_WB_OK) || cand >= c.empty_value || !(cand < gie_pair_dist(seen))) continue;
-            if (inside) {
-                if (__hip_atomic_fetch_min(&L.prop[nv], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == GIE_NOPROP)
-                    L.pend[pi ^ 1][__hip_atomic_fetch_add(&L.npend[pi ^ 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint16_t)nv;
-            } else { gie_amin64(&wr[(gie_vaddr)L.nslot[k] * GIE_VBSZ + nv], key); xmask |= 1u << k; }
         }
         gie_wave_sync();
-        np = L.npend[pi ^ 1];
     }
     GIE_WPROF_MARK(8);
+    /* ---- what the block proposes to its neighbours' voxels: the halo's proposal cells into the other proposal plane */
+    unsigned xmask = 0;
+    {
+        const int hidx[6] = { 7 | (la << 3) | (lb << 6), 0 | (la << 3) | (lb << 6), la | (7 << 3) | (lb << 6), la | (0 << 3) | (lb << 6), la | (lb << 3) | (7 << 6), la | (lb << 3) | (0 << 6) };
+        const int hcell[6] = { GIE_WB_P(-1, la, lb), GIE_WB_P(8, la, lb), GIE_WB_P(la, -1, lb), GIE_WB_P(la, 8, lb), GIE_WB_P(la, lb, -1), GIE_WB_P(la, lb, 8) };
+        uint64_t hq[6];
+#pragma unroll
+        for (int f = 0; f < 6; f++) hq[f] = L.prop[hcell[f]];
+#pragma unroll
+        for (int f = 0; f < 6; f++)
+            if (hq[f] != GIE_NOPROP) { gie_amin64(&wr[(gie_vaddr)L.nslot[f] * GIE_VBSZ + hidx[f]], hq[f]); xmask |= 1u << f; }     /* (only voxels of live neighbours may be lowered) */
+    }
     /* ---- write back: changed pairs, the closest obstacle of every voxel committed in this round */
-#pragma unroll 1
-    for (int j = 0; j < 8; j++) {
-        const int v = lane + 64 * j;
-        if ((inv8 >> j) & 1u) continue;
-        const uint64_t pr = L.pair[v];
-        if (pr != pv[j]) gie_st(&c.g_pair[base + v], pr);
-        if (L.flag[v] & GIE_WB_DONE) {
-            int cw[3];
-            gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
-            gie_st(&c.g_coc[base + v], gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]));
-            gie_touch(c, base + v);
+    {
+        unsigned wm = (chg | done) & ~inv8;
+        while (wm != 0u) {                                /* (stores only; no wave-level operation inside) */
+            const int j = __ffs((int)wm) - 1;
+            wm &= wm - 1u;
+            const int ex = (la - j) & 7, ey = (lb - j) & 7;
+            const gie_vaddr a = base + (ex | (ey << 3) | (j << 6));
+            const uint64_t pr = L.pair[GIE_WB_P(ex, ey, j)];
+            if ((chg >> j) & 1u) gie_st(&c.g_pair[a], pr);
+            if ((done >> j) & 1u) {
+                int cw[3];
+                gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
+                gie_st(&c.g_coc[a], gie_pack_crd(cw[0] + c.upvt[0], cw[1] + c.upvt[1], cw[2] + c.upvt[2]));
+                gie_touch(c, a);
+            }
         }
     }
     /* ---- (i) neighbour blocks that received a proposal take part in the next round; (ii) what the block-run proposes to voxels
@@ -3007,20 +3047,17 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
         for (int k = 0; k < 6; k++) if (__ballot((xmask >> k) & 1u) != 0ull) any6 |= 1u << k;   /* wave-uniform */
         const bool act = lane < 6 && ((any6 >> lane) & 1u);
         const int ns = act ? L.nslot[lane] : 0;
-        const int p = lane & 7, q = lane >> 3;
-        const int hx[6] = { -1, 8, p, p, p, p }, hy[6] = { p, p, -1, 8, q, q }, hz[6] = { q, q, q, q, -1, 8 };
-        uint64_t key[14], old[14];
-        int nid[14], bi[14];
+        const int hx[6] = { -1, 8, la, la, la, la }, hy[6] = { la, la, -1, 8, lb, lb }, hz[6] = { lb, lb, lb, lb, -1, 8 };
+        uint64_t old[14];
         unsigned hitm = 0;
 #pragma unroll
         for (int t = 0; t < 14; t++) {
-            const uint64_t pr = t < 8 ? (((inv8 >> t) & 1u) ? L.pair[lane + 64 * t] : 0ull) : ((L.hflag[t - 8][lane] & GIE_WB_INVOL) ? L.halo[t - 8][lane] : 0ull);
-            key[t] = pr & ~GIE_PAIR_NEW; nid[t] = 0; bi[t] = 0; old[t] = 0;
-            if (!(pr & GIE_PAIR_NEW)) continue;
-            const int x = g0[0] + (t < 8 ? (lane & 7) : hx[t < 8 ? 0 : t - 8]) - c.pvt[0], y = g0[1] + (t < 8 ? (lane >> 3) : hy[t < 8 ? 0 : t - 8]) - c.pvt[1],
-                      z = g0[2] + (t < 8 ? t : hz[t < 8 ? 0 : t - 8]) - c.pvt[2];
-            nid[t] = gie_lid(c, x, y, z); bi[t] = gie_bdr_index(c, x, y, z);
-            hitm |= 1u << t;
+            /* t < 8: my voxel of layer t if it lies inside the volume; t >= 8: my halo cell of face t - 8 if it does */
+            const int ux = t < 8 ? ((la - t) & 7) : hx[t < 8 ? 0 : t - 8], uy = t < 8 ? ((lb - t) & 7) : hy[t < 8 ? 0 : t - 8], uz = t < 8 ? t : hz[t < 8 ? 0 : t - 8];
+            const int cell = GIE_WB_P(ux, uy, uz);
+            const bool isin = t < 8 ? ((inv8 >> t) & 1u) != 0u : (L.flag[cell] & GIE_WB_INVOL) != 0u;
+            const uint64_t pr = isin ? L.pair[cell] : 0ull;
+            if (pr & GIE_PAIR_NEW) hitm |= 1u << t;
         }
         const bool anyhit = __ballot(hitm != 0u) != 0ull;
         /* stage 1 */
@@ -3028,10 +3065,16 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
         if (act) fx = gie_axchg32(&c.wb_flag[(round + 1) & 1][ns], (int32_t)1);
         if (anyhit) {
 #pragma unroll
-            for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) old[t] = gie_amin64(&c.lprop[bi[t]], key[t]);
+            for (int t = 0; t < 14; t++) {
+                old[t] = 0;
+                if ((hitm >> t) & 1u) {
+                    const int ux = t < 8 ? ((la - t) & 7) : hx[t < 8 ? 0 : t - 8], uy = t < 8 ? ((lb - t) & 7) : hy[t < 8 ? 0 : t - 8], uz = t < 8 ? t : hz[t < 8 ? 0 : t - 8];
+                    old[t] = gie_amin64(&c.lprop[gie_bdr_index(c, g0[0] + ux - c.pvt[0], g0[1] + uy - c.pvt[1], g0[2] + uz - c.pvt[2])], L.pair[GIE_WB_P(ux, uy, uz)] & ~GIE_PAIR_NEW);
+                }
+            }
         }
-        const bool first = act && fx == 0;
-        const unsigned long long fm = __ballot(first);
+        const bool firstact = act && fx == 0;
+        const unsigned long long fm = __ballot(firstact);
         int mine = 0;
 #pragma unroll
         for (int t = 0; t < 14; t++) if (((hitm >> t) & 1u) && old[t] == GIE_NOPROP) mine++; else hitm &= ~(1u << t);
@@ -3042,20 +3085,21 @@ __device__ __forceinline__ void gie_wave_b_block(const gie_ctx &c, gie_gridbar &
         }
         const int total = anyhit ? __shfl(incl, 63) : 0;
         /* stage 2: lane 0 appends to the list of voxels, lane 1 to the list of blocks */
-        int base = 0;
+        int abase = 0;
         {   /* (one atomic instruction: see gie_wave_a_block) */
             int32_t *ap = nullptr; int av = 0;
             if (lane == 0 && total > 0) { ap = &c.cnt[GIE_CNT_INL]; av = total; }
             if (lane == 1 && fm != 0ull) { ap = &c.lvlb_next[round + 1]; av = __popcll(fm); }
-            if (ap != nullptr) base = gie_aadd32(ap, av);
+            if (ap != nullptr) abase = gie_aadd32(ap, av);
         }
-        const int qb0 = __shfl(base, 0), ab0 = __shfl(base, 1);
-        if (first) gie_st(&c.wb_list[(round + 1) & 1][ab0 + __popcll(fm & ((1ull << lane) - 1ull))], (int32_t)ns);
+        const int qb0 = __shfl(abase, 0), ab0 = __shfl(abase, 1);
+        if (firstact) gie_st(&c.wb_list[(round + 1) & 1][ab0 + __popcll(fm & ((1ull << lane) - 1ull))], (int32_t)ns);
         if (total > 0) {
             int qb = qb0 + incl - mine;
 #pragma unroll
             for (int t = 0; t < 14; t++) if ((hitm >> t) & 1u) {
-                if (qb < c.qcap_c) gie_st(&c.qc[1][qb], (int32_t)nid[t]); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+                const int ux = t < 8 ? ((la - t) & 7) : hx[t < 8 ? 0 : t - 8], uy = t < 8 ? ((lb - t) & 7) : hy[t < 8 ? 0 : t - 8], uz = t < 8 ? t : hz[t < 8 ? 0 : t - 8];
+                if (qb < c.qcap_c) gie_st(&c.qc[1][qb], (int32_t)gie_lid(c, g0[0] + ux - c.pvt[0], g0[1] + uy - c.pvt[1], g0[2] + uz - c.pvt[2])); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
                 qb++;
             }
         }
