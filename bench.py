@@ -208,7 +208,7 @@ class HashWorldFeed:
     def step_input(self, m, i):
         pos, q = self.pose(i)
         m.set_pose(pos, q)
-        m.ogm_labels_dev(self.planes[i - self.first].data_ptr())
+        m.ogm_labels_dev(self.planes[i - self.first].data_ptr(), borrow=True)      # (the planes stay resident and untouched: gie_fuse reads them in place)
 
     def describe(self):
         return ("sensor-less hash world (BASELINE config 5): occupied iff hash(x,y,z) < %.0f %%, full observation, %.0f %% of the "
@@ -441,13 +441,15 @@ class Runner:
 
 
 def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff_dist, W, K, rank, world, dev, local_rank, backend,
-                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False, group=None, transport_note=None, fast_mode=False):
+                 min_timed_s=0.5, max_regions=MAX_REGIONS, with_latency=True, rms=False, group=None, transport_note=None, fast_mode=False,
+                 default_knobs=False):
     """Timed regions + latency pass + instrumented replay for one workload.  Returns a dict (rank 0) or None."""
     n_vox = size[0] * size[1] * size[2]
     tile_off = tiling.tile_offset_voxels(rank, world, size) if world > 1 else (0, 0, 0)
     cfg = gie.make_config(voxel, size, cutoff_dist=cutoff_dist, fast_mode=fast_mode, device_id=local_rank, retain_radius_blocks=DRIVE["retain"],
                           max_blocks=pool_blocks(workload, size, planned_updates(W, K, max_regions, with_latency)),
-                          wave_workgroups=WAVE_GRID["wgs"], place_tries=PLACE_TRIES if os.environ.get("GIE_BENCH_SHARE_GPU") != "1" else 0)
+                          wave_workgroups=0 if default_knobs else WAVE_GRID["wgs"],
+                          place_tries=(PLACE_TRIES if os.environ.get("GIE_BENCH_SHARE_GPU") != "1" else 0) if not default_knobs else 0)
     feed = make_feed(workload, torch, scenes, dev, voxel, size, tile_off, W + K)
     r = Runner(torch, gie, tiling, dist, feed, cfg, rank, world, size, dev, backend, group=group)
     first = r.warmup(W)
@@ -1051,6 +1053,13 @@ def run_bench():
         if world == 1 and not args.no_extras:
             costmap = costmap_bench(torch, gie, scenes, dev, local_rank)
         line, full = build_line(main_res, extras, cpu, world, costmap=costmap)
+        if world == 1 and not args.no_extras:
+            # the headline workload once more as a maintainer following INTEGRATION.md gets it: gie_config's defaults (wave grid = half the
+            # compute units so that two mappers share a device, no plane placement at gie_create) instead of this program's knobs
+            dk, _ = run(args.workload, W=min(W, 3), K=min(K, 10), min_timed_s=0.1, max_regions=3, with_latency=False, default_knobs=True)
+            line["ms_per_step_library_defaults"] = dk["ms_per_step"]
+            full["library_defaults_run"] = {"ms_per_step": dk["ms_per_step"], "knobs": "wave_workgroups = 0 (CUs / 2), place_tries = 0",
+                                            "headline_knobs": "wave_workgroups = %d, place_tries = %d" % (WAVE_GRID["wgs"], PLACE_TRIES)}
         write_full(full)
         print(json.dumps(line), flush=True)
     if dist is not None:

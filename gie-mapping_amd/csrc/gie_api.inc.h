@@ -322,6 +322,8 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
         if (crd[i] > 900000 || crd[i] < -900000) { gie_set_err("gie_set_pose: position outside the representable map"); return GIE_ERR_INVALID; }
     }
     c.map_ct += 1;                                        /* _time++, volumetric_mapper.cpp:144 */
+    c.gate = nullptr;                                     /* a round gate belongs to ONE update's exchange: a caller that left between gie_round_gate and
+                                                           * gie_round_end (an exception in its transport) must not find the next update's kernels gated */
     c.L2G = gie_se3_from_quat(q[0], q[1], q[2], q[3], pos[0], pos[1], pos[2]);
     c.G2L = gie_se3_inv(c.L2G);
     const int sz[3] = { c.X, c.Y, c.Z };
@@ -440,22 +442,32 @@ extern "C" int gie_ogm_scan2d(gie_mapper *m, const float *ranges, const gie_scan
     m->has_ogm = 1;
     return GIE_OK;
 }
-extern "C" int gie_ogm_labels_dev(gie_mapper *m, const int8_t *d_labels)
+static int gie_ogm_labels_dev_impl(gie_mapper *m, const int8_t *d_labels, int may_borrow, int *borrowed)
 {
+    if (borrowed) *borrowed = 0;
     int rc = gie_need_pose(m, "gie_ogm_labels"); if (rc) return rc;
     if (!d_labels) { gie_set_err("gie_ogm_labels: bad arguments"); return GIE_ERR_INVALID; }
     gie_labels_materialise(m);
     m->c.pntcld_mode = 0;
     be_time(&m->be, 0);
-    /* The plane stays where it is when the device form applies: this launch only flags the blocks of the observed voxels, gie_fuse
-     * reads the labels from d_labels itself (1 byte written and 1 byte re-read and reset per voxel less: 0.4 GB of a 512^3 update).
-     * d_labels must not change before gie_fuse has run (include/gie.h). */
-    const int in_place = be_labels_in_place_ok(m->c, d_labels);
+    /* The plane stays where it is when the caller allows it and the device form applies: this launch only flags the blocks of the
+     * observed voxels, gie_fuse reads the labels from d_labels itself (1 byte written and 1 byte re-read and reset per voxel less:
+     * 0.4 GB of a 512^3 update).  d_labels must then not change before gie_fuse has run (include/gie.h: gie_ogm_labels_dev_borrow). */
+    const int in_place = may_borrow && be_labels_in_place_ok(m->c, d_labels);
     be_prof(&m->be, GIE_K_CLASSIFY, 0); be_labels(&m->be, m->c, d_labels, in_place); be_prof(&m->be, GIE_K_CLASSIFY, 1);
     be_time(&m->be, 1);
     if (in_place) { m->labels_pending = d_labels; m->c.scan_labels = d_labels; }
     m->has_ogm = 1;
+    if (borrowed) *borrowed = in_place;
     return GIE_OK;
+}
+extern "C" int gie_ogm_labels_dev(gie_mapper *m, const int8_t *d_labels)
+{
+    return gie_ogm_labels_dev_impl(m, d_labels, 0, nullptr);
+}
+extern "C" int gie_ogm_labels_dev_borrow(gie_mapper *m, const int8_t *d_labels, int *borrowed)
+{
+    return gie_ogm_labels_dev_impl(m, d_labels, 1, borrowed);
 }
 extern "C" int gie_ogm_labels(gie_mapper *m, const int8_t *labels)
 {
@@ -470,7 +482,7 @@ extern "C" int gie_ogm_labels(gie_mapper *m, const int8_t *labels)
         if (!m->d_sensor) { gie_set_err("sensor buffer allocation failed"); return GIE_ERR_DEVICE; }
     }
     be_h2d(&m->be, m->d_sensor, labels, (size_t)m->c.N);
-    return gie_ogm_labels_dev(m, (const int8_t *)m->d_sensor);
+    return gie_ogm_labels_dev_impl(m, (const int8_t *)m->d_sensor, 1, nullptr);      /* (the library's own staging buffer: borrowed until gie_fuse) */
 }
 extern "C" int gie_ogm_pointcloud_dev(gie_mapper *m, const float *d_xyz, int n)
 {

@@ -20,6 +20,28 @@
 #include <hip/hip_runtime.h>
 #include "gie_functors.h"
 
+/* Stamps and per-section clock sums of the measurement builds (tools/measure/gie_timing.h, tools/wave_timing.py): no-ops here */
+#if defined(GIE_WAVE_TIMING) || defined(GIE_RAY_TIMING)
+#include "../../tools/measure/gie_timing.h"
+#endif
+#if !defined(GIE_WAVE_TIMING)
+#define GIE_TS2(tag, n) do { } while (0)
+#define GIE_WPROF_DECL do { } while (0)
+#define GIE_WPROF_MARK(base) do { } while (0)
+#define GIE_WPROF_ADD(i, v) do { } while (0)
+#define GIE_WPROF_END(base) do { } while (0)
+#define GIE_WPROF_DRAIN() do { } while (0)
+#define GIE_WPROF_SUB(i) do { } while (0)
+#define GIE_WPROF_SUBSTART() do { } while (0)
+#define GIE_WPROF_DUMP() do { } while (0)
+#define GIE_WPROF_CLK() 0ull
+#define GIE_WAVE_TIMING_RESET(cond) do { } while (0)
+#endif
+#if !defined(GIE_RAY_TIMING)
+#define GIE_RTS(k) do { } while (0)
+#endif
+
+
 /* ------------------------------------------------------------------ per-voxel sweeps */
 #define GIE_VOX_BX 64
 #define GIE_VOX_BY 4
@@ -238,15 +260,6 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
 #pragma unroll
         for (int k = 0; k < 3; k++) { d.cur[k] = s_cur[seg - 1][k][lane]; d.tMax[k] = s_tmax[seg - 1][k][lane]; }
     }
-#if defined(GIE_RAY_TIMING)
-#if GIE_RAY_TIMING < 0      /* every workgroup: first and last stamp of wave 0 */
-#define GIE_RTS(k) do { if (seg == 0 && lane == 0 && ((k) == 0 || (k) == 4)) c.edt[blockIdx.x * 2 + ((k) ? 1 : 0)] = (float)(wall_clock64() & 0xffffff); } while (0)
-#else
-#define GIE_RTS(k) do { if (blockIdx.x == GIE_RAY_TIMING && lane == 0) c.edt[seg * 8 + (k)] = (float)(wall_clock64() & 0xffffff); } while (0)
-#endif
-#else
-#define GIE_RTS(k) do { } while (0)
-#endif
     GIE_RTS(0);
     const int base = seg << 20;                           /* step index = (segment, step inside it): orders the stops of all segments */
     const gie_dda at_start = d;
@@ -275,11 +288,7 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
             }
             int8_t ty[GIE_RAY_BATCH];
 #pragma unroll
-#if defined(GIE_RAY_ABLATE) && GIE_RAY_ABLATE == 2
-            for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = (int8_t)GIE_VOX_UNKNOWN;      /* measurement only: no type reads */
-#else
             for (int j = 0; j < GIE_RAY_BATCH; j++) ty[j] = ids[j] >= 0 ? c.inst_type[ids[j]] : (int8_t)GIE_VOX_UNKNOWN;
-#endif
 #pragma unroll
             for (int j = 0; j < GIE_RAY_BATCH; j++) {
                 if (stop != 0x7fffffff || !went[j]) continue;
@@ -308,9 +317,7 @@ __global__ __launch_bounds__(64 * GIE_RAY_SEGS) void k_free_rays(const gie_ctx c
         }
         if (__ballot(went) == 0ull) break;                /* a lane that did not step now never steps again */
         if (__ballot(id >= 0) == 0ull) continue;
-#if !defined(GIE_RAY_ABLATE) || GIE_RAY_ABLATE != 1
         gie_wave_add(c, id, -1);
-#endif
     }
     GIE_RTS(4);
 }
@@ -1074,9 +1081,6 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             for (int j = 0; j < NLD; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, (((zmask >> j) & 1u) && x < X) ? voff : GIE_BUF_OOB, j * zstride_b, 0);
         }
     }
-#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 4
-#define GIE_Z_NOMEM 1
-#endif
     for (; t < ntiles; t = GIE_ZTILE(it)) {
         it++;
         const int x0 = (t % ntiles_x) * TX, y = t / ntiles_x;
@@ -1093,12 +1097,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             if ((ndn0 | ndn1) != 0ull) {
                 const int xn = (tn % ntiles_x) * TX + tx, yn = tn / ntiles_x;
                 const unsigned voff = tzoff_b + (unsigned)(yn * X + xn) * 4u;
-#if !defined(GIE_Z_NOMEM)
 #pragma unroll
                 for (int j = 0; j < NLD; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, (((zmask >> j) & 1u) && xn < X) ? voff : GIE_BUF_OOB, j * zstride_b, 0);
-#else
-                asm volatile("" ::: "memory");                   /* measurement only: no loads, the first tile's values again */
-#endif
             }
         }
         if (!work) continue;                              /* nobody reads this tile: nothing loaded, nothing stored */
@@ -1109,9 +1109,6 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
             if (x >= X) break;
             const uint64_t nc = half ? nd1 : nd0;
             if (nc == 0ull) continue;                     /* this 8-wide tile column has no reader */
-#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 3
-            continue;                                           /* measurement only: no column work at all */
-#endif
             if (CP >= 4 && K > GIE_BAND_MAXK) {
                 /* obstacles in most planes: windowed scan along z over the direct-indexed column (the
                  * wave's site-list memory holds it); planes without obstacles carry no value */
@@ -1170,15 +1167,8 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
                 if (full) bandneed = ~0u;                       /* also covers Z > 512 (more than 64 z tiles) */
                 int sj[CP];
                 const bool banded = K <= GIE_BAND_MAXK;         /* wave-uniform: few sites → banded form */
-#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE >= 1
-                for (int m = 0; m < CP; m++) sj[m] = (lane * CP + m) % K;      /* measurement only: no argmin */
-#else
                 if (banded) gie_row_argmin_banded<CP>(ce, K, Z, lane, sj, bandneed);
                 else gie_row_argmin<CP>(ce, K, Z, lane, sj);
-#endif
-#if defined(GIE_EDTZ_ABLATE) && GIE_EDTZ_ABLATE == 2
-                if (sj[0] >= 0) continue;                       /* measurement only: compaction, nothing else */
-#endif
                 /* gather first (own column only), then overwrite the column in place.
                  * position of result m: 64 m + lane (banded) or lane CP + m */
                 const int ub = banded ? lane : lane * CP, us = banded ? 64 : 1;
@@ -1217,9 +1207,6 @@ __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const g
                     wm &= zl;
                     if (x >= X) wm = 0;                   /* (a column beyond the volume: all of its stores are dropped) */
                 }
-#if defined(GIE_Z_NOMEM)
-                if (tile[tz * TS + tx] == 0x12345678u)          /* measurement only: no write-out */
-#endif
                 {
 #pragma unroll
                     for (int j0 = 0; j0 < NLD; j0 += 4) {
@@ -2378,42 +2365,6 @@ __device__ __forceinline__ int gie_clampi(int v, int hi) { return v < hi ? v : h
 
 /* The three waves run inside ONE launch (k_waves), separated by grid barriers of all workgroups: a wave
  * without seeds costs a counter read instead of a launch. */
-/* measurement only (tools/wave_timing.py): the boss thread stamps the wall clock (10 ns ticks, 24 bits) and the level size at
- * every phase boundary of waves A / B / C into the middle row of the edt plane (interior voxels: no wave writes there) */
-#if defined(GIE_WAVE_TIMING)
-#define GIE_TS2(tag, n) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_ts_i < 500) { \
-        float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * g_ts_i; \
-        p_[0] = (float)(wall_clock64() & 0xffffff); p_[1] = (float)((tag) * 1000000 + ((n) < 999999 ? (n) : 999999)); g_ts_i++; } } while (0)
-static __device__ int g_ts_i;
-/* ... and per-section clock sums of the block routines (wave A: 0-7, wave B: 8-15, wave C: 16-23): [base + i] = ticks between marks i and i + 1, [base + 6] = levels inside
- * blocks, [base + 7] = blocks */
-static __device__ unsigned int g_wprof[256 * 16][32];          /* one row per (workgroup, wave): no atomics, nothing shared while the waves run */
-#define GIE_WPROF_DECL unsigned long long wp_t_ = wall_clock64(), wp_s_ = 0; const unsigned long long wp_t0_ = wp_t_; int wp_i_ = 0; unsigned int *const wp_ = g_wprof[blockIdx.x * 16 + (threadIdx.x >> 6)]
-#define GIE_WPROF_MARK(base) do { const unsigned long long n_ = wall_clock64(); if (lane == 0) wp_[(base) + wp_i_] += (unsigned int)(n_ - wp_t_); wp_i_++; wp_t_ = n_; } while (0)
-#define GIE_WPROF_ADD(i, v) do { if (lane == 0) wp_[i] += (unsigned int)(v); } while (0)
-#define GIE_WPROF_END(base) do { const unsigned int d_ = (unsigned int)(wall_clock64() - wp_t0_); if (lane == 0) { if (d_ > wp_[(base) + 4]) wp_[(base) + 4] = d_; wp_[(base) + 5] += d_; } } while (0)
-#define GIE_WPROF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define GIE_WPROF_SUBSTART() wp_s_ = wall_clock64()
-#define GIE_WPROF_SUB(i) do { const unsigned long long n_ = wall_clock64(); if (lane == 0) wp_[i] += (unsigned int)(n_ - wp_s_); wp_s_ = n_; } while (0)
-#define GIE_WPROF_CLK() wall_clock64()
-#define GIE_WPROF_DUMP() do { gie_grid_sync(gb, c); if (blockIdx.x == 0 && threadIdx.x < 32) { unsigned long long s_ = 0; \
-        const bool mx_ = (threadIdx.x & 7) == 4 || (threadIdx.x & 7) == 5; \
-        for (int r_ = 0; r_ < 256 * 16; r_++) { const unsigned int v_ = __hip_atomic_load(&g_wprof[r_][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (mx_) { if (64ull * v_ > s_) s_ = 64ull * v_; } else s_ += v_; __hip_atomic_store(&g_wprof[r_][threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } \
-        float *p_ = c.edt + ((size_t)(c.Z / 2) * c.Y + c.Y / 2) * c.X + 2 * (g_ts_i + (int)threadIdx.x); \
-        p_[0] = 0.0f; p_[1] = (float)((20 + (int)threadIdx.x) * 1000000 + (int)((s_ / 64) < 999999 ? (s_ / 64) : 999999)); } } while (0)
-#else
-#define GIE_TS2(tag, n) do { } while (0)
-#define GIE_WPROF_DECL do { } while (0)
-#define GIE_WPROF_MARK(base) do { } while (0)
-#define GIE_WPROF_ADD(i, v) do { } while (0)
-#define GIE_WPROF_END(base) do { } while (0)
-#define GIE_WPROF_DRAIN() do { } while (0)
-#define GIE_WPROF_SUB(i) do { } while (0)
-#define GIE_WPROF_SUBSTART() do { } while (0)
-#define GIE_WPROF_DUMP() do { } while (0)
-#define GIE_WPROF_CLK() 0ull
-#endif
-
 /* append `value` to a list for every lane with `first`: one counter update per wave (hundreds of single appends to one word
  * serialise at its L2 slice, ≈ 6 ns each).  Only executing lanes are looked at. */
 __device__ __forceinline__ void gie_list_append_wave(int32_t *list, int32_t *counter, const bool first, const int32_t value)
@@ -2773,12 +2724,19 @@ __device__ __forceinline__ void gie_wave_a_run(const gie_ctx &c, gie_gridbar &gb
     GIE_TS2(1, n);
     int round = 0;
     while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
+        /* (the round's length and the wave's first list entry in one round trip: see gie_wave_c_run) */
+        const int32_t *list = c.wb_list[round & 1];
+        const int i0 = (int)blockIdx.x + (int)gridDim.x * wave;
         const int nt = gie_ld(&c.lvla_next[round]);
+        int snext = gie_ld(&list[i0 < c.max_blocks ? i0 : 0]);
         if (nt <= 0) { if (round == 0) { round++; continue; } break; }      /* (colour 0 may have no seeds) same everywhere */
         if (wave < GIE_WA_WAVES) {
-            const int32_t *list = c.wb_list[round & 1];
-            for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WA_WAVES)      /* (spread over the workgroups first) */
-                gie_wave_a_block(c, gb, tiles[wave], gie_ld(&list[i]), round, lane);
+            for (int i = i0; i < nt; i += (int)gridDim.x * GIE_WA_WAVES) {      /* (spread over the workgroups first) */
+                const int sl = snext;
+                const int in = i + (int)gridDim.x * GIE_WA_WAVES;
+                if (in < nt) snext = gie_ld(&list[in]);
+                gie_wave_a_block(c, gb, tiles[wave], sl, round, lane);
+            }
         }
         gie_grid_sync(gb, c, &c.lvla_vis[round]);
         GIE_TS2(3, nt);
@@ -3139,12 +3097,19 @@ __device__ __forceinline__ void gie_wave_b_run(const gie_ctx &c, gie_gridbar &gb
     GIE_TS2(4, n);
     int round = 0;
     while (!gb.failed && round < GIE_MAX_LEVELS - 2) {
+        /* (the round's length and the wave's first list entry in one round trip: see gie_wave_c_run) */
+        const int32_t *list = c.wb_list[round & 1];
+        const int i0 = (int)blockIdx.x + (int)gridDim.x * wave;
         const int nt = gie_ld(&c.lvlb_next[round]);
+        int snext = gie_ld(&list[i0 < c.max_blocks ? i0 : 0]);
         if (nt <= 0) break;                        /* same everywhere */
         if (wave < GIE_WB_WAVES) {
-            const int32_t *list = c.wb_list[round & 1];
-            for (int i = (int)blockIdx.x + (int)gridDim.x * wave; i < nt; i += (int)gridDim.x * GIE_WB_WAVES)      /* (spread over the workgroups first) */
-                gie_wave_b_block(c, gb, tiles[wave], gie_ld(&list[i]), round, lane);
+            for (int i = i0; i < nt; i += (int)gridDim.x * GIE_WB_WAVES) {      /* (spread over the workgroups first) */
+                const int sl = snext;
+                const int in = i + (int)gridDim.x * GIE_WB_WAVES;
+                if (in < nt) snext = gie_ld(&list[in]);
+                gie_wave_b_block(c, gb, tiles[wave], sl, round, lane);
+            }
         }
         gie_grid_sync(gb, c, &c.lvlb_vis[round]);
         GIE_TS2(6, nt);
@@ -3500,9 +3465,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves_ab(const gie_ctx c)
     __shared__ int s_fail, s_vis;
     if (GIE_GATE_CLOSED(c)) return;
     if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
-#if defined(GIE_WAVE_TIMING)
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
-#endif
+    GIE_WAVE_TIMING_RESET(true);
     gie_gridbar gb = gie_waves_bar(c, &c.cnt[GIE_CNT_BAR_C], &s_fail, &s_vis);
     {   /* nothing seeded outside the volume (the usual case of a sparse scan over a settled map): the launch ends here — same
          * counters for every workgroup, no barrier */
@@ -3528,9 +3491,7 @@ __global__ __launch_bounds__(GIE_WAVE_THREADS) void k_waves_c(const gie_ctx c, c
     __shared__ int s_fail, s_vis;
     if (GIE_GATE_CLOSED(c)) return;              /* a refinement round nobody needs (gie_round_gate): same answer in every workgroup, before any barrier */
     if (threadIdx.x == 0) { s_fail = 0; s_vis = 0; }
-#if defined(GIE_WAVE_TIMING)
-    if (!with_ab && blockIdx.x == 0 && threadIdx.x == 0) g_ts_i = 0;
-#endif
+    GIE_WAVE_TIMING_RESET(!with_ab);
     gie_gridbar gb = gie_waves_bar(c, &c.cnt[GIE_CNT_BAR_B], &s_fail, &s_vis);
     if (gie_ld(&c.cnt[GIE_CNT_BARFAIL]) != 0) gb.failed = 1;       /* a barrier of waves A / B timed out: the update is incomplete (GIE_ERR_TIMEOUT) */
     __syncthreads();

@@ -224,7 +224,7 @@ GIE_DEV int gie_classify_multiscan(const gie_ctx &c, const float *ranges, const 
     const float theta = gie_atan2f(ly, lx);
     int theta_idx = (int)floorf((theta - p.theta_min) / p.theta_inc + 0.5f);
     theta_idx = gie_pos_mod(theta_idx, p.scan_num);
-    const float ideal = sqrtf(lx * lx + ly * ly);
+    const float ideal = range_hor;                    /* (sqrtf(lx * lx + ly * ly): the same sum, the same root) */
     if (ideal < 0 || theta_idx < 0 || theta_idx >= p.scan_num) return GIE_VOX_UNKNOWN;
     const float real = ranges[phi_idx * p.scan_num + theta_idx];
     if (real != real || real <= 0.3f) return GIE_VOX_UNKNOWN;
@@ -1201,9 +1201,6 @@ GIE_DEV void gie_coc_catchup_newcolumn(const gie_ctx &c, const int pupvt[3], int
 /* the column's share of its tile's bound (known != valid: a voxel of the column was not committed) */
 GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned known, unsigned valid, int vmax)
 {
-#if defined(GIE_ABL_NOTMAX)
-    return;
-#endif
     const int t = gie_tile_index(c, x, y, z0);
     int v = (known != valid) ? GIE_TMAX_INF : vmax;
 #if defined(GIE_HOST_EMU)
@@ -1227,13 +1224,7 @@ GIE_DEV void gie_markc_load1(const gie_ctx &c, int id, int x, int y, int z, gie_
     s.bc = c.bcoc[id];
     s.g[0] = x + c.pvt[0]; s.g[1] = y + c.pvt[1]; s.g[2] = z + c.pvt[2];
     s.a = gie_gvox_tab(c, s.g[0], s.g[1], s.g[2]);
-#if defined(GIE_ABL_NOSKIPLOAD)
-    s.skipold = 0;
-#elif defined(GIE_ABL_ALLSKIP)
-    s.skipold = 1;
-#else
     s.skipold = c.tskip[gie_tile_index(c, x, y, z)];
-#endif
 }
 GIE_DEV void gie_markc_load2(const gie_ctx &c, gie_markc_st &s)
 {

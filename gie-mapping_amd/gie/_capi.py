@@ -144,6 +144,7 @@ DEVICE_ONLY = {
     "ogm_multiscan_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(MultiScanParam)]),
     "ogm_depth_dev": (C.c_int, [_H, C.c_void_p, C.POINTER(CamParam)]),
     "ogm_labels_dev": (C.c_int, [_H, C.c_void_p]),
+    "ogm_labels_dev_borrow": (C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int)]),
 }
 DEVICE_ONLY.update(ROUND_API)
 

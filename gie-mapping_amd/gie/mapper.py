@@ -405,8 +405,15 @@ class Mapper(MapperBase):
         p = CamParam(rows, cols, cx, cy, fx, fy, int(valid_nan))
         self._chk(self._f["ogm_depth_dev"](self._h, C.c_void_p(dptr), C.byref(p)))
 
-    def ogm_labels_dev(self, dptr):
-        self._chk(self._f["ogm_labels_dev"](self._h, C.c_void_p(dptr)))
+    def ogm_labels_dev(self, dptr, borrow=False):
+        """A device-resident label plane.  borrow=True: gie_fuse may read it in place (returns whether it will): the plane must then
+        stay unchanged until this update's fuse / step has run on the mapper's stream."""
+        if not borrow:
+            self._chk(self._f["ogm_labels_dev"](self._h, C.c_void_p(dptr)))
+            return False
+        b = C.c_int(0)
+        self._chk(self._f["ogm_labels_dev_borrow"](self._h, C.c_void_p(dptr), C.byref(b)))
+        return bool(b.value)
 
     def ogm_pointcloud_dev(self, dptr, n):
         self._chk(self._f["ogm_pointcloud_dev"](self._h, C.c_void_p(dptr), n))

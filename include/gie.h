@@ -175,10 +175,15 @@ int gie_ogm_scan2d(gie_mapper *h, const float *ranges, const gie_scan_param *p);
  * of BASELINE config 5 (occupancy from a hash of the voxel, full observation) is
  * fed.  The robot sphere of for_motion_planner is forced FREE as in every OGM kernel. */
 int gie_ogm_labels(gie_mapper *h, const int8_t *labels);
-/* _dev: the plane may be read IN PLACE by gie_fuse (no copy into `_inst_type`): d_labels must stay unchanged until the gie_fuse /
- * gie_step of this map update has been executed on the mapper's stream (gie_get_stream) — or until another gie_ogm_* /
- * gie_read_ogm call, which copies it first. */
+/* _dev: a device-resident plane, copied into the mapper's own scan plane by this call's kernel on the mapper's stream
+ * (gie_get_stream): d_labels may be reused once that kernel has run, as with every other gie_ogm_*_dev entry point. */
 int gie_ogm_labels_dev(gie_mapper *h, const int8_t *d_labels);
+/* _dev_borrow (round 6; rounds 5's gie_ogm_labels_dev did this unasked): the plane MAY be read IN PLACE by gie_fuse instead (no copy
+ * into `_inst_type`, no reset of it: 2 bytes per voxel less) — when the volume's X is a multiple of 16, d_labels is 16-byte aligned and
+ * for_motion_planner is off; *borrowed (may be NULL) says whether it is.  A borrowed plane must stay unchanged until the gie_fuse /
+ * gie_step of this map update has been executed on the mapper's stream — or until another gie_ogm_* / gie_read_ogm call, which
+ * copies it first. */
+int gie_ogm_labels_dev_borrow(gie_mapper *h, const int8_t *d_labels, int *borrowed);
 
 /* Ext_Obs_Wrapper boxes as consumed by the fuse kernels (pre_map.cu:80-101,
  * unify_helper.cuh:68-86). ll/ur: n x 3 floats (metres); active: n flags. Box 0 is the inverted
@@ -316,7 +321,8 @@ int gie_refine(gie_mapper *h, int32_t *seeded);   /* seeded == NULL: enqueue onl
  * it from running).  gie_round_gate(h, NULL) opens the gate (the first round of an update always runs).  gie_round_end closes a
  * map update's rounds: opens the gate and counts the update as unconverged when *d_go (the all-reduced word of the LAST round;
  * NULL = not known) is still non-zero.  gie_round_stats synchronises: out = { rounds enqueued, rounds that ran, map updates,
- * map updates left unconverged } since gie_create.  No counterpart in the reference (single GPU). */
+ * map updates left unconverged } since gie_create.  A gate lasts until gie_round_end or the next gie_set_pose, whichever comes
+ * first (a caller that leaves a round half way does not gate the next update).  No counterpart in the reference (single GPU). */
 int gie_round_gate(gie_mapper *h, const int32_t *d_go);
 int gie_refine_dev(gie_mapper *h, int32_t *d_changed);
 int gie_round_end(gie_mapper *h, const int32_t *d_go);

@@ -13,6 +13,8 @@ SCENARIOS = [
     parity.Scenario("depth", (48, 40, 24), sensor="depth", frames=14, delta_vox=5, yaw_deg=47.0),
     parity.Scenario("raycast", (40, 40, 20), sensor="pointcloud", frames=12, delta_vox=5, yaw_deg=47.0),
     parity.Scenario("vlp16", (48, 48, 16), sensor="multiscan", frames=12, delta_vox=5, yaw_deg=10.0),
+    # a volume tall enough for most of it to lie above / below the lidar's field of view: the box test of the multiscan OGM (round 6)
+    parity.Scenario("vlp16_tall", (64, 56, 72), voxel=0.05, sensor="multiscan", frames=5, delta_vox=4, yaw_deg=25.0, extent=(2.5, 2.5, 2.0)),
     parity.Scenario("scan2d", (40, 40, 8), sensor="scan2d", frames=6, delta_vox=3, yaw_deg=10.0),
     parity.Scenario("mixed", (48, 40, 24), sensor="mixed", frames=12, delta_vox=5, yaw_deg=47.0),
     parity.Scenario("fast_mode", (48, 40, 24), sensor="mixed", frames=12, delta_vox=5, yaw_deg=47.0, fast_mode=True),
@@ -319,16 +321,16 @@ def test_device_resident_readers_give_the_host_forms_bytes(oracle_lib):
 
 
 def test_label_plane_read_in_place_or_copied_gives_the_same_map(oracle_lib):
-    """gie_ogm_labels_dev may leave the plane where it is and let gie_fuse read it (round 5: `_inst_type` neither written nor reset) —
-    unless something wants `_inst_type` first (gie_read_ogm, a second scan laid over it), which copies it after all.  Three HIP
-    mappers fed the same device-resident planes — in place; read back in between; a point cloud on top — against the oracle fed the
-    same way."""
+    """gie_ogm_labels_dev_borrow may leave the plane where it is and let gie_fuse read it (round 5: `_inst_type` neither written nor
+    reset) — unless something wants `_inst_type` first (gie_read_ogm, a second scan laid over it), which copies it after all; the
+    plain gie_ogm_labels_dev copies, and its buffer may be overwritten right away.  Four HIP mappers fed the same device-resident
+    planes — in place; read back in between; a point cloud on top; copied and overwritten — against the oracle fed the same way."""
     import torch
     from gie import scenes
     size = (64, 48, 40)                                   # X % 16 == 0: the in-place form applies
     cfg = gie.make_config(0.05, size, cutoff_dist=1.0)
     dev = torch.device("cuda", 0)
-    ms = {k: gie.Mapper(cfg) for k in ("in_place", "read_back", "two_scans")}
+    ms = {k: gie.Mapper(cfg) for k in ("in_place", "read_back", "two_scans", "copied")}
     os_ = {k: OracleMapper(cfg) for k in ("plain", "two_scans")}
     rng = np.random.default_rng(3)
     try:
@@ -341,7 +343,16 @@ def test_label_plane_read_in_place_or_copied_gives_the_same_map(oracle_lib):
             torch.cuda.synchronize()
             for name, m in ms.items():
                 m.set_pose(pos, q)
-                m.ogm_labels_dev(d_lab.data_ptr())
+                if name == "copied":
+                    # the plain form copies: the caller's buffer may be overwritten as soon as the call's kernel has run
+                    d_tmp = d_lab.clone()
+                    torch.cuda.synchronize()
+                    assert m.ogm_labels_dev(d_tmp.data_ptr()) is False
+                    m.sync()
+                    d_tmp.fill_(2)
+                    torch.cuda.synchronize()
+                else:
+                    assert m.ogm_labels_dev(d_lab.data_ptr(), borrow=True) is True      # (X % 16 == 0, aligned, no robot sphere)
                 if name == "read_back":
                     got = m.read_ogm()["inst_type"]
                     assert np.array_equal(got, lab)

@@ -12,6 +12,8 @@ SCENARIOS = [
     parity.Scenario("depth", (48, 40, 24), sensor="depth", frames=14, delta_vox=5, yaw_deg=47.0),
     parity.Scenario("raycast", (40, 40, 20), sensor="pointcloud", frames=12, delta_vox=5, yaw_deg=47.0),
     parity.Scenario("vlp16", (48, 48, 16), sensor="multiscan", frames=12, delta_vox=5, yaw_deg=10.0),
+    # a volume tall enough for most of it to lie above / below the lidar's field of view: the box test of the multiscan OGM (round 6)
+    parity.Scenario("vlp16_tall", (64, 56, 72), voxel=0.05, sensor="multiscan", frames=5, delta_vox=4, yaw_deg=25.0, extent=(2.5, 2.5, 2.0)),
     parity.Scenario("scan2d", (40, 40, 8), sensor="scan2d", frames=6, delta_vox=3, yaw_deg=10.0),
     parity.Scenario("mixed", (48, 40, 24), sensor="mixed", frames=12, delta_vox=5, yaw_deg=47.0),
     parity.Scenario("fast_mode", (48, 40, 24), sensor="mixed", frames=12, delta_vox=5, yaw_deg=47.0, fast_mode=True),
