@@ -50,7 +50,9 @@ GIE_HD gie_se3 gie_se3_from_quat(float qw, float qx, float qy, float qz, float t
     return s;
 }
 
-/* Rigid inverse: R^T, -R^T t, the three products of a row subtracted from left to right (the reference's counterpart: se3.cuh:91-108). */
+/* Rigid inverse: R^T, -R^T t.  These are the same twelve assignments, in the same order, as the reference's se3.cuh:91-108 (REMODE's
+ * SE3<T>::inv, GPL): the fp32 result depends on the order the three products of a row are subtracted in (left to
+ * right), so there is one way to write it that reproduces the reference bit for bit, and this is it. */
 GIE_HD gie_se3 gie_se3_inv(const gie_se3 a)
 {
     gie_se3 r;
