@@ -1002,7 +1002,7 @@ template <int CP, int TX, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, (CP <= 8 ? 4 : 2)) void k_edt_z(const gie_ctx c, const int ntiles_x, const int ntiles, const int full)
 {
     static_assert(TX == 16 && WAVES == 8, "a workgroup tile spans two 8-voxel tile columns, one column per wave and half");
-    if (full == 0 && gie_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) return;   /* few known tiles: k_edt_z_direct (launched next to this one) does the pass */
+    if (full == 0 && gie_z_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) return;   /* few known tiles: k_edt_z_direct (launched next to this one) does the pass */
     const int repair = c.cnt[GIE_CNT_ZSTREAM];            /* the streaming form (k_edt_z_stream, launched before this one) has done the volume: only the tiles it flagged */
     if (repair && c.cnt[GIE_CNT_ZFAIL] == 0) return;      /* ... and it finished every column (a walk over the flags of 16 K tiles was 40 us of nothing) */
     constexpr int LP = 64 * CP;
@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int
 {
     __shared__ uint8_t s_occ[1024 + 2 * (32 + 2 * GIE_ZS_R)];        /* plane holds obstacles, for planes -W .. Z + W (0 outside the volume) */
     const int Z = c.Z, X = c.X, Y = c.Y;
-    if (full == 0 && gie_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) { gie_edt_z_direct_body(c); return; }   /* few known tiles: the list form, in this launch (one launch less
+    if (full == 0 && gie_z_use_lists(c, c.cnt[GIE_CNT_TL_KNOWN])) { gie_edt_z_direct_body(c); return; }   /* few known tiles: the list form, in this launch (one launch less
                                                                                                          * per update than with a kernel of its own: 4.5 us each on the sparse workloads) */
     if (*c.zcount <= GIE_BAND_MAXK) return;               /* planes with obstacles are few: the column kernel's envelope forms (same answer in every workgroup) */
     if (blockIdx.x == 0 && threadIdx.x == 0) c.cnt[GIE_CNT_ZSTREAM] = 1;
@@ -2220,7 +2220,7 @@ __global__ __launch_bounds__(256, PNT ? 3 : 4) void k_fuse_rows(const gie_ctx c,
 __device__ __forceinline__ void gie_edt_z_direct_body(const gie_ctx &c)
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
-    if (!gie_use_lists(c, n)) return;                     /* many known tiles: the column kernel (launched next to this one) does the pass */
+    if (!gie_z_use_lists(c, n)) return;                     /* many known tiles: the column kernel (launched next to this one) does the pass */
     /* workgroup = known tile; its four waves split the planes with obstacles between them (the
      * pass is a chain of dependent plane reads per tile: a quarter of the chain each), merge their
      * minima through LDS, and each wave finishes two of the tile's eight z */

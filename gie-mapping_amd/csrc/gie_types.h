@@ -250,6 +250,18 @@ GIE_HD int gie_use_lists(const gie_ctx &c, int listed)
     if (c.force_lists >= 0) return c.force_lists;
     return (long long)listed * 8 <= (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
 }
+/* pass Z of the batch EDT: the list form (a workgroup per known tile, planes taken outwards from the tile) however many tiles are
+ * known, if the volume is at most eight tiles high — a column of 40 voxels is too short for the column kernel's LDS tiles
+ * to pay (BASELINE config 4, 320 x 320 x 40: GIE_Z_SHORT_LISTS) */
+#ifndef GIE_Z_SHORT_LISTS
+#define GIE_Z_SHORT_LISTS 1
+#endif
+GIE_HD int gie_z_use_lists(const gie_ctx &c, int listed)
+{
+    if (c.force_lists >= 0) return c.force_lists;
+    if (GIE_Z_SHORT_LISTS && c.tfd[2] <= 8) return 1;
+    return gie_use_lists(c, listed);
+}
 GIE_HD int gie_tile_index(const gie_ctx &c, int x, int y, int z) { return ((z >> 3) * c.tfd[1] + (y >> 3)) * c.tfd[0] + (x >> 3); }
 GIE_HD int gie_vox_in_blk(int gx, int gy, int gz) { return ((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7); }
 GIE_HD int gie_d2(int ax, int ay, int az, int bx, int by, int bz)
