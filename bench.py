@@ -742,7 +742,7 @@ def costmap_bench(torch, gie, scenes, dev, local_rank, K=10):
     return out
 
 
-TRAFFIC_FILE = "traffic_r05.json"
+TRAFFIC_FILE = "traffic_r06.json"
 
 
 def csrc_hash():
@@ -759,7 +759,7 @@ def csrc_hash():
 
 
 def load_traffic(workload, size, world):
-    """PMC bytes per map update and stage from the committed rocprofv3 profile of this exact workload (profiles/traffic_r05.json,
+    """PMC bytes per map update and stage from the committed rocprofv3 profile of this exact workload (profiles/traffic_r06.json,
     written by tools/profile_round.sh + tools/merge_traffic.py), or {"stale": why} when the profile was taken on other kernel
     sources than this build's, or None."""
     tp = os.path.join(ROOT, "profiles", TRAFFIC_FILE)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merge the traffic_entry.json files tools/profile_round.sh leaves under gpurun_out/prof_<tag>/ into profiles/traffic_r05.json
+"""Merge the traffic_entry.json files tools/profile_round.sh leaves under gpurun_out/prof_<tag>/ into profiles/traffic_r06.json
 (what bench.py's roofline.traffic reads):   python tools/merge_traffic.py <workload>_<X>x<Y>x<Z>=<entry.json> [...]"""
 import json
 import os

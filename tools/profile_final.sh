@@ -1,9 +1,9 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: the round's committed evidence.  tools/profile_final.sh r05
+# Runs ON THE GPU BOX: the round's committed evidence.  tools/profile_final.sh r06
 #   C5 (the driver's command without extras): kernel stats + HBM traffic (PMC, separate passes) + SQ counters
 #   lidar workloads and BASELINE configs 2 / 3 / 4: kernel stats + HBM traffic
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$(pwd)
 bash tools/profile_round.sh ${R}_c5 "--gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline" > /dev/null 2>&1
 bash tools/pmc_run.sh > gpurun_out/${R}_c5_sq_counters.txt 2>&1

@@ -25,7 +25,7 @@ T=$(find $OUT/trace -name "*.db" | head -1); F=$(find $OUT/fetch -name "*.db" | 
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (MI355X)"; python tools/rocpd_summary.py stats "$T"; echo; echo "# bench.py line of the same (profiled) run:"; cat $OUT/bench_trace.json; } > $OUT/kernel_stats.txt
 { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes) -- python bench.py $ARGS"; python tools/rocpd_summary.py pmc "$F" "$W" $OUT/traffic.json; } > $OUT/hbm_traffic.txt
 # the entry bench.py's roofline.traffic reads: stamped with the content hash of the kernel sources (bench.csrc_hash) so that it is
-# only ever priced against durations of the same kernels; merge it into profiles/traffic_r05.json with tools/merge_traffic.py
+# only ever priced against durations of the same kernels; merge it into profiles/traffic_r06.json with tools/merge_traffic.py
 python - "$OUT/traffic.json" "$TAG" "$ARGS" > $OUT/traffic_entry.json <<'PY'
 import json, sys
 sys.path.insert(0, ".")
