@@ -256,11 +256,14 @@ GIE_HD int gie_use_lists(const gie_ctx &c, int listed)
 #ifndef GIE_Z_SHORT_LISTS
 #define GIE_Z_SHORT_LISTS 1
 #endif
+#ifndef GIE_Z_LIST_DIV
+#define GIE_Z_LIST_DIV 8          /* the list form while at most 1 / GIE_Z_LIST_DIV of the tiles are known */
+#endif
 GIE_HD int gie_z_use_lists(const gie_ctx &c, int listed)
 {
     if (c.force_lists >= 0) return c.force_lists;
     if (GIE_Z_SHORT_LISTS && c.tfd[2] <= 8) return 1;
-    return gie_use_lists(c, listed);
+    return (long long)listed * GIE_Z_LIST_DIV <= (long long)c.tfd[0] * c.tfd[1] * c.tfd[2];
 }
 GIE_HD int gie_tile_index(const gie_ctx &c, int x, int y, int z) { return ((z >> 3) * c.tfd[1] + (y >> 3)) * c.tfd[0] + (x >> 3); }
 GIE_HD int gie_vox_in_blk(int gx, int gy, int gz) { return ((gz & 7) << 6) | ((gy & 7) << 3) | (gx & 7); }
