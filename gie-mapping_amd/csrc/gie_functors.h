@@ -7,37 +7,6 @@
 
 #include "gie_ops.h"
 
-#if defined(GIE_HOST_EMU)
-#define GIE_DEVM inline
-#else
-#define GIE_DEVM __device__ __forceinline__
-#endif
-
-#if !defined(GIE_HOST_EMU)
-/* Append slots for the threads of a WORKGROUP that have `flag` set: ballot inside the waves, LDS prefix across them, ONE
- * atomic on the counter per workgroup (the list builders below append from thousands of waves to one counter; per-wave
- * atomics on one word serialise at ~10 ns each).  Every thread of the workgroup has to call it (block barriers inside). */
-__device__ __forceinline__ int gie_wg_reserve(int32_t *counter, const bool flag)
-{
-    __shared__ int s_cnt[16];
-    __shared__ int s_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) s_cnt[wave] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < nw; w++) tot += s_cnt[w];
-        s_base = tot ? atomicAdd(counter, tot) : 0;
-    }
-    __syncthreads();
-    int base = s_base;
-    for (int w = 0; w < wave; w++) base += s_cnt[w];
-    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-    __syncthreads();                                       /* the scratch is reused by the next call */
-    return flag ? slot : -1;
-}
-#endif
 
 /* skip(c, id, x, y, z): cheap test (at most one small load, issued for a whole z-column up
  * front by k_voxz) that is true only when operator() would do nothing for the voxel. */
@@ -153,23 +122,19 @@ struct op_frontier { static constexpr bool rolled = false;
     GIE_DEVM int finish(const gie_ctx &c, int id, int x, int y, int z, const st &s) const { push_seed(c, gie_frontier_finish(c, id, x, y, z, s), id); return 0; }
     GIE_DEVM void operator()(const gie_ctx &c, int x, int y, int z) const { push_seed(c, gie_frontier_voxel(c, x, y, z), gie_lid(c, x, y, z)); }
     GIE_DEVM void push_seed(const gie_ctx &c, const int push, const int id) const {
-#if defined(GIE_HOST_EMU)
-        if (push) gie_push32(c, c.qc[0], &c.cnt[GIE_CNT_C], c.qcap_c, id);
-#else
         const unsigned long long m = __ballot(push);
         if (m) {
             const int lane = __lane_id();
             const int leader = __ffsll((long long)m) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&c.cnt[GIE_CNT_C], __popcll(m));
+            if (lane == leader) base = gie_aadd32(&c.cnt[GIE_CNT_C], __popcll(m));
             base = __shfl(base, leader);
             if (push) {
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < c.qcap_c) c.qc[0][slot] = id;
-                else atomicOr(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
+                else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
             }
         }
-#endif
     }
 };
 
@@ -204,12 +169,8 @@ struct op_tile_summary {
         /* the tiles whose every voxel is looked at, as a list (order is irrelevant): k_frontier_tiles takes a tile per wave from it
          * — a list of its own, so that consecutive entries cost the same (with the plain face tiles in between, the few waves
          * whose stride met the tx = 0 tiles did all the work).  The voxels on the faces go by patches of the faces (tsum != 0). */
-#if defined(GIE_HOST_EMU)
-        if (v == 1) c.tl_front[c.cnt[GIE_CNT_TL_FRONT]++] = t;
-#else
         const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FRONT], v == 1);
         if (slot >= 0) c.tl_front[slot] = t;
-#endif
     } };
 struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
 struct op_halo_need { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_need_voxel(c, face, i, in); } };
@@ -236,12 +197,8 @@ struct op_query { const int32_t *xyz; gie_voxel *out; GIE_DEVM void operator()(c
 /* (called for every thread of a workgroup: t = -1 past the end) */
 struct op_fuse_list { GIE_DEVM void operator()(const gie_ctx &c, int t) const {
         const int v = t >= 0 ? gie_fuse_tile_listed(c, t) : 0;
-#if defined(GIE_HOST_EMU)
-        if (v) c.tl_front[c.cnt[GIE_CNT_TL_FUSE]++] = t;
-#else
         const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FUSE], v != 0);
         if (slot >= 0) c.tl_front[slot] = t;
-#endif
     } };
 struct op_pair_flush { gie_flush_boxes b; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_pair_flush_voxel(c, b, i); } };
 /* test hook (gie_debug_nbr_check): item i = (slot, direction); counts the rows of the neighbour table that do not say what the hash says —
@@ -255,11 +212,7 @@ struct op_nbr_check { int32_t *bad; GIE_DEVM void operator()(const gie_ctx &c, i
         const int row = c.g_nbr[8 * (size_t)slot + k];
         const int named = (row >= 0 && row < c.max_blocks && c.g_key[row] == gie_pack_crd(b[0], b[1], b[2])) ? row : -1;
         if (named != gie_hash_find(c, b[0], b[1], b[2])) {
-#if defined(GIE_HOST_EMU)
-            *bad += 1;
-#else
-            atomicAdd(bad, 1);
-#endif
+            gie_aadd32(bad, 1);
         }
     } };
 struct op_evict { GIE_DEVM void operator()(const gie_ctx &c, int slot) const { if (slot < c.pool_count[0]) gie_evict_slot(c, slot); } };

@@ -9,41 +9,9 @@
 
 #include "gie_types.h"
 
-/* ------------------------------------------------------------------ memory primitives */
-#if defined(GIE_HOST_EMU)
-/* test-only sequential emulation (tests/emu): plain memory */
-template <class T> static inline T gie_ld(const T *p) { return *p; }
-template <class T> static inline void gie_st(T *p, T v) { *p = v; }
-static inline uint64_t gie_amin64(uint64_t *p, uint64_t v) { uint64_t o = *p; if (v < o) *p = v; return o; }
-static inline uint64_t gie_acas64(uint64_t *p, uint64_t c, uint64_t v) { uint64_t o = *p; if (o == c) *p = v; return o; }
-static inline uint64_t gie_aand64(uint64_t *p, uint64_t v) { uint64_t o = *p; *p = o & v; return o; }
-static inline uint32_t gie_axchg32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
-static inline int32_t gie_axchg32(int32_t *p, int32_t v) { int32_t o = *p; *p = v; return o; }
-static inline int32_t gie_aadd32(int32_t *p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
-static inline int32_t gie_aor32(int32_t *p, int32_t v) { int32_t o = *p; *p = o | v; return o; }
-#define GIE_DEV static inline
-#else
-/* agent-scope relaxed accesses: served by L2, never by a stale per-CU L1 line */
-template <class T> __device__ __forceinline__ T gie_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T> __device__ __forceinline__ void gie_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t gie_amin64(uint64_t *p, uint64_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t gie_acas64(uint64_t *p, uint64_t c, uint64_t v) { __hip_atomic_compare_exchange_strong(p, &c, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return c; }
-__device__ __forceinline__ uint64_t gie_aand64(uint64_t *p, uint64_t v) { return __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t gie_axchg32(uint32_t *p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t gie_axchg32(int32_t *p, int32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t gie_aadd32(int32_t *p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t gie_aor32(int32_t *p, int32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define GIE_DEV __device__ __forceinline__
-#endif
-
-#if defined(GIE_HOST_EMU)
-#define GIE_UNROLL6
-#define GIE_UNROLL_BATCH
-#define GIE_DEV_COLD static
-#else
-#define GIE_DEV_COLD __device__ __forceinline__   /* (a real call would push the kernarg context through scratch: measured 5x slower) */
-#define GIE_UNROLL6 _Pragma("unroll 6")
-#define GIE_UNROLL_BATCH _Pragma("unroll")
+/* memory primitives, function qualifiers, loop pragmas: gie_platform.h (gfx950) — or the test backend's own, included before this file */
+#ifndef GIE_PLATFORM_DEFINED
+#include "gie_platform.h"
 #endif
 
 /* append to a frontier queue; overflow raises the sticky error flag */
@@ -64,9 +32,6 @@ GIE_DEV void gie_push64a(const gie_ctx &c, uint64_t *q, gie_vaddr *qaddr, int32_
  * A / B).  Only executing lanes are looked at, so it is safe in divergent code. */
 GIE_DEV void gie_push64a_wave(const gie_ctx &c, uint64_t *q, gie_vaddr *qaddr, int32_t *counter, int cap, bool push, uint64_t v, gie_vaddr a)
 {
-#if defined(GIE_HOST_EMU)
-    if (push) gie_push64a(c, q, qaddr, counter, cap, v, a);
-#else
     const unsigned long long m = __ballot(push);
     if (!m) return;
     const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
@@ -77,7 +42,6 @@ GIE_DEV void gie_push64a_wave(const gie_ctx &c, uint64_t *q, gie_vaddr *qaddr, i
         const int i = base + __popcll(m & ((1ull << lane) - 1ull));
         if (i < cap) { gie_st(&q[i], v); gie_st(&qaddr[i], a); } else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
     }
-#endif
 }
 GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap, int32_t v)
 {
@@ -87,9 +51,6 @@ GIE_DEV void gie_push32(const gie_ctx &c, int32_t *q, int32_t *counter, int cap,
 
 GIE_DEV void gie_push32_wave(const gie_ctx &c, int32_t *q, int32_t *counter, int cap, bool push, int32_t v)
 {
-#if defined(GIE_HOST_EMU)
-    if (push) gie_push32(c, q, counter, cap, v);
-#else
     const unsigned long long m = __ballot(push);
     if (!m) return;
     const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
@@ -100,7 +61,6 @@ GIE_DEV void gie_push32_wave(const gie_ctx &c, int32_t *q, int32_t *counter, int
         const int i = base + __popcll(m & ((1ull << lane) - 1ull));
         if (i < cap) gie_st(&q[i], v); else gie_aor32(&c.cnt[GIE_CNT_ERR], GIE_ERRF_QUEUE);
     }
-#endif
 }
 
 /* ray_count[id] += val for every lane with id >= 0, with equal targets of NEIGHBOURING lanes merged
@@ -112,9 +72,6 @@ GIE_DEV void gie_push32_wave(const gie_ctx &c, int32_t *q, int32_t *counter, int
  * Safe in divergent code: only executing lanes are looked at. */
 GIE_DEV void gie_wave_add(const gie_ctx &c, int id, int val)
 {
-#if defined(GIE_HOST_EMU)
-    if (id >= 0) c.ray_count[id] += val;
-#else
     const int lane = __lane_id();
     const unsigned long long exec = __ballot(1);
     const unsigned long long valid = __ballot(id >= 0);
@@ -128,7 +85,6 @@ GIE_DEV void gie_wave_add(const gie_ctx &c, int id, int val)
         const int end = (lane == 63 || !stops) ? 64 : __ffsll((long long)stops) - 1;
         gie_aadd32(&c.ray_count[id], val * (end - lane));
     }
-#endif
 }
 
 /* every cell whose _ray_count changes flags its tile, so that getAllocKeys (ray_finalize) only
@@ -515,12 +471,7 @@ GIE_DEV void gie_fuse_row8_labels(int thresh, uint64_t it8, uint64_t go8, uint64
     uint64_t o8 = (go8 & ~fF) | (half & fF), y8 = (gy8 & ~fF) | (ONES & fF);
     uint32_t ob = (uint32_t)((mO * 0x0102040810204080ull) >> 56);             /* bit i: voxel i carries an OCCUPIED label */
     while (ob) {
-#if defined(GIE_HOST_EMU)
-        int i = 0;
-        while (!((ob >> i) & 1u)) i++;
-#else
         const int i = __ffs((int)ob) - 1;
-#endif
         ob &= ob - 1u;
         uint8_t occ = (uint8_t)(go8 >> (8 * i));
         int8_t ty = (int8_t)(gy8 >> (8 * i));
@@ -824,11 +775,6 @@ GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, g
 
 /* `nb(k, nid)` = the Mark-time pair of the in-volume neighbour k (local index nid): from memory (gie_nbpair_mem), or from
  * the tile a wave has staged in LDS (k_frontier_tiles) */
-#if defined(GIE_HOST_EMU)
-#define GIE_DEV_MEMBER inline
-#else
-#define GIE_DEV_MEMBER __device__ __forceinline__
-#endif
 struct gie_nbpair_mem { const uint64_t *pair; GIE_DEV_MEMBER uint64_t operator()(int, int nid) const { return pair[nid]; } };
 /* `sink.ab(c, push, crd, a)` = the outside neighbour at global coordinate crd (address a) joins frontier B (push == 1) or
  * frontier A (push == 2); called by every executing lane for every direction: straight into the queues with one atomic per
@@ -915,9 +861,6 @@ GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
  * obstacles of (in-plane distance)² + (z - plane)².  A few dozen reads — for rare lookups only. */
 GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
 {
-#if defined(GIE_HOST_EMU)
-    return gie_bcoc_dist(c.bcoc[gie_lid(c, x, y, z)], x, y, z, c.max_width * c.max_width);   /* the emulation fills the whole plane */
-#else
     const int K = *c.zcount;
     const size_t plane = (size_t)c.X * c.Y, o = (size_t)y * c.X + x;
     int best = c.max_width * c.max_width;
@@ -938,7 +881,6 @@ GIE_DEV int gie_batch_dist_direct(const gie_ctx &c, int x, int y, int z)
         }
     }
     return best;
-#endif
 }
 
 /* UpdateHashBatch for one voxel whose final pair is `pr` (type FNT is handled by the callers).
@@ -1140,9 +1082,7 @@ GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* all
                 for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++)
                     if (!c.tskip_prev[(z * c.tfd[1] + y) * c.tfd[0] + x]) v = 1;
             }
-#if defined(GIE_HOST_EMU)
-            c.cnt[GIE_CNT_TSKIP] += 1;
-#endif
+            GIE_COUNT_TSKIP(c);
         }
     }
     c.tskip[t] = (uint8_t)v;
@@ -1172,9 +1112,7 @@ GIE_DEV void gie_coc_catchup_newcolumn(const gie_ctx &c, const int pupvt[3], int
      * thousand tiles, bound by how many round trips a lane makes one after the other */
     const bool cin = px >= 0 && px < c.X && py >= 0 && py < c.Y;
     uint8_t fl[8]; uint64_t pr[8];
-#if !defined(GIE_HOST_EMU)
-#pragma unroll
-#endif
+GIE_UNROLL
     for (int k = 0; k < 8; k++) {
         const int pz = z0 + k + c.prev_shift[2];
         const bool in = k < nz && cin && pz >= 0 && pz < c.Z;
@@ -1183,9 +1121,7 @@ GIE_DEV void gie_coc_catchup_newcolumn(const gie_ctx &c, const int pupvt[3], int
     }
     const int gz0 = z0 + c.pvt[2];
     const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)], slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
-#if !defined(GIE_HOST_EMU)
-#pragma unroll
-#endif
+GIE_UNROLL
     for (int k = 0; k < 8; k++) {
         if (fl[k] != 2 || gie_pair_dist(pr[k]) == c.empty_value) continue;   /* (EMPTY cannot happen: an update without obstacles clears no tile) */
         const int gz = gz0 + k;
@@ -1203,9 +1139,6 @@ GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned k
 {
     const int t = gie_tile_index(c, x, y, z0);
     int v = (known != valid) ? GIE_TMAX_INF : vmax;
-#if defined(GIE_HOST_EMU)
-    if (v > c.tmax[t]) c.tmax[t] = v;
-#else
     /* the eight lanes of a wave that share (lane >> 3) hold one row of one tile in every form of the sweep (inactive ones are the
      * row's upper end, past the volume); lane ^ 32 is the same tile two (sweep, 32 lanes along x) or four (list) rows on */
     const int lane = __lane_id();
@@ -1216,7 +1149,6 @@ GIE_DEV void gie_markc_column(const gie_ctx &c, int x, int y, int z0, unsigned k
     const bool paired = ((ex >> (lane ^ 32)) & 1ull) && ot == t;
     if (paired) v = v > ov ? v : ov;
     if ((lane & 7) == 0 && !(paired && lane >= 32) && v > 0) __hip_atomic_fetch_max(&c.tmax[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
 GIE_DEV void gie_markc_load1(const gie_ctx &c, int id, int x, int y, int z, gie_markc_st &s)
@@ -1422,9 +1354,6 @@ GIE_DEV void gie_halo_export_sparse_voxel(const gie_ctx &c, int face, int i, gie
 {
     const gie_halo_voxel h = gie_halo_record(c, face, i);
     const bool known = h.vox_type != GIE_VOX_UNKNOWN;
-#if defined(GIE_HOST_EMU)
-    if (known) { const int s = gie_aadd32(count, 1); out[s].index = i; out[s].v = h; }
-#else
     const unsigned long long m = __ballot(known);
     if (!m) return;
     const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
@@ -1432,7 +1361,6 @@ GIE_DEV void gie_halo_export_sparse_voxel(const gie_ctx &c, int face, int i, gie
     if (lane == leader) base = gie_aadd32(count, __popcll(m));
     base = __shfl(base, leader);
     if (known) { const int s = base + __popcll(m & ((1ull << lane) - 1ull)); out[s].index = i; out[s].v = h; }
-#endif
 }
 /* ghost voxels just outside `face`: mark the blocks they need … */
 GIE_DEV void gie_halo_need_rec(const gie_ctx &c, int face, int i, const gie_halo_voxel &v)

@@ -8,7 +8,7 @@
  * (EDT passes, ballot compaction, persistent BFS kernels) are NOT exercised here — only
  * `pytest -m gpu` covers them.
  */
-#define GIE_HOST_EMU 1
+#include "gie_platform_emu.h"   /* plain memory + a wavefront of one lane under the product's gie_ops.h / gie_functors.h (defines GIE_HOST_EMU) */
 #define GIE_TEST_HOOKS 1      /* the emulation is test infrastructure: the switches of gie_api.inc.h read the environment here */
 #include <algorithm>
 #include <cstring>
@@ -213,6 +213,11 @@ static void be_edt(be_state *, const gie_ctx &c, int)
         const int id = gie_lid(c, x, y, u);
         if (bs < 0) c.bcoc[id] = GIE_BCOC_NONE;
         else { const uint32_t v = c.cxy2[gie_lid(c, x, y, bs)]; c.bcoc[id] = gie_pack_bcoc((int)(v & 0xffff), (int)(v >> 16), bs); }
+    }
+    {   /* the planes with obstacles, ascending (k_edt_prep on the device): gie_batch_dist_direct walks them */
+        int K = 0;
+        for (int z = 0; z < Z; z++) if (c.cxy2[gie_lid(c, 0, 0, z)] != 0xffffffffu) c.zlist[K++] = (uint16_t)z;
+        *c.zcount = K;
     }
 }
 /* wave A in the canonical checkerboard block-round schedule (oracle/gie_oracle.c wave_a): sequential statement on the
