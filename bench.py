@@ -358,7 +358,8 @@ class Runner:
         self.updates = 0
         self.checked_pivot = False
 
-    def step(self, i):
+    def step(self, i, mid=None):
+        """mid: (event, stream) recorded on the mapper's stream between the tile's own work and the face-layer exchange (latency pass)"""
         m = self.m
         self.feed.step_input(m, i)
         if not self.checked_pivot and self.feed.kind == "labels":       # the label planes were built for this pivot
@@ -370,6 +371,8 @@ class Runner:
         else:
             m.step()
         self.updates += 1
+        if mid is not None:
+            mid[0].record(mid[1])
         if self.exchange:
             t, d = self.tiling, self.dist
             if self.backend != "nccl":
@@ -426,15 +429,18 @@ class Runner:
         torch = self.torch
         self.feed.prepare(first, K)
         s = torch.cuda.ExternalStream(self.m.stream_handle(), device=self.dev)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         self.barrier()
         for j in range(K):
             evs[j][0].record(s)
-            self.step(first + j)
+            self.step(first + j, mid=(evs[j][2], s) if self.exchange else None)
             evs[j][1].record(s)
         self.barrier()
         self.m.sync()
-        return [a.elapsed_time(b) for a, b in evs]
+        # N > 1: the part of a step behind the tile's own fuse / EDT / Mark — export, transfers, import, obtainFrontiers + waves, refinement
+        # rounds — as far as it is enqueued on the mapper's stream (the stream-ordered RCCL modes; host-staged rounds wait on the host)
+        self.exchange_ms = [c.elapsed_time(b) for a, b, c in evs] if self.exchange else []
+        return [a.elapsed_time(b) for a, b, c in evs]
 
     def close(self):
         self.m.close()
@@ -645,7 +651,10 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
         out["config"].update({
             "exchange": "RCCL" if backend == "nccl" else "gloo, host staging", "rccl_ranks": world if backend == "nccl" else 0,
             "halo_mode": halo_mode, "halo_max_rounds": r.halo_rounds, "rounds_per_update": round(rounds_per_step, 3),
-            "updates_unconverged": (round_stats or {}).get("updates_unconverged"), "exchange_notes": notes})
+            "updates_unconverged": (round_stats or {}).get("updates_unconverged"), "exchange_notes": notes,
+            # what follows the tile's own sweep in a step (face export, transfers, import, merge end, refinement rounds), median over the
+            # latency pass; nothing of it overlaps the tile's own work (obtainFrontiers reads the ghosts): overlap_frac 0
+            "exchange_ms_per_step": round(percentile(getattr(r, "exchange_ms", []) or [0.0], 0.5), 4), "overlap_frac": 0.0})
     if model_errors:
         out["roofline_model_errors"] = sorted(model_errors)
     if accuracy is not None:
