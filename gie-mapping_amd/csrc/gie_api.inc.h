@@ -57,6 +57,8 @@ struct gie_mapper {
     int track_want;                       /* gie_stream_enable: taken over by the next gie_fuse (an update runs in ONE order of kernels from its fuse to its merge) */
     const int8_t *labels_pending;         /* the last scan is a label plane left in place (c.scan_labels until gie_fuse): materialised into `_inst_type` if anything else wants it */
     int coc_pending;                      /* voxels of the current tskip tiles have their records in the pair plane only (gie_ops.h "deferred records") */
+    int lazy_pending;                     /* tiles may be flagged in tlazy: their pairs are not in the pair plane (gie_ops.h "lazy pairs") */
+    uint32_t *bcoc_alt;                   /* the other batch-obstacle plane (pass Z never writes the one the lazy pairs are derived from) */
     int tsp_pvt[3];                       /* the pivot tskip_prev's tiles refer to */
     int flushed_ct;                       /* map tick (c.map_ct) of the pose the owed pairs were last written for ahead of gie_fuse (gie_owed_pairs_before_import) */
     /* CostMap publishing without a stall (gie_costmap_publish / gie_costmap_acquire): device staging + two pinned host buffers */
@@ -196,6 +198,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.cy1 = gie_dalloc<uint16_t>(m, N);
     c.cxy2 = gie_dalloc<uint32_t>(m, N);
     c.bcoc = gie_dalloc<uint32_t>(m, N);
+    m->bcoc_alt = gie_dalloc<uint32_t>(m, N);
     c.pair = gie_dalloc<uint64_t>(m, N);      /* zero-initialised: SURVEY App. B #3 */
     c.wl = gie_dalloc<uint32_t>(m, N);
     for (int i = 0; i < 3; i++) c.tfd[i] = (cfg->local_size[i] + 7) / 8;
@@ -207,6 +210,8 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tmax_prev = c.tmax ? c.tmax + ntile : nullptr;
     c.tskip = gie_dalloc<uint8_t>(m, 2 * ntile);
     c.tskip_prev = c.tskip ? c.tskip + ntile : nullptr;
+    c.tlazy = gie_dalloc<uint8_t>(m, ntile);
+    c.bcoc_lazy = c.bcoc; c.lazy_ok = 0; m->lazy_pending = 0;
     c.coc_defer = 0; c.qdefer = 0; c.scan_labels = nullptr;
     for (int i = 0; i < 3; i++) { c.ts_pvt[i] = 0; m->tsp_pvt[i] = 0; c.pp_pvt[i] = c.pp_upvt[i] = 0; }
     c.ucol = gie_dalloc<uint8_t>(m, (((size_t)X * Y * ((Z + 7) / 8)) + 3) & ~(size_t)3);
@@ -340,6 +345,8 @@ extern "C" int gie_set_pose(gie_mapper *m, const float pos[3], const float q[4])
     }
     c.wr_inside = 1;
     for (int i = 0; i < 3; i++) if (c.pvt[i] - c.upvt[i] < 0 || c.pvt[i] - c.upvt[i] + sz[i] > c.wr[i]) c.wr_inside = 0;
+    c.lazy_ok = c.wr_inside;                              /* "lazy pairs": not for one tile of several (its faces lie inside the whole volume: the refinement rounds read them) */
+    for (int i = 0; i < 3; i++) if (m->next_off[i] != 0 || m->next_whole[i] != sz[i]) c.lazy_ok = 0;
     c.tab_prev = nullptr;                                 /* the block table belongs to the pose before: the next gie_fuse builds this one's (from it) */
     const uint32_t f = (uint32_t)c.map_ct & 0x3ffffu;
     if (f == 0) {                                         /* stamp wrap: clear the stamp planes once */
@@ -710,11 +717,20 @@ extern "C" int gie_fuse(gie_mapper *m)
         if (c.oldskip) be_tile_oldskip(&m->be, c, m->commit_upvt);
         if (m->coc_pending && !c.catchup_fast) {
             gie_catchup p;
-            p.flags = c.tskip_prev; p.all = 0;
+            /* (after a fuse WITHOUT a merge the flags are that fuse's, whose sweep never ran: also its tiles flagged 1 — "the sweep stores
+             * them" — still hold voxels the merge before left to its pair plane: every flagged tile is caught up; round 6) */
+            p.flags = c.tskip_prev; p.all = unmerged ? 1 : 0;
             for (int i = 0; i < 3; i++) { p.fpvt[i] = m->tsp_pvt[i]; p.ppvt[i] = m->commit_pvt[i]; p.pupvt[i] = m->commit_upvt[i]; }
             be_coc_catchup(&m->be, c, p);
         }
         if (m->coc_pending) m->coc_pending = c.oldskip;       /* what stays deferred lies in this update's tskip tiles (none without the bound) */
+        /* "lazy pairs": the flagged tiles this update's sweep will not leave flagged again get their pairs into the plane now — the batch
+         * obstacles they are derived from are still there, and the next Mark reads old pairs by local index */
+        if (m->lazy_pending) {
+            const int stay = (gie_fused_mode(m) && c.oldskip && c.lazy_ok) ? 1 : 0;      /* (what the sweep's short way will go by: tskip 2, records deferred) */
+            be_pair_materialise(&m->be, c, stay);
+            m->lazy_pending = stay;
+        }
         be_prof(&m->be, GIE_K_ALLOC, 1);
         c.qdefer = m->coc_pending;
         for (int i = 0; i < 3; i++) { c.pp_pvt[i] = m->commit_pvt[i]; c.pp_upvt[i] = m->commit_upvt[i]; }
@@ -749,6 +765,7 @@ extern "C" int gie_batch_edt(gie_mapper *m)
 {
     int rc = gie_need_pose(m, "gie_batch_edt"); if (rc) return rc;
     be_time(&m->be, 4);
+    if (m->c.bcoc == m->c.bcoc_lazy) { uint32_t *t = m->c.bcoc; m->c.bcoc = m->bcoc_alt; m->bcoc_alt = t; }      /* ("lazy pairs": pass Z writes the OTHER plane) */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 0);
     be_edt_prep(&m->be, m->c);          /* plane list + reader masks (the tile skip flags are gie_fuse's since round 5) */
     be_prof(&m->be, GIE_K_EDT_ZFACES, 1);
@@ -779,6 +796,10 @@ extern "C" int gie_merge_begin(gie_mapper *m)
         c.coc_defer = (c.fused && c.oldskip) ? 1 : 0;      /* (also for one tile of several: the face layers are exported through gie_deferred_coc) */
         if (!c.fused) gie_catchup_everything(m);
     }
+    /* "lazy pairs": from this Mark on the flagged tiles' pairs are the ones of THIS update's batch obstacles at THIS update's pivots */
+    m->c.bcoc_lazy = m->c.bcoc;
+    for (int i = 0; i < 3; i++) { m->c.pp_pvt[i] = m->c.pvt[i]; m->c.pp_upvt[i] = m->c.upvt[i]; }
+    if (m->c.fused && m->c.coc_defer && m->c.lazy_ok) m->lazy_pending = 1;
     if (m->c.fused) be_markc(&m->be, m->c, m->c.tl_known);
     else be_vox_list<false>(&m->be, m->c, op_mark(), m->c.tl_known, GIE_CNT_TL_KNOWN, 0);
     be_prof(&m->be, kmark, 1);

@@ -496,6 +496,15 @@ static void be_tile_oldskip(be_state *b, const gie_ctx &c, const int pupvt[3])
     GIE_LAUNCH(b, k_tile_oldskip, dim3((ntile + 255) / 256), dim3(256), 0, c, ntile, c.wc_list[0], count);
     if (c.catchup_fast) GIE_LAUNCH(b, k_coc_catchup_new, dim3(b->cu_total * 8), dim3(256), 0, c, pupvt[0], pupvt[1], pupvt[2], c.wc_list[0], count);
 }
+/* "lazy pairs": the flagged tiles that will not stay flagged get their pairs into the plane (gie_fuse) */
+static void be_pair_materialise(be_state *b, const gie_ctx &c, int stay)
+{
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    /* the list lives in wave C's second tile list (ntile words, not in use between two merges), its length in a spare counter (zero: the frame clear) */
+    int32_t *const count = &c.cnt[GIE_CNT_STATE2];
+    GIE_LAUNCH(b, k_pair_lazy_list, dim3((ntile + 255) / 256), dim3(256), 0, c, ntile, stay, c.wc_list[1], count);
+    GIE_LAUNCH(b, k_pair_lazy_run, dim3(b->cu_total * 8), dim3(256), 0, c, c.wc_list[1], count);
+}
 static void be_coc_catchup(be_state *b, const gie_ctx &c, const gie_catchup &p)
 {
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];

@@ -1455,6 +1455,26 @@ __global__ __launch_bounds__(256) void k_coc_catchup_new(const gie_ctx c, const 
     for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) gie_coc_catchup_newcolumn(c, pupvt, list[e], lane);
 }
 
+/* "lazy pairs" (gie_ops.h): the flagged tiles that this update's sweep will not leave flagged again (stay: it will leave tskip-2 tiles
+ * flagged) — listed by a thread per tile, then a wave per listed tile puts the tile's 512 pairs into the plane and takes the flag away */
+__global__ __launch_bounds__(256) void k_pair_lazy_list(const gie_ctx c, const int ntile, const int stay, int32_t *list, int32_t *count)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool need = t < ntile && c.tlazy[t] != 0 && !(stay && c.tskip[t] == 2);
+    const int slot = gie_wg_reserve(count, need);
+    if (slot >= 0) list[slot] = t;
+}
+__global__ __launch_bounds__(256) void k_pair_lazy_run(const gie_ctx c, const int32_t *list, const int32_t *count)
+{
+    const int n = *count;
+    const int lane = threadIdx.x & 63;
+    for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) {
+        const int t = list[e];
+        gie_pair_materialise_column(c, t, lane);
+        if (lane == 0) c.tlazy[t] = 0;
+    }
+}
+
 /* the records a fused update left to its pair plane, for the tiles that are no tskip tiles any more (gie_ops.h "deferred records"):
  * k_coc_catchup_list — a thread per tile of the flags' plane decides (gie_coc_catchup_tile: nearly always "nothing to do") and the
  * tiles found go onto a list (one atomic per wave); k_coc_catchup_run — a wave per listed tile, a lane per z-column.  Two launches
@@ -1559,25 +1579,90 @@ __global__ __launch_bounds__(256) void k_voxa(const gie_ctx c, const F f, const 
  * generic staged sweep tests the type first and loads behind the branch — four dependent round trips per column instead of
  * two; on the C5 volume the sweep is bound by how many bytes it keeps in flight, and by its stores (tools/sweep_probe.hip:
  * this device writes at ~4.1 TB/s and reads at ~6.5, one after the other). */
-__device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const int x, const int y, const int z0)
+/* "LAZY PAIRS" (round 6, gie_ops.h).  A tskip tile with deferred records inside the wave range — 3/4 of the headline volume — has
+ * nothing to decide: no stored record can win, every voxel is known (the update before committed them all), its batch obstacle lies
+ * inside the volume, so MarkLimitedObserve's answer is (batch distance, batch obstacle in wave-range coordinates): a function of the
+ * batch-obstacle plane, which is NOT copied into the pair plane any more — the tile is flagged, readers derive (gie_pair_of_bcoc).
+ * What is left of the sweep there: the columns' `ucol` bytes (Mark "has written" the indices; gie_markc_column_fast), and per TILE
+ * the flag and the BOUND for the next update's gie_tile_oldskip, here.  Any upper bound of the largest distance in the tile will do
+ * (a larger bound clears fewer tiles, never a wrong one), and the distance is the exact EDT's, so by the triangle inequality
+ * sqrt(d(v)) <= sqrt(d(s)) + |v - s|: eight samples, the voxel (1, 1, 1) of every octant, none of whose voxels is farther than
+ * |(2, 2, 2)| < 4 from it.  (A sample without a batch obstacle: an update without obstacles — it clears no tile, so it cannot be
+ * here — but if it is: the bound is "infinite".)  A thread per tile: the sweep's threads would each wait for the samples' round
+ * trip behind the flags', a chain per virtual workgroup that — with the bytes gone — was what the sweep's time consisted of. */
+__device__ __forceinline__ void gie_markc_lazy_tile(const gie_ctx &c, const int t)
 {
-    if (x >= c.X || y >= c.Y) return;
+    if (!c.tknown[t] || c.tskip[t] != 2) return;
+    const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+    const int x = tx * 8, y = ty * 8, z0 = tz * 8;
+    const size_t plane = (size_t)c.X * c.Y;
+    const size_t id0 = ((size_t)z0 * c.Y + y) * c.X + x;
+    uint32_t sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sb[k] = c.bcoc[id0 + (size_t)(1 + 4 * (k >> 2)) * plane + (size_t)(1 + 4 * ((k >> 1) & 1)) * c.X + (size_t)(1 + 4 * (k & 1))];
+    int vmax = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int sx = x + 1 + 4 * (k & 1), sy = y + 1 + 4 * ((k >> 1) & 1), sz = z0 + 1 + 4 * (k >> 2);
+        int v = GIE_TMAX_INF;
+        if (sb[k] != GIE_BCOC_NONE) {
+            const int dx = sx - (int)(sb[k] & 1023u), dy = sy - (int)((sb[k] >> 10) & 1023u), dz = sz - (int)(sb[k] >> 20);
+            const int r = (int)ceilf(sqrtf((float)(dx * dx + dy * dy + dz * dz))) + 4;
+            v = r * r + 1;
+        }
+        vmax = v > vmax ? v : vmax;
+    }
+    c.tmax[t] = vmax;
+    c.tlazy[t] = 1;
+}
+/* What a column's thread looks at first: is the tile known, how are its old records treated, the column's `ucol` byte (packed
+ * into one word), and the (at most two) block slots its eight voxels lie in.  k_markc loads these for a run of virtual workgroups
+ * at once, and the column then asks for its types, batch obstacles AND stored records in one batch: two round trips per column
+ * instead of four (flags; types + slots; stored records; stores) — away from the lazy tiles the sweep is a chain of round
+ * trips, not a stream (round 6: without the read of the stored records 0.35 -> 0.24 ms, of which their bytes explain a fifth). */
+struct gie_markc_pre { uint32_t flags; int32_t slot_lo, slot_hi; };
+__device__ __forceinline__ gie_markc_pre gie_markc_flags(const gie_ctx &c, const int x, const int y, const int z0)
+{
+    gie_markc_pre p = { 0u, -1, -1 };
+    if (x >= c.X || y >= c.Y || z0 >= c.Z) return p;
     const int t = gie_tile_index(c, x, y, z0);
-    if (!c.tknown[t]) return;
+    const int nz = min(8, c.Z - z0);
+    const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz0 = z0 + c.pvt[2];
+    const uint32_t kn = c.tknown[t], sk = c.tskip[t], ub = c.ucol[gie_ucol_index(c, x, y, z0)];
+    p.slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
+    p.slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
+    p.flags = (kn ? 1u : 0u) | (sk << 8) | (ub << 16);
+    return p;
+}
+__device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const int x, const int y, const int z0, const gie_markc_pre pre)
+{
+    const uint32_t flags = pre.flags;
+    if (!(flags & 1u)) return;                          /* (outside the volume, or a tile without a known voxel) */
+    const int t = gie_tile_index(c, x, y, z0);
     const size_t plane = (size_t)c.X * c.Y;
     const size_t id0 = ((size_t)z0 * c.Y + y) * c.X + x;
     const int nz = min(8, c.Z - z0);
     const int gx = x + c.pvt[0], gy = y + c.pvt[1], gz0 = z0 + c.pvt[2];
-    int8_t ty[8]; uint32_t bc[8];
+    const int skipold = (int)((flags >> 8) & 255u);
+    const bool nostore = c.coc_defer && skipold == 2;     /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
+    const size_t ui = gie_ucol_index(c, x, y, z0);
+    const unsigned ub = flags >> 16;                    /* indices that have just turned known: their old pair says nothing about `_edt_D` */
+    if (nostore && c.lazy_ok) {                         /* a lazy tile (gie_markc_lazy_tile): the column's byte, nothing else */
+        if (ub) c.ucol[ui] = (uint8_t)0;
+        return;
+    }
+    int8_t ty[8]; uint32_t bc[8]; gie_vaddr a[8]; uint64_t oc[8];
+    const int slot_lo = pre.slot_lo, slot_hi = pre.slot_hi;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const size_t id = id0 + (size_t)(k < nz ? k : 0) * plane;
         ty[k] = c.glb_type[id]; bc[k] = __builtin_nontemporal_load(&c.bcoc[id]);      /* (the batch obstacles are read once, here; the pairs below written once: non-temporal, -3 %) */
+        const int gz = gz0 + k;
+        const int slot = ((gz >> 3) == (gz0 >> 3)) ? slot_lo : slot_hi;
+        a[k] = slot < 0 ? (gie_vaddr)-1 : (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
+        oc[k] = 0;
+        if (!skipold && k < nz && a[k] >= 0) oc[k] = c.g_coc[a[k]];      /* (asked for before the type is known: an unknown voxel's record is read for nothing) */
     }
-    const int skipold = c.tskip[t];
-    const bool nostore = c.coc_defer && skipold == 2;     /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
-    const size_t ui = gie_ucol_index(c, x, y, z0);
-    const unsigned ub = c.ucol[ui];                     /* indices that have just turned known: their old pair says nothing about `_edt_D` */
     if (nostore && c.wr_inside) {
         /* A tskip tile with deferred records — 82 % of the C5 volume — and nothing to decide: no stored record can win (dold is
          * "infinite"), the batch obstacle lies inside the volume and the volume inside the wave range, so MarkLimitedObserve's
@@ -1592,6 +1677,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
             const uint32_t ox = (uint32_t)(c.pvt[0] - c.upvt[0]), oy = (uint32_t)(c.pvt[1] - c.upvt[1]), oz = (uint32_t)(c.pvt[2] - c.upvt[2]);
             int vmax = 0;
             uint64_t *const pp = c.pair + id0;
+            /* (one tile of several — lazy_ok 0 — gets here and stores: its faces lie inside the whole volume and the refinement rounds read them) */
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 if (!((want >> k) & 1u)) continue;
@@ -1609,21 +1695,14 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
             return;
         }
     }
-    const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)];
-    const int slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
-    gie_vaddr a[8]; int dold[8]; uint64_t oc[8];
+    int dold[8];
     unsigned want = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int gz = gz0 + k;
-        const int slot = ((gz >> 3) == (gz0 >> 3)) ? slot_lo : slot_hi;
-        a[k] = slot < 0 ? (gie_vaddr)-1 : (gie_vaddr)slot * GIE_VBSZ + gie_vox_in_blk(gx, gy, gz);
         if (k < nz && ty[k] != GIE_VOX_UNKNOWN) want |= 1u << k;
-        dold[k] = GIE_TMAX_INF; oc[k] = 0;
+        dold[k] = GIE_TMAX_INF;
     }
     if (!skipold) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && a[k] >= 0) oc[k] = c.g_coc[a[k]];
 #pragma unroll
         for (int k = 0; k < 8; k++) if (((want >> k) & 1u) && a[k] >= 0) dold[k] = gie_gdist(c, oc[k], gx, gy, gz0 + k);
     }
@@ -1657,12 +1736,17 @@ __global__ __launch_bounds__(256, 5) void k_markc(const gie_ctx c, const int32_t
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
     const int lane = threadIdx.x & 63;
+    if (c.coc_defer && c.lazy_ok) {
+        const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+        for (int t = (int)(blockIdx.x * 256 + threadIdx.x); t < ntile; t += (int)gridDim.x * 256) gie_markc_lazy_tile(c, t);
+    }
     if (gie_use_lists(c, n)) {
         const int waves = gridDim.x * 4;
         for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
             const int t = list[e];
             const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
-            gie_markc_column_fast(c, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), tz * 8);
+            const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+            gie_markc_column_fast(c, x, y, tz * 8, gie_markc_flags(c, x, y, tz * 8));
         }
     } else {
         constexpr int LY = 64 / LX, WY = 4 * LY;
@@ -1675,9 +1759,18 @@ __global__ __launch_bounds__(256, 5) void k_markc(const gie_ctx c, const int32_t
         int v = (int)blockIdx.x * per;
         const int vend = min(nv, ((int)blockIdx.x + 1) * per);
         int vx = v % gx, vy = (v / gx) % gy, vz = v / (gx * gy);
-        for (; v < vend; v++) {
-            gie_markc_column_fast(c, vx * LX + lx, vy * WY + ly, vz * 8);
-            if (++vx == gx) { vx = 0; if (++vy == gy) { vy = 0; vz++; } }
+        /* four virtual workgroups per trip (the default grid gives a workgroup exactly four): their flags first, together */
+        for (; v < vend; v += 4) {
+            int qx[4], qy[4], qz[4]; gie_markc_pre fl[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                qx[j] = vx; qy[j] = vy; qz[j] = v + j < vend ? vz : gz;       /* (past the run's end: a slab outside the volume) */
+                if (++vx == gx) { vx = 0; if (++vy == gy) { vy = 0; vz++; } }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) fl[j] = gie_markc_flags(c, qx[j] * LX + lx, qy[j] * WY + ly, qz[j] * 8);
+#pragma unroll
+            for (int j = 0; j < 4; j++) gie_markc_column_fast(c, qx[j] * LX + lx, qy[j] * WY + ly, qz[j] * 8, fl[j]);
         }
     }
 }
@@ -1785,12 +1878,13 @@ __device__ __forceinline__ void gie_frontier_tile(const gie_ctx &c, gie_fr_tile 
     /* ---- one batch of loads: types and Mark-time pairs of the tile and of the one-voxel halo around it */
     uint64_t pv[8], hv[6];
     int8_t tv[8], ht[6];
+    const bool lz = c.tlazy[t] != 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const bool in = colin && z0 + j < c.Z;
         const size_t id = in ? (size_t)(z0 + j) * plane + col : 0;
         tv[j] = c.glb_type[id];
-        pv[j] = c.pair[id];
+        pv[j] = lz ? gie_pair_of_bcoc(c, c.bcoc_lazy[id], x, y, z0 + j) : c.pair[id];      /* ("lazy pairs": wave-uniform) */
         if (!in) tv[j] = -1;
     }
     {   /* halo face f (0:-x 1:+x 2:-y 3:+y 4:-z 5:+z), the lane's position (a, b) on it */
@@ -1803,7 +1897,7 @@ __device__ __forceinline__ void gie_frontier_tile(const gie_ctx &c, gie_fr_tile 
             const bool in = gie_in_loc(c, hx[f], hy[f], hz[f]);
             const int id = in ? gie_lid(c, hx[f], hy[f], hz[f]) : 0;
             ht[f] = c.glb_type[id];
-            hv[f] = c.pair[id];
+            hv[f] = gie_pair_get(c, id, in ? hx[f] : 0, in ? hy[f] : 0, in ? hz[f] : 0);      /* (the neighbour tile's flag: the same byte for the whole face) */
             if (!in) ht[f] = -1;
         }
     }
@@ -1948,7 +2042,7 @@ __global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_
             gie_frontier_load1(c, id, vx, vy, vz, s);
             pre.nty = pre.a >= 0 ? c.g_type[pre.a] : (int8_t)0;
             pre.ncoc = pre.a >= 0 ? c.g_coc[pre.a] : (uint64_t)0;
-            const gie_nbpair_mem nb = { c.pair };
+            const gie_nbpair_mem nb = { &c };
             const gie_absink_lds sink = { &W };
             push = gie_frontier_finish_nb(c, id, vx, vy, vz, s, nb, sink, &pre);      /* (an UNKNOWN voxel: nothing, as before) */
         }
@@ -3195,6 +3289,7 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &g
     const int hy[6] = { y0 + la, y0 + la, y0 - 1, y0 + 8, y0 + lb, y0 + lb };
     const int hz[6] = { z0 + lb, z0 + lb, z0 + lb, z0 + lb, z0 - 1, z0 + 8 };
     unsigned hin = 0;                                     /* my halo cells inside the volume */
+    const bool lz = gie_ld(&c.tlazy[t]) != 0;              /* "lazy pairs": the tile's pairs are not in the plane */
     {
         uint64_t cv[8], hv[6];
         unsigned vin = 0;                                 /* my voxels inside the volume (kept as bits in a register: sixteen lane masks held across the loads cost more scalar registers than the kernel has) */
@@ -3204,14 +3299,20 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &g
             const bool in = x < c.X && y < c.Y && z < c.Z;
             const int id = in ? z * plane + y * c.X + x : 0;
             vin |= (in ? 1u : 0u) << j;
-            pv[j] = gie_ld(&c.pair[id]);
+            /* ("lazy pairs": a flagged tile's pairs are derived from its batch obstacles — the flag is the tile's, the branch wave-uniform) */
+            pv[j] = lz ? gie_pair_of_bcoc(c, gie_ld(&c.bcoc_lazy[id]), x, y, z) : gie_ld(&c.pair[id]);
             cv[j] = gie_ld(&rd[id]);
             tys |= (uint64_t)(uint8_t)c.glb_type[id] << (8 * j);
         }
 #pragma unroll
         for (int f = 0; f < 6; f++) {
             const bool in = gie_in_loc(c, hx[f], hy[f], hz[f]);
-            hv[f] = gie_ld(&c.pair[in ? gie_lid(c, hx[f], hy[f], hz[f]) : 0]);
+            const int hid = in ? gie_lid(c, hx[f], hy[f], hz[f]) : 0;
+            /* (the neighbour tile's flag, the same for the face's 64 lanes; a neighbour that is putting its pairs into the plane right now —
+             * it runs in this round too — takes its flag away when they are there: a reader sees the flag and derives the Mark-time pair,
+             * which is what the halo is for, or sees none and finds the pairs) */
+            const bool hlz = in && gie_ld(&c.tlazy[gie_tile_index(c, hx[f], hy[f], hz[f])]) != 0;
+            hv[f] = hlz ? gie_pair_of_bcoc(c, gie_ld(&c.bcoc_lazy[hid]), hx[f], hy[f], hz[f]) : gie_ld(&c.pair[hid]);
             hin |= (in ? 1u : 0u) << f;
         }
 #pragma unroll
@@ -3362,7 +3463,12 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &g
             }
             if (colin && (newbits & ~ub) != 0u) gie_st(ucp, (uint8_t)(ub | newbits));
         }
+        /* ("lazy pairs": a flagged tile that changes puts ALL its pairs into the plane, then takes its flag away) */
         unsigned dm = dirty;
+        if (lz) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (x0 + ((la - j) & 7) < c.X && y0 + ((lb - j) & 7) < c.Y && z0 + j < c.Z) dm |= 1u << j;
+        }
         while (__ballot(dm != 0u) != 0ull) {              /* as many trips as the busiest lane has changed voxels; stores only */
             const int j = dm != 0u ? __ffs((int)dm) - 1 : 0;
             const int ex = (la - j) & 7, ey = (lb - j) & 7;
@@ -3376,9 +3482,13 @@ __device__ __forceinline__ void gie_wave_c_tile(const gie_ctx &c, gie_gridbar &g
                 const int id = z * plane + y * c.X + x;
                 const uint64_t pr = L.pair[GIE_WC_P(ex, ey, j)];
                 gie_st(&c.pair[id], pr);
-                if (c.fused) gie_commit_merged(c, id, (int8_t)(tys >> (8 * j)), slot, x, y, z, pr);
+                if (c.fused && ((dirty >> j) & 1u)) gie_commit_merged(c, id, (int8_t)(tys >> (8 * j)), slot, x, y, z, pr);
             }
             dm &= dm - 1u;
+        }
+        if (lz) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              /* the pairs first, the flag behind them */
+            if (lane == 0) gie_st(&c.tlazy[t], (uint8_t)0);
         }
     }
     GIE_WPROF_DRAIN();

@@ -498,6 +498,50 @@ GIE_DEV void gie_fuse_load2(const gie_ctx &c, gie_fuse_st &s)
     s.occ = c.g_occ[s.a];
     s.ty = c.g_type[s.a];
 }
+/* ================================================================== lazy pairs (round 6)
+ * In a tile the fused sweep handles by its short way — tskip 2 with deferred records, the volume inside the wave range: 82 % of the
+ * headline volume — MarkLimitedObserve's answer is a function of the batch obstacle alone: (|voxel - obstacle|^2, obstacle in
+ * wave-range coordinates), or (EMPTY, none) without one.  The sweep wrote those 8 bytes per voxel for somebody to read them back
+ * unchanged; since round 6 it does not: it flags the tile (`tlazy`), and whoever wants the pair of a voxel of a flagged tile derives
+ * it from the batch-obstacle plane the flags refer to (`bcoc_lazy`, which alternates with the plane the next batch EDT writes) at the
+ * pivots of the merge that left it (pp_pvt / pp_upvt).  A flagged tile gets its pairs into the plane when
+ *   - wave C changes a pair of it (the tile's wave writes all 512 and takes the flag away),
+ *   - the next gie_fuse finds that it will not be flagged again (gie_pair_materialise_tile: before the next Mark reads old pairs by
+ *     local index), or every flag falls (the reference's order of kernels, a ray-cast scan, an update without the bound).
+ * The flags are ONE plane that is never swapped or cleared with the frame: it says what the pair plane holds now.
+ * Readers: obtainFrontiers and wave C (tile loads and halos), the pair flush and the catch-up of stored records in gie_fuse, the
+ * exports and the single-voxel readers. */
+GIE_DEV uint64_t gie_pair_of_bcoc(const gie_ctx &c, uint32_t bc, int x, int y, int z)
+{
+    if (bc == GIE_BCOC_NONE) return gie_pair_make(c.empty_value, GIE_PAR_NONE);
+    const int cx = (int)(bc & 1023u), cy = (int)((bc >> 10) & 1023u), cz = (int)(bc >> 20);
+    const int dx = x - cx, dy = y - cy, dz = z - cz;
+    return gie_pair_make(dx * dx + dy * dy + dz * dz, gie_pack_wr(cx + c.pp_pvt[0] - c.pp_upvt[0], cy + c.pp_pvt[1] - c.pp_upvt[1], cz + c.pp_pvt[2] - c.pp_upvt[2]));
+}
+/* the pair of local voxel (x, y, z) = index id of the update the pair plane is from */
+GIE_DEV uint64_t gie_pair_get(const gie_ctx &c, int id, int x, int y, int z)
+{
+    return c.tlazy[gie_tile_index(c, x, y, z)] ? gie_pair_of_bcoc(c, c.bcoc_lazy[id], x, y, z) : c.pair[id];
+}
+GIE_DEV uint64_t gie_pair_get_id(const gie_ctx &c, int id)
+{
+    const int plane = c.X * c.Y, z = id / plane, r = id - z * plane, y = r / c.X, x = r - y * c.X;
+    return gie_pair_get(c, id, x, y, z);
+}
+/* all 512 pairs of a flagged tile into the pair plane (one lane per z-column: l = 0 .. 63); the caller takes the flag away */
+GIE_DEV void gie_pair_materialise_column(const gie_ctx &c, int t, int l)
+{
+    const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
+    const int x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+    if (x >= c.X || y >= c.Y) return;
+    for (int k = 0; k < 8; k++) {
+        const int z = tz * 8 + k;
+        if (z >= c.Z) break;
+        const int id = gie_lid(c, x, y, z);
+        c.pair[id] = gie_pair_of_bcoc(c, c.bcoc_lazy[id], x, y, z);
+    }
+}
+
 /* ---- `_edt_D` (the float distance plane of the CostMap) is DERIVED, not stored (round 4).  UpdateHashBatch writes it for every
  * known voxel from the voxel's final pair — sqrtf(dist), or X^2+Y^2+Z^2 for "see nothing" (EMPTY, 0xffffffff) — except where the
  * pair is (EMPTY, some parent): obstacle outside the wave range, "don't update" (unify_helper.cuh:467-475); UNKNOWN voxels keep
@@ -517,7 +561,7 @@ GIE_DEV size_t gie_ucol_index(const gie_ctx &c, int x, int y, int z) { return ((
 GIE_DEV float gie_edt_value(const gie_ctx &c, int id)
 {
     const int plane = c.X * c.Y, z = id / plane, r = id - z * plane;
-    const uint64_t pr = c.pair[id];
+    const uint64_t pr = gie_pair_get_id(c, id);
     const bool marked = (c.ucol[(size_t)(z >> 3) * plane + r] >> (z & 7)) & 1u;
     return (!marked && !gie_pair_keeps_edt(c, pr)) ? gie_edt_of_pair(c, pr) : c.edt[id];
 }
@@ -759,7 +803,7 @@ GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, g
     int8_t ty[7];
     uint8_t tf[6];
     ty[0] = c.glb_type[id];
-    s.p0 = c.pair[id];      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
+    s.p0 = gie_pair_get(c, id, x, y, z);      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
@@ -775,7 +819,7 @@ GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, g
 
 /* `nb(k, nid)` = the Mark-time pair of the in-volume neighbour k (local index nid): from memory (gie_nbpair_mem), or from
  * the tile a wave has staged in LDS (k_frontier_tiles) */
-struct gie_nbpair_mem { const uint64_t *pair; GIE_DEV_MEMBER uint64_t operator()(int, int nid) const { return pair[nid]; } };
+struct gie_nbpair_mem { const gie_ctx *c; GIE_DEV_MEMBER uint64_t operator()(int, int nid) const { return gie_pair_get_id(*c, nid); } };
 /* `sink.ab(c, push, crd, a)` = the outside neighbour at global coordinate crd (address a) joins frontier B (push == 1) or
  * frontier A (push == 2); called by every executing lane for every direction: straight into the queues with one atomic per
  * wave and call (gie_absink_queues), or collected per tile in LDS (k_frontier_tiles) */
@@ -842,7 +886,7 @@ GIE_DEV int gie_frontier_finish_nb(const gie_ctx &c, int id, int x, int y, int z
 }
 GIE_DEV int gie_frontier_finish(const gie_ctx &c, int id, int x, int y, int z, const gie_frontier_st &s)
 {
-    const gie_nbpair_mem nb = { c.pair };
+    const gie_nbpair_mem nb = { &c };
     return gie_frontier_finish_nb(c, id, x, y, z, s, nb, gie_absink_queues());
 }
 GIE_DEV int gie_frontier_voxel(const gie_ctx &c, int x, int y, int z)
@@ -942,7 +986,7 @@ GIE_DEV void gie_pair_flush_voxel(const gie_ctx &c, const gie_flush_boxes &b, in
                                                                    * (a voxel of a cleared tile whose record was left to the pair plane carries no mark either: those are
                                                                    * brought up to date by the catch-up over the OLD tiles, which gie_fuse runs whenever this form of the
                                                                    * flush does — gie_coc_catchup_column stores the ones outside the new volume too) */
-    const uint64_t pr = c.pair[id];
+    const uint64_t pr = gie_pair_get(c, id, x, y, z);
     if (gie_pair_dist(pr) != c.empty_value) {         /* committed by that update: the pair it would have stored */
         int cw[3];
         gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
@@ -1117,7 +1161,7 @@ GIE_UNROLL
         const int pz = z0 + k + c.prev_shift[2];
         const bool in = k < nz && cin && pz >= 0 && pz < c.Z;
         fl[k] = in ? c.tskip_prev[gie_tile_index(c, px, py, pz)] : (uint8_t)0;
-        pr[k] = in ? c.pair[gie_lid(c, px, py, pz)] : gie_pair_make(c.empty_value, GIE_PAR_NONE);
+        pr[k] = in ? gie_pair_get(c, gie_lid(c, px, py, pz), px, py, pz) : gie_pair_make(c.empty_value, GIE_PAR_NONE);
     }
     const int gz0 = z0 + c.pvt[2];
     const int slot_lo = c.blk_tab[gie_tab_index(c, gx, gy, gz0)], slot_hi = c.blk_tab[gie_tab_index(c, gx, gy, gz0 + nz - 1)];
@@ -1210,7 +1254,8 @@ GIE_DEV int gie_markc_finish(const gie_ctx &c, int id, int x, int y, int z, cons
         gie_edt_before_keep(c, id, pr, (ub >> (z & 7)) & 1u);
         if ((ub >> (z & 7)) & 1u) *u = (uint8_t)(ub & ~(1u << (z & 7)));
     }
-    c.pair[id] = pr;
+    if (c.coc_defer && s.skipold == 2 && c.lazy_ok) c.tlazy[gie_tile_index(c, x, y, z)] = 1;      /* "lazy pairs": pr is gie_pair_of_bcoc(s.bc) here, and is not stored */
+    else c.pair[id] = pr;
     if (!(c.coc_defer && s.skipold == 2)) gie_commit_pair<false>(c, id, s.a, pr);       /* (a tskip tile of the second update running: the pair plane is the record — "deferred records" below) */
     const int d = gie_pair_dist(pr);
     return d == c.empty_value ? GIE_TMAX_INF : d + 1;
@@ -1282,7 +1327,7 @@ GIE_DEV void gie_coc_catchup_column(const gie_ctx &c, const gie_catchup &p, int 
         }
         const int px = gx - p.ppvt[0], py = gy - p.ppvt[1], pz = gz - p.ppvt[2];
         if (!gie_in_loc(c, px, py, pz)) continue;          /* (cannot happen: a tskip tile lies inside the volume of the merge before) */
-        const uint64_t pr = c.pair[gie_lid(c, px, py, pz)];
+        const uint64_t pr = gie_pair_get(c, gie_lid(c, px, py, pz), px, py, pz);
         if (gie_pair_dist(pr) == c.empty_value) continue;  /* (cannot happen either: such an update clears no tile) */
         if ((gz >> 3) != slot_bz) {                        /* (one coalesced table read instead of a chain of hash probes where the table covers the voxel) */
             slot_bz = gz >> 3;
@@ -1306,7 +1351,7 @@ GIE_DEV bool gie_deferred_coc(const gie_ctx &c, int gx, int gy, int gz, uint64_t
     if (!gie_in_loc(c, lx, ly, lz) || !c.tskip[gie_tile_index(c, lx, ly, lz)]) return false;
     const int px = gx - c.pp_pvt[0], py = gy - c.pp_pvt[1], pz = gz - c.pp_pvt[2];
     if (!gie_in_loc(c, px, py, pz)) return false;
-    const uint64_t pr = c.pair[gie_lid(c, px, py, pz)];
+    const uint64_t pr = gie_pair_get(c, gie_lid(c, px, py, pz), px, py, pz);
     if (gie_pair_dist(pr) == c.empty_value) return false;
     int cw[3];
     gie_unpack_wr(gie_pair_par(pr), &cw[0], &cw[1], &cw[2]);
@@ -1452,7 +1497,7 @@ GIE_DEV int gie_refine_entry(const gie_ctx &c, int j)
 /* ================================================================== export for the readers */
 GIE_DEV void gie_export_pair(const gie_ctx &c, int id, int32_t *dist_sq, int32_t *coc_xyz)
 {
-    const uint64_t pr = c.pair[id];
+    const uint64_t pr = gie_pair_get_id(c, id);
     const int d = gie_pair_dist(pr);
     if (dist_sq) dist_sq[id] = d;
     if (coc_xyz) {

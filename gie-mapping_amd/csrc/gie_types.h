@@ -120,6 +120,13 @@ typedef struct gie_ctx {
     int skip2_ok;           /* tskip_prev describes the tiles of the update right before this one, at the pose prev_shift refers to: a tile may be flagged 2 */
     int catchup_fast;       /* gie_tile_oldskip also says which tiles of this update need their deferred records stored (tskip_prev is the update before's, at prev_shift) */
     int coc_defer;          /* Mark + commit leaves the stored obstacle of skip tiles' voxels unwritten this update (gie_ops.h "deferred records") */
+    /* LAZY PAIRS (round 6, gie_ops.h "lazy pairs"): in a tile the sweep's short way handles (tskip 2, records deferred, volume inside the wave
+     * range) the pair of a voxel is a function of its batch obstacle, and the sweep does not store it: the tile is flagged, readers derive */
+    uint8_t *tlazy;         /* per tile: the pairs of the tile's voxels are NOT in the pair plane: they are gie_pair_of_bcoc(bcoc_lazy[id]) at pivots pp_pvt / pp_upvt.
+                             * ONE plane, never swapped or cleared with the frame: it says what the pair plane holds NOW (set by the sweep, taken away by whoever
+                             * writes the tile's pairs) */
+    const uint32_t *bcoc_lazy; /* the batch-obstacle plane the flags refer to (the one of the last merge; `bcoc` alternates between two planes) */
+    int lazy_ok;            /* this update's sweep may leave pairs out: the volume lies inside the wave range and is not one tile of several */
     int qdefer;             /* readers of single global voxels (gie_query_global*): a voxel of a tskip tile has its record in the pair plane ... */
     int pp_pvt[3], pp_upvt[3]; /* ... which was written at this pivot / wave-range pivot */
     int prev_valid;         /* tmax_prev describes the map update right before this one */

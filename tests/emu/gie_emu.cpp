@@ -181,6 +181,15 @@ static void be_coc_catchup(be_state *, const gie_ctx &c, const gie_catchup &p)
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
     for (int t = 0; t < ntile; t++) if (gie_coc_catchup_tile(c, p, t)) for (int l = 0; l < 64; l++) gie_coc_catchup_column(c, p, t, l);
 }
+static void be_pair_materialise(be_state *, const gie_ctx &c, int stay)
+{   /* k_pair_lazy_list + k_pair_lazy_run: the flagged tiles that will not be flagged again */
+    const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
+    for (int t = 0; t < ntile; t++) {
+        if (!c.tlazy[t] || (stay && c.tskip[t] == 2)) continue;
+        for (int l = 0; l < 64; l++) gie_pair_materialise_column(c, t, l);
+        c.tlazy[t] = 0;
+    }
+}
 static void be_tile_oldskip(be_state *, const gie_ctx &c, const int pupvt[3])
 {   /* k_tile_oldskip + k_coc_catchup_new */
     const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
@@ -401,7 +410,7 @@ static void be_wave_b(be_state *, const gie_ctx &c)
                             const int cl3[3] = { sn[e].cc[0] - c.pvt[0], sn[e].cc[1] - c.pvt[1], sn[e].cc[2] - c.pvt[2] };
                             if (gie_in_whole(c, cl3[0], cl3[1], cl3[2]) && !gie_in_loc(c, cl3[0], cl3[1], cl3[2])) continue;   /* (tiling: gie_frontier_outside) */
                             const int nid = gie_lid(c, nb[0], nb[1], nb[2]);
-                            const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? pdist(c.pair[nid]) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
+                            const int ref = (c.glb_type[nid] != GIE_VOX_UNKNOWN) ? pdist(gie_pair_get_id(c, nid)) : gie_batch_dist_direct(c, nb[0], nb[1], nb[2]);
                             if (ref > cand) {
                                 uint64_t *lp = &c.lprop[gie_bdr_index(c, nb[0], nb[1], nb[2])];
                                 if (*lp == GIE_NOPROP) inl.push_back(nid);
@@ -434,6 +443,13 @@ static void be_wave_b(be_state *, const gie_ctx &c)
 /* wave C in the canonical tile-round schedule: sequential statement on the device data structures — the seeds are
  * the voxels of qc[0] with their pairs in cand[1]; proposals across tile borders travel through the candidate planes (parity of
  * the round) like on the device, proposals inside a tile through a scratch plane (the device keeps those in LDS) */
+/* "lazy pairs": whoever writes a pair of a flagged tile first puts the tile's 512 pairs into the plane (gie_wave_c_tile's write-back) */
+static void emu_pair_store(const gie_ctx &c, int id, uint64_t pr)
+{
+    const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y), t = gie_tile_index(c, x, y, z);
+    if (c.tlazy[t]) { for (int l = 0; l < 64; l++) gie_pair_materialise_column(c, t, l); c.tlazy[t] = 0; }
+    c.pair[id] = pr;
+}
 static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
 {
     const int n0 = c.cnt[GIE_CNT_C] < c.qcap_c ? c.cnt[GIE_CNT_C] : c.qcap_c;
@@ -442,8 +458,8 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     auto tile = [&](int id) { const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y); return gie_tile_index(c, x, y, z); };
     auto set_pair = [&](int id, uint64_t pr) {
-        if (c.glb_type[id] == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, id, id % c.X, (id / c.X) % c.Y, id / (c.X * c.Y), c.pair[id]);
-        c.pair[id] = pr;
+        if (c.glb_type[id] == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, id, id % c.X, (id / c.X) % c.Y, id / (c.X * c.Y), gie_pair_get_id(c, id));
+        emu_pair_store(c, id, pr);
         if (c.fused) {
             const int x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
             gie_commit_merged(c, id, c.glb_type[id], c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])], x, y, z, pr);
@@ -471,7 +487,7 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
             while (!L.empty()) {
                 c.cnt[GIE_CNT_VIS_C] += (int)L.size(); *reinterpret_cast<long long *>(&c.cnt[GIE_CNT_TOT_C]) += (long long)L.size();
                 std::vector<uint64_t> par(L.size());
-                for (size_t e = 0; e < L.size(); e++) par[e] = gie_pair_par(c.pair[L[e]]);
+                for (size_t e = 0; e < L.size(); e++) par[e] = gie_pair_par(gie_pair_get_id(c, L[e]));
                 std::vector<int> touched, Ln;
                 for (size_t e = 0; e < L.size(); e++) {
                     const int id = L[e], x = id % c.X, y = (id / c.X) % c.Y, z = id / (c.X * c.Y);
@@ -491,7 +507,7 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
                 }
                 for (int nid : touched) {
                     if (lp[(size_t)nid] == GIE_NOPROP) continue;
-                    if (gie_pair_dist(c.pair[nid]) > gie_pair_dist(lp[(size_t)nid])) { set_pair(nid, lp[(size_t)nid]); Ln.push_back(nid); }
+                    if (gie_pair_dist(gie_pair_get_id(c, nid)) > gie_pair_dist(lp[(size_t)nid])) { set_pair(nid, lp[(size_t)nid]); Ln.push_back(nid); }
                     lp[(size_t)nid] = GIE_NOPROP;
                 }
                 L.swap(Ln);
@@ -500,7 +516,7 @@ static void be_wave_c(be_state *, const gie_ctx &c, int record_seeds, int)
         std::vector<int> next;
         for (int nid : xtouched) {
             if (xplane[nid] == GIE_NOPROP) continue;
-            if (gie_pair_dist(c.pair[nid]) > gie_pair_dist(xplane[nid])) { set_pair(nid, xplane[nid]); next.push_back(nid); }
+            if (gie_pair_dist(gie_pair_get_id(c, nid)) > gie_pair_dist(xplane[nid])) { set_pair(nid, xplane[nid]); next.push_back(nid); }
             xplane[nid] = GIE_NOPROP;
         }
         cur.swap(next);
@@ -540,7 +556,8 @@ static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int
     int round = 0;
     while (!list[round & 1].empty()) {
         uint64_t *rd = c.cand[(round + 1) & 1], *wr = c.cand[round & 1];
-        const std::vector<uint64_t> snap(c.pair, c.pair + c.N);       /* the halos of the round */
+        std::vector<uint64_t> snap((size_t)c.N);       /* the halos of the round */
+        for (int i = 0; i < c.N; i++) snap[(size_t)i] = gie_pair_get_id(c, i);
         list[(round + 1) & 1].clear();
         long long vis = 0;
         for (const int t : list[round & 1]) {
@@ -556,7 +573,7 @@ static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int
                 pair[v] = 0; prop[v] = GIE_NOPROP;                   /* a position outside the volume: distance 0, never improved */
                 if (in[v]) {
                     const int id = gie_lid(c, x, y, z);
-                    pair[v] = c.pair[id]; prop[v] = rd[id];
+                    pair[v] = gie_pair_get_id(c, id); prop[v] = rd[id];
                     if (prop[v] != GIE_NOPROP) { rd[id] = GIE_NOPROP; pend.push_back(v); }
                 }
                 loaded[v] = pair[v];
@@ -584,7 +601,7 @@ static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int
                         if (d >= c.empty_value) continue;
                         const bool inside = (unsigned)ux < 8u && (unsigned)uy < 8u && (unsigned)uz < 8u;
                         const int nid = gie_lid(c, nx, ny, nz);
-                        const uint64_t seen = inside ? pair[ux + 8 * uy + 64 * uz] : (g_emu_wave_c_device == 2 ? c.pair[nid] : snap[(size_t)nid]);   /* (2: the other end of the device's race — a halo read sees the write-backs of the tiles taken before this one in the same round) */
+                        const uint64_t seen = inside ? pair[ux + 8 * uy + 64 * uz] : (g_emu_wave_c_device == 2 ? gie_pair_get_id(c, nid) : snap[(size_t)nid]);   /* (2: the other end of the device's race — a halo read sees the write-backs of the tiles taken before this one in the same round) */
                         if (!(d < gie_pair_dist(seen)) && (inside || round != 0 || r0filter)) continue;
                         const uint64_t key = gie_pair_make(d, par);
                         if (inside) {
@@ -601,7 +618,7 @@ static void be_wave_c_device(be_state *, const gie_ctx &c, int record_seeds, int
                 const int x = x0 + (v & 7), y = y0 + ((v >> 3) & 7), z = z0 + (v >> 6);
                 const int id = gie_lid(c, x, y, z);
                 if (c.glb_type[id] == GIE_VOX_UNKNOWN) gie_edt_unknown_touch(c, id, x, y, z, loaded[v]);
-                c.pair[id] = pair[v];
+                emu_pair_store(c, id, pair[v]);
                 if (c.fused) gie_commit_merged(c, id, c.glb_type[id], c.blk_tab[gie_tab_index(c, x + c.pvt[0], y + c.pvt[1], z + c.pvt[2])], x, y, z, pair[v]);
             }
             const int dt[6] = { -1, 1, -c.tfd[0], c.tfd[0], -c.tfd[0] * c.tfd[1], c.tfd[0] * c.tfd[1] };

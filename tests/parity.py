@@ -84,6 +84,13 @@ UNEVEN_DRIVES = [
 ]
 
 
+# A fuse WITHOUT a merge, then a jump (round 6): the tiles the abandoned fuse flagged 1 — "the sweep will store them" — still held
+# voxels whose records the merge before had left to its pair plane, and only the tiles flagged 2 were caught up; found while the
+# lazy pairs were built (the unfixed sources fail frame 4: 95 voxels near a corner of the volume keep a stale closest obstacle).
+FUSE_ONLY_THEN_JUMP = Scenario("fuse_only_then_jump", (64, 64, 64), voxel=0.05, sensor="labels", seed=5, p_occ=0.01, toggle=0.25, frames=7, cutoff_dist=1.0,
+                               steps=[(1, 0, 0), (2, 1, 0), (1, 0, -1), (9, -7, 6), (1, 1, 1), (0, 0, 1)])
+
+
 def _feed(m, kind, data, kw):
     if kind == "depth":
         m.ogm_depth(data, **kw)

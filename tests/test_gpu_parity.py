@@ -784,6 +784,13 @@ IRREGULAR = [("mixed", (3, 6), ()), ("blink_empty_scans", (3, 6, 7, 11), ()), ("
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse_only,stream_on", [((3,), ()), ((3,), (5,)), ((2, 3), ())], ids=["f3", "f3-s5", "f2_3"])
+def test_fuse_without_merge_then_jump(oracle_lib, fuse_only, stream_on):
+    """parity.FUSE_ONLY_THEN_JUMP: an abandoned fuse's tiles flagged 1 hold deferred records too (round 6)."""
+    parity.run_irregular(parity.FUSE_ONLY_THEN_JUMP, OracleMapper, gie.Mapper, fuse_only=set(fuse_only), stream_on=set(stream_on))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,fuse_only,stream_on", IRREGULAR, ids=["%s-f%s-s%s" % (n, "_".join(map(str, f)), "_".join(map(str, s))) for n, f, s in IRREGULAR])
 def test_irregular_call_orders(oracle_lib, name, fuse_only, stream_on):
     """gie_fuse without a merge behind it, and runs that change between the fused sweep and the reference's order (see

@@ -241,6 +241,11 @@ def test_irregular_call_orders_emulation(oracle_lib, name, fuse_only, stream_on)
     parity.run_irregular(sc, OracleMapper, EmuMapper, fuse_only=set(fuse_only), stream_on=set(stream_on))
 
 
+@pytest.mark.parametrize("fuse_only,stream_on", [((3,), ()), ((3,), (5,)), ((2, 3), ())], ids=["f3", "f3-s5", "f2_3"])
+def test_fuse_without_merge_then_jump_emulation(oracle_lib, fuse_only, stream_on):
+    parity.run_irregular(parity.FUSE_ONLY_THEN_JUMP, OracleMapper, EmuMapper, fuse_only=set(fuse_only), stream_on=set(stream_on))
+
+
 def _jumping_robot(make_b, updates=150):
     """A robot that lands on new ground in every update (jumps of 100 voxels) with block retention on: every update erases all it
     held.  The tombstones of the erased blocks use up the hash table's EMPTY cells — 125 per update against a table of 512

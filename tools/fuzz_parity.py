@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="volume sides of 96 ... 192 voxels (thousands of active blocks per wave round)")
     ap.add_argument("--only", type=int, default=-1, help="run scenario number N of the seed only")
     ap.add_argument("--device-wave-c", action="store_true", help="with --emu: the emulation runs its model of the DEVICE's wave C tile rounds (gie_emu.cpp be_wave_c_device) instead of the canonical statement")
+    ap.add_argument("--irregular", action="store_true", help="every third scenario through parity.run_irregular: random updates stop after gie_fuse, random updates run with gie_stream_enable")
     ap.add_argument("--drive", default=None, choices=[None, "line", "random"], help="line: constant steps along x (rounds 1-5); random: per-frame steps on all axes with jumps; default: half and half")
     ap.add_argument("--focus", default=None, choices=[None, "retain"], help="retain: every scenario erases blocks (retain_radius_blocks 1-3) on a drive that turns round")
     args = ap.parse_args()
@@ -133,7 +134,15 @@ def main():
         desc = "%s %s voxel %.2f %s frames %d delta %d cutoff %.1f fast %d planner %d boxes %d retain %d turn %d" % (
             sc.name, sc.size, sc.voxel, sc.sensor, sc.frames, sc.delta_vox, sc.cutoff_dist, sc.fast_mode, sc.for_motion_planner, sc.ext_boxes, sc.retain, sc.turn) + (" steps %s" % (sc.steps,) if sc.steps else "")
         try:
-            st = parity.run_and_compare(sc, OracleMapper, Under, production=bool(i % 2))
+            if args.irregular and i % 3 == 0:
+                # the staged ABI off the beaten path: some updates stop after gie_fuse, some run with the changed-block flags on
+                fo = set(int(k) for k in range(1, sc.frames) if rng.random() < 0.25)
+                so = set(int(k) for k in range(1, sc.frames) if rng.random() < 0.2)
+                desc += " fuse-only %s stream %s" % (sorted(fo), sorted(so))
+                parity.run_irregular(sc, OracleMapper, Under, fuse_only=fo, stream_on=so)
+                st = []
+            else:
+                st = parity.run_and_compare(sc, OracleMapper, Under, production=bool(i % 2))
         except AssertionError as e:
             print("MISMATCH seed %d #%d: %s\n   %s" % (args.seed, i - 1, desc, str(e).splitlines()[0]), flush=True)
             sys.exit(1)

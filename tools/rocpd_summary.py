@@ -19,7 +19,7 @@ SHORT = [
     (r"op_classify|k_labels16", "ogm_classify"), (r"op_register_point", "ray_register"), (r"k_free_rays|op_free_ray", "ray_free"),
     (r"op_raycast_finalize", "ray_finalize"), (r"op_fuse|k_fuse_rows", "fuse"), (r"k_edt_y", "edt_pass_y"), (r"k_edt_x", "edt_pass_x"),
     (r"k_edt_prep", "edt_prep"), (r"k_edt_z_direct", "edt_pass_z.direct"), (r"k_edt_z_stream", "edt_pass_z.stream"), (r"k_edt_z", "edt_pass_z.column"), (r"k_round_note", "halo.round_note"), (r"k_markc|op_markc|op_tile_oldskip", "mark_commit"), (r"op_pair_flush|op_evict|op_rehash", "block_alloc"), (r"op_mark", "mark"), (r"k_frontier_faces", "frontiers.faces"), (r"op_frontier|k_frontier_tiles", "frontiers.tiles"), (r"k_waves_ab", "waves.ab"), (r"k_waves_c", "waves.c"), (r"k_waves", "waves"), (r"op_commit", "commit"),
-    (r"k_tile_oldskip", "block_alloc.oldskip"), (r"k_coc_catchup_list", "block_alloc.catchup_list"), (r"k_coc_catchup_run", "block_alloc.catchup_run"), (r"k_coc_catchup_new", "block_alloc.catchup_new"), (r"k_flush_clear", "block_alloc.flush_clear"), (r"k_cell_alloc", "block_alloc.cell_alloc"), (r"k_block_init", "block_alloc.block_init"), (r"op_stream", "stream_changed"), (r"k_place_probe", "create.place_probe"), (r"k_cell_alloc|k_block_init|k_clear|k_flush_clear|op_cell_|k_pool_advance|rocprim", "block_alloc"),
+    (r"k_tile_oldskip", "block_alloc.oldskip"), (r"k_pair_lazy_list", "block_alloc.lazy_list"), (r"k_pair_lazy_run", "block_alloc.lazy_run"), (r"k_coc_catchup_list", "block_alloc.catchup_list"), (r"k_coc_catchup_run", "block_alloc.catchup_run"), (r"k_coc_catchup_new", "block_alloc.catchup_new"), (r"k_flush_clear", "block_alloc.flush_clear"), (r"k_cell_alloc", "block_alloc.cell_alloc"), (r"k_block_init", "block_alloc.block_init"), (r"op_stream", "stream_changed"), (r"k_place_probe", "create.place_probe"), (r"k_cell_alloc|k_block_init|k_clear|k_flush_clear|op_cell_|k_pool_advance|rocprim", "block_alloc"),
 
 ]
 
