@@ -864,8 +864,9 @@ static int gie_fetch_counters(gie_mapper *m)
     const int e = m->h_cnt[GIE_CNT_ERR];
     {   /* GIE_DEBUG_COUNTS=1: the lengths of the device-side lists of the last map update, on stderr */
         static const int dbg = GIE_SWITCH("GIE_DEBUG_COUNTS", 0);
-        if (dbg) fprintf(stderr, "gie counts: tiles known %d, frontier tiles %d, fuse tiles %d, seeds A/B/C %d %d %d, tiles without a read of the stored records %d\n", m->h_cnt[GIE_CNT_TL_KNOWN],
-                         m->h_cnt[GIE_CNT_TL_FRONT], m->h_cnt[GIE_CNT_TL_FUSE], m->h_cnt[GIE_CNT_SEED_A], m->h_cnt[GIE_CNT_SEED_B], m->h_cnt[GIE_CNT_SEED_C], m->h_cnt[GIE_CNT_TSKIP]);
+        if (dbg) fprintf(stderr, "gie counts: tiles known %d, frontier tiles %d, fuse tiles %d, seeds A/B/C %d %d %d, tiles without a read of the stored records %d, tiles caught up %d, lazy tiles written out %d\n", m->h_cnt[GIE_CNT_TL_KNOWN],
+                         m->h_cnt[GIE_CNT_TL_FRONT], m->h_cnt[GIE_CNT_TL_FUSE], m->h_cnt[GIE_CNT_SEED_A], m->h_cnt[GIE_CNT_SEED_B], m->h_cnt[GIE_CNT_SEED_C], m->h_cnt[GIE_CNT_TSKIP],
+                         m->h_cnt[GIE_CNT_STATE1], m->h_cnt[GIE_CNT_STATE2]);
     }
     if (e & ~GIE_ERRF_BARRIER) {
         std::string s = "device capacity exceeded:";

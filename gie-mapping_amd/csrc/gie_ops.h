@@ -1109,11 +1109,19 @@ GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* all
     }
     int v = 0;
     if (can && allow) {
-        long long d = 0;
+        long long d = 0, dl = 0;
         for (int z = o0[2]; z <= o1[2] && can; z++) for (int y = o0[1]; y <= o1[1] && can; y++) for (int x = o0[0]; x <= o1[0]; x++) {
-            const int w = c.tmax_prev[(z * c.tfd[1] + y) * c.tfd[0] + x];
+            const int ot = (z * c.tfd[1] + y) * c.tfd[0] + x;
+            const int w = c.tmax_prev[ot];
             if (w <= 0 || w == GIE_TMAX_INF) { can = false; break; }
             if (w - 1 > d) d = w - 1;
+            /* what the bound of a LAZY tile would be ("lazy pairs" below: the sweep bounds such a tile from a few samples, up to
+             * (sqrt(d) + 5)^2): a tile only becomes one if it would also stay one — a tile of the layer where the exact bound clears
+             * and the loose one does not would be lazy in one update, swept in the next, and every turn costs a catch-up of its
+             * 512 records and 512 pairs written out (round 6: 17 K tiles caught up and 13 K written out per update of the headline) */
+            long long wl = w - 1;
+            if (!c.tlazy[ot]) { long long r = (long long)sqrtf((float)wl); while (r * r < wl) r++; wl = (r + 5) * (r + 5); }
+            if (wl > dl) dl = wl;
         }
         /* |obstacle - voxel| <= sqrt(d) < distance to the nearest face, on every axis.  2 = ... and the voxels' tiles of the update before
          * were such tiles too: only then does the sweep leave the tile's records to the pair plane ("deferred records").  A tile at the
@@ -1121,7 +1129,7 @@ GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* all
          * catch-up of its 512 records — more than the stores it saves (round 5, the projective lidar workload: 0.07 ms per update). */
         if (can && d < reach2) {
             v = 1;
-            if (c.skip2_ok) {
+            if (c.skip2_ok && (dl < reach2 || !c.lazy_ok)) {
                 v = 2;
                 for (int z = o0[2]; z <= o1[2]; z++) for (int y = o0[1]; y <= o1[1]; y++) for (int x = o0[0]; x <= o1[0]; x++)
                     if (!c.tskip_prev[(z * c.tfd[1] + y) * c.tfd[0] + x]) v = 1;

@@ -209,7 +209,7 @@ enum {
     GIE_CNT_SEED_A, GIE_CNT_SEED_B, GIE_CNT_SEED_C,
     GIE_CNT_ZSTREAM,                            /* pass Z: the streaming form has done the volume, the column kernel only repairs the tiles flagged in zredo */
     GIE_CNT_ZFAIL,                              /* pass Z, streaming form: slabs it gave up (the column kernel has nothing to repair when 0) */
-    GIE_CNT_STATE1, GIE_CNT_STATE2,             /* (unused) */
+    GIE_CNT_STATE1, GIE_CNT_STATE2,             /* lengths of the fuse-time tile lists: deferred records to store (be_tile_oldskip, be_coc_catchup), lazy tiles to write out (be_pair_materialise) */
     GIE_CNT_FRAME_END = 28,                     /* [0, FRAME_END) minus ERR are zeroed every frame */
     GIE_CNT_TOT_A = 28, GIE_CNT_TOT_B = 30, GIE_CNT_TOT_C = 32, /* 64-bit running totals (2 words each) */
     GIE_CNT_BAR_B = 34,                         /* grid-barrier word of wave C's launch (first word of the second cleared range) */
