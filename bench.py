@@ -55,7 +55,8 @@ ALG_BYTES = {
 LAYOUT_BYTES = {
     "ogm_classify": 1, "fuse": 6, "edt_pass_y": 3, "edt_pass_x": 6, "edt_pass_z": 8,
     "mark": 25, "frontiers": 9, "commit": 25, "mark_commit": 13,    # (round 4: `_edt_D` is derived from the pairs, no 4-byte store; round 5: the stored
-                                                                    #  obstacle of a tskip tile's voxels is left to the pair plane: type 1 + batch obstacle 4 + pair 8)
+                                                                    #  obstacle of a tskip tile's voxels is left to the pair plane: type 1 + batch obstacle 4 + pair 8;
+                                                                    #  round 6: only the tiles on the volume's faces have to be swept at all, kernel_roof())
 }
 WAVE_VISIT_BYTES = 64      # own record + six 8-byte read-modify-writes
 RAY_CELL_BYTES = 13        # row R: 1 B label read + 4 B atomic + 4 B return + ray state amortised
@@ -553,6 +554,15 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
             u = units.get(name, n_vox)
             b = alg[name] * u
             lay = LAYOUT_BYTES.get(name, alg[name]) * u
+            if name == "mark_commit":
+                # round 6 ("lazy pairs"): a cleared tile whose records are deferred is not swept at all -- its pairs are derived from the
+                # batch-obstacle plane by whoever reads them -- and only a tile on a face of the volume can never be one: what the
+                # layout HAS to move is the face tiles' 13 B per voxel (how many tiles are lazy in a given update is the scene's business)
+                tiles = [(e + 7) // 8 for e in size]
+                inner = 1
+                for t_ in tiles:
+                    inner *= max(t_ - 2, 0)
+                lay = lay * (1.0 - inner / float(tiles[0] * tiles[1] * tiles[2]))
             what = {"alg_bytes_per_voxel": alg[name], "layout_bytes_per_voxel": LAYOUT_BYTES.get(name, alg[name]), "voxels_per_launch": u}
         elif name == "waves":
             b = lay = WAVE_VISIT_BYTES * visits_instr

@@ -221,6 +221,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.zlist = gie_dalloc<uint16_t>(m, (size_t)c.Z + 8);
     c.zcount = gie_dalloc<int32_t>(m, 4);
     c.tl_known = gie_dalloc<int32_t>(m, ntile);
+    c.tl_swept = gie_dalloc<int32_t>(m, ntile);
     c.tl_front = gie_dalloc<int32_t>(m, ntile);
     { const int force = GIE_SWITCH("GIE_TILE_LIST", -1); c.force_lists = force < 0 ? -1 : (force != 0); }   /* tests force lists / sweeps */
     const int bdr = 2 * (X * Y + Y * Z + X * Z);

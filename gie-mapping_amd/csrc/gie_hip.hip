@@ -394,7 +394,9 @@ static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list)
     static const int lx = GIE_SWITCH("GIE_MARKC_LX", 32);
     static const int mult = GIE_SWITCH("GIE_VOXA_MULT", 64);     /* workgroups per compute unit of the dense sweep: 16 / 32 / 48 / 64 / 96 / 128 measured 1.00 / 0.80 / 0.78 / 0.76 / 0.78 / 0.79 ms at 512^3 (round 4; 64 = exactly four virtual workgroups each) */
     if (generic) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0, lx == 16 || lx == 8 || lx == 32 ? lx : 64); return; }
-    const dim3 g(b->cu_total * mult), t(256);
+    /* with lazy tiles the kernel walks the swept tiles, a wave each (k_markc): a grid that is resident at once */
+    static const int lmult = GIE_SWITCH("GIE_MARKC_LGRID", 40);      /* (5 / 10 / 20 / 40 / 64 / 96 per compute unit: 0.193 / 0.186 / 0.178 / 0.174 / 0.179 / 0.180 ms on the headline — a wave per swept tile, no second tile behind it) */
+    const dim3 g(b->cu_total * ((c.coc_defer && c.lazy_ok) ? lmult : mult)), t(256);
     if (lx == 16) GIE_LAUNCH(b, k_markc<16>, g, t, 0, c, list);
     else if (lx == 64) GIE_LAUNCH(b, k_markc<64>, g, t, 0, c, list);
     else GIE_LAUNCH(b, k_markc<32>, g, t, 0, c, list);

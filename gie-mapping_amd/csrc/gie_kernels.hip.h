@@ -1425,6 +1425,9 @@ __global__ __launch_bounds__(64 * GIE_PREP_WAVES) void k_edt_prep(const gie_ctx 
         /* the same tiles as a list (mark / commit / pass Z visit only these when they are few): one atomic per workgroup */
         const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_KNOWN], k);
         if (slot >= 0) c.tl_known[slot] = t;
+        /* ... and the ones among them that are not flagged 2 (gie_fuse has flagged): what the fused sweep walks when the others are lazy */
+        const int slot2 = gie_wg_reserve(&c.cnt[GIE_CNT_TL_SWEPT], k && c.tskip[t] != 2);
+        if (slot2 >= 0) c.tl_swept[slot2] = t;
         /* (the tiles whose stored records Mark need not read — tskip — are flagged by gie_fuse since round 5: be_tile_oldskip) */
     }
 }
@@ -1614,6 +1617,17 @@ __device__ __forceinline__ void gie_markc_lazy_tile(const gie_ctx &c, const int 
     }
     c.tmax[t] = vmax;
     c.tlazy[t] = 1;
+    /* Mark "has written" the tile's indices: its 64 `ucol` bytes, eight rows of eight (a whole tile: tskip 2) */
+    uint8_t *const u0 = c.ucol + gie_ucol_index(c, x, y, z0);
+    if ((c.X & 7) == 0) {
+        uint64_t ub[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) ub[r] = *reinterpret_cast<const uint64_t *>(u0 + (size_t)r * c.X);
+#pragma unroll
+        for (int r = 0; r < 8; r++) if (ub[r]) *reinterpret_cast<uint64_t *>(u0 + (size_t)r * c.X) = 0ull;
+    } else {
+        for (int r = 0; r < 8; r++) for (int q = 0; q < 8; q++) if (u0[(size_t)r * c.X + q]) u0[(size_t)r * c.X + q] = 0;
+    }
 }
 /* What a column's thread looks at first: is the tile known, how are its old records treated, the column's `ucol` byte (packed
  * into one word), and the (at most two) block slots its eight voxels lie in.  k_markc loads these for a run of virtual workgroups
@@ -1647,10 +1661,7 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     const bool nostore = c.coc_defer && skipold == 2;     /* a tskip tile with deferred records: the sweep neither reads nor writes the global map here */
     const size_t ui = gie_ucol_index(c, x, y, z0);
     const unsigned ub = flags >> 16;                    /* indices that have just turned known: their old pair says nothing about `_edt_D` */
-    if (nostore && c.lazy_ok) {                         /* a lazy tile (gie_markc_lazy_tile): the column's byte, nothing else */
-        if (ub) c.ucol[ui] = (uint8_t)0;
-        return;
-    }
+    if (nostore && c.lazy_ok) return;                   /* (a lazy tile: gie_markc_lazy_tile has done what there is to do; never listed) */
     int8_t ty[8]; uint32_t bc[8]; gie_vaddr a[8]; uint64_t oc[8];
     const int slot_lo = pre.slot_lo, slot_hi = pre.slot_hi;
 #pragma unroll
@@ -1731,18 +1742,28 @@ __device__ __forceinline__ void gie_markc_column_fast(const gie_ctx &c, const in
     if (ub & known) c.ucol[ui] = (uint8_t)(ub & ~known);           /* (the byte is this thread's) */
     gie_markc_column(c, x, y, z0, known, valid, vmax);
 }
+#ifndef GIE_MARKC_OCC
+#define GIE_MARKC_OCC 5
+#endif
 template <int LX>
-__global__ __launch_bounds__(256, 5) void k_markc(const gie_ctx c, const int32_t *list)   /* (five waves per SIMD: 96 registers; one more costs the sweep a tenth of its time) */
+__global__ __launch_bounds__(256, GIE_MARKC_OCC) void k_markc(const gie_ctx c, const int32_t *list)   /* (five waves per SIMD: 96 registers; one more costs the sweep a tenth of its time) */
 {
     const int n = c.cnt[GIE_CNT_TL_KNOWN];
     const int lane = threadIdx.x & 63;
-    if (c.coc_defer && c.lazy_ok) {
+    const bool lazy = c.coc_defer && c.lazy_ok;
+    if (lazy) {
         const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
         for (int t = (int)(blockIdx.x * 256 + threadIdx.x); t < ntile; t += (int)gridDim.x * 256) gie_markc_lazy_tile(c, t);
     }
-    if (gie_use_lists(c, n)) {
+    /* With lazy tiles the sweep is a WALK: a wave per tile of the swept list (k_edt_prep: known, not flagged 2).  The volume-order
+     * sweep below started 16 K workgroups of which 7 K found four lazy runs and left, and 2 K found four runs to sweep one after
+     * the other, 40 us each — per-workgroup stamps (round 6) showed 740 workgroups resident where 1280 fit, the launch as long as
+     * the workgroups could be started, not as long as the work took. */
+    if (lazy || gie_use_lists(c, n)) {
         const int waves = gridDim.x * 4;
-        for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += waves) {
+        if (lazy) { list = c.tl_swept; }
+        const int nl = lazy ? c.cnt[GIE_CNT_TL_SWEPT] : n;
+        for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < nl; e += waves) {
             const int t = list[e];
             const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
             const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
@@ -1756,8 +1777,14 @@ __global__ __launch_bounds__(256, 5) void k_markc(const gie_ctx c, const int32_t
         const int lx = lane % LX, ly = (int)(threadIdx.x >> 6) * LY + lane / LX;
         /* (the virtual workgroup's coordinates by carry, not by three divisions per trip: the scalar unit is shared by the four
          * SIMDs of a compute unit, and round 5's counters had this sweep issue 108 M scalar against 190 M vector instructions) */
-        int v = (int)blockIdx.x * per;
-        const int vend = min(nv, ((int)blockIdx.x + 1) * per);
+        /* Workgroup ids are dealt round-robin over the eight XCDs, and a run of virtual workgroups is a fixed stretch of an x row: with
+         * the identity mapping the runs that hold the volume's -x / +x faces (every fourth run each) all land on XCDs 0, 4 / 3, 7 —
+         * with most tiles lazy those are the runs with work in them, and four XCDs swept while four had finished (round 6,
+         * per-workgroup stamps: 0.16 against 0.30 ms of the launch).  The runs of eight consecutive workgroups are rotated by
+         * the group's number, so that every XCD gets every eighth run of each kind. */
+        const int wg = ((int)gridDim.x & 7) ? (int)blockIdx.x : (((int)blockIdx.x & ~7) | (((int)blockIdx.x + ((int)blockIdx.x >> 3)) & 7));
+        int v = wg * per;
+        const int vend = min(nv, (wg + 1) * per);
         int vx = v % gx, vy = (v / gx) % gy, vz = v / (gx * gy);
         /* four virtual workgroups per trip (the default grid gives a workgroup exactly four): their flags first, together */
         for (; v < vend; v += 4) {

@@ -138,6 +138,7 @@ typedef struct gie_ctx {
     uint16_t *zlist;        /* the planes with obstacles, ascending */
     int32_t *zcount;        /* how many */
     int32_t *tl_known;      /* tiles that hold a known voxel (built by k_edt_prep); count in cnt[GIE_CNT_TL_KNOWN] */
+    int32_t *tl_swept;      /* ... and, of those, the tiles not flagged 2 in tskip — the ones the fused sweep walks while the others are lazy (k_markc); count in cnt[GIE_CNT_TL_SWEPT] */
     int32_t *tl_front;      /* tiles obtainFrontiers has to look at (tsum); count in cnt[GIE_CNT_TL_FRONT] */
     int force_lists;        /* -1: every kernel chooses lists or a volume sweep from its list's length; 0 / 1: forced (tests) */
     uint64_t *lprop;        /* per boundary-face voxel: wave-B proposal for inside voxels */
@@ -199,7 +200,8 @@ typedef struct gie_ctx {
 
 enum {
     GIE_CNT_A = 0, GIE_CNT_B, GIE_CNT_C,        /* seed counts from obtainFrontiers */
-    GIE_CNT_FREE3, GIE_CNT_FREE4, GIE_CNT_FREE5, /* (unused since the waves run in block / tile rounds) */
+    GIE_CNT_TL_SWEPT,                           /* entries in tl_swept */
+    GIE_CNT_FREE4, GIE_CNT_FREE5,               /* (unused since the waves run in block / tile rounds) */
     GIE_CNT_LV0, GIE_CNT_LV1, GIE_CNT_LV2,      /* wave C: entries expanded in a level (rotating) */
     GIE_CNT_ERR,                                /* sticky error flags */
     GIE_CNT_NEWBLK,                             /* blocks allocated this frame */
