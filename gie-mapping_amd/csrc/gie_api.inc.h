@@ -207,6 +207,7 @@ extern "C" gie_mapper *gie_create(const gie_config *cfg)
     c.tunk = c.tflag + ntile; c.tsum = c.tflag + 2 * ntile; c.tray = c.tflag + 3 * ntile; c.tact = c.tflag + 4 * ntile;
     c.tknown = c.tflag + 5 * ntile; c.tknown_prev = c.tflag + 6 * ntile;
     c.tmax = gie_dalloc<int32_t>(m, 2 * ntile);
+    c.tbmax = gie_dalloc<int32_t>(m, ntile);
     c.tmax_prev = c.tmax ? c.tmax + ntile : nullptr;
     c.tskip = gie_dalloc<uint8_t>(m, 2 * ntile);
     c.tskip_prev = c.tskip ? c.tskip + ntile : nullptr;
@@ -680,6 +681,7 @@ extern "C" int gie_fuse(gie_mapper *m)
         add(c.zocc, (size_t)c.Z);
         add(c.zredo, (size_t)((c.X + 15) / 16) * c.Y * sizeof(uint32_t));
         add(c.tmax, ntile * sizeof(int32_t));
+        add(c.tbmax, ntile * sizeof(int32_t));
         add(c.tskip, ntile);
         add(c.cnt, GIE_CNT_ERR * sizeof(int32_t));                 /* per-frame counters (the sticky error flag survives) */
         add(c.cnt + GIE_CNT_ERR + 1, (GIE_CNT_FRAME_END - GIE_CNT_ERR - 1) * sizeof(int32_t));

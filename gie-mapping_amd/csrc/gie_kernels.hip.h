@@ -1308,7 +1308,7 @@ __device__ __noinline__ bool gie_zs_wide_trip(const uint32_t *cxy2, uint32_t *bc
     }
     return true;
 }
-__global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int full, const int nseg, const int seg_len)
+__global__ __launch_bounds__(256, 6) void k_edt_z_stream(const gie_ctx c, const int full, const int nseg, const int seg_len)
 {
     __shared__ uint8_t s_occ[1024 + 2 * (32 + 2 * GIE_ZS_R)];        /* plane holds obstacles, for planes -W .. Z + W (0 outside the volume) */
     const int Z = c.Z, X = c.X, Y = c.Y;
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int
 #pragma unroll
                 for (int j = 0; j < GIE_ZS_C; j++) wk[2 * GIE_ZS_R + j] = gie_zs_key(v[j], (pm >> j) & 1ull, x8, y8, 2 * GIE_ZS_R + j);
             }
-            uint32_t worst = 0;
+            uint32_t wlo = 0, whi = 0;                    /* the largest key of the trip's first / last eight planes (a trip is two tiles high) */
 #pragma unroll
             for (int t = 0; t < GIE_ZS_C; t++) {
                 const int p = GIE_ZS_R + t;
@@ -1366,11 +1366,25 @@ __global__ __launch_bounds__(256) void k_edt_z_stream(const gie_ctx c, const int
 #pragma unroll
                 for (int d = 1; d <= GIE_ZS_R; d++) b = min(b, min(wk[p - d], wk[p + d]) + ((uint32_t)(d * d) << 24));
                 const bool in = zc + t < z1;              /* wave-uniform */
-                if (in) worst = max(worst, b);
+                if (in) { if (t < 8) wlo = max(wlo, b); else whi = max(whi, b); }
                 const int s = zc - GIE_ZS_R + (int)((b >> 18) & 63u);
                 const int cx = x8 - (int)((b >> 13) & 31u), cy = y8 - (int)((b >> 8) & 31u);
                 /* stored at once (no second copy of the trip in registers); a slab given up below is redone as a whole by the column kernel */
                 __builtin_amdgcn_raw_buffer_store_b32(gie_pack_bcoc(cx, cy, s), rs_out, in ? voff : GIE_BUF_OOB, (unsigned)min(zc + t, Z - 1) * pstride, GIE_ZS_STAUX);
+            }
+            const uint32_t worst = max(wlo, whi);
+            {   /* the largest distance of each of the sixteen tiles the trip has crossed a row of (exact below 81; "81 or more" otherwise):
+                 * what the fused sweep bounds its lazy tiles by (k_markc) — eight lanes per tile, one atomic per tile and row */
+                static_assert(GIE_ZS_C == 16, "a trip is two tiles high");
+                uint32_t m0 = x < X ? (wlo >> 24) : 0u, m1 = x < X ? (whi >> 24) : 0u;
+                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, 1)); m1 = max(m1, (uint32_t)__shfl_xor((int)m1, 1));
+                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, 2)); m1 = max(m1, (uint32_t)__shfl_xor((int)m1, 2));
+                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, 4)); m1 = max(m1, (uint32_t)__shfl_xor((int)m1, 4));
+                if ((lane & 7) == 0 && x < X) {
+                    const int t0 = gie_tile_index(c, x, y, zc);
+                    __hip_atomic_fetch_max(&c.tbmax[t0], (int32_t)m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (zc + 8 < z1) __hip_atomic_fetch_max(&c.tbmax[t0 + c.tfd[0] * c.tfd[1]], (int32_t)m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if (__any(x < X && worst >= GIE_ZS_LIMIT)) {  /* wave-uniform: a position of this trip has no obstacle inside the window */
                 if (wide == 2) { failed = true; break; }
@@ -1600,20 +1614,25 @@ __device__ __forceinline__ void gie_markc_lazy_tile(const gie_ctx &c, const int 
     const int x = tx * 8, y = ty * 8, z0 = tz * 8;
     const size_t plane = (size_t)c.X * c.Y;
     const size_t id0 = ((size_t)z0 * c.Y + y) * c.X + x;
-    uint32_t sb[8];
+    /* the bound: pass Z's streaming form has recorded the tile's largest distance on its way (exact below 81) — otherwise eight samples */
+    const int wb = c.cnt[GIE_CNT_ZSTREAM] ? c.tbmax[t] : 0x7fffffff;
+    int vmax = wb <= 80 ? wb + 1 : 0;
+    if (wb > 80) {
+        uint32_t sb[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) sb[k] = c.bcoc[id0 + (size_t)(1 + 4 * (k >> 2)) * plane + (size_t)(1 + 4 * ((k >> 1) & 1)) * c.X + (size_t)(1 + 4 * (k & 1))];
-    int vmax = 0;
+        for (int k = 0; k < 8; k++) sb[k] = c.bcoc[id0 + (size_t)(1 + 4 * (k >> 2)) * plane + (size_t)(1 + 4 * ((k >> 1) & 1)) * c.X + (size_t)(1 + 4 * (k & 1))];
+        vmax = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int sx = x + 1 + 4 * (k & 1), sy = y + 1 + 4 * ((k >> 1) & 1), sz = z0 + 1 + 4 * (k >> 2);
-        int v = GIE_TMAX_INF;
-        if (sb[k] != GIE_BCOC_NONE) {
-            const int dx = sx - (int)(sb[k] & 1023u), dy = sy - (int)((sb[k] >> 10) & 1023u), dz = sz - (int)(sb[k] >> 20);
-            const int r = (int)ceilf(sqrtf((float)(dx * dx + dy * dy + dz * dz))) + 4;
-            v = r * r + 1;
+        for (int k = 0; k < 8; k++) {
+            const int sx = x + 1 + 4 * (k & 1), sy = y + 1 + 4 * ((k >> 1) & 1), sz = z0 + 1 + 4 * (k >> 2);
+            int v = GIE_TMAX_INF;
+            if (sb[k] != GIE_BCOC_NONE) {
+                const int dx = sx - (int)(sb[k] & 1023u), dy = sy - (int)((sb[k] >> 10) & 1023u), dz = sz - (int)(sb[k] >> 20);
+                const int r = (int)ceilf(sqrtf((float)(dx * dx + dy * dy + dz * dz))) + 4;
+                v = r * r + 1;
+            }
+            vmax = v > vmax ? v : vmax;
         }
-        vmax = v > vmax ? v : vmax;
     }
     c.tmax[t] = vmax;
     c.tlazy[t] = 1;
@@ -1752,6 +1771,7 @@ __global__ __launch_bounds__(256, GIE_MARKC_OCC) void k_markc(const gie_ctx c, c
     const int lane = threadIdx.x & 63;
     const bool lazy = c.coc_defer && c.lazy_ok;
     if (lazy) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) c.cnt[GIE_CNT_LAZY_EXACT] = c.cnt[GIE_CNT_ZSTREAM] ? 1 : 0;      /* (gie_tile_oldskip's margin, next update) */
         const int ntile = c.tfd[0] * c.tfd[1] * c.tfd[2];
         for (int t = (int)(blockIdx.x * 256 + threadIdx.x); t < ntile; t += (int)gridDim.x * 256) gie_markc_lazy_tile(c, t);
     }

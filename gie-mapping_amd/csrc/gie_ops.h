@@ -1120,7 +1120,7 @@ GIE_DEV int gie_tile_oldskip(const gie_ctx &c, int t, int allow = 1)      /* all
              * and the loose one does not would be lazy in one update, swept in the next, and every turn costs a catch-up of its
              * 512 records and 512 pairs written out (round 6: 17 K tiles caught up and 13 K written out per update of the headline) */
             long long wl = w - 1;
-            if (!c.tlazy[ot]) { long long r = (long long)sqrtf((float)wl); while (r * r < wl) r++; wl = (r + 5) * (r + 5); }
+            if (!c.tlazy[ot] && !c.cnt[GIE_CNT_LAZY_EXACT]) { long long r = (long long)sqrtf((float)wl); while (r * r < wl) r++; wl = (r + 5) * (r + 5); }      /* (no margin while the lazy tiles' bounds are pass Z's exact ones) */
             if (wl > dl) dl = wl;
         }
         /* |obstacle - voxel| <= sqrt(d) < distance to the nearest face, on every axis.  2 = ... and the voxels' tiles of the update before

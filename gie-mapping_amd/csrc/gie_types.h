@@ -106,6 +106,7 @@ typedef struct gie_ctx {
     uint8_t *tray;          /* per tile: a ray touched it this scan (ray-casting OGM) */
     uint8_t *tact;          /* per tile: fuse has to look at it (overlaps an existing block, or held a known voxel last frame) */
     uint8_t *tsum;          /* per tile: obtainFrontiers has something to look at */
+    int32_t *tbmax;            /* per tile: the largest batch-EDT distance of this update as far as pass Z's streaming form has seen it (values above 80: "or more"; k_edt_z_stream, read by k_markc for the lazy tiles' bounds) */
     int32_t *tmax, *tmax_prev; /* per tile: 1 + the largest distance this / the previous (fused) map update committed in it; 0x7fffffff: a voxel of
                                 * the tile was not committed; 0: the tile was not looked at */
     uint8_t *ucol;          /* per z-column of eight voxels (index ((z >> 3) * Y + y) * X + x), bit z & 7: the local index has turned from unknown to known and Mark has not written its pair since (gie_ops.h "`_edt_D` is derived") */
@@ -224,6 +225,7 @@ enum {
     GIE_CNT_TSKIP = 41,                         /* tiles whose stored records Mark does not read (counted by the test-only emulation) */
     GIE_CNT_INL = 43,                           /* wave B: voxels inside the volume that received a proposal (listed in qc[1]) */
     GIE_CNT_AUX_END = 44,                       /* [BAR_B, AUX_END) is zeroed every frame too */
+    GIE_CNT_LAZY_EXACT = 44,                    /* the last fused sweep took its lazy tiles' bounds from pass Z (exact), not from samples (gie_tile_oldskip's hysteresis); kept across updates */
     GIE_CNT_NUM = 48
 };
 #define GIE_MAX_LEVELS 4096

@@ -104,7 +104,7 @@ template <bool STAGED, class F> static void be_vox_list(be_state *b, const gie_c
         }
     }
 }
-static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0); }
+static void be_markc(be_state *b, const gie_ctx &c, const int32_t *list) { c.cnt[GIE_CNT_LAZY_EXACT] = 1; be_vox_list<true>(b, c, op_markc(), list, GIE_CNT_TL_KNOWN, 0); }      /* (every tile's bound is exact here) */
 static void be_fuse(be_state *b, const gie_ctx &c, const int32_t *list) { be_vox_list<true>(b, c, op_fuse(), list, GIE_CNT_TL_FUSE, 0); }
 /* the device takes the listed tiles (tsum == 1) a wave per tile and the face voxels by patches of the faces; here: every voxel
  * the tile summary does not rule out (op_frontier::tile_skip / skip), same decisions per voxel */
