@@ -170,7 +170,7 @@ struct op_tile_summary {
          * — a list of its own, so that consecutive entries cost the same (with the plain face tiles in between, the few waves
          * whose stride met the tx = 0 tiles did all the work).  The voxels on the faces go by patches of the faces (tsum != 0). */
         const int slot = gie_wg_reserve(&c.cnt[GIE_CNT_TL_FRONT], v == 1);
-        if (slot >= 0) c.tl_front[slot] = t;
+        if (slot >= 0) c.tl_front[slot] = t | (c.tlazy[t] ? (int32_t)0x80000000 : 0);      /* (bit 31: the tile is lazy — the entry's reader need not ask the flag before it knows which plane to load) */
     } };
 struct op_halo_export { int face; gie_halo_voxel *out; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_export_voxel(c, face, i, out); } };
 struct op_halo_need { int face; const gie_halo_voxel *in; GIE_DEVM void operator()(const gie_ctx &c, int i) const { gie_halo_need_voxel(c, face, i, in); } };

@@ -1913,8 +1913,9 @@ __device__ __forceinline__ uint32_t gie_fr_srcbit(const gie_ctx &c, const uint64
     const int n0 = nw[0] + c.upvt[0] - c.pvt[0], n1 = nw[1] + c.upvt[1] - c.pvt[1], n2 = nw[2] + c.upvt[2] - c.pvt[2];
     return (!gie_in_loc(c, n0, n1, n2) && gie_in_wr(c, nw[0], nw[1], nw[2])) ? GIE_FR_SRC : 0u;
 }
-__device__ __forceinline__ void gie_frontier_tile(const gie_ctx &c, gie_fr_tile &L, const int t, const int lane, int &ncq)
+__device__ __forceinline__ void gie_frontier_tile(const gie_ctx &c, gie_fr_tile &L, const int te, const int lane, int &ncq)
 {
+    const int t = te & 0x7fffffff;                             /* (bit 31 of a list entry: the tile is lazy, op_tile_summary) */
     const int tx = t % c.tfd[0], ty = (t / c.tfd[0]) % c.tfd[1], tz = t / (c.tfd[0] * c.tfd[1]);
     const int x0 = tx * 8, y0 = ty * 8, z0 = tz * 8;
     const int lx = lane & 7, ly = lane >> 3;
@@ -1925,7 +1926,7 @@ __device__ __forceinline__ void gie_frontier_tile(const gie_ctx &c, gie_fr_tile 
     /* ---- one batch of loads: types and Mark-time pairs of the tile and of the one-voxel halo around it */
     uint64_t pv[8], hv[6];
     int8_t tv[8], ht[6];
-    const bool lz = c.tlazy[t] != 0;
+    const bool lz = te < 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const bool in = colin && z0 + j < c.Z;
@@ -2086,10 +2087,12 @@ __global__ __launch_bounds__(64 * GIE_FF_WAVES) void k_frontier_faces(const gie_
             pre.k = f;
             pre.a = gie_gvox_tab(c, ox + c.pvt[0], oy + c.pvt[1], oz + c.pvt[2]);
             gie_frontier_st s;
-            gie_frontier_load1(c, id, vx, vy, vz, s);
+            /* (a lazy tile never touches a face of the WHOLE volume, and one tile of several has no lazy tiles: the face voxel's pair and its
+             * neighbours' are in the plane — no flag to wait for) */
+            gie_frontier_load1<true>(c, id, vx, vy, vz, s);
             pre.nty = pre.a >= 0 ? c.g_type[pre.a] : (int8_t)0;
             pre.ncoc = pre.a >= 0 ? c.g_coc[pre.a] : (uint64_t)0;
-            const gie_nbpair_mem nb = { &c };
+            const gie_nbpair_plane nb = { c.pair };
             const gie_absink_lds sink = { &W };
             push = gie_frontier_finish_nb(c, id, vx, vy, vz, s, nb, sink, &pre);      /* (an UNKNOWN voxel: nothing, as before) */
         }

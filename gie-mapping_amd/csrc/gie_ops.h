@@ -798,12 +798,15 @@ struct gie_frontier_st { uint64_t p0; uint32_t tys; uint32_t tfm; };   /* tys: o
 
 /* every read that does not depend on another one is issued together — own pair + type, six
  * neighbour types, six tile flags: one memory round trip per voxel (the sweep is latency-bound) */
+/* PLANE: the voxel lies in a tile that touches a face of the whole volume — such a tile is never cleared, so never lazy: its pair is in
+ * the plane, no flag to ask first (k_frontier_faces: one dependent round trip less per face voxel) */
+template <bool PLANE = false>
 GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, gie_frontier_st &s)
 {
     int8_t ty[7];
     uint8_t tf[6];
     ty[0] = c.glb_type[id];
-    s.p0 = gie_pair_get(c, id, x, y, z);      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
+    s.p0 = PLANE ? c.pair[id] : gie_pair_get(c, id, x, y, z);      /* Mark-time value: this kernel never writes `pair` (seeds go to cand[1]) */
     const int dx[6] = { -1, 1, 0, 0, 0, 0 }, dy[6] = { 0, 0, -1, 1, 0, 0 }, dz[6] = { 0, 0, 0, 0, -1, 1 };
     GIE_UNROLL6
     for (int k = 0; k < 6; k++) {
@@ -820,6 +823,8 @@ GIE_DEV void gie_frontier_load1(const gie_ctx &c, int id, int x, int y, int z, g
 /* `nb(k, nid)` = the Mark-time pair of the in-volume neighbour k (local index nid): from memory (gie_nbpair_mem), or from
  * the tile a wave has staged in LDS (k_frontier_tiles) */
 struct gie_nbpair_mem { const gie_ctx *c; GIE_DEV_MEMBER uint64_t operator()(int, int nid) const { return gie_pair_get_id(*c, nid); } };
+/* ... of a voxel ON a face of the whole volume of an untiled mapper: its neighbours lie in tiles that touch the face too — never lazy */
+struct gie_nbpair_plane { const uint64_t *pair; GIE_DEV_MEMBER uint64_t operator()(int, int nid) const { return pair[nid]; } };
 /* `sink.ab(c, push, crd, a)` = the outside neighbour at global coordinate crd (address a) joins frontier B (push == 1) or
  * frontier A (push == 2); called by every executing lane for every direction: straight into the queues with one atomic per
  * wave and call (gie_absink_queues), or collected per tile in LDS (k_frontier_tiles) */
