@@ -326,6 +326,12 @@ def make_feed(workload, torch, scenes, dev, voxel, size, tile_off, nframes):
     return LidarFeed(torch, scenes, dev, voxel, p["sensor"], nframes, preset=p)
 
 
+def dominant_stage(prof):
+    """The stage that certainly holds the update's longest kernel: prof = {stage: (total ms, launches of the stage's timer)}.  A stage
+    of several kernel launches (STAGE_LAUNCHES) competes with the lower bound of its longest kernel, stage time / launches."""
+    return max(prof, key=lambda k: prof[k][0] / max(prof[k][1], 1) / STAGE_LAUNCHES.get(k, 1))
+
+
 def percentile(xs, p):
     xs = sorted(xs)
     if not xs:
@@ -601,7 +607,7 @@ def run_workload(torch, gie, scenes, tiling, dist, workload, size, voxel, cutoff
     # other candidate -- otherwise the two launches of `waves` (0.19 + 0.08 ms on the headline, profiles/r06_c5_kernel_stats.txt)
     # would pass for one kernel longer than pass X's 0.26.  Where a several-launch stage does win (the flood frames of the projective
     # lidar workloads: waves A / B alone are most of the update) the entry is the stage's: its bytes over its time.
-    dom = max(prof, key=lambda k: prof[k][0] / STAGE_LAUNCHES.get(k, 1))
+    dom = dominant_stage(prof)
     dom_roof = sweeps.get(dom) or {}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": dom_roof.get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom_roof.get("frac"), "traffic": dom_roof.get("traffic"),

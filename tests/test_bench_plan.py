@@ -182,3 +182,13 @@ def test_presets_are_the_baseline_configs():
     import gie
     for k, want in (("c2", 1600), ("c4", 10000), ("c3", 1000000)):          # cutoff in voxels², SURVEY 8 config shorthands
         assert gie.make_config(P[k]["voxel"], P[k]["size"], cutoff_dist=P[k]["cutoff"]).cutoff_grids_sq == want
+
+
+def test_dominant_kernel_is_a_kernel_not_a_stage_of_several_launches():
+    """bench.dominant_stage: `waves` is two launches — on the headline their sum is as long as pass X, each of them is shorter"""
+    import bench
+    headline = {"edt_pass_x": (0.2612 * 20, 20), "waves": (0.2617 * 20, 20), "edt_pass_z": (0.26 * 20, 20), "mark_commit": (0.12 * 20, 20), "block_alloc": (0.13 * 20, 20)}
+    assert bench.dominant_stage(headline) == "edt_pass_x"
+    flood = {"edt_pass_x": (0.11 * 10, 10), "waves": (1.2 * 10, 10), "ogm_classify": (0.245 * 10, 10)}      # waves A / B alone are most of the update
+    assert bench.dominant_stage(flood) == "waves"
+    assert bench.dominant_stage({"fuse": (1.0, 4), "frontiers": (1.9, 4)}) == "fuse"
